@@ -1,0 +1,262 @@
+#!/usr/bin/env python
+"""bench.py -- MSMC-VQ-GAN GAN-phase train step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One "step" = one full ``VQGANTrainer.train_step`` in the GAN phase (autoencoder forward, mel/STFT
+loss, D step, G step, clipping, both optimizer steps, gradient all-reduces when N>1) on one
+synthetic batch per rank (B=16/GPU, T=400, hop 300, 40-frame vocoder window).
+Workload = BASELINE configs[1]: CSMSC msmc_vq_gan.yaml with 4 heads x 256 codewords, bf16 autocast
+for the GEMM/conv bodies, fp32 VQ search (indices must be bit-exact).  Weak scaling: per-GPU batch
+fixed.  Rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline      the dominant hand-written kernel inside the timed region (HIP events on the launch
+                stream), algorithmic bytes / duration against the gfx950 HBM peak
+  vq_microbench the "VQ argmin GB/s" half of the BASELINE metric: msmc_vq_search at N=2^20 frames
+  cpu_baseline  the oracle (oracle/step.py, plain PyTorch fp32) timed on this box's host cores on a
+                bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'msmc-tts_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FLOP_PER_STEP = 3.006e12       # reference GAN step at B=16, T=400 (torch FlopCounter)
+FLOP_PER_STEP_ELIDED = 2.65e12  # without the discarded D weight-gradients of the G step
+
+
+def vq_bytes_per_frame(D, H):
+    """read x, write quant, int64 indices, head-averaged diff."""
+    return 4 * D + 4 * D + 8 * H + 4 * D // H
+
+
+class KernelTimer(object):
+    """HIP-event timing of named C-ABI launches on the current (launch) stream."""
+
+    def __init__(self):
+        self.records = {}
+        self.enabled = False
+
+    def wrap(self, module, fn_name, label, work):
+        inner = getattr(module, fn_name)
+        timer = self
+
+        def timed(*args, **kw):
+            if not timer.enabled:
+                return inner(*args, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = inner(*args, **kw)
+            e.record()
+            timer.records.setdefault(label, []).append((s, e, work(*args, **kw)))
+            return out
+
+        setattr(module, fn_name, timed)
+
+    def summary(self):
+        out = {}
+        for label, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _ in recs]
+            byts = [b for _, _, b in recs]
+            out[label] = dict(launches=len(ms), avg_ms=sum(ms) / len(ms), avg_bytes=sum(byts) / len(byts),
+                              total_ms=sum(ms))
+        return out
+
+
+def build(args, device, rank, world):
+    from msmctts_amd.configs import csmsc_config
+    from msmctts_amd.tasks import build_task
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    from msmctts_amd.utils.config import Config
+    cfg = Config(csmsc_config(embedding_sizes=args.codewords, n_heads=args.heads, batch_size=args.batch,
+                              warmup_steps=0))
+    torch.manual_seed(cfg.seed)
+    task = build_task(cfg, mode='train')
+    trainer = build_trainer(cfg, task, num_gpus=world, rank=rank)      # moves to GPU; arms RCCL reducer if world>1
+    trainer.optimizer = build_optimizer(trainer.model, cfg.optimizer)
+    trainer.amp_dtype = torch.bfloat16 if args.dtype == 'bf16' else None
+    trainer.model.train()
+    return cfg, trainer
+
+
+def cpu_baseline(cfg, state_dict, batch, windows, steps, threads):
+    """Oracle train step on host cores: same state, same batch, same windows (bounded sample)."""
+    from oracle.step import OracleTrainer
+    torch.set_num_threads(threads)
+    task = cfg.task.to_dict()
+    tcfg = {k: v for k, v in cfg.trainer.to_dict().items() if k != '_name'}
+    tr = OracleTrainer({k: v.detach().float().cpu() for k, v in state_dict.items()}, task, tcfg)
+    cb = {k: v.detach().cpu() for k, v in batch.items() if torch.is_tensor(v)}
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        tr.train_step(cb, 10 + i, windows=windows)
+        times.append(time.perf_counter() - t0)
+    timed = sorted(times[1:])
+    return timed[len(timed) // 2]
+
+
+def vq_microbench(device, H, K, D=256, N=1 << 20, iters=20):
+    from msmctts_amd.hip import vq
+    g = torch.Generator(device='cpu').manual_seed(0)
+    x = torch.randn(N, D, generator=g).to(device)
+    embed = torch.randn(H, D // H, K, generator=g).to(device)
+    et, en = vq.vq_prepare(embed)
+    for _ in range(3):
+        vq.vq_search(x, et, en)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        vq.vq_search(x, et, en)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters          # includes three small output allocations per call (cached allocator)
+    byts = N * vq_bytes_per_frame(D, H)
+    return dict(kernel='vq_search_kernel', N=N, D=D, H=H, K=K, ms=ms, GBps=byts / ms / 1e6,
+                frac_hbm=byts / ms / 1e6 / HBM_PEAK_GBS, Mframes_per_s=N / ms / 1e3,
+                fp32_TFLOPs=2.0 * K * D * N / ms / 1e9)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--frames', type=int, default=400)
+    ap.add_argument('--heads', type=int, default=4)
+    ap.add_argument('--codewords', type=int, default=256)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--cpu-steps', type=int, default=2, help='timed oracle steps for cpu_baseline (0 = skip)')
+    ap.add_argument('--no-microbench', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank)
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+
+    from msmctts_amd.hip import lib, vq as hipvq
+    from msmctts_amd.synthetic import make_batch
+    assert lib.backend() == 'gfx950'
+    cfg, trainer = build(args, device, rank, world)
+    state0 = {k: v.detach().clone() for k, v in trainer.model.state_dict().items()} if rank == 0 and world == 1 else None
+    batch = make_batch(args.batch, args.frames, 80, 300, seed=1234, rank=rank, device='cpu')
+    lengths_host = batch['mel_length'].tolist()
+    batch = {k: v.to(device) for k, v in batch.items()}
+    batch['mel_length_host'] = lengths_host
+    import random
+    trainer.rng = random.Random(1234 + rank)
+
+    timer = KernelTimer()
+    D = cfg.task.autoencoder.quantizer_config.embedding_dims
+    timer.wrap(hipvq, 'vq_search', 'vq_search_kernel',
+               lambda x, et, en: (x.numel() // x.shape[-1]) * vq_bytes_per_frame(x.shape[-1], et.shape[0]))
+
+    def step(i):
+        trainer.model.zero_grad()
+        trainer.optimizer.zero_grad()
+        return trainer.train_step(batch, 10 + i)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    timer.enabled = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        log = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        fr = torch.tensor([float(sum(lengths_host))], device=device, dtype=torch.float64)
+        dist.all_reduce(fr)
+        frames_per_step = float(fr.item())
+    else:
+        frames_per_step = float(sum(lengths_host))
+    ms_per_step = elapsed / args.steps * 1e3
+    value = frames_per_step / (elapsed / args.steps)
+
+    if rank != 0:
+        return
+    ks = timer.summary()
+    roof = None
+    if ks:
+        label, rec = max(ks.items(), key=lambda kv: kv[1]['total_ms'])
+        ach = rec['avg_bytes'] / rec['avg_ms'] / 1e6
+        roof = dict(kernel=label, bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
+                    traffic=None, launches=rec['launches'], avg_us=rec['avg_ms'] * 1e3,
+                    bytes_per_launch=rec['avg_bytes'],
+                    note='training-size launches (N<=B*T frames) are launch-latency bound; see vq_microbench')
+    out = {
+        'metric': 'mel-frames/sec MSMC-VQ-GAN train step (GAN phase)', 'value': value, 'unit': 'mel-frames/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': 'CSMSC msmc_vq_gan 2-stage %d-head x %d-codeword VQ + HifiGAN + MPD/MRD, GAN phase'
+                               % (args.heads, args.codewords),
+                   'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'frames': args.frames,
+                   'mel_frames_per_step': frames_per_step, 'parallelism': 'dp%d' % world,
+                   'vq_search': 'fp32 (bit-exact indices)'},
+        'step_tflops': FLOP_PER_STEP_ELIDED * (args.batch / 16.0) * world / (elapsed / args.steps) / 1e12,
+        'step_flop_model': 'SURVEY 8d: 3.006 TFLOP/step at B=16,T=400 minus the elided D weight-grads of the G step '
+                           '= 2.65 TFLOP',
+        'roofline': roof,
+        'losses': {k: float(v) for k, v in log['loss'].items()},
+    }
+    if not args.no_microbench:
+        out['vq_microbench'] = [vq_microbench(device, args.heads, args.codewords),
+                                vq_microbench(device, 4, 64)]
+    if world == 1 and args.cpu_steps > 0:
+        cores = os.cpu_count() or 1
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except Exception:
+            pass
+        r = random.Random(99)
+        fw = []
+        for n in lengths_host:
+            s = r.randrange(max(1, n - 40))
+            fw.append((s, s + 40))
+        sw = [(s * 300, e * 300) for s, e in fw]
+        sec = cpu_baseline(cfg, state0, batch, (fw, sw), args.cpu_steps, cores)
+        out['cpu_baseline'] = dict(value=frames_per_step / sec, unit='mel-frames/s', cores=cores, kind='port',
+                                   sample='%d timed GAN-phase oracle steps (median) after 1 warm-up, same B=%d T=%d '
+                                          'batch and weights, fp32, torch %s' % (args.cpu_steps, args.batch,
+                                                                                args.frames, torch.__version__),
+                                   s_per_step=sec)
+        out['speedup_vs_cpu'] = value / out['cpu_baseline']['value']
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

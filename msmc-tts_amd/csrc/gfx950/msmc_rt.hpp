@@ -1,0 +1,81 @@
+// msmc_rt.hpp -- gfx950 device runtime vocabulary used by every kernel in csrc/.
+//
+// Thin, zero-cost names for the CDNA4 intrinsics the kernels rely on (64-wide wavefront
+// cross-lane moves, f32 and bf16 MFMA) plus the launch macro.  Kernels include <msmc_rt.hpp> (found via -I csrc/gfx950) and never
+// touch the builtins directly; tests/emu/msmc_rt.hpp provides the same vocabulary for the CPU
+// interpreter that the -m "not gpu" tests use to check kernel logic (test infrastructure only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define MSMC_WAVE 64
+#define MSMC_DEV static __device__ __forceinline__
+#define MSMC_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define MSMC_LAUNCH(kernel, grid, block, lds, stream, ...) \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__)
+
+typedef hipStream_t msmc_stream_t;
+
+// ---- 64-lane cross-lane moves ------------------------------------------------------------
+MSMC_DEV float wave_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+MSMC_DEV int wave_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
+MSMC_DEV float wave_down(float v, int delta) { return __shfl_down(v, delta, 64); }
+MSMC_DEV float wave_bcast(float v, int lane) { return __shfl(v, lane, 64); }
+MSMC_DEV int wave_bcast(int v, int lane) { return __shfl(v, lane, 64); }
+
+// Intra-wave LDS hand-off point: lanes of ONE wave exchange data through LDS (a wave executes its
+// LDS instructions in order, so no hardware barrier is needed); this only stops the compiler from
+// moving LDS accesses across the hand-off.
+MSMC_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- matrix cores --------------------------------------------------------------------------
+// f32-in / f32-accumulate: exact fp32, bit-identical to a k-ordered fmaf chain.
+//   16x16x4 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D reg r -> row 4*(l>>4)+r, col l&15
+//   32x32x2 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31
+MSMC_DEV f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+MSMC_DEV f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// bf16 in / f32 accumulate:
+//   32x32x16: A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31], e=0..7, D as 32x32x2
+//   16x16x32: A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][j=l&15],          D as 16x16x4
+MSMC_DEV f32x16 mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+MSMC_DEV f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// ---- bf16 <-> f32 (round to nearest even), bit-level so host and device agree ---------------
+MSMC_DEV unsigned short f32_to_bf16_bits(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+MSMC_DEV float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+
+// ---- host-side helpers used by the C-ABI launchers ------------------------------------------
+#define MSMC_BACKEND_NAME "gfx950"
+#define MSMC_NUM_CU 256              // MI355X: 8 XCDs x 32 CUs
+static inline int msmc_check_launch() { return (int)hipGetLastError(); }
+// Kernels that carve more than 64 KiB of dynamic LDS must opt in once per function.
+static inline int msmc_allow_lds(const void* fn, int bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}

@@ -1,0 +1,495 @@
+// vq.hip -- multi-head nearest-codeword search with EMA codebook update for gfx950.
+//
+// Replaces Quantize.forward / MultiHeadQuantize.forward
+//   (reference msmctts/networks/vqgantts/modules.py:24-67, :137-151; numerical spec SURVEY.md app. B).
+//
+// msmc_vq_search: one persistent launch for all heads.  Each wave owns 16-frame tiles whose rows
+// are streamed HBM -> registers (prefetch, one tile ahead) -> LDS with full-row coalesced
+// loads; the transposed codebook of the resident heads sits in LDS; x.e products run on the
+// f32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, k-ordered fmaf chain, two independent
+// accumulators per wave to cover the 40-cycle dependent latency); the arg-min is a per-lane
+// running minimum over the accumulator fragment followed by a two-step wave xor-reduce; the
+// gather, straight-through value and squared error are formed in LDS in place and written back
+// with full-row stores.  Algorithmic HBM bytes per frame: 4D (x) + 4D (quant) + 8H (ind) + 4D/H (diff).
+//
+// msmc_vq_ema_update: deterministic two-stage reduction (per-tile counting sort of the indices in
+// LDS, ordered per-codeword sums, fixed-order reduction over tiles) then the EMA / Laplace
+// smoothing / renormalisation of the three buffers in place.
+#include <msmc_rt.hpp>
+#include <msmc_hip.h>
+
+#define VQ_TILE 16
+#define VQ_LDS_LIMIT (160 * 1024)
+
+// ------------------------------------------------------------------------------------------------
+// prepare: embed [H][d][K] -> embed_t [H][K][d], enorm [H][K]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void vq_prepare_kernel(const float* __restrict__ embed, float* __restrict__ embed_t,
+                                                       float* __restrict__ enorm, int d, int K) {
+    const int h = blockIdx.y;
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= K) return;
+    const float* e = embed + (size_t)h * d * K + k;
+    float* et = embed_t + ((size_t)h * K + k) * d;
+    float acc = 0.f;
+    for (int j = 0; j < d; ++j) {
+        float v = e[(size_t)j * K];
+        et[j] = v;
+        float sq = v * v;           // pow(2) then sum(0): square rounded, then added (modules.py:29)
+        acc = acc + sq;
+    }
+    enorm[(size_t)h * K + k] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// search
+// ------------------------------------------------------------------------------------------------
+struct VqLds {
+    int cb, en, xt, dacc, bidx, total;      // byte offsets
+};
+
+static inline VqLds vq_lds_layout(int D, int H, int K, int hpg, int nw) {
+    const int d = D / H;
+    VqLds L;
+    L.cb = 0;
+    L.en = L.cb + hpg * K * (d + 4) * 4;
+    L.xt = L.en + hpg * K * 4;
+    L.dacc = L.xt + nw * VQ_TILE * (D + 4) * 4;
+    L.bidx = L.dacc + nw * VQ_TILE * d * 4;
+    L.total = L.bidx + nw * VQ_TILE * H * 4;
+    return L;
+}
+
+template <int NLD>
+__global__ __launch_bounds__(256) void vq_search_kernel(const float* __restrict__ x, const float* __restrict__ embed_t,
+                                                       const float* __restrict__ enorm, float* __restrict__ quant,
+                                                       float* __restrict__ diff, int64_t* __restrict__ ind, int N, int D,
+                                                       int H, int K, int hpg, VqLds L) {
+    MSMC_DYN_LDS(smem);
+    const int d = D / H;
+    const int ES = d + 4;
+    const int XS = D + 4;
+    const int DV = D / 4;
+    const int nw = blockDim.x >> 6;
+    const int w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int f = lane & 15;
+    const int g = lane >> 4;
+    float* cb = (float*)(smem + L.cb);
+    float* en = (float*)(smem + L.en);
+    float* xt = (float*)(smem + L.xt) + w * VQ_TILE * XS;
+    float* dacc = (float*)(smem + L.dacc) + w * VQ_TILE * d;
+    int* bidx = (int*)(smem + L.bidx) + w * VQ_TILE * H;
+
+    const int ngroups = (H + hpg - 1) / hpg;
+    const int numTiles = (N + VQ_TILE - 1) / VQ_TILE;
+    const int numIters = (numTiles + nw - 1) / nw;
+
+    // ---- stage the codebook of heads [h0, h0+cnt) : rows of d floats -> stride ES
+    auto stage_group = [&](int h0, int cnt) {
+        const int rows = cnt * K;
+        const int dv = d >> 2;
+        const f32x4* src = (const f32x4*)(embed_t + (size_t)h0 * K * d);
+        for (int e = threadIdx.x; e < rows * dv; e += blockDim.x) {
+            int r = e / dv, c4 = e - r * dv;
+            *(f32x4*)(cb + r * ES + c4 * 4) = src[e];
+        }
+        for (int e = threadIdx.x; e < rows; e += blockDim.x) en[e] = enorm[(size_t)h0 * K + e];
+    };
+
+    if (ngroups == 1) {
+        stage_group(0, H);
+        __syncthreads();
+    }
+
+    f32x4 pre[NLD];
+    auto prefetch = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            int e = i * 64 + lane;
+            int row = e / DV, c4 = e - row * DV;
+            int n = tile * VQ_TILE + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < VQ_TILE * DV && n < N) v = *(const f32x4*)(x + (size_t)n * D + c4 * 4);
+            pre[i] = v;
+        }
+    };
+
+    int it = blockIdx.x;
+    if (it < numIters && it * nw + w < numTiles) prefetch(it * nw + w);
+
+    for (; it < numIters; it += gridDim.x) {
+        const int tile = it * nw + w;
+        const bool active = tile < numTiles;
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                int e = i * 64 + lane;
+                int row = e / DV, c4 = e - row * DV;
+                if (e < VQ_TILE * DV) *(f32x4*)(xt + row * XS + c4 * 4) = pre[i];
+            }
+        }
+        wave_sync();                 // tile rows were written by other lanes of this wave
+        {   // issue the next tile's loads now; they land while this tile computes
+            const int nt = (it + gridDim.x) * nw + w;
+            if (it + (int)gridDim.x < numIters && nt < numTiles) prefetch(nt);
+        }
+
+        for (int grp = 0; grp < ngroups; ++grp) {
+            const int h0 = grp * hpg;
+            const int cnt = (H - h0 < hpg) ? (H - h0) : hpg;
+            if (ngroups > 1) {
+                __syncthreads();
+                stage_group(h0, cnt);
+                __syncthreads();
+            }
+            if (!active) continue;
+            for (int hl = 0; hl < cnt; ++hl) {
+                const int h = h0 + hl;
+                const float* cbh = cb + hl * K * ES;
+                const float* enh = en + hl * K;
+                float* xr = xt + f * XS + h * d;
+                // |x|^2 : four interleaved partial sums, combined across the 4 lane groups
+                float xx = 0.f;
+                for (int j = g; j < d; j += 4) {
+                    float v = xr[j];
+                    float sq = v * v;
+                    xx = xx + sq;
+                }
+                xx = xx + wave_xor(xx, 16);
+                xx = xx + wave_xor(xx, 32);
+
+                float best = __builtin_inff();
+                int bi = 0;
+                const int ntile = K >> 4;
+                int ct = 0;
+                for (; ct + 2 <= ntile; ct += 2) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    const float* a0 = cbh + (ct * 16 + f) * ES + g;
+                    const float* a1 = a0 + 16 * ES;
+                    const float* b = xr + g;
+                    for (int s = 0; s < d; s += 4) {
+                        float bv = b[s];
+                        acc0 = mfma_f32_16x16x4(a0[s], bv, acc0);
+                        acc1 = mfma_f32_16x16x4(a1[s], bv, acc1);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int code = ct * 16 + 4 * g + r;
+                        float t2 = 2.f * acc0[r];
+                        float dist = (xx - t2) + enh[code];
+                        if (dist < best) { best = dist; bi = code; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int code = ct * 16 + 16 + 4 * g + r;
+                        float t2 = 2.f * acc1[r];
+                        float dist = (xx - t2) + enh[code];
+                        if (dist < best) { best = dist; bi = code; }
+                    }
+                }
+                if (ct < ntile) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
+                    const float* a0 = cbh + (ct * 16 + f) * ES + g;
+                    const float* b = xr + g;
+                    for (int s = 0; s < d; s += 4) acc0 = mfma_f32_16x16x4(a0[s], b[s], acc0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int code = ct * 16 + 4 * g + r;
+                        float t2 = 2.f * acc0[r];
+                        float dist = (xx - t2) + enh[code];
+                        if (dist < best) { best = dist; bi = code; }
+                    }
+                }
+                // first-minimum across the four lane groups that share frame f
+#pragma unroll
+                for (int m = 16; m <= 32; m <<= 1) {
+                    float od = wave_xor(best, m);
+                    int oi = wave_xor(bi, m);
+                    if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+                }
+                if (g == 0) bidx[f * H + h] = bi;
+
+                // gather + straight-through value + squared error, in place
+                const float* qrow = cbh + bi * ES;
+                float* drow = dacc + f * d;
+                const int q4 = d >> 2;
+                for (int j = g * q4; j < (g + 1) * q4; ++j) {
+                    float xv = xr[j];
+                    float e = qrow[j] - xv;
+                    xr[j] = xv + e;
+                    float sq = e * e;
+                    drow[j] = (h == 0) ? sq : (drow[j] + sq);
+                }
+            }
+        }
+
+        wave_sync();                 // epilogue results (xt, dacc, bidx) are read by other lanes below
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                int e = i * 64 + lane;
+                int row = e / DV, c4 = e - row * DV;
+                int n = tile * VQ_TILE + row;
+                if (e < VQ_TILE * DV && n < N)
+                    *(f32x4*)(quant + (size_t)n * D + c4 * 4) = *(const f32x4*)(xt + row * XS + c4 * 4);
+            }
+            const int q4 = d >> 2;
+            const float fh = (float)H;
+            for (int e = lane; e < VQ_TILE * q4; e += 64) {
+                int row = e / q4, c4 = e - row * q4;
+                int n = tile * VQ_TILE + row;
+                if (n < N) {
+                    f32x4 v = *(const f32x4*)(dacc + row * d + c4 * 4);
+                    if (H > 1) { v[0] = v[0] / fh; v[1] = v[1] / fh; v[2] = v[2] / fh; v[3] = v[3] / fh; }
+                    *(f32x4*)(diff + (size_t)n * d + c4 * 4) = v;
+                }
+            }
+            for (int e = lane; e < VQ_TILE * H; e += 64) {
+                int row = e / H;
+                int n = tile * VQ_TILE + row;
+                if (n < N) ind[(size_t)tile * VQ_TILE * H + e] = (int64_t)bidx[e];
+            }
+        }
+        wave_sync();                 // next iteration overwrites the tile
+    }
+}
+
+typedef void (*vq_search_fn)(const float*, const float*, const float*, float*, float*, int64_t*, int, int, int, int,
+                             int, VqLds);
+
+// ------------------------------------------------------------------------------------------------
+// EMA statistics, stage 1: per (tile, head) ordered per-codeword sums
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_stats_kernel(const float* __restrict__ x, const int64_t* __restrict__ ind,
+                                                      const int64_t* __restrict__ length, float* __restrict__ part,
+                                                      float* __restrict__ pcnt, int N, int T, int D, int H, int K,
+                                                      int TN) {
+    MSMC_DYN_LDS(smem);
+    int* ids = (int*)smem;              // [TN]
+    int* sorted = ids + TN;             // [TN]
+    int* cnt = sorted + TN;             // [K]
+    int* off = cnt + K;                 // [K + 1]
+    const int tile = blockIdx.x, h = blockIdx.y;
+    const int d = D / H;
+    const int n0 = tile * TN;
+    for (int e = threadIdx.x; e < TN; e += blockDim.x) {
+        int n = n0 + e;
+        int code = -1;
+        if (n < N) {
+            int b = n / T, t = n - b * T;
+            if ((int64_t)t < length[b]) code = (int)ind[(size_t)n * H + h];
+        }
+        ids[e] = code;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        int c = 0;
+        for (int e = 0; e < TN; ++e) c += (ids[e] == k) ? 1 : 0;
+        cnt[k] = c;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k <= K; k += blockDim.x) {
+        int o = 0;
+        for (int q = 0; q < k; ++q) o += cnt[q];
+        off[k] = o;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        int p = off[k];
+        for (int e = 0; e < TN; ++e)
+            if (ids[e] == k) sorted[p++] = e;
+    }
+    __syncthreads();
+    // ordered sums: a "slot" of min(d, 64) lanes owns one codeword at a time
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int lanes_per_code = d < 64 ? d : 64;
+    const int slots_per_wave = 64 / lanes_per_code;
+    const int slot = w * slots_per_wave + lane / lanes_per_code;
+    const int nslots = nw * slots_per_wave;
+    const int j0 = lane % lanes_per_code;
+    const bool lane_on = (lane / lanes_per_code) < slots_per_wave;
+    const size_t pbase = ((size_t)tile * H + h) * K;
+    for (int k = slot; k < K; k += nslots) {
+        if (!lane_on) continue;
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        const int r1 = off[k + 1];
+        for (int r = off[k]; r < r1; ++r) {
+            const float* row = x + (size_t)(n0 + sorted[r]) * D + h * d + j0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (j0 + 64 * q < d) acc[q] = acc[q] + row[64 * q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (j0 + 64 * q < d) part[(pbase + k) * d + j0 + 64 * q] = acc[q];
+        if (j0 == 0) pcnt[pbase + k] = (float)cnt[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// EMA statistics, stage 2: fixed-order reduction over tiles + buffer update (one workgroup per head)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_ema_kernel(const float* __restrict__ part, const float* __restrict__ pcnt,
+                                                    float* __restrict__ embed, float* __restrict__ cluster_size,
+                                                    float* __restrict__ embed_avg, int ntiles, int H, int d, int K,
+                                                    float decay, float omd, float eps, float keps) {
+    MSMC_DYN_LDS(smem);
+    float* cs = (float*)smem;           // [K] updated cluster sizes
+    float* red = cs + K;                // [256]
+    const int h = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float c = 0.f;
+        for (int t = 0; t < ntiles; ++t) c = c + pcnt[((size_t)t * H + h) * K + k];
+        float v = cluster_size[(size_t)h * K + k] * decay;
+        v = fmaf(c, omd, v);
+        cluster_size[(size_t)h * K + k] = v;
+        cs[k] = v;
+    }
+    __syncthreads();
+    float p = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) p = p + cs[k];
+    red[threadIdx.x] = p;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const float n = red[0];
+    const float den = n + keps;
+    for (int e = threadIdx.x; e < d * K; e += blockDim.x) {
+        const int j = e / K, k = e - j * K;
+        float s = 0.f;
+        for (int t = 0; t < ntiles; ++t) s = s + part[(((size_t)t * H + h) * K + k) * d + j];
+        const size_t o = ((size_t)h * d + j) * K + k;
+        float a = embed_avg[o] * decay;
+        a = fmaf(s, omd, a);
+        embed_avg[o] = a;
+        float sm = (cs[k] + eps) / den * n;
+        embed[o] = a / sm;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restrict__ gq, const float* __restrict__ gd,
+                                                         const float* __restrict__ x, const float* __restrict__ q,
+                                                         float* __restrict__ gx, long total4, int D, int d, float invH) {
+    const int DV = D >> 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long)gridDim.x * blockDim.x) {
+        long n = e / DV;
+        int c = (int)(e - n * DV) * 4;
+        f32x4 g = *(const f32x4*)(gq + e * 4);
+        if (gd) {
+            f32x4 xv = *(const f32x4*)(x + e * 4);
+            f32x4 qv = *(const f32x4*)(q + e * 4);
+            f32x4 dv = *(const f32x4*)(gd + n * d + (c % d));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = g[i] + (dv[i] * invH) * (2.f * (xv[i] - qv[i]));
+        }
+        *(f32x4*)(gx + e * 4) = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int msmc_vq_prepare(const float* embed, float* embed_t, float* enorm, int H, int d, int K, msmc_stream stream) {
+    if (H <= 0 || d <= 0 || K <= 0) return MSMC_E_SHAPE;
+    dim3 grid((K + 63) / 64, H);
+    MSMC_LAUNCH(vq_prepare_kernel, grid, dim3(64), 0, (msmc_stream_t)stream, embed, embed_t, enorm, d, K);
+    return msmc_check_launch();
+}
+
+int msmc_vq_search(const float* x, const float* embed_t, const float* enorm, float* quant, float* diff,
+                   int64_t* ind, int N, int D, int H, int K, msmc_stream stream) {
+    if (N < 0 || H <= 0 || D <= 0 || D % H) return MSMC_E_SHAPE;
+    const int d = D / H;
+    if (d % 4 || K % 16 || K <= 0) return MSMC_E_SHAPE;
+    if (N == 0) return 0;
+    // pick the widest workgroup and the most resident heads that fit LDS
+    int nw = 4, hpg = H;
+    VqLds L;
+    for (;;) {
+        L = vq_lds_layout(D, H, K, hpg, nw);
+        if (L.total <= VQ_LDS_LIMIT) break;
+        if (hpg > 1) { hpg = (hpg + 1) / 2; continue; }
+        if (nw > 1) { nw >>= 1; hpg = H; continue; }
+        return MSMC_E_SHAPE;
+    }
+    const int nld = (VQ_TILE * (D / 4) + 63) / 64;
+    vq_search_fn fn = nullptr;
+    if (nld <= 1) fn = vq_search_kernel<1>;
+    else if (nld <= 2) fn = vq_search_kernel<2>;
+    else if (nld <= 4) fn = vq_search_kernel<4>;
+    else if (nld <= 8) fn = vq_search_kernel<8>;
+    else if (nld <= 16) fn = vq_search_kernel<16>;
+    else if (nld <= 32) fn = vq_search_kernel<32>;
+    else return MSMC_E_SHAPE;
+    int rc = msmc_allow_lds((const void*)fn, L.total);
+    if (rc) return rc;
+    const int numTiles = (N + VQ_TILE - 1) / VQ_TILE;
+    const int numIters = (numTiles + nw - 1) / nw;
+    const int grid = numIters < MSMC_NUM_CU ? numIters : MSMC_NUM_CU;
+    MSMC_LAUNCH(fn, dim3(grid), dim3(64 * nw), (size_t)L.total, (msmc_stream_t)stream, x, embed_t, enorm, quant, diff,
+                ind, N, D, H, K, hpg, L);
+    return msmc_check_launch();
+}
+
+static inline int vq_stats_tile(int N) {
+    int TN = 256;
+    while (TN < 4096 && (N + TN - 1) / TN > 64) TN <<= 1;
+    return TN;
+}
+
+size_t msmc_vq_ema_workspace(int N, int D, int H, int K) {
+    if (N <= 0 || H <= 0 || D % H) return 0;
+    const int d = D / H;
+    const int TN = vq_stats_tile(N);
+    const size_t ntiles = (size_t)(N + TN - 1) / TN;
+    return ntiles * H * K * (size_t)(d + 1) * sizeof(float);
+}
+
+int msmc_vq_ema_update(const float* x, const int64_t* ind, const int64_t* length, float* embed, float* cluster_size,
+                       float* embed_avg, void* workspace, size_t workspace_bytes, int B, int T, int D, int H, int K,
+                       float decay, float eps, msmc_stream stream) {
+    const int N = B * T;
+    if (N <= 0 || H <= 0 || D % H || K <= 0) return MSMC_E_SHAPE;
+    const int d = D / H;
+    if (d > 512) return MSMC_E_SHAPE;
+    if (workspace_bytes < msmc_vq_ema_workspace(N, D, H, K)) return MSMC_E_WORKSPACE;
+    const int TN = vq_stats_tile(N);
+    const int ntiles = (N + TN - 1) / TN;
+    float* part = (float*)workspace;
+    float* pcnt = part + (size_t)ntiles * H * K * d;
+    const size_t lds1 = (size_t)(2 * TN + 2 * K + 1) * sizeof(int);
+    MSMC_LAUNCH(vq_stats_kernel, dim3(ntiles, H), dim3(256), lds1, (msmc_stream_t)stream, x, ind, length, part, pcnt, N,
+                T, D, H, K, TN);
+    int rc = msmc_check_launch();
+    if (rc) return rc;
+    const float omd = (float)(1.0 - (double)decay);
+    const float keps = (float)((double)K * (double)eps);
+    const size_t lds2 = (size_t)(K + 256) * sizeof(float);
+    MSMC_LAUNCH(vq_ema_kernel, dim3(H), dim3(256), lds2, (msmc_stream_t)stream, (const float*)part, (const float*)pcnt,
+                embed, cluster_size, embed_avg, ntiles, H, d, K, decay, omd, eps, keps);
+    return msmc_check_launch();
+}
+
+int msmc_vq_backward(const float* g_quant, const float* g_diff, const float* x, const float* quant, float* gx, int N,
+                     int D, int H, msmc_stream stream) {
+    if (N < 0 || H <= 0 || D % H || (D / H) % 4) return MSMC_E_SHAPE;
+    if (N == 0) return 0;
+    const long total4 = (long)N * (D / 4);
+    long blocks = (total4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    MSMC_LAUNCH(vq_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, g_quant, g_diff, x,
+                quant, gx, total4, D, D / H, 1.0f / (float)H);
+    return msmc_check_launch();
+}
+
+}  // extern "C"

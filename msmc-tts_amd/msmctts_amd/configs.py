@@ -1,0 +1,54 @@
+"""The CSMSC MSMC-VQ-GAN configuration as data (values of reference
+examples/csmsc/configs/msmc_vq_gan.yaml:7-135), with the BASELINE.json overrides as arguments.
+
+``csmsc_config()`` returns a plain dict accepted by ``Config``; any YAML with the same keys works too.
+BASELINE configs: #1 ``downsample_scales=[1], n_heads=1, embedding_sizes=64, batch_size=4``;
+#2/#3 ``embedding_sizes=256``; #5 ``in_dim=1024, n_heads=8, embedding_sizes=512``.
+"""
+
+
+def _fft_block_cfg():
+    return dict(max_seq_len=2400, n_layers=4, n_head=2, d_k=64, d_v=64, d_inner=1024, fft_conv1d_kernel=3,
+                fft_conv1d_padding=1, dropout=0.2, attn_dropout=0.1, fused_layernorm=False)
+
+
+def csmsc_config(downsample_scales=(1, 4), n_heads=4, embedding_sizes=64, in_dim=80, batch_size=16,
+                 warmup_steps=50000, sample_lengths=12000):
+    enc = dict(downsample_scales=list(downsample_scales), **_fft_block_cfg())
+    return {
+        'id': 'msmc_vqgan',
+        'task': {
+            '_name': 'MSMCTTS', '_mode': 'train_autoencoder',
+            'autoencoder': {
+                '_name': 'MSMCVQGAN', 'in_dim': in_dim, 'n_model_size': 256,
+                'encoder_config': enc,
+                'quantizer_config': dict(embedding_sizes=embedding_sizes, embedding_dims=256, n_heads=n_heads,
+                                         prior_config=dict(kernel_size=5, dilation_rate=1, n_layers=1), norm=False),
+                'frame_decoder_config': _fft_block_cfg(),
+                'pred_mel': True,
+                'decoder_config': dict(upsample_rates=[6, 5, 5, 2], upsample_kernel_sizes=[12, 11, 11, 4],
+                                       upsample_initial_channel=512, resblock_kernel_sizes=[3, 7, 11],
+                                       resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]]),
+            },
+            'discriminator': {
+                '_name': 'UnivNetDiscriminator',
+                'mrd_config': dict(hop_lengths=[15, 30, 50, 120, 240], hidden_channels=[128, 128, 256, 256, 512],
+                                   domain='double', mel_scale=True, sample_rate=24000),
+                'mpd_config': dict(periods=[2, 3, 5, 7, 11], channels=16, max_channels=512),
+            },
+        },
+        'save_checkpoint_dir': '', 'pretrain_checkpoint_path': '', 'restore_checkpoint_path': '',
+        'resume_training': True, 'training_steps': 800000, 'iters_per_checkpoint': 50000, 'seed': 1234,
+        'cudnn': {'enabled': True, 'benchmark': True},
+        'trainer': dict(_name='VQGANTrainer', grad_clip_thresh=1.0, warmup_steps=warmup_steps,
+                        sample_lengths=sample_lengths, lambda_vq=1, lambda_pr=0.1, lambda_frame=450, lambda_fm=2,
+                        lambda_stft=45),
+        'optimizer': {'_default': dict(_name='AdamW', learning_rate=2e-4, betas=[0.8, 0.99], eps=1e-8,
+                                       weight_decay=0.0)},
+        'dataloader': dict(batch_size=batch_size, num_workers=8),
+        'dataset': dict(_name='MelDataset', samplerate=24000, feature=['mel', 'wav'], dimension=[in_dim, 1],
+                        frameshift=[300, 1], padding_value=[-4, 0], pre_load=False, segment_length=-1),
+        'lr_scheduler': dict(_name='ExponentialDecayLRScheduler', warmup_steps=200000, decay_scale=200000,
+                             decay_learning_rate=0.5, final_learning_rate=1e-5),
+        'distributed': dict(dist_backend='nccl', dist_url='tcp://localhost:54321'),
+    }

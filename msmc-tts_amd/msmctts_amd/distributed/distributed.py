@@ -1,0 +1,131 @@
+"""Data parallelism over RCCL/xGMI (re-expression of reference msmctts/distributed/distributed.py:21-31,154-204).
+
+The reference broadcasts every ``state_dict`` tensor separately at start-up (636 messages) and, after
+each *whole* backward, flattens all gradients into one buffer, all-reduces it, divides and copies it
+back.  Here, for one process per GPU on a fully connected xGMI node:
+
+* ``init_distributed`` keeps the reference signature; backend "nccl" is RCCL on ROCm.
+* start-up sync is ONE flat broadcast per dtype (params + buffers, VQ codebooks included);
+* gradients are grouped into size-bounded buckets per top-level child (``autoencoder`` /
+  ``discriminator`` never share a bucket, so the D step and the G step each complete their own
+  buckets); a bucket is all-reduced asynchronously on RCCL's stream as soon as its last gradient has
+  been accumulated, i.e. overlapped with the rest of backward; ``GradReducer.finish()`` (called by the
+  trainer after ``backward()``) flushes partially filled buckets, waits, and writes the averaged
+  values back.  Parameters that received no gradient (frozen tables, the vocoder during warm-up, the
+  discriminator during the G step) are simply not communicated -- the reference reduces the stale D
+  gradients on every G backward.
+* VQ codebook statistics are, like the reference, NOT synchronised by default (each rank EMA-updates
+  from its local batch; rank 0's codebook is checkpointed).
+"""
+import torch
+import torch.distributed as dist
+
+DEFAULT_BUCKET_BYTES = 32 * 1024 * 1024
+
+
+def init_distributed(rank, num_gpus, group_name, dist_backend, dist_url):
+    """One process per GPU; same arguments as the reference (group_name is accepted and unused)."""
+    if dist_backend == 'nccl':
+        assert torch.cuda.is_available(), 'Distributed mode requires a GPU.'
+        torch.cuda.set_device(rank % max(1, torch.cuda.device_count()))
+    if not dist.is_initialized():
+        dist.init_process_group(dist_backend, init_method=dist_url, world_size=num_gpus, rank=rank)
+
+
+def broadcast_state(module, src=0):
+    """Coalesced start-up broadcast of every tensor in ``state_dict`` (one message per dtype)."""
+    by_dtype = {}
+    for t in module.state_dict().values():
+        if torch.is_tensor(t):
+            by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    for tensors in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.broadcast(flat, src)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+class _Bucket(object):
+    def __init__(self, params):
+        self.params = params
+        self.ready = []
+        self.pending = set(id(p) for p in params)
+
+
+class GradReducer(object):
+    """Bucketed, backward-overlapped gradient averaging."""
+
+    def __init__(self, module, bucket_bytes=DEFAULT_BUCKET_BYTES, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.buckets = []
+        self._owner = {}
+        self._inflight = []
+        children = list(module.named_children()) or [('', module)]
+        for _, child in children:
+            params = [p for p in child.parameters() if p.requires_grad]
+            cur, size = [], 0
+            for p in reversed(params):               # gradients arrive roughly in reverse registration order
+                cur.append(p)
+                size += p.numel() * p.element_size()
+                if size >= bucket_bytes:
+                    self._add(cur)
+                    cur, size = [], 0
+            if cur:
+                self._add(cur)
+        for b in self.buckets:
+            for p in b.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _add(self, params):
+        b = _Bucket(list(params))
+        self.buckets.append(b)
+        for p in params:
+            self._owner[id(p)] = b
+
+    def _on_grad(self, p):
+        b = self._owner[id(p)]
+        if id(p) in b.pending:
+            b.pending.discard(id(p))
+            b.ready.append(p)
+            if not b.pending:
+                self._launch(b)
+
+    def _launch(self, b):
+        ps = [p for p in b.params if any(p is r for r in b.ready)]   # fixed (registration) order on every rank
+        if ps:
+            flat = torch.cat([p.grad.reshape(-1) for p in ps])
+            work = dist.all_reduce(flat, group=self.group, async_op=True)
+            self._inflight.append((work, flat, ps))
+        b.ready = []
+        b.pending = set(id(p) for p in b.params)
+
+    def finish(self):
+        """Flush partial buckets, wait for the collectives, write back grad / world_size."""
+        for b in self.buckets:
+            if b.ready:
+                self._launch(b)
+        for work, flat, ps in self._inflight:
+            work.wait()
+            flat.div_(self.world)
+            off = 0
+            for p in ps:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n
+        self._inflight = []
+
+
+def apply_gradient_allreduce(module, bucket_bytes=DEFAULT_BUCKET_BYTES):
+    """Reference entry point: sync initial state from rank 0 and arm gradient averaging.
+
+    Returns the same module (no wrapper class, like the reference) with ``module.grad_reducer`` set;
+    trainers call ``module.grad_reducer.finish()`` after each ``backward()``.
+    """
+    with torch.no_grad():
+        broadcast_state(module, 0)
+    module.grad_reducer = GradReducer(module, bucket_bytes)
+    return module

@@ -1,0 +1,94 @@
+"""Loader for ``libmsmc_hip.so`` -- the gfx950 kernels behind the C ABI in ``include/msmc_hip.h``.
+
+The library is built in-tree (``msmc-tts_amd/lib/libmsmc_hip.so``) by ``__graft_entry__.build()``.
+There is deliberately no fallback: a missing library, a failed launch or a host tensor raises.
+``use_library_for_tests`` exists only so that the CPU test-suite can point the *same* Python ops at
+the kernel interpreter build (tests/emu); the product never calls it.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libmsmc_hip.so'))
+
+_lib = None
+_host_pointers_ok = False
+
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+_SIGNATURES = {
+    'msmc_backend': (ctypes.c_char_p, []),
+    'msmc_abi_version': (_i, []),
+    'msmc_vq_prepare': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'msmc_vq_search': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'msmc_vq_ema_workspace': (_sz, [_i, _i, _i, _i]),
+    'msmc_vq_ema_update': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _f, _f, _vp]),
+    'msmc_vq_backward': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+}
+
+
+def exported_symbols():
+    """Names every build of the library must export (checked by the CPU test-suite)."""
+    return sorted(_SIGNATURES)
+
+
+def _bind(handle):
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.restype = res
+        fn.argtypes = args
+    return handle
+
+
+def load(path=None):
+    path = DEFAULT_PATH if path is None else path
+    if not os.path.isfile(path):
+        raise RuntimeError(
+            'msmctts_amd: HIP extension %s not found. Build it with `python -c "import __graft_entry__ as g; '
+            'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.' % path)
+    return _bind(ctypes.CDLL(path))
+
+
+def get():
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def use_library_for_tests(path):
+    """TEST HOOK: bind another build of the C ABI (the CPU kernel interpreter, backend 'emu')."""
+    global _lib, _host_pointers_ok
+    _lib = load(path)
+    _host_pointers_ok = _lib.msmc_backend() == b'emu'
+    return _lib
+
+
+def backend():
+    return get().msmc_backend().decode()
+
+
+def ptr(t, dtype=None):
+    """Raw pointer of a contiguous tensor; refuses host memory unless the interpreter build is bound."""
+    if t is None:
+        return None
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError('expected %s, got %s' % (dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError('msmc HIP ops take contiguous tensors')
+    if not t.is_cuda and not _host_pointers_ok:
+        raise RuntimeError('msmc HIP ops run on the GPU only (got a %s tensor); there is no CPU path' % t.device)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream(t):
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return ctypes.c_void_p(0)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed with code %d' % (what, rc))

@@ -1,0 +1,79 @@
+"""Multi-head EMA vector quantiser ops over the gfx950 kernels (csrc/vq.hip).
+
+Replaces the arithmetic of ``Quantize.forward`` / ``MultiHeadQuantize.forward``
+(reference msmctts/networks/vqgantts/modules.py:24-67, :137-151).
+"""
+import torch
+
+from . import lib
+
+
+def vq_prepare(embed):
+    """embed [H, d, K] -> (embed_t [H, K, d], enorm [H, K])."""
+    H, d, K = embed.shape
+    embed_t = torch.empty((H, K, d), dtype=torch.float32, device=embed.device)
+    enorm = torch.empty((H, K), dtype=torch.float32, device=embed.device)
+    L = lib.get()
+    lib.check(L.msmc_vq_prepare(lib.ptr(embed, torch.float32), lib.ptr(embed_t), lib.ptr(enorm), H, d, K,
+                                lib.stream(embed)), 'msmc_vq_prepare')
+    return embed_t, enorm
+
+
+class _VQSearch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, embed_t, enorm):
+        H, K, d = embed_t.shape
+        D = H * d
+        assert x.shape[-1] == D, (x.shape, embed_t.shape)
+        xc = x.contiguous().float()
+        N = xc.numel() // D
+        quant = torch.empty_like(xc)
+        diff = torch.empty(xc.shape[:-1] + (d,), dtype=torch.float32, device=x.device)
+        ind = torch.empty(xc.shape[:-1] + (H,), dtype=torch.int64, device=x.device)
+        L = lib.get()
+        lib.check(L.msmc_vq_search(lib.ptr(xc), lib.ptr(embed_t, torch.float32), lib.ptr(enorm, torch.float32),
+                                   lib.ptr(quant), lib.ptr(diff), lib.ptr(ind), N, D, H, K, lib.stream(xc)),
+                  'msmc_vq_search')
+        ctx.save_for_backward(xc, quant)
+        ctx.heads = H
+        ctx.mark_non_differentiable(ind)
+        return quant, diff, ind
+
+    @staticmethod
+    def backward(ctx, g_quant, g_diff, _g_ind):
+        xc, quant = ctx.saved_tensors
+        D = xc.shape[-1]
+        N = xc.numel() // D
+        if g_quant is None:
+            g_quant = torch.zeros_like(xc)
+        g_quant = g_quant.contiguous().float()
+        g_diff = None if g_diff is None else g_diff.contiguous().float()
+        gx = torch.empty_like(xc)
+        L = lib.get()
+        lib.check(L.msmc_vq_backward(lib.ptr(g_quant), lib.ptr(g_diff), lib.ptr(xc), lib.ptr(quant), lib.ptr(gx),
+                                     N, D, ctx.heads, lib.stream(xc)), 'msmc_vq_backward')
+        return gx, None, None
+
+
+def vq_search(x, embed_t, enorm):
+    """x [..., D] -> (quant [..., D] straight-through, diff [..., d], ind [..., H] int64)."""
+    return _VQSearch.apply(x, embed_t, enorm)
+
+
+def vq_ema_update(x, ind, length, embed, cluster_size, embed_avg, decay, eps, workspace=None):
+    """In-place EMA update of the packed buffers embed [H,d,K], cluster_size [H,K], embed_avg [H,d,K]
+    from the valid frames of x [B,T,D] / ind [B,T,H] (t < length[b])."""
+    B, T, D = x.shape
+    H, d, K = embed.shape
+    L = lib.get()
+    need = int(L.msmc_vq_ema_workspace(B * T, D, H, K))
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+    xc = x.detach().contiguous().float()
+    length = length.to(device=x.device, dtype=torch.int64).contiguous()
+    lib.check(L.msmc_vq_ema_update(lib.ptr(xc), lib.ptr(ind.contiguous(), torch.int64), lib.ptr(length),
+                                   lib.ptr(embed, torch.float32), lib.ptr(cluster_size, torch.float32),
+                                   lib.ptr(embed_avg, torch.float32), lib.ptr(workspace),
+                                   workspace.numel() * workspace.element_size(), B, T, D, H, K, float(decay),
+                                   float(eps), lib.stream(xc)), 'msmc_vq_ema_update')
+    return workspace

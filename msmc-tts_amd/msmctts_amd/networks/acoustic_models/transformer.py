@@ -1,0 +1,126 @@
+"""Feed-forward Transformer (FFT) blocks used by the multi-stage encoder and the frame decoder
+(drop-in for reference msmctts/networks/acoustic_models/transformer.py:71-424).
+
+SURVEY.md 8a/E1: this stack stays on stock PyTorch-ROCm operators in round 1 (hipBLASLt GEMMs,
+MIOpen k=3 convolutions, fused SDPA-free softmax) -- north_star's kernel list does not name
+attention; a fused MFMA version is the first "next" row.  Module / parameter names
+and numerics follow the reference: fused QKV projection, post-LayerNorm, key-padding mask with
+-inf, conv feed-forward, output zeroed on padding after both sub-layers.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def get_sinusoid_encoding_table(n_position, d_hid, padding_idx=None):
+    """(n_position, d_hid) float32 table, row ``padding_idx`` zeroed (transformer.py:388-407)."""
+    pos = np.arange(n_position, dtype=np.float64)[:, None]
+    idx = np.arange(d_hid)[None, :]
+    angle = pos / np.power(10000, 2 * (idx // 2) / d_hid)
+    table = np.empty_like(angle)
+    table[:, 0::2] = np.sin(angle[:, 0::2])
+    table[:, 1::2] = np.cos(angle[:, 1::2])
+    if padding_idx is not None:
+        table[padding_idx] = 0.0
+    return torch.FloatTensor(table)
+
+
+def get_attn_key_pad_mask(seq_k, seq_q):
+    return seq_k.eq(0).unsqueeze(1).expand(-1, seq_q.size(1), -1)
+
+
+def get_non_pad_mask(seq):
+    assert seq.dim() == 2
+    return seq.ne(0).unsqueeze(-1)
+
+
+class ScaledDotProductAttention(nn.Module):
+    def __init__(self, temperature, attn_dropout=0.1, name=None):
+        super().__init__()
+        self.temperature, self.name = temperature, name
+        if attn_dropout > 0:
+            self.dropout = nn.Dropout(attn_dropout)
+
+    def forward(self, q, k, v, mask=None, acts=None):
+        attn = torch.bmm(q, k.transpose(1, 2)) / self.temperature
+        if mask is not None:
+            attn = attn.masked_fill(mask, -math.inf)
+        attn = torch.softmax(attn, dim=2)
+        if hasattr(self, 'dropout'):
+            attn = self.dropout(attn)
+        return torch.bmm(attn, v), attn
+
+
+class MultiHeadAttention(nn.Module):
+    def __init__(self, n_head, d_model, d_k, d_v, dropout, name, attn_dropout=0.1, fused_layernorm=False):
+        super().__init__()
+        self.n_head, self.d_k, self.d_v, self.name = n_head, d_k, d_v, name
+        self.linear = nn.Linear(d_model, n_head * (2 * d_k + d_v))
+        nn.init.xavier_normal_(self.linear.weight)
+        self.attention = ScaledDotProductAttention(float(np.power(d_k, 0.5)), attn_dropout, name + '.scaled_dot')
+        self.layer_norm = nn.LayerNorm(d_model)      # apex FusedLayerNorm is disabled in every shipped config
+        self.fc = nn.Linear(n_head * d_v, d_model)
+        nn.init.xavier_normal_(self.fc.weight)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x, mask=None, acts=None):
+        bs, T, _ = x.shape
+        H, dk, dv = self.n_head, self.d_k, self.d_v
+        qkv = self.linear(x).view(bs, T, H, 2 * dk + dv).permute(2, 0, 1, 3).reshape(H * bs, T, 2 * dk + dv)
+        q, k, v = qkv[..., :dk], qkv[..., dk:2 * dk], qkv[..., 2 * dk:]
+        out, attn = self.attention(q, k, v, mask=None if mask is None else mask.repeat(H, 1, 1))
+        out = out.view(H, bs, T, dv).permute(1, 2, 0, 3).reshape(bs, T, H * dv)
+        out = self.dropout(self.fc(out)) + x
+        return self.layer_norm(out), attn
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, d_in, d_hid, fft_conv1d_kernel, fft_conv1d_padding, dropout, name, fused_layernorm=False):
+        super().__init__()
+        self.name = name
+        self.w_1 = nn.Conv1d(d_in, d_hid, kernel_size=fft_conv1d_kernel, padding=fft_conv1d_padding)
+        self.w_2 = nn.Conv1d(d_hid, d_in, kernel_size=fft_conv1d_kernel, padding=fft_conv1d_padding)
+        self.layer_norm = nn.LayerNorm(d_in)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x, acts=None):
+        h = self.w_2(F.relu(self.w_1(x.transpose(1, 2)))).transpose(1, 2)
+        return self.layer_norm(self.dropout(h) + x)
+
+
+class FFTBlock(nn.Module):
+    def __init__(self, d_model, d_inner, n_head, d_k, d_v, fft_conv1d_kernel, fft_conv1d_padding, dropout, name,
+                 attn_dropout=0.1, fused_layernorm=False):
+        super().__init__()
+        self.slf_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout, name + '.slf_attn', attn_dropout)
+        self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, fft_conv1d_kernel, fft_conv1d_padding, dropout,
+                                               name + '.pos_ffn')
+
+    def forward(self, input, non_pad_mask=None, slf_attn_mask=None, acts=None):
+        keep = non_pad_mask.to(input.dtype)
+        out, attn = self.slf_attn(input, mask=slf_attn_mask)
+        out = self.pos_ffn(out * keep) * keep
+        return out, attn
+
+
+class FFTBlocks(nn.Module):
+    def __init__(self, max_seq_len, n_layers, n_head, d_k, d_v, d_model, d_inner, fft_conv1d_kernel,
+                 fft_conv1d_padding, dropout, name, attn_dropout=0.1, fused_layernorm=False):
+        super().__init__()
+        self.name, self.d_model, self.max_seq_len = name, d_model, max_seq_len
+        self.position = nn.Embedding.from_pretrained(
+            get_sinusoid_encoding_table(max_seq_len + 1, d_model, padding_idx=0), freeze=True)
+        self.layer_stack = nn.ModuleList([
+            FFTBlock(d_model, d_inner, n_head, d_k, d_v, fft_conv1d_kernel, fft_conv1d_padding, dropout,
+                     '%s.layer_stack.%d' % (name, i), attn_dropout, fused_layernorm) for i in range(n_layers)])
+
+    def forward(self, seq, pos, return_attns=False, acts=None):
+        mask = get_attn_key_pad_mask(pos, pos)
+        keep = get_non_pad_mask(pos)
+        out = seq + self.position(pos)
+        for layer in self.layer_stack:
+            out, _ = layer(out, non_pad_mask=keep, slf_attn_mask=mask)
+        return out, keep

@@ -1,0 +1,127 @@
+"""UnivNet-style discriminator: multi-resolution spectrogram (MRD) + multi-period (MPD)
+(drop-in for reference msmctts/networks/hifigan/discriminator.py:15-190).
+
+Quirks reproduced on purpose: LeakyReLU slope is 0.2 here; the MRD feature
+maps the trainer sees are *post*-activation (the reference's in-place LeakyReLU aliases the stored
+tensors, discriminator.py:28,71-76) while MPD's are pre-activation (:146-149).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ...utils.audio import TorchSTFT
+from ..layers import WNConv2d
+from .common import get_padding
+
+LRELU_SLOPE = 0.2
+
+
+class _Stage(nn.Module):
+    """Keeps the reference's nn.Sequential child index of the conv ('1' for the first stage, '2' after)."""
+
+    def __init__(self, conv, first):
+        super().__init__()
+        self.key = '1' if first else '2'
+        self.add_module(self.key, conv)
+
+    def forward(self, x):
+        return self._modules[self.key](x)
+
+
+class DiscriminatorR(nn.Module):
+    def __init__(self, in_channels, hidden_channels=512):
+        super().__init__()
+        h = hidden_channels
+        chans = [in_channels, h // 32, h // 16, h // 8, h // 4, h // 2, h, 1]
+        strides = [1, 2, 1, 2, 1, 2, 1]
+        self.discriminator = nn.ModuleList([
+            _Stage(WNConv2d(chans[i], chans[i + 1], (3, 3), (strides[i], strides[i]), reflect_pad=1), i == 0)
+            for i in range(7)])
+
+    def forward(self, x):
+        fmaps = []
+        for i, stage in enumerate(self.discriminator):
+            if i > 0:
+                x = F.leaky_relu(x, LRELU_SLOPE)
+                fmaps.append(x)                      # aliased post-activation map, see module docstring
+            x = stage(x)
+        return x, fmaps
+
+
+class MultiResolutionDiscriminator(nn.Module):
+    def __init__(self, hop_lengths=[15, 30, 50, 120, 240, 480], hidden_channels=[128, 128, 256, 256, 512, 512],
+                 domain='double', mel_scale=True, sample_rate=24000):
+        super().__init__()
+        self.stfts = nn.ModuleList([
+            TorchSTFT(fft_size=h * 4, hop_size=h, win_size=h * 4, normalized=True, domain=domain,
+                      mel_scale=mel_scale, sample_rate=sample_rate) for h in hop_lengths])
+        self.domain = domain
+        self.discriminators = nn.ModuleList([DiscriminatorR(2 if domain == 'double' else 1, c)
+                                             for _, c in zip(hop_lengths, hidden_channels)])
+
+    def forward(self, x):
+        scores, feats = [], []
+        for stft, disc in zip(self.stfts, self.discriminators):
+            mag, _ = stft.transform(x.squeeze(1) if x.dim() == 3 else x)
+            mag = torch.stack(torch.chunk(mag, 2, dim=1), dim=1) if self.domain == 'double' else mag.unsqueeze(1)
+            s, f = disc(mag)
+            scores.append(s)
+            feats.append(f)
+        return scores, feats
+
+
+class DiscriminatorP(nn.Module):
+    def __init__(self, period, ch=32, max_ch=1024, kernel_size=5, stride=3, use_spectral_norm=False):
+        super().__init__()
+        assert not use_spectral_norm
+        self.period = period
+        c1, c2, c3, c4 = ch, ch * 4, min(max_ch, ch * 16), min(max_ch, ch * 32)
+        pad = (get_padding(kernel_size, 1), 0)
+        self.convs = nn.ModuleList([
+            WNConv2d(1, c1, (kernel_size, 1), (stride, 1), pad), WNConv2d(c1, c2, (kernel_size, 1), (stride, 1), pad),
+            WNConv2d(c2, c3, (kernel_size, 1), (stride, 1), pad), WNConv2d(c3, c4, (kernel_size, 1), (stride, 1), pad),
+            WNConv2d(c4, c4, (5, 1), (1, 1), (2, 0))])
+        self.conv_post = WNConv2d(c4, 1, (3, 1), (1, 1), (1, 0))
+
+    def forward(self, x):
+        fmap = []
+        b, c, t = x.shape
+        if t % self.period != 0:
+            n_pad = self.period - (t % self.period)
+            x = F.pad(x, (0, n_pad), 'reflect')
+            t = t + n_pad
+        x = x.view(b, c, t // self.period, self.period)
+        for conv in self.convs:
+            x = conv(x)
+            fmap.append(x)
+            x = F.leaky_relu(x, LRELU_SLOPE)
+        x = self.conv_post(x)
+        return torch.flatten(x, 1, -1), fmap
+
+
+class MultiPeriodDiscriminator(nn.Module):
+    def __init__(self, periods=[2, 3, 5, 7, 11], channels=32, max_channels=1024):
+        super().__init__()
+        self.discriminators = nn.ModuleList([DiscriminatorP(p, channels, max_channels) for p in periods])
+
+    def forward(self, y):
+        outs, fmaps = [], []
+        for d in self.discriminators:
+            o, f = d(y)
+            outs.append(o)
+            fmaps.append(f)
+        return outs, fmaps
+
+
+class Discriminator(nn.Module):
+    def __init__(self, mrd_config, mpd_config):
+        super().__init__()
+        self.mrd = MultiResolutionDiscriminator(**mrd_config)
+        self.mpd = MultiPeriodDiscriminator(**mpd_config)
+
+    def forward(self, y):
+        if y.dim() == 2:
+            y = y.unsqueeze(1)
+        s1, f1 = self.mrd(y)
+        s2, f2 = self.mpd(y)
+        return s1 + s2, f1 + f2

@@ -1,0 +1,125 @@
+"""EMA vector quantisers and the WaveNet residual stack (drop-in for reference
+msmctts/networks/vqgantts/modules.py).
+
+``Quantize`` / ``MultiHeadQuantize`` keep the reference's constructor arguments, buffer names and
+layouts (``embed`` (sub_dim, K), ``cluster_size`` (K,), ``embed_avg`` (sub_dim, K)) and call
+signatures, but one forward is three HIP launches for *all* heads (csrc/vq.hip): codebook
+transpose + norms, fused search/gather/straight-through/squared-error, and -- in training with
+``update`` -- the deterministic EMA update.  The per-head buffers are views into head-packed
+tensors so the kernels see [H][d][K] while ``state_dict`` keeps the reference keys.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ...hip import vq as hipvq
+from ..layers import WNConv1d
+
+
+class Quantize(nn.Module):
+    """Single-codebook EMA quantiser (reference modules.py:10-116)."""
+
+    def __init__(self, embed_dim, n_embed, decay=0.99, eps=1e-5):
+        super().__init__()
+        self.dim, self.n_embed, self.decay, self.eps = embed_dim, n_embed, decay, eps
+        embed = torch.randn(embed_dim, n_embed)
+        self.register_buffer('embed', embed)
+        self.register_buffer('cluster_size', torch.zeros(n_embed))
+        self.register_buffer('embed_avg', embed.clone())
+        self._ws = None
+
+    def _packed(self):
+        return self.embed.unsqueeze(0), self.cluster_size.unsqueeze(0), self.embed_avg.unsqueeze(0)
+
+    def forward(self, input, input_length=None, update=True, sort=False):
+        if sort:
+            raise NotImplementedError('sort=True (full ranking) is never used in training (modules.py:62-65)')
+        embed, cs, ea = self._packed()
+        embed_t, enorm = hipvq.vq_prepare(embed)
+        quant, diff, ind = hipvq.vq_search(input, embed_t, enorm)
+        if self.training and update:
+            x3 = input.detach().reshape(input.shape[0], -1, input.shape[-1])
+            self._ws = hipvq.vq_ema_update(x3, ind.reshape(x3.shape[0], x3.shape[1], -1), input_length, embed, cs, ea,
+                                           self.decay, self.eps, self._ws)
+        return quant, diff, ind.squeeze(-1)
+
+    def embed_code(self, embed_id):
+        return F.embedding(embed_id, self.embed.transpose(0, 1))
+
+
+class MultiHeadQuantize(nn.Module):
+    """H independent codebooks over contiguous feature chunks (reference modules.py:119-169)."""
+
+    def __init__(self, embed_dim, n_embed, n_head, decay=0.99, eps=1e-5):
+        super().__init__()
+        assert embed_dim % n_head == 0
+        self.dim, self.n_embed, self.n_head, self.decay, self.eps = embed_dim, n_embed, n_head, decay, eps
+        self.quantizers = nn.ModuleList([Quantize(embed_dim // n_head, n_embed, decay, eps) for _ in range(n_head)])
+        self._pack = None
+        self._ws = None
+
+    def _packed(self):
+        """Head-packed buffers; (re)built whenever the per-head buffers stopped being views of them
+        (construction, .to()/.cuda(), a non-in-place load)."""
+        qs = self.quantizers
+        p = self._pack
+        ok = p is not None and all(
+            q.embed.data_ptr() == p[0][h].data_ptr() and q.cluster_size.data_ptr() == p[1][h].data_ptr()
+            and q.embed_avg.data_ptr() == p[2][h].data_ptr() for h, q in enumerate(qs))
+        if not ok:
+            p = (torch.stack([q.embed for q in qs]).contiguous(), torch.stack([q.cluster_size for q in qs]).contiguous(),
+                 torch.stack([q.embed_avg for q in qs]).contiguous())
+            for h, q in enumerate(qs):
+                q._buffers['embed'], q._buffers['cluster_size'], q._buffers['embed_avg'] = p[0][h], p[1][h], p[2][h]
+            self._pack = p
+        return p
+
+    def forward(self, input, input_length=None, update=True, sort=False):
+        if sort:
+            raise NotImplementedError('sort=True (full ranking) is never used in training (modules.py:62-65)')
+        embed, cs, ea = self._packed()
+        embed_t, enorm = hipvq.vq_prepare(embed)
+        quant, diff, ind = hipvq.vq_search(input, embed_t, enorm)
+        if self.training and update:
+            x3 = input.detach().reshape(input.shape[0], -1, input.shape[-1])
+            self._ws = hipvq.vq_ema_update(x3, ind.reshape(x3.shape[0], x3.shape[1], -1), input_length, embed, cs, ea,
+                                           self.decay, self.eps, self._ws)
+        return quant, diff, ind
+
+
+class ResStack(nn.Module):
+    """Un-conditioned WaveNet stack used by PriorPredictor (reference modules.py:182-259).
+
+    The reference materialises an all-zero conditioning tensor per layer (modules.py:236); adding
+    zeros is the identity, so it is skipped.  ``p_dropout`` stays hard-wired at 0.1 like the reference.
+    """
+
+    def __init__(self, hidden_channels, kernel_size, dilation_rate, n_layers, gin_channels=0, p_dropout=0.1):
+        super().__init__()
+        assert kernel_size % 2 == 1
+        assert gin_channels == 0, 'conditioning is never used on the MSMC-VQ-GAN path'
+        self.hidden_channels, self.n_layers = hidden_channels, n_layers
+        self.in_layers = nn.ModuleList()
+        self.res_skip_layers = nn.ModuleList()
+        self.drop = nn.Dropout(p_dropout)
+        for i in range(n_layers):
+            dil = dilation_rate ** i
+            self.in_layers.append(WNConv1d(hidden_channels, 2 * hidden_channels, kernel_size, dilation=dil,
+                                           padding=int((kernel_size * dil - dil) / 2)))
+            out_ch = 2 * hidden_channels if i < n_layers - 1 else hidden_channels
+            self.res_skip_layers.append(WNConv1d(hidden_channels, out_ch, 1))
+
+    def forward(self, x, x_mask, g=None, **kwargs):
+        C = self.hidden_channels
+        output = None
+        for i in range(self.n_layers):
+            x_in = self.in_layers[i](x)
+            acts = self.drop(torch.tanh(x_in[:, :C]) * torch.sigmoid(x_in[:, C:]))
+            rs = self.res_skip_layers[i](acts)
+            if i < self.n_layers - 1:
+                x = (x + rs[:, :C]) * x_mask
+                skip = rs[:, C:]
+            else:
+                skip = rs
+            output = skip if output is None else output + skip
+        return output * x_mask

@@ -1,0 +1,224 @@
+"""MSMC-VQ-GAN autoencoder (drop-in for reference msmctts/networks/vqgantts/msmc_vqgan.py:14-410).
+
+Same classes, constructor kwargs (the YAML surface), ``state_dict`` keys and output dictionary.
+The quantiser calls the gfx950 VQ kernels; the vocoder is ``HifiGANGenerator``.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ...utils.utils import get_mask_from_lengths
+from ..acoustic_models.transformer import FFTBlocks
+from ..hifigan.generator import Generator as HifiGANGenerator
+from .modules import MultiHeadQuantize, Quantize, ResStack
+
+
+def _positions(lengths, device):
+    """1..len per utterance, 0 on padding (msmc_vqgan.py:56-58)."""
+    width = int(lengths.max())
+    pos = torch.arange(1, width + 1, device=device).unsqueeze(0).repeat(lengths.shape[0], 1)
+    return pos.masked_fill(get_mask_from_lengths(lengths.to(device), width), 0)
+
+
+class MultiStageEncoder(nn.Module):
+    def __init__(self, in_channels, downsample_scales=[1], max_seq_len=2400, n_layers=4, n_head=2, d_k=64, d_v=64,
+                 d_inner=1024, fft_conv1d_kernel=3, fft_conv1d_padding=1, dropout=0.2, attn_dropout=0.1,
+                 fused_layernorm=False):
+        super().__init__()
+        self.downsample_scales = list(downsample_scales)
+        self.encoders = nn.ModuleList([
+            FFTBlocks(max_seq_len=max_seq_len, n_layers=n_layers, n_head=n_head, d_k=d_k, d_v=d_v,
+                      d_model=in_channels, d_inner=d_inner, fft_conv1d_kernel=fft_conv1d_kernel,
+                      fft_conv1d_padding=fft_conv1d_padding, dropout=dropout, attn_dropout=attn_dropout,
+                      fused_layernorm=fused_layernorm, name='encoder_%d' % i)
+            for i in range(len(self.downsample_scales))])
+
+    def forward(self, input, input_length):
+        outputs = []
+        feat, flen = input, input_length
+        for enc, scale in zip(self.encoders, self.downsample_scales):
+            if scale > 1:                          # stages are chained: pool the previous stage's output
+                feat = F.avg_pool1d(feat.transpose(1, 2), kernel_size=scale, stride=scale,
+                                    ceil_mode=True).transpose(1, 2)
+                flen = torch.ceil(flen / scale).int()
+            feat, _ = enc(feat, _positions(flen, feat.device))
+            outputs.append((feat, flen))
+        return outputs
+
+
+class PriorPredictor(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=5, dilation_rate=1, n_layers=4):
+        super().__init__()
+        self.enc = ResStack(in_channels, kernel_size, dilation_rate, n_layers)
+        self.proj = nn.Conv1d(in_channels, out_channels, 1)
+
+    def forward(self, x, x_lengths):
+        x = x.transpose(1, 2)
+        x_mask = (~get_mask_from_lengths(x_lengths.to(x.device), x.shape[2])).unsqueeze(1).to(x.dtype)
+        h = self.enc(x, x_mask)
+        o = self.proj(h) * x_mask
+        return h.transpose(1, 2), o.transpose(1, 2)
+
+
+class MultiStageQuantizer(nn.Module):
+    def __init__(self, n_model_size, upsample_scales, embedding_sizes=512, embedding_dims=256, n_heads=4,
+                 prior_config={}, norm=False, upsampling='repeat', dropout=0.1, update_codebook=True):
+        super().__init__()
+        self.upsample_scales, self.upsampling = list(upsample_scales), upsampling
+        self.dropout, self.update_codebook = dropout, update_codebook
+        self.quantizer, self.predictor = nn.ModuleList(), nn.ModuleList()
+        self.preprocessor, self.postprocessor = nn.ModuleList(), nn.ModuleList()
+        if upsampling != 'repeat':
+            self.transposed_conv = nn.ModuleList()
+        for i, u in enumerate(self.upsample_scales):
+            width = n_model_size * (1 if i == 0 else 2)
+            self.predictor.append(PriorPredictor(n_model_size, embedding_dims, **prior_config))
+            pre = [nn.Conv1d(width, embedding_dims, 1), nn.Tanh(), nn.Conv1d(embedding_dims, embedding_dims, 1)]
+            if norm:
+                pre.append(nn.BatchNorm1d(embedding_dims, eps=1e-05, affine=False))
+            self.preprocessor.append(nn.Sequential(*pre))
+            self.quantizer.append(Quantize(embedding_dims, embedding_sizes) if n_heads == 1 else
+                                  MultiHeadQuantize(embedding_dims, embedding_sizes, n_heads))
+            self.postprocessor.append(nn.Sequential(
+                nn.Linear(embedding_dims * (1 if i == 0 else 2), embedding_dims), nn.Tanh(),
+                nn.Linear(embedding_dims, n_model_size)))
+            if upsampling != 'repeat':
+                k = u * 2 if u % 2 == 0 else u * 2 + 1
+                self.transposed_conv.append(nn.ConvTranspose1d(n_model_size, n_model_size, k, u, padding=(k - u) // 2))
+
+    def forward(self, encoder_states, from_encoder=True):
+        states = list(encoder_states)
+        if from_encoder:
+            states = states[::-1]                   # coarse -> fine
+        residual = None
+        quants, diffs, inds, preds = [], [], [], []
+        for i, (emb, length) in enumerate(states):
+            if residual is None:
+                pred_q = None
+            else:
+                residual = residual[:, :int(length.max())]
+                hid, pred_q = self.predictor[i](residual, length)
+                residual = residual + F.dropout(hid, p=self.dropout, training=self.training)
+            if emb is None:
+                q_in = pred_q
+            elif from_encoder:
+                pre_in = emb if residual is None else torch.cat((emb, residual), dim=-1)
+                q_in = self.preprocessor[i](pre_in.transpose(1, 2)).transpose(1, 2)
+            else:
+                q_in = emb
+            quant, dff, ind = self.quantizer[i](q_in, length, update=self.update_codebook)
+            post_in = quant if residual is None else torch.cat((residual, quant), dim=-1)
+            post = F.dropout(self.postprocessor[i](post_in), p=self.dropout, training=self.training)
+            residual = post if residual is None else residual + post
+            quants.append(quant)
+            diffs.append(dff)
+            inds.append(ind)
+            preds.append({'predictor_outputs': pred_q, 'target_outputs': quant, 'target_indices': ind,
+                          'target_lengths': length})
+            if self.upsampling == 'mapping':
+                residual = self.transposed_conv[i](residual.transpose(1, 2)).transpose(1, 2)
+            elif self.upsampling == 'residual':
+                up = self.transposed_conv[i](residual.transpose(1, 2)).transpose(1, 2)
+                residual = torch.repeat_interleave(residual, self.upsample_scales[i], dim=1) + \
+                    F.dropout(up, p=self.dropout, training=self.training)
+            else:
+                residual = torch.repeat_interleave(residual, self.upsample_scales[i], dim=1)
+        out = {'residual_output': residual, 'quantizer_outputs': tuple(quants), 'quantizer_diffs': tuple(diffs),
+               'quantizer_indices': tuple(inds), 'quantizer_lengths': [s[1] for s in states],
+               'predictor_diffs': None}
+        if self.training:
+            out['predictor_diffs'] = self.compute_embedding_loss(preds, methods=['mse'], loss_weights=[1.0])
+        return out
+
+    def compute_embedding_loss(self, pred_states, methods=['mse'], loss_weights=[1.0]):
+        losses = {'total_loss': 0}
+        for i, st in enumerate(pred_states):
+            p = st['predictor_outputs']
+            if p is None:
+                continue
+            weights = loss_weights[i] if isinstance(loss_weights[0], (list, tuple)) else loss_weights
+            for method, weight in zip(methods, weights):
+                if method == 'mse':
+                    loss = F.mse_loss(p, st['target_outputs'].detach(), reduction='none').mean(-1)
+                elif method == 'softmax':
+                    B, T, D = p.shape
+                    loss = F.cross_entropy(p.view(-1, D), st['target_indices'].detach().view(-1),
+                                           reduction='none').view(B, T)
+                else:
+                    raise NotImplementedError('%s loss belongs to predictor training (SURVEY.md 8f)' % method)
+                lengths = st['target_lengths']
+                loss = loss.masked_fill(get_mask_from_lengths(lengths.to(loss.device), loss.shape[1]), 0)
+                loss = loss.sum() / lengths.sum()
+                losses['embed_loss_%s_%d' % (method, i)] = loss
+                losses['total_loss'] = losses['total_loss'] + loss * weight
+        return losses
+
+
+class MSMCVQGAN(nn.Module):
+    def __init__(self, in_dim, n_model_size, encoder_config=None, quantizer_config=None, frame_decoder_config=None,
+                 decoder_config=None, pred_mel=False):
+        super().__init__()
+        self.in_linear = nn.Linear(in_dim, n_model_size)
+        self.encoder = MultiStageEncoder(n_model_size, **encoder_config)
+        self.quantizer = MultiStageQuantizer(n_model_size, list(encoder_config['downsample_scales'])[::-1],
+                                             **quantizer_config)
+        decoder_config = dict(decoder_config)
+        decoder_config['num_mels'] = n_model_size
+        self.decoder = HifiGANGenerator(**decoder_config)
+        if frame_decoder_config is not None:
+            self.frame_decoder = FFTBlocks(d_model=n_model_size, name='frame_decoder', **frame_decoder_config)
+        if pred_mel:
+            self.mel_predictor = nn.Linear(n_model_size, in_dim)
+
+    def _decode_frames(self, x, lengths):
+        if hasattr(self, 'frame_decoder'):
+            x, _ = self.frame_decoder(x, _positions(lengths, x.device))
+        return x
+
+    def forward(self, mel, mel_length, warmup=False, window=None):
+        enc = self.encoder(self.in_linear(mel), mel_length)
+        qs = self.quantizer(enc)
+        feats, lens = zip(*enc)
+        out = {'encoder_outputs': feats[::-1], 'encoder_lengths': lens[::-1],
+               'encoder_indices': qs['quantizer_indices'], 'encoder_diffs': qs['quantizer_diffs'],
+               'decoder_diffs': qs['predictor_diffs']}
+        dec_in = self._decode_frames(qs['residual_output'], mel_length)
+        if hasattr(self, 'mel_predictor'):
+            out['mel_outputs'] = self.mel_predictor(dec_in)
+        if not warmup:
+            if window is not None:
+                assert len(window) == dec_in.shape[0]
+                dec_in = torch.stack([dec_in[i, s:e] for i, (s, e) in enumerate(window)], dim=0)
+            out['decoder_outputs'] = self.decoder(dec_in.transpose(1, 2)).transpose(1, 2)
+        return out
+
+    def analysis(self, mel, mel_length):
+        enc = self.encoder(self.in_linear(mel), mel_length)
+        qs = self.quantizer(enc)
+        if self.training:
+            feats, lens = zip(*enc)
+            return {'encoder_outputs': feats[::-1], 'encoder_lengths': lens[::-1],
+                    'encoder_indices': qs['quantizer_indices'], 'encoder_diffs': qs['quantizer_diffs'],
+                    'decoder_diffs': qs['predictor_diffs'], 'quantizer_states': qs}
+        return qs
+
+    def synthesis(self, quantizer_outputs, quantizer_lengths):
+        qs = quantizer_outputs
+        if not isinstance(quantizer_outputs, dict):
+            qs = self.quantizer(zip(quantizer_outputs, quantizer_lengths), from_encoder=False)
+        dec_in = self._decode_frames(qs['residual_output'], quantizer_lengths[-1])
+        wav = self.decoder(dec_in.transpose(1, 2)).transpose(1, 2)
+        if self.training:
+            out = {'decoder_outputs': wav}
+            if hasattr(self, 'mel_predictor'):
+                out['mel_outputs'] = self.mel_predictor(dec_in)
+            return out
+        return wav
+
+    def compute_embedding_loss(self, quantizer_outputs, quantizer_lengths, quantizer_states, methods=['mse'],
+                               loss_weights=[1.0]):
+        states = [{'predictor_outputs': quantizer_outputs[i],
+                   'target_outputs': quantizer_states['quantizer_outputs'][i],
+                   'target_indices': quantizer_states['quantizer_indices'][i],
+                   'target_lengths': quantizer_lengths[i]} for i in range(len(quantizer_outputs))]
+        return self.quantizer.compute_embedding_loss(states, methods, loss_weights)

@@ -1,0 +1,97 @@
+"""Spectral feature losses (drop-in for reference msmctts/trainers/criterions/stft_loss.py).
+
+``MelLoss`` (:55-114) and ``MultiResolutionSTFTLoss`` (:117-173).  The reference rebuilds the librosa
+mel basis and re-uploads it on every call because its cache test never hits (:84-87), and it
+host-syncs on ``torch.min/max`` (:79-82); here the Slaney basis (same values: librosa.filters.mel
+defaults, restated) and the window are built once per device and nothing syncs.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _hz_from_slaney_mel(m):
+    f_sp, brk = 200.0 / 3, 1000.0
+    brk_mel, step = brk / f_sp, np.log(6.4) / 27.0
+    return np.where(m >= brk_mel, brk * np.exp(step * (m - brk_mel)), f_sp * m)
+
+
+def _slaney_mel_from_hz(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp, brk = 200.0 / 3, 1000.0
+    brk_mel, step = brk / f_sp, np.log(6.4) / 27.0
+    return np.where(f >= brk, brk_mel + np.log(np.maximum(f, 1e-10) / brk) / step, f / f_sp)
+
+
+def mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
+    """float32 (n_mels, 1 + n_fft//2): Slaney-scale, area-normalised triangles (librosa default)."""
+    bins = np.linspace(0.0, sr / 2.0, 1 + n_fft // 2)
+    edges = _hz_from_slaney_mel(np.linspace(_slaney_mel_from_hz(fmin), _slaney_mel_from_hz(fmax), n_mels + 2))
+    width = np.diff(edges)
+    ramps = edges[:, None] - bins[None, :]
+    lower = -ramps[:-2] / width[:-1, None]
+    upper = ramps[2:] / width[1:, None]
+    fb = np.maximum(0.0, np.minimum(lower, upper))
+    fb *= (2.0 / (edges[2:] - edges[:-2]))[:, None]
+    return fb.astype(np.float32)
+
+
+class MelLoss(nn.Module):
+    def __init__(self, fft_size, hop_size, win_size, sample_rate, num_mels):
+        super().__init__()
+        self.sample_rate, self.fft_size, self.hop_size = sample_rate, fft_size, hop_size
+        self.win_size, self.num_mels = win_size, num_mels
+        self.fmin, self.fmax = 0, sample_rate // 2
+        self._basis = torch.from_numpy(mel_filterbank(sample_rate, fft_size, num_mels, self.fmin, self.fmax))
+        self._cache = {}
+
+    def _consts(self, like):
+        key = (str(like.device), like.dtype)
+        if key not in self._cache:
+            self._cache[key] = (self._basis.to(like), torch.hann_window(self.win_size, dtype=like.dtype,
+                                                                        device=like.device))
+        return self._cache[key]
+
+    def mel_spectrogram(self, y, center=False):
+        basis, window = self._consts(y)
+        pad = int((self.fft_size - self.hop_size) / 2)
+        y = F.pad(y.unsqueeze(1), (pad, pad), mode='reflect').squeeze(1)
+        spec = torch.stft(y, self.fft_size, hop_length=self.hop_size, win_length=self.win_size, window=window,
+                          center=center, pad_mode='reflect', normalized=False, onesided=True, return_complex=True)
+        spec = torch.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-9)
+        return torch.log(torch.clamp(torch.matmul(basis, spec), min=1e-5))
+
+    def forward(self, predicts, targets):
+        with torch.autocast(device_type=predicts.device.type, enabled=False):
+            return F.l1_loss(self.mel_spectrogram(predicts.float()), self.mel_spectrogram(targets.float()))
+
+
+class STFTLoss(nn.Module):
+    def __init__(self, fft_size, hop_size, win_size, mel_scale=False, sample_rate=24000):
+        super().__init__()
+        assert not mel_scale, 'mel-scaled MR-STFT is not used by any shipped config'
+        self.fft_size, self.hop_size, self.win_size = fft_size, hop_size, win_size
+
+    def _mag(self, x):
+        win = torch.hann_window(self.win_size, dtype=x.dtype, device=x.device)
+        s = torch.stft(x, self.fft_size, self.hop_size, self.win_size, win, return_complex=True)
+        return torch.sqrt(torch.clamp(s.real ** 2 + s.imag ** 2, min=1e-7)).transpose(2, 1)
+
+    def forward(self, predicts, targets):
+        p, t = self._mag(predicts), self._mag(targets)
+        sc = torch.norm(t - p, p='fro') / torch.norm(t, p='fro')
+        mag = F.l1_loss(torch.log(torch.clamp(p, min=1e-5, max=10)), torch.log(torch.clamp(t, min=1e-5, max=10)))
+        return sc, mag
+
+
+class MultiResolutionSTFTLoss(nn.Module):
+    def __init__(self, fft_sizes=[1024, 2048, 512], win_sizes=[600, 1200, 300], hop_sizes=[120, 240, 60],
+                 mel_scale=False, sample_rate=24000):
+        super().__init__()
+        self.loss_layers = nn.ModuleList([STFTLoss(n, h, w, mel_scale, sample_rate)
+                                          for n, w, h in zip(fft_sizes, win_sizes, hop_sizes)])
+
+    def forward(self, fake_signals, true_signals):
+        sc, mg = zip(*[layer(fake_signals, true_signals) for layer in self.loss_layers])
+        return {'sc_loss': sum(sc) / len(sc), 'mag_loss': sum(mg) / len(mg)}

@@ -1,0 +1,175 @@
+"""Parity checks shared by the CPU (kernel interpreter) and GPU (real gfx950 library) test modules.
+
+Every check drives the PRODUCT path (msmctts_amd modules -> ctypes -> C ABI) and compares it with
+the golden fixtures generated from the reference and/or with the oracle on the same seeded inputs.
+Tolerances: fp32 outputs 1e-3 abs (north_star), VQ indices bit-exact, post-step VQ buffers 1e-5.
+"""
+import copy
+import random
+
+import numpy as np
+import torch
+
+from _util import SMALL_TRAINER, fmap_digest, json_field, load_npz, small_task_cfg, t
+
+TOL = 1e-3
+
+
+def close(a, b, tol=TOL, rel=0.0, what=''):
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().double().cpu().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.abs(a - b)
+    assert (err <= tol + rel * np.abs(b)).all(), '%s: max err %.3e (tol %.1e rel %.1e)' % (what, err.max(), tol, rel)
+
+
+def small_config():
+    from msmctts_amd.utils.config import Config
+    task = small_task_cfg()
+    task['_name'] = 'MSMCTTS'
+    return Config({'id': 'small', 'task': task, 'trainer': dict(SMALL_TRAINER, _name='VQGANTrainer'),
+                   'optimizer': {'_default': dict(_name='AdamW', learning_rate=2e-4, betas=[0.8, 0.99], eps=1e-8,
+                                                  weight_decay=0.0)},
+                   'dataset': dict(samplerate=24000, feature=['mel', 'wav'], frameshift=[300, 1])})
+
+
+def build_small(device):
+    from msmctts_amd.tasks import build_task
+    cfg = small_config()
+    task = build_task(cfg, mode='train')
+    sd = {k: t(v) for k, v in load_npz('small_state.npz').items()}
+    task.load_state_dict(sd)
+    for m in task.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return cfg, task.to(device).train()
+
+
+# ------------------------------------------------------------------------------------------------
+def check_vq_cases(device):
+    from msmctts_amd.networks.vqgantts.modules import MultiHeadQuantize, Quantize
+    z = load_npz('vq_cases.npz')
+    for c in json_field(z['cases']):
+        name, H, K, D = c['name'], c['H'], c['K'], c['D']
+        q = Quantize(D, K) if H == 1 else MultiHeadQuantize(D, K, H)
+        heads = [q] if H == 1 else list(q.quantizers)
+        for h, m in enumerate(heads):
+            e = t(z['%s.init.embed.%d' % (name, h)])
+            m.embed.copy_(e)
+            m.embed_avg.copy_(e)
+            m.cluster_size.zero_()
+        q = q.to(device).train()
+        heads = [q] if H == 1 else list(q.quantizers)
+        ln = t(z['%s.len' % name]).to(device)
+        for step in (0, 1):
+            x = t(z['%s.s%d.x' % (name, step)]).to(device).requires_grad_(True)
+            qq, dd, ii = q(x, ln, update=True)
+            assert np.array_equal(ii.cpu().numpy(), z['%s.s%d.ind' % (name, step)]), (name, step)
+            scale = float(np.abs(z['%s.s%d.quant' % (name, step)]).max())
+            close(qq, z['%s.s%d.quant' % (name, step)], 5e-6 * max(1.0, scale), what=name + ' quant')
+            close(dd, z['%s.s%d.diff' % (name, step)], 5e-6 * max(1.0, scale * scale), 1e-5, what=name + ' diff')
+            w = (torch.arange(dd.numel(), device=device).view_as(dd) / dd.numel())
+            (qq.sum() * 0.5 + (dd * w).sum()).backward()
+            close(x.grad, z['%s.s%d.grad_x' % (name, step)], 5e-6 * max(1.0, scale), 1e-5, what=name + ' grad')
+            for h, m in enumerate(heads):
+                ref = z['%s.s%d.embed.%d' % (name, step, h)]
+                close(m.embed, ref, 1e-5 * max(1.0, float(np.abs(ref).max())), 1e-5, what=name + ' embed')
+                close(m.cluster_size, z['%s.s%d.cluster_size.%d' % (name, step, h)], 1e-6, 1e-6)
+                close(m.embed_avg, z['%s.s%d.embed_avg.%d' % (name, step, h)], 1e-5, 1e-6)
+        q.eval()
+        qq, dd, ii = q(t(z['%s.s0.x' % name]).to(device), ln, update=True)
+        assert np.array_equal(ii.cpu().numpy(), z['%s.eval.ind' % name])
+
+
+def check_state_dict_surface():
+    import json
+    import os
+    from _util import GOLDEN
+    from msmctts_amd.tasks import build_task
+    from msmctts_amd.utils.config import Config
+    with open(os.path.join(GOLDEN, 'schedule.json')) as f:
+        ref = json.load(f)
+    from msmctts_amd.configs import csmsc_config
+    task = build_task(Config(csmsc_config(embedding_sizes=64)), mode='train')
+    mine = [[k, list(v.shape)] for k, v in task.state_dict().items()]
+    assert mine == ref['csmsc_state_dict']
+    counts = {c: sum(p.numel() for p in m.parameters()) for c, m in task.named_children()}
+    assert counts == ref['csmsc_param_counts']
+
+
+def check_modules(device):
+    z = load_npz('small_modules.npz')
+    cfg, task = build_small(device)
+    win = [tuple(int(v) for v in r) for r in z['windows']]
+    out = task.autoencoder(t(z['batch.mel']).to(device), t(z['batch.mel_length']).to(device), warmup=False,
+                           window=win)
+    for i in range(2):
+        assert np.array_equal(out['encoder_indices'][i].cpu().numpy(), z['ae.encoder_indices.%d' % i])
+        close(out['encoder_outputs'][i], z['ae.encoder_outputs.%d' % i], what='enc')
+        close(out['encoder_diffs'][i], z['ae.encoder_diffs.%d' % i], what='diffs')
+    close(out['mel_outputs'], z['ae.mel_outputs'], what='mel')
+    close(out['decoder_outputs'], z['ae.decoder_outputs'], what='wav')
+    close(out['decoder_diffs']['embed_loss_mse_1'], z['ae.embed_loss_mse_1'])
+    sd = task.state_dict()
+    for k, v in z.items():
+        if k.startswith('ae.post.'):
+            close(sd[k[len('ae.post.'):]], v, 1e-5, 1e-5, what=k)
+    close(task.autoencoder.decoder(t(z['gen.in']).to(device)), z['gen.out'], what='gen')
+    for tag in ('real', 'fake'):
+        scores, fmaps = task.discriminator(t(z['disc.%s.in' % tag]).to(device))
+        assert len(scores) == 4 and [len(f) for f in fmaps] == [6, 6, 5, 5]
+        for i, s in enumerate(scores):
+            close(s, z['disc.%s.score.%d' % (tag, i)], what='score')
+        for i, fl in enumerate(fmaps):
+            for j, f in enumerate(fl):
+                assert list(f.shape) == z['disc.%s.fmap_shape.%d.%d' % (tag, i, j)].tolist()
+                close(fmap_digest(f), z['disc.%s.fmap.%d.%d' % (tag, i, j)], what='fmap %d %d' % (i, j))
+
+
+def check_train_steps(device):
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    z = load_npz('small_steps.npz')
+    for tag, iteration in (('warm', 0), ('gan', 6)):
+        cfg, task = build_small(device)
+        tr = build_trainer(cfg, task, num_gpus=0, rank=0)
+        tr.model = task
+        tr.optimizer = build_optimizer(task, cfg.optimizer)
+        fw = [tuple(int(v) for v in r) for r in z['windows']]
+        sw = [(s * 300, e * 300) for s, e in fw]
+        tr.random_select = lambda ml: (fw, sw)
+        batch = {k[len('batch.'):]: t(v).to(device) for k, v in z.items() if k.startswith('batch.')}
+        snaps = {}
+        real_step = tr.optimizer.step
+
+        def spy(names=None):
+            key = names[0] if isinstance(names, (list, tuple)) else names
+            snaps[key] = {n: p.grad.detach().clone() for n, p in task.named_parameters()
+                          if n.startswith(key + '.') and p.grad is not None}
+            return real_step(names)
+
+        tr.optimizer.step = spy
+        task.zero_grad()
+        log = tr.train_step(batch, iteration)
+        want = {k[len(tag) + 6:]: float(v) for k, v in z.items() if k.startswith(tag + '.loss.')}
+        assert set(want) == set(log['loss']), (sorted(want), sorted(log['loss']))
+        for k, v in want.items():
+            got = float(log['loss'][k])
+            assert abs(got - v) <= TOL * max(1.0, abs(v)), (tag, k, got, v)
+        for child, gd in snaps.items():
+            names = json_field(z['%s.grad_names.%s' % (tag, child)])
+            assert set(names) == set(gd), (set(names) ^ set(gd))
+            for n, w in zip(names, z['%s.grad_l2.%s' % (tag, child)]):
+                g = gd[n].double().norm().item()
+                assert abs(g - w) <= 2e-3 * max(w, 1e-3) + 1e-6, (tag, n, g, w)
+            for k, v in z.items():
+                if k.startswith('%s.grad.%s.' % (tag, child)):
+                    close(gd[k[len(tag) + 6:]], v, 1e-5, 2e-3, what=k)
+        sd = task.state_dict()
+        for k, v in z.items():
+            if k.startswith(tag + '.post.'):
+                n = k[len(tag) + 6:]
+                if n.endswith(('.embed', '.cluster_size', '.embed_avg')):
+                    close(sd[n], v, 1e-5, 1e-4, what=n)
+                else:
+                    close(sd[n], v, 4.5e-4, what=n)

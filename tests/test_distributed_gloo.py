@@ -1,0 +1,144 @@
+"""CPU, world_size 2 over gloo: the data-parallel path (msmctts_amd/distributed/distributed.py).
+
+* start-up broadcast makes every rank's parameters AND buffers equal to rank 0's;
+* bucketed, hook-driven all-reduce averages gradients: N ranks x shard == 1 process x full batch;
+* parameters that received no gradient are not communicated and keep ``grad is None``;
+* the product VQGANTrainer steps in lock-step on 2 ranks (kernel interpreter build), parameters stay
+  identical across ranks while VQ codebooks -- like the reference -- are NOT synchronised.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 3))
+        self.b = nn.Sequential(nn.Linear(3, 8), nn.Tanh(), nn.Linear(8, 1))
+        self.register_buffer('stat', torch.zeros(4))
+
+
+def _toy_worker(rank, world, port, out):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd')]
+    from msmctts_amd.distributed.distributed import apply_gradient_allreduce, init_distributed
+    torch.set_num_threads(1)
+    init_distributed(rank, world, 'g', 'gloo', 'tcp://127.0.0.1:%d' % port)
+    torch.manual_seed(100 + rank)                      # different init per rank: broadcast must fix it
+    m = Toy()
+    m.stat.fill_(float(rank + 1))
+    apply_gradient_allreduce(m, bucket_bytes=600)      # tiny buckets -> several collectives per backward
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 6, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    # step 1: only child a participates (like the D-frozen G step)
+    loss = ((m.a(xs) - ys) ** 2).mean()
+    loss.backward()
+    m.grad_reducer.finish()
+    ga = [p.grad.clone() for p in m.a.parameters()]
+    b_none = all(p.grad is None for p in m.b.parameters())
+    # step 2: both children
+    m.zero_grad()
+    loss = (m.b(m.a(xs)) ** 2).mean()
+    loss.backward()
+    m.grad_reducer.finish()
+    gb = [p.grad.clone() for p in m.parameters()]
+    out[rank] = dict(state={k: v.clone() for k, v in m.state_dict().items()}, ga=ga, b_none=b_none, gb=gb,
+                     nbuckets=len(m.grad_reducer.buckets))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_full_batch():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_toy_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0['nbuckets'] >= 3
+    for k in r0['state']:
+        assert torch.equal(r0['state'][k], r1['state'][k]), k
+    assert float(r0['state']['stat'][0]) == 1.0                      # rank 0's buffer won
+    ref = Toy()
+    ref.load_state_dict(r0['state'])
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 6, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    ((ref.a(x) - y) ** 2).mean().backward()
+    for a, b, c in zip(r0['ga'], r1['ga'], [p.grad for p in ref.a.parameters()]):
+        assert torch.equal(a, b)
+        assert torch.allclose(a, c, atol=1e-6)
+    assert r0['b_none'] and r1['b_none']
+    ref.zero_grad()
+    (ref.b(ref.a(x)) ** 2).mean().backward()
+    for a, b, c in zip(r0['gb'], r1['gb'], [p.grad for p in ref.parameters()]):
+        assert torch.equal(a, b)
+        assert torch.allclose(a, c, atol=1e-6)
+
+
+def _trainer_worker(rank, world, port, out):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd'), os.path.join(ROOT, 'tests')]
+    import random
+    import _parity
+    from msmctts_amd.distributed.distributed import init_distributed
+    from msmctts_amd.hip import lib
+    from msmctts_amd.synthetic import make_batch
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    torch.set_num_threads(2)
+    lib.use_library_for_tests(os.path.join(ROOT, 'tests', 'emu', 'libmsmc_emu.so'))
+    init_distributed(rank, world, 'g', 'gloo', 'tcp://127.0.0.1:%d' % port)
+    cfg, task = _parity.build_small('cpu')
+    if rank == 1:
+        with torch.no_grad():
+            for p in task.parameters():
+                p.add_(0.01)                                          # must be overwritten by the broadcast
+    tr = build_trainer(cfg, task, num_gpus=world, rank=rank)
+    tr.optimizer = build_optimizer(tr.model, cfg.optimizer)
+    tr.rng = random.Random(5 + rank)
+    batch = make_batch(3, 24, 80, 300, seed=11, rank=rank)
+    logs = []
+    for it in (0, 6):                                                 # one warm-up step, one GAN step
+        tr.model.zero_grad()
+        tr.optimizer.zero_grad()
+        logs.append({k: float(v) for k, v in tr.train_step(batch, it)['loss'].items()})
+    out[rank] = dict(state={k: v.clone() for k, v in tr.model.state_dict().items()}, logs=logs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_vqgan_trainer_two_ranks_stay_in_sync():
+    import subprocess
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'tests', 'emu')])
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_trainer_worker, args=(2, port, out), nprocs=2, join=True)
+    s0, s1 = out[0]['state'], out[1]['state']
+    n_param = n_buf_diff = 0
+    for k in s0:
+        if k.endswith(('.embed', '.cluster_size', '.embed_avg')):
+            n_buf_diff += int(not torch.equal(s0[k], s1[k]))          # per-rank EMA, reference semantics
+        else:
+            assert torch.equal(s0[k], s1[k]), k
+            n_param += 1
+    assert n_param > 300 and n_buf_diff > 0
+    assert out[0]['logs'][0]['frame_loss'] != out[1]['logs'][0]['frame_loss']     # different shards
+    assert all(torch.isfinite(torch.tensor(list(l.values()))).all() for l in out[0]['logs'])

@@ -1,0 +1,146 @@
+"""GPU (-m gpu): the product path over the real gfx950 library against
+  (1) the golden fixtures generated from the reference (tests/golden),
+  (2) the oracle on the same seeded inputs at sizes it finishes in seconds,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Bars: VQ indices / quantised values bit-exact vs the C oracle; fp32 module outputs, losses and
+gradients within 1e-3 of the reference; post-step VQ buffers within 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+import _parity
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def real_library():
+    from msmctts_amd.hip import lib
+    assert lib.backend() == 'gfx950', 'GPU tests must run on the real HIP library'
+    torch.backends.cuda.matmul.allow_tf32 = False
+    yield
+
+
+def test_vq_fixture_cases():
+    _parity.check_vq_cases(DEV)
+
+
+def test_modules_match_reference():
+    _parity.check_modules(DEV)
+
+
+def test_train_steps_match_reference():
+    _parity.check_train_steps(DEV)
+
+
+@pytest.mark.parametrize('H,K,D,N', [(1, 64, 256, 777), (4, 64, 256, 6400), (4, 256, 256, 1600), (8, 512, 256, 530),
+                                     (4, 16, 32, 51), (2, 48, 24, 1), (4, 64, 256, 16), (4, 64, 256, 17)])
+def test_vq_search_bit_exact_vs_c_oracle(H, K, D, N):
+    from msmctts_amd.hip import vq
+    from oracle import cvq
+    rng = np.random.default_rng(H * 1000 + K + N)
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    e = rng.standard_normal((H, D // H, K)).astype(np.float32)
+    want = cvq.search(x, e)
+    et, en = vq.vq_prepare(torch.from_numpy(e).to(DEV))
+    assert np.array_equal(et.cpu().numpy(), e.transpose(0, 2, 1))
+    q, d, i = vq.vq_search(torch.from_numpy(x).to(DEV), et, en)
+    assert np.array_equal(i.cpu().numpy(), want['ind'])
+    assert np.array_equal(q.cpu().numpy(), want['quant'])
+    assert np.array_equal(d.cpu().numpy(), want['diff'])
+
+
+def test_vq_search_near_ties_and_duplicates():
+    from msmctts_amd.hip import vq
+    from oracle import cvq
+    rng = np.random.default_rng(0)
+    H, K, d = 4, 64, 64
+    e = rng.standard_normal((H, d, K)).astype(np.float32)
+    e[:, :, 7] = e[:, :, 3]                                  # exact duplicate -> first-minimum rule picks 3
+    e[:, :, 9] = e[:, :, 5] * np.float32(1 + 1e-7)
+    x = rng.standard_normal((2048, H * d)).astype(np.float32)
+    x[:512] = np.tile(e[:, :, 3].reshape(-1), (512, 1)) + rng.standard_normal((512, H * d)).astype(np.float32) * 1e-4
+    want = cvq.search(x, e)
+    et, en = vq.vq_prepare(torch.from_numpy(e).to(DEV))
+    q, dd, i = vq.vq_search(torch.from_numpy(x).to(DEV), et, en)
+    assert np.array_equal(i.cpu().numpy(), want['ind'])
+    assert (want['ind'][:512] == 3).all() and not (want['ind'] == 7).any()
+
+
+def test_vq_search_vs_torch_oracle_gap_contract():
+    """Against the plain-PyTorch oracle (BLAS accumulation order): identical wherever the fp64 top-2 gap
+    exceeds 1e-4 * scale (SURVEY.md section 7 'hard parts')."""
+    from msmctts_amd.hip import vq
+    from oracle.vq import np_search
+    rng = np.random.default_rng(5)
+    H, K, D, N = 4, 256, 256, 20000
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    e = rng.standard_normal((H, D // H, K)).astype(np.float32)
+    et, en = vq.vq_prepare(torch.from_numpy(e).to(DEV))
+    _, _, i = vq.vq_search(torch.from_numpy(x).to(DEV), et, en)
+    got = i.cpu().numpy()
+    ref = np_search(x, [e[h] for h in range(H)])
+    bad = np.argwhere(got != ref)
+    for n, h in bad:
+        xh = x[n, h * 64:(h + 1) * 64].astype(np.float64)
+        dist = ((xh[:, None] - e[h].astype(np.float64)) ** 2).sum(0)
+        top = np.sort(dist)[:2]
+        assert top[1] - top[0] <= 1e-4 * max(1.0, top[0]), (n, h, top)
+    assert len(bad) <= 5
+
+
+def test_vq_full_size_properties():
+    """BASELINE sizes (N = 2^20 frames, D=256): idempotence and index range (no oracle at this size)."""
+    from msmctts_amd.hip import vq
+    N, D, H, K = 1 << 20, 256, 4, 256
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(N, D, generator=g).to(DEV)
+    e = torch.randn(H, D // H, K, generator=g).to(DEV)
+    et, en = vq.vq_prepare(e)
+    q, d, i = vq.vq_search(x, et, en)
+    assert int(i.min()) >= 0 and int(i.max()) < K
+    gathered = torch.stack([e[h].t()[i[:, h]] for h in range(H)], 1).reshape(N, D)
+    assert (q - gathered).abs().max().item() <= 1e-5 * 8      # x + (e - x) is e up to one rounding
+    q2, d2, i2 = vq.vq_search(gathered, et, en)                # quantising codewords returns them: idempotent
+    assert torch.equal(i2, i)
+    assert d2.max().item() <= 1e-9
+    want = ((gathered - x) ** 2).reshape(N, H, D // H).mean(1)
+    assert (d - want).abs().max().item() <= 1e-4
+    # a sample of rows against the C oracle, bit for bit
+    from oracle import cvq
+    rows = torch.arange(0, N, 4099, device=DEV)
+    w = cvq.search(x[rows].cpu().numpy(), e.cpu().numpy())
+    assert np.array_equal(i[rows].cpu().numpy(), w['ind'])
+
+
+def test_vq_ema_matches_torch_oracle_large():
+    from msmctts_amd.hip import vq
+    from oracle.vq import multi_head_quantize
+    B, T, D, H, K = 16, 400, 256, 4, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T, D, generator=g)
+    ln = torch.randint(T // 2, T + 1, (B,), generator=g)
+    e = torch.randn(H, D // H, K, generator=g)
+    heads = [(e[h].clone(), torch.rand(K, generator=g) * 5, e[h].clone() * 1.5) for h in range(H)]
+    cs0 = torch.stack([h[1] for h in heads]).clone()
+    ea0 = torch.stack([h[2] for h in heads]).clone()
+    q, dd, ind = multi_head_quantize(x, ln, heads, True)
+    emb, cs, ea = e.clone().to(DEV), cs0.to(DEV), ea0.to(DEV)
+    et, en = vq.vq_prepare(emb)
+    _, _, gi = vq.vq_search(x.to(DEV), et, en)
+    assert torch.equal(gi.cpu(), ind)
+    vq.vq_ema_update(x.to(DEV), gi, ln.to(DEV), emb, cs, ea, 0.99, 1e-5)
+    for h in range(H):
+        _parity.close(cs[h], heads[h][1], 1e-5, 1e-6, 'cluster_size')
+        _parity.close(ea[h], heads[h][2], 1e-5, 1e-5, 'embed_avg')
+        _parity.close(emb[h], heads[h][0], 1e-5, 1e-5, 'embed')
+    emb2, cs2, ea2 = e.clone().to(DEV), cs0.to(DEV), ea0.to(DEV)
+    vq.vq_ema_update(x.to(DEV), gi, ln.to(DEV), emb2, cs2, ea2, 0.99, 1e-5)
+    assert torch.equal(emb, emb2) and torch.equal(ea, ea2)            # deterministic reduction order
+
+
+def test_no_cpu_fallback():
+    from msmctts_amd.hip import vq
+    with pytest.raises(RuntimeError):
+        vq.vq_prepare(torch.randn(1, 4, 16))

@@ -1,0 +1,116 @@
+"""CPU: host-side logic of the product package -- config surface, plugin registry, state_dict contract,
+C-ABI exports, LR schedule, synthetic batch contract, loud failure without the GPU."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from _util import GOLDEN
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The product library loads and exports exactly what include/msmc_hip.h declares (no compute calls)."""
+    import __graft_entry__ as g
+    g.build()
+    from msmctts_amd.hip import lib
+    header = open(os.path.join(ROOT, 'include', 'msmc_hip.h')).read()
+    declared = set(re.findall(r'\b(msmc_[a-z0-9_]+)\s*\(', header))
+    assert declared == set(lib.exported_symbols())
+    handle = ctypes.CDLL(lib.DEFAULT_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert lib.load().msmc_backend() == b'gfx950'
+
+
+def test_product_refuses_host_tensors_without_test_hook():
+    from msmctts_amd.hip import lib
+    saved = (lib._lib, lib._host_pointers_ok)
+    try:
+        lib._lib, lib._host_pointers_ok = lib.load(), False
+        with pytest.raises(RuntimeError, match='GPU only'):
+            lib.ptr(torch.zeros(4))
+    finally:
+        lib._lib, lib._host_pointers_ok = saved
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from msmctts_amd.hip import lib
+    with pytest.raises(RuntimeError, match='not found'):
+        lib.load(str(tmp_path / 'libmsmc_hip.so'))
+
+
+def test_config_surface():
+    from msmctts_amd.utils.config import Config, read_yaml
+    p = os.path.join(GOLDEN, '_cfg.yaml')
+    with open(p, 'w') as f:
+        f.write('id: x\noptimizer:\n  _default:\n    learning_rate: 2e-4\n    name: None\ncudnn:\n  benchmark: True\n')
+    try:
+        c = Config(p)
+        assert isinstance(c.optimizer._default.learning_rate, float) and c.optimizer._default.learning_rate == 2e-4
+        assert c.optimizer._default.name is None
+        assert c.cudnn.enabled is True and c.cudnn.benchmark is True            # merged over defaults
+        assert c.distributed.dist_backend == 'nccl' and c.training_steps == 1000000
+        assert c.to_dict()['optimizer']['_default']['learning_rate'] == 2e-4
+        with pytest.raises(AttributeError):
+            c.nope
+    finally:
+        os.remove(p)
+
+
+def test_registry_and_state_dict_contract():
+    import _parity
+    _parity.check_state_dict_surface()
+    from msmctts_amd.networks import find_modules
+    with pytest.raises(RuntimeError):
+        find_modules({'x': {'_name': 'NoSuchNetwork'}})
+    from msmctts_amd.configs import csmsc_config
+    nets = dict(find_modules({k: v for k, v in csmsc_config()['task'].items() if k[:1] != '_'}))
+    assert type(nets['autoencoder']).__name__ == 'MSMCVQGAN'
+    assert type(nets['discriminator']).__name__ == 'Discriminator'
+    frozen = [n for n, p in nets['autoencoder'].named_parameters() if not p.requires_grad]
+    assert frozen == ['encoder.encoders.0.position.weight', 'encoder.encoders.1.position.weight',
+                      'frame_decoder.position.weight']
+
+
+def test_multihead_buffers_are_views_of_packed_storage():
+    from msmctts_amd.networks.vqgantts.modules import MultiHeadQuantize
+    q = MultiHeadQuantize(32, 16, 4)
+    e, c, a = q._packed()
+    assert e.shape == (4, 8, 16) and c.shape == (4, 16)
+    sd = {k: torch.full_like(v, float(i)) for i, (k, v) in enumerate(q.state_dict().items())}
+    q.load_state_dict(sd)                                     # in-place copy keeps the packing
+    e2, _, _ = q._packed()
+    assert e2.data_ptr() == e.data_ptr()
+    assert torch.equal(e2[1], sd['quantizers.1.embed'])
+    q2 = q.double().float()                                  # _apply re-creates buffers -> repacked lazily
+    e3, _, _ = q2._packed()
+    assert torch.equal(e3[2], sd['quantizers.2.embed'])
+    assert q2.quantizers[2].embed.data_ptr() == e3[2].data_ptr()
+
+
+def test_lr_schedule_matches_reference():
+    from msmctts_amd.trainers.lr_schedulers import build_lr_scheduler
+    with open(os.path.join(GOLDEN, 'schedule.json')) as f:
+        s = json.load(f)
+    sch = build_lr_scheduler(dict(_name='ExponentialDecayLRScheduler', warmup_steps=200000, decay_scale=200000,
+                                  decay_learning_rate=0.5, final_learning_rate=1e-5))
+    for step, lr in zip(s['lr_steps'], s['lr_values']):
+        assert abs(max(1e-5, sch.get_scale(step) * 2e-4) - lr) < 1e-12
+
+
+def test_synthetic_batch_contract():
+    from msmctts_amd.synthetic import make_batch
+    b = make_batch(8, 40, 80, 300, seed=1, rank=0)
+    ln = b['mel_length']
+    assert b['mel'].shape == (8, 40, 80) and b['wav'].shape == (8, 12000, 1) and ln.dtype == torch.int64
+    assert int(ln.max()) == 40 and bool((ln[:-1] >= ln[1:]).all()) and int(ln.min()) >= 20
+    assert torch.equal(b['wav_length'], ln * 300)
+    for i, l in enumerate(ln.tolist()):
+        assert bool((b['mel'][i, l:] == -4).all()) and bool((b['wav'][i, l * 300:] == 0).all())
+    b2 = make_batch(8, 40, 80, 300, seed=1, rank=1)
+    assert not torch.equal(b['mel'], b2['mel'])
