@@ -91,21 +91,50 @@ def build(args, device, rank, world):
     return cfg, trainer
 
 
-def cpu_baseline(cfg, state_dict, batch, windows, steps, threads):
-    """Oracle train step on host cores: same state, same batch, same windows (bounded sample)."""
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def say(msg):
+    sys.stderr.write('[bench %7.1fs] %s\n' % (time.perf_counter() - T_START, msg))
+    sys.stderr.flush()
+
+
+T_START = time.perf_counter()
+
+
+def cpu_baseline(cfg, state_dict, batch, windows, steps, threads, sample):
+    """Oracle train step on host cores: same weights, the first ``sample`` utterances of the same batch,
+    same windows (a bounded sample of the workload; throughput is per mel-frame of the sample)."""
     from oracle.step import OracleTrainer
     torch.set_num_threads(threads)
     task = cfg.task.to_dict()
     tcfg = {k: v for k, v in cfg.trainer.to_dict().items() if k != '_name'}
     tr = OracleTrainer({k: v.detach().float().cpu() for k, v in state_dict.items()}, task, tcfg)
-    cb = {k: v.detach().cpu() for k, v in batch.items() if torch.is_tensor(v)}
+    cb = {k: v.detach().cpu()[:sample] for k, v in batch.items() if torch.is_tensor(v)}
+    T = int(cb['mel_length'].max())
+    cb['mel'], cb['wav'] = cb['mel'][:, :T], cb['wav'][:, :T * 300]
+    windows = (windows[0][:sample], windows[1][:sample])
     times = []
     for i in range(steps + 1):
         t0 = time.perf_counter()
         tr.train_step(cb, 10 + i, windows=windows)
         times.append(time.perf_counter() - t0)
+        say('cpu oracle step %d: %.2f s' % (i, times[-1]))
     timed = sorted(times[1:])
-    return timed[len(timed) // 2]
+    return timed[len(timed) // 2], float(cb['mel_length'].sum())
 
 
 def vq_microbench(device, H, K, D=256, N=1 << 20, iters=20):
@@ -141,6 +170,8 @@ def main():
     ap.add_argument('--codewords', type=int, default=256)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--cpu-steps', type=int, default=2, help='timed oracle steps for cpu_baseline (0 = skip)')
+    ap.add_argument('--cpu-batch', type=int, default=4, help='utterances of the batch in the cpu_baseline sample')
+    ap.add_argument('--cpu-threads', type=int, default=0, help='0 = min(available cores, 32)')
     ap.add_argument('--no-microbench', action='store_true')
     args = ap.parse_args()
 
@@ -177,8 +208,11 @@ def main():
         trainer.optimizer.zero_grad()
         return trainer.train_step(batch, 10 + i)
 
+    say('built model; starting warm-up')
     for i in range(args.warmup):
         step(i)
+        torch.cuda.synchronize()
+        say('warm-up step %d done' % i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -204,6 +238,7 @@ def main():
         frames_per_step = float(sum(lengths_host))
     ms_per_step = elapsed / args.steps * 1e3
     value = frames_per_step / (elapsed / args.steps)
+    say('timed %d steps: %.2f ms/step' % (args.steps, ms_per_step))
 
     if rank != 0:
         return
@@ -234,23 +269,23 @@ def main():
     if not args.no_microbench:
         out['vq_microbench'] = [vq_microbench(device, args.heads, args.codewords),
                                 vq_microbench(device, 4, 64)]
+        say('vq microbench done')
     if world == 1 and args.cpu_steps > 0:
-        cores = os.cpu_count() or 1
-        try:
-            cores = len(os.sched_getaffinity(0))
-        except Exception:
-            pass
+        cores = host_cores()
         r = random.Random(99)
         fw = []
         for n in lengths_host:
             s = r.randrange(max(1, n - 40))
             fw.append((s, s + 40))
         sw = [(s * 300, e * 300) for s, e in fw]
-        sec = cpu_baseline(cfg, state0, batch, (fw, sw), args.cpu_steps, cores)
-        out['cpu_baseline'] = dict(value=frames_per_step / sec, unit='mel-frames/s', cores=cores, kind='port',
-                                   sample='%d timed GAN-phase oracle steps (median) after 1 warm-up, same B=%d T=%d '
-                                          'batch and weights, fp32, torch %s' % (args.cpu_steps, args.batch,
-                                                                                args.frames, torch.__version__),
+        threads = args.cpu_threads or min(cores, 32)
+        sec, sample_frames = cpu_baseline(cfg, state0, batch, (fw, sw), args.cpu_steps, threads, args.cpu_batch)
+        out['cpu_baseline'] = dict(value=sample_frames / sec, unit='mel-frames/s', cores=threads, kind='port',
+                                   sample='oracle (plain PyTorch fp32) GAN-phase train step on the first %d utterances '
+                                          '(%d mel frames) of the same batch with the same weights; median of %d timed '
+                                          'steps after 1 warm-up; %d of %d visible cores; torch %s'
+                                          % (args.cpu_batch, sample_frames, args.cpu_steps, threads, cores,
+                                             torch.__version__),
                                    s_per_step=sec)
         out['speedup_vs_cpu'] = value / out['cpu_baseline']['value']
     print(json.dumps(out))

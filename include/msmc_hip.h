@@ -68,6 +68,63 @@ int msmc_vq_ema_update(const float* x, const int64_t* ind, const int64_t* length
 int msmc_vq_backward(const float* g_quant, const float* g_diff, const float* x, const float* quant,
                      float* gx, int N, int D, int H, msmc_stream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * G1/G2/D1/D2  channels-last implicit-GEMM convolution family on the matrix cores.
+ * Replaces the cuDNN/MIOpen convolutions behind
+ *   Generator.forward / ResBlock1.forward   reference msmctts/networks/hifigan/generator.py:40-55, common.py:44-51
+ *   DiscriminatorP.forward                  reference msmctts/networks/hifigan/discriminator.py:135-154
+ *   DiscriminatorR.forward                  reference msmctts/networks/hifigan/discriminator.py:71-76
+ * One "gather" kernel serves forward convolutions (dilated / strided / reflect- or zero-padded),
+ * transposed convolutions and every data-gradient (as per-phase sub-lattices); one kernel computes
+ * weight gradients.  Activations are channels-last [B][H][W][C] (1-D signals: H = 1); dtype 0 = fp32
+ * (exact-fp32 MFMA), 1 = bf16 storage with fp32 accumulation.
+ * ------------------------------------------------------------------------------------------- */
+#define MSMC_CONV_MAX_TAPS 16
+
+typedef struct msmc_conv_desc {
+    const void* x;          /* input  [B][Hin][Win][Cin]                                                  */
+    const void* w;          /* weight slices [nslice][Cout][Cin], same dtype as x                          */
+    const float* bias;      /* [Cout] fp32 or NULL                                                         */
+    const void* mask_src;   /* NULL, or [B][Hout][Wout][Cout]: v *= (mask_src > 0 ? 1 : mask_slope)        */
+    const void* res;        /* NULL, or [B][Hout][Wout][Cout]: v = v + res                                 */
+    const void* res2;       /* NULL, or same shape: v = res2 + v                                           */
+    void* out;              /* [B][Hout][Wout][Cout]                                                       */
+    int dtype;              /* 0 fp32, 1 bf16                                                              */
+    int B, Hin, Win, Cin, Hout, Wout, Cout;
+    /* output sub-lattice: (oy, ox) = (oy0 + qy*osy, ox0 + qx*osx), qy < QH, qx < QW                       */
+    int QH, QW, oy0, osy, ox0, osx;
+    /* input coordinate of tap t at lattice point q: (qy*isy + iy0 + tap_dy[t], qx*isx + ix0 + tap_dx[t])  */
+    int isy, isx, iy0, ix0;
+    int ntaps;
+    int tap_dy[MSMC_CONV_MAX_TAPS], tap_dx[MSMC_CONV_MAX_TAPS], tap_w[MSMC_CONV_MAX_TAPS];
+    int pad_mode;           /* 0 = zeros outside the input, 1 = reflect                                    */
+    float in_slope;         /* leaky-ReLU slope applied to x on load (1 = identity)                        */
+    float mask_slope;
+    float out_div;          /* v = v / out_div when != 1                                                   */
+} msmc_conv_desc;
+
+/* out[q] = epilogue( sum_t sum_ci w[tap_w[t]][co][ci] * act(x[in(q, t)][ci]) + bias[co] ). */
+int msmc_conv_gather(const msmc_conv_desc* desc, msmc_stream stream);
+
+/* dw[tap_w[t]][co][ci] += sum_{b,q} g[b][out(q)][co] * act(x[b][in(q, t)][ci])   (fp32 atomics; caller zeroes dw).
+ * Geometry fields as for the forward convolution it differentiates; desc->x = x, desc->out unused,
+ * g has the forward output's shape [B][Hout][Wout][Cout] and dtype. */
+int msmc_conv_wgrad(const msmc_conv_desc* desc, const void* g, float* dw, msmc_stream stream);
+
+/* Weight-norm weight preparation: v [R][inner...] with norm over everything but dim 0 (torch weight_norm dim=0).
+ * Writes scaled weights w = g * v / ||v|| into a kernel layout given by element strides:
+ *   dst[tap*s_tap + a*s_a + b*s_b] for v[a][b][tap], a < A, b < Bc, tap < T   (A is dim 0). dtype as above. */
+int msmc_wn_prepare(const float* v, const float* g, void* dst, float* inv_norm, int A, int Bc, int T, long s_tap,
+                    long s_a, long s_b, int dtype, msmc_stream stream);
+
+/* Backward of the above from dW given in the same strided layout (fp32):
+ *   gg[a] = sum(dW*v)/||v||,  gv = g/||v|| * (dW - v * sum(dW*v)/||v||^2). */
+int msmc_wn_backward(const float* v, const float* g, const float* dw, float* gv, float* gg, int A, int Bc, int T,
+                     long s_tap, long s_a, long s_b, msmc_stream stream);
+
+/* Column sums: out[c] = sum_rows g[row][c] (bias gradients); g dtype as above, out fp32 (overwritten). */
+int msmc_colsum(const void* g, float* out, long rows, int C, int dtype, msmc_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define MSMC_WAVE 64
 #define MSMC_DEV static __device__ __forceinline__
+#define MSMC_DEV_INLINE __device__ __forceinline__
 #define MSMC_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define MSMC_LAUNCH(kernel, grid, block, lds, stream, ...) \
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__)

@@ -29,6 +29,24 @@ _SIGNATURES = {
 }
 
 
+MAX_TAPS = 16
+
+
+class ConvDesc(ctypes.Structure):
+    """msmc_conv_desc of include/msmc_hip.h."""
+    _fields_ = [('x', _vp), ('w', _vp), ('bias', _vp), ('mask_src', _vp), ('res', _vp), ('res2', _vp), ('out', _vp),
+                ('dtype', _i), ('B', _i), ('Hin', _i), ('Win', _i), ('Cin', _i), ('Hout', _i), ('Wout', _i),
+                ('Cout', _i), ('QH', _i), ('QW', _i), ('oy0', _i), ('osy', _i), ('ox0', _i), ('osx', _i),
+                ('isy', _i), ('isx', _i), ('iy0', _i), ('ix0', _i), ('ntaps', _i),
+                ('tap_dy', _i * MAX_TAPS), ('tap_dx', _i * MAX_TAPS), ('tap_w', _i * MAX_TAPS),
+                ('pad_mode', _i), ('in_slope', _f), ('mask_slope', _f), ('out_div', _f)]
+
+
+_SIGNATURES.update({
+    'msmc_conv_gather': (_i, [ctypes.POINTER(ConvDesc), _vp]),
+})
+
+
 def exported_symbols():
     """Names every build of the library must export (checked by the CPU test-suite)."""
     return sorted(_SIGNATURES)

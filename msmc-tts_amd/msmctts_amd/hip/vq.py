@@ -36,6 +36,7 @@ class _VQSearch(torch.autograd.Function):
                   'msmc_vq_search')
         ctx.save_for_backward(xc, quant)
         ctx.heads = H
+        ctx.in_dtype = x.dtype
         ctx.mark_non_differentiable(ind)
         return quant, diff, ind
 
@@ -52,7 +53,7 @@ class _VQSearch(torch.autograd.Function):
         L = lib.get()
         lib.check(L.msmc_vq_backward(lib.ptr(g_quant), lib.ptr(g_diff), lib.ptr(xc), lib.ptr(quant), lib.ptr(gx),
                                      N, D, ctx.heads, lib.stream(xc)), 'msmc_vq_backward')
-        return gx, None, None
+        return gx.to(ctx.in_dtype), None, None
 
 
 def vq_search(x, embed_t, enorm):

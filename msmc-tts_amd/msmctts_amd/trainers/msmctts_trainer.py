@@ -98,7 +98,8 @@ class VQGANTrainer(BaseTrainer):
     def _amp(self):
         if self.amp_dtype is None:
             return contextlib.nullcontext()
-        return torch.autocast(device_type='cuda', dtype=self.amp_dtype)
+        device_type = next(self.model.parameters()).device.type
+        return torch.autocast(device_type=device_type, dtype=self.amp_dtype)
 
     def train_step(self, batch, iteration):
         losses = {}

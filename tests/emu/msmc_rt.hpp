@@ -55,6 +55,7 @@ void run_grid(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void
 
 #define MSMC_WAVE 64
 #define MSMC_DEV static inline
+#define MSMC_DEV_INLINE inline
 #define MSMC_DYN_LDS(name) char* name = emu::dyn_lds
 
 template <class F>

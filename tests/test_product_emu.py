@@ -33,3 +33,48 @@ def test_modules_match_reference():
 
 def test_train_steps_match_reference():
     _parity.check_train_steps('cpu')
+
+
+@pytest.mark.parametrize('H,K,D,N', [
+    (4, 256, 256, 200),    # codebook of one head per LDS pass: 4 restaged groups per tile
+    (1, 64, 256, 100),     # single head, d=256: falls back to 2-wave workgroups
+    (8, 64, 64, 333),      # d=8; several persistent iterations per workgroup (interpreter has 3 "CUs")
+    (2, 48, 24, 1),        # odd tile count of codewords, single frame
+])
+def test_vq_search_shapes_bit_exact_vs_c_oracle(H, K, D, N):
+    import numpy as np
+    from msmctts_amd.hip import vq
+    from oracle import cvq
+    rng = np.random.default_rng(H + K + N)
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    e = rng.standard_normal((H, D // H, K)).astype(np.float32)
+    want = cvq.search(x, e)
+    et, en = vq.vq_prepare(torch.from_numpy(e))
+    q, d, i = vq.vq_search(torch.from_numpy(x), et, en)
+    assert np.array_equal(i.numpy(), want['ind'])
+    assert np.array_equal(q.numpy(), want['quant'])
+    assert np.array_equal(d.numpy(), want['diff'])
+
+
+def test_vq_rejects_unsupported_shapes():
+    from msmctts_amd.hip import vq
+    with pytest.raises(RuntimeError, match='msmc_vq_search'):
+        vq.vq_search(torch.randn(4, 6), torch.randn(2, 16, 3), torch.randn(2, 16))     # d % 4 != 0
+
+
+def test_train_step_runs_under_bf16_autocast():
+    """dtype plumbing of the bf16 bench configuration (numerics are checked on the GPU)."""
+    import random
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    from msmctts_amd.synthetic import make_batch
+    cfg, task = _parity.build_small('cpu')
+    tr = build_trainer(cfg, task, num_gpus=0, rank=0)
+    tr.optimizer = build_optimizer(task, cfg.optimizer)
+    tr.amp_dtype = torch.bfloat16
+    tr.rng = random.Random(0)
+    batch = make_batch(3, 24, 80, 300, seed=2)
+    for it in (0, 6):
+        task.zero_grad()
+        log = tr.train_step(batch, it)
+        assert all(torch.isfinite(torch.as_tensor(float(v))) for v in log['loss'].values())
