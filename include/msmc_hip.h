@@ -101,6 +101,7 @@ typedef struct msmc_conv_desc {
     float in_slope;         /* leaky-ReLU slope applied to x on load (1 = identity)                        */
     float mask_slope;
     float out_div;          /* v = v / out_div when != 1                                                   */
+    float out_slope;        /* leaky-ReLU slope applied to v last (1 = identity)                           */
 } msmc_conv_desc;
 
 /* out[q] = epilogue( sum_t sum_ci w[tap_w[t]][co][ci] * act(x[in(q, t)][ci]) + bias[co] ). */
@@ -111,16 +112,35 @@ int msmc_conv_gather(const msmc_conv_desc* desc, msmc_stream stream);
  * g has the forward output's shape [B][Hout][Wout][Cout] and dtype. */
 int msmc_conv_wgrad(const msmc_conv_desc* desc, const void* g, float* dw, msmc_stream stream);
 
-/* Weight-norm weight preparation: v [R][inner...] with norm over everything but dim 0 (torch weight_norm dim=0).
- * Writes scaled weights w = g * v / ||v|| into a kernel layout given by element strides:
- *   dst[tap*s_tap + a*s_a + b*s_b] for v[a][b][tap], a < A, b < Bc, tap < T   (A is dim 0). dtype as above. */
-int msmc_wn_prepare(const float* v, const float* g, void* dst, float* inv_norm, int A, int Bc, int T, long s_tap,
-                    long s_a, long s_b, int dtype, msmc_stream stream);
+/* Weight-norm (torch weight_norm, dim=0) for MANY convolutions in one launch.
+ * Item i: v [A][Bc][T] fp32 contiguous (A = dim 0, the normalised axis; T = taps), g [A] fp32.
+ *   prepare : w = v * (g / ||v||) written to up to two kernel layouts
+ *             dst_k[tap*s_k[0] + a*s_k[1] + b*s_k[2]]  (dtype: 0 fp32, 1 bf16), inv_norm[a] = 1/||v||
+ *   backward: from dw (fp32, layout s_1):  gg[a] = sum(dw*v)*inv_norm,
+ *             gv = (g*inv_norm) * (dw - v * sum(dw*v) * inv_norm^2)
+ * ``items`` is a DEVICE array; item i owns blocks [block0, block0 + A) of the grid of total_blocks. */
+typedef struct msmc_wn_item {
+    const float* v;
+    const float* g;
+    void* dst1;
+    void* dst2;             /* may be NULL */
+    float* inv_norm;        /* [A] */
+    const float* dw;        /* backward: gradient wrt w in layout 1 (fp32) */
+    float* gv;              /* backward: [A][Bc][T] */
+    float* gg;              /* backward: [A] */
+    long s1[3];
+    long s2[3];
+    int A, Bc, T, dtype, block0, pad_;
+} msmc_wn_item;
 
-/* Backward of the above from dW given in the same strided layout (fp32):
- *   gg[a] = sum(dW*v)/||v||,  gv = g/||v|| * (dW - v * sum(dW*v)/||v||^2). */
-int msmc_wn_backward(const float* v, const float* g, const float* dw, float* gv, float* gg, int A, int Bc, int T,
-                     long s_tap, long s_a, long s_b, msmc_stream stream);
+int msmc_wn_prepare_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream);
+int msmc_wn_backward_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream);
+
+/* Backward of ReflectionPad2d(p) fused with the leaky-ReLU' mask, channels-last:
+ *   gx[b][y][x][c] = (sum of gp over the padded positions that reflect onto (y, x)) * (mask_src > 0 ? 1 : slope)
+ * gp [B][H+2p][W+2p][C], gx and mask_src [B][H][W][C] (mask_src may be NULL). */
+int msmc_reflect_fold(const void* gp, const void* mask_src, void* gx, int B, int H, int W, int C, int p, float slope,
+                      int dtype, msmc_stream stream);
 
 /* Column sums: out[c] = sum_rows g[row][c] (bias gradients); g dtype as above, out fp32 (overwritten). */
 int msmc_colsum(const void* g, float* out, long rows, int C, int dtype, msmc_stream stream);

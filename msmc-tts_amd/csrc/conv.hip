@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(msmc_conv_desc d, CvGe
             if (res) v = v + Elt<T>::ld(res + o);
             if (res2) v = Elt<T>::ld(res2 + o) + v;
             if (d.out_div != 1.f) v = v / d.out_div;
+            if (d.out_slope != 1.f) v = v > 0.f ? v : v * d.out_slope;
             Elt<T>::st(out + o, v);
         }
     }
@@ -264,3 +265,333 @@ extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
     if (d->dtype == 1) return cv_launch<unsigned short>(d, stream);
     return MSMC_E_SHAPE;
 }
+
+// ================================================================================================
+// weight gradient
+// ================================================================================================
+template <typename T> struct WgTraits;
+template <> struct WgTraits<float> { static constexpr int KP = 64, KSTEP = 2; };
+template <> struct WgTraits<unsigned short> { static constexpr int KP = 128, KSTEP = 16; };
+
+struct WgGeom {
+    int P, chunksPerItem, totalChunks, chunksPerWg;
+};
+
+// Stage a [KP points][64 channels] operand TRANSPOSED into lds[ch][KP (+pad)]: each work-item moves
+// 4 points x VEC4 channels through a register transpose (global reads stay 8/16-byte wide along C).
+template <typename T, bool IS_X>
+MSMC_DEV void wg_stage(T* lds, int LS, const msmc_conv_desc& d, const T* base, int C, int c0, int p0, int P, int tap,
+                       float slope, int tid) {
+    constexpr int KP = WgTraits<T>::KP;
+    // 64 channels = 16 groups of 4; KP points = KP/4 groups of 4
+    for (int e = tid; e < 16 * (KP / 4); e += 256) {
+        const int cg = e & 15, pg = e >> 4;
+        const int c = c0 + cg * 4;
+        float v[4][4];                              // [point][channel]
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const int p = p0 + pg * 4 + pp;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) v[pp][cc] = 0.f;
+            if (p >= P || c >= C) continue;
+            const int qy = p / d.QW, qx = p - qy * d.QW;
+            size_t off;
+            bool inside = true;
+            if (IS_X) {
+                int iy = qy * d.isy + d.iy0 + d.tap_dy[tap], ix = qx * d.isx + d.ix0 + d.tap_dx[tap];
+                if (d.pad_mode == 1) {
+                    iy = reflect_index(iy, d.Hin);
+                    ix = reflect_index(ix, d.Win);
+                } else {
+                    inside = (iy >= 0) && (iy < d.Hin) && (ix >= 0) && (ix < d.Win);
+                }
+                off = ((size_t)iy * d.Win + ix) * C + c;
+            } else {
+                const int oy = d.oy0 + qy * d.osy, ox = d.ox0 + qx * d.osx;
+                off = ((size_t)oy * d.Wout + ox) * C + c;
+            }
+            if (!inside) continue;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                if (c + cc < C) {
+                    float f = Elt<T>::ld(base + off + cc);
+                    v[pp][cc] = (slope != 1.f && f <= 0.f) ? f * slope : f;
+                }
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            T* dst = lds + (size_t)(cg * 4 + cc) * LS + pg * 4;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) Elt<T>::st(dst + pp, v[pp][cc]);
+        }
+    }
+}
+
+MSMC_DEV f32x16 wg_mma(const float* ap, const float* bp, int g, f32x16 acc) {
+    // KP = 64 points: lane group g takes points 8t + 4g + e, both operands alike
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        f32x4 a4 = *(const f32x4*)(ap + 8 * t + 4 * g);
+        f32x4 b4 = *(const f32x4*)(bp + 8 * t + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma_f32_32x32x2(a4[e], b4[e], acc);
+    }
+    return acc;
+}
+MSMC_DEV f32x16 wg_mma(const unsigned short* ap, const unsigned short* bp, int g, f32x16 acc) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {               // KP = 128 points, 16 per MFMA
+        bf16x8 a = __builtin_bit_cast(bf16x8, *(const u16x8*)(ap + 16 * t + 8 * g));
+        bf16x8 b = __builtin_bit_cast(bf16x8, *(const u16x8*)(bp + 16 * t + 8 * g));
+        acc = mfma_bf16_32x32x16(a, b, acc);
+    }
+    return acc;
+}
+
+template <typename T, int TAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(msmc_conv_desc d, const T* __restrict__ gptr,
+                                                        float* __restrict__ dw, WgGeom G) {
+    MSMC_DYN_LDS(smem);
+    constexpr int KP = WgTraits<T>::KP, LS = KP + Elt<T>::VEC;
+    T* gt = (T*)smem;                   // [64 co][LS]
+    T* xt = gt + 64 * LS;               // [64 ci][LS]
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 31, g = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;  // wave tile: co rows [32*wm, +32), ci cols [32*wn, +32)
+    const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+    // a wave whose 32x32 tile lies entirely beyond Cout x Cin has nothing to compute (thin layers)
+    const bool wave_live = (co0 + 32 * wm < d.Cout) && (ci0 + 32 * wn < d.Cin);
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int ch0 = blockIdx.x * G.chunksPerWg;
+    int ch1 = ch0 + G.chunksPerWg;
+    if (ch1 > G.totalChunks) ch1 = G.totalChunks;
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const int b = ch / G.chunksPerItem;
+        const int p0 = (ch - b * G.chunksPerItem) * KP;
+        const T* gb = gptr + (size_t)b * d.Hout * d.Wout * d.Cout;
+        const T* xb = (const T*)d.x + (size_t)b * d.Hin * d.Win * d.Cin;
+        __syncthreads();
+        wg_stage<T, false>(gt, LS, d, gb, d.Cout, co0, p0, G.P, 0, d.mask_slope, tid);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            if (t < d.ntaps) {
+                if (t > 0) __syncthreads();
+                wg_stage<T, true>(xt, LS, d, xb, d.Cin, ci0, p0, G.P, t, d.in_slope, tid);
+                __syncthreads();
+                if (wave_live)
+                    acc[t] = wg_mma(gt + (size_t)(32 * wm + i) * LS, xt + (size_t)(32 * wn + i) * LS, g, acc[t]);
+            }
+        }
+    }
+    // D fragment: row (co) = 32*wm + (r&3) + 8*(r>>2) + 4*g, col (ci) = 32*wn + i
+    const int ci = ci0 + 32 * wn + i;
+    if (!wave_live || ci >= d.Cin) return;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        if (t >= d.ntaps) continue;
+        float* dst = dw + (size_t)d.tap_w[t] * d.Cout * d.Cin;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (co < d.Cout) atomicAdd(dst + (size_t)co * d.Cin + ci, acc[t][r]);
+        }
+    }
+}
+
+template <typename T>
+static int wg_launch(const msmc_conv_desc* d, const void* g, float* dw, msmc_stream stream) {
+    constexpr int KP = WgTraits<T>::KP, LS = KP + Elt<T>::VEC;
+    WgGeom G;
+    G.P = d->QH * d->QW;
+    G.chunksPerItem = (G.P + KP - 1) / KP;
+    G.totalChunks = G.chunksPerItem * d->B;
+    const int tiles = ((d->Cout + 63) / 64) * ((d->Cin + 63) / 64);
+    int nsplit = (2 * MSMC_NUM_CU + tiles - 1) / tiles;
+    if (nsplit > G.totalChunks) nsplit = G.totalChunks;
+    if (nsplit < 1) nsplit = 1;
+    G.chunksPerWg = (G.totalChunks + nsplit - 1) / nsplit;
+    nsplit = (G.totalChunks + G.chunksPerWg - 1) / G.chunksPerWg;
+    dim3 grid((unsigned)nsplit, (unsigned)((d->Cout + 63) / 64), (unsigned)((d->Cin + 63) / 64));
+    const size_t lds = (size_t)2 * 64 * LS * sizeof(T);
+    const T* gp = (const T*)g;
+    if (d->ntaps <= 4) MSMC_LAUNCH((conv_wgrad_kernel<T, 4>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, G);
+    else if (d->ntaps <= 8) MSMC_LAUNCH((conv_wgrad_kernel<T, 8>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, G);
+    else if (d->ntaps <= 12) MSMC_LAUNCH((conv_wgrad_kernel<T, 12>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, G);
+    else MSMC_LAUNCH((conv_wgrad_kernel<T, 16>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, G);
+    return msmc_check_launch();
+}
+
+extern "C" int msmc_conv_wgrad(const msmc_conv_desc* d, const void* g, float* dw, msmc_stream stream) {
+    if (!d || !g || !dw || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0) return MSMC_E_SHAPE;
+    if (d->ntaps <= 0 || d->ntaps > MSMC_CONV_MAX_TAPS) return MSMC_E_SHAPE;
+    if (d->dtype == 0) return wg_launch<float>(d, g, dw, stream);
+    if (d->dtype == 1) return wg_launch<unsigned short>(d, g, dw, stream);
+    return MSMC_E_SHAPE;
+}
+
+// ================================================================================================
+// weight norm (multi-tensor) and bias gradient
+// ================================================================================================
+MSMC_DEV float block_sum(float v, float* red) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = red[tid] + red[tid + s];
+        __syncthreads();
+    }
+    float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+MSMC_DEV int wn_find(const msmc_wn_item* items, int n, int blk) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (items[mid].block0 <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+MSMC_DEV void wn_store(void* dst, int dtype, long off, float v) {
+    if (dtype == 0) ((float*)dst)[off] = v;
+    else ((unsigned short*)dst)[off] = f32_to_bf16_bits(v);
+}
+
+__global__ __launch_bounds__(256) void wn_prepare_kernel(const msmc_wn_item* __restrict__ items, int nitems) {
+    __shared__ float red[256];
+    const msmc_wn_item it = items[wn_find(items, nitems, blockIdx.x)];
+    const int a = blockIdx.x - it.block0;
+    const int n = it.Bc * it.T;
+    const float* v = it.v + (size_t)a * n;
+    float ss = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) ss = fmaf(v[e], v[e], ss);
+    ss = block_sum(ss, red);
+    const float norm = sqrtf(ss);
+    const float scale = it.g[a] / norm;
+    if (threadIdx.x == 0) it.inv_norm[a] = 1.f / norm;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int b = e / it.T, t = e - b * it.T;
+        const float wv = v[e] * scale;
+        wn_store(it.dst1, it.dtype, t * it.s1[0] + a * it.s1[1] + b * it.s1[2], wv);
+        if (it.dst2) wn_store(it.dst2, it.dtype, t * it.s2[0] + a * it.s2[1] + b * it.s2[2], wv);
+    }
+}
+
+__global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __restrict__ items, int nitems) {
+    __shared__ float red[256];
+    const msmc_wn_item it = items[wn_find(items, nitems, blockIdx.x)];
+    const int a = blockIdx.x - it.block0;
+    const int n = it.Bc * it.T;
+    const float* v = it.v + (size_t)a * n;
+    float dot = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int b = e / it.T, t = e - b * it.T;
+        dot = fmaf(it.dw[t * it.s1[0] + a * it.s1[1] + b * it.s1[2]], v[e], dot);
+    }
+    dot = block_sum(dot, red);
+    const float inv = it.inv_norm[a], gval = it.g[a];
+    if (threadIdx.x == 0) it.gg[a] = dot * inv;
+    const float k1 = gval * inv, k2 = dot * inv * inv;
+    float* gv = it.gv + (size_t)a * n;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int b = e / it.T, t = e - b * it.T;
+        gv[e] = k1 * (it.dw[t * it.s1[0] + a * it.s1[1] + b * it.s1[2]] - v[e] * k2);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ out, long rows, int C,
+                                                    int rows_per_block) {
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (long r = r0; r < r1; ++r) s = s + Elt<T>::ld(g + r * C + c);
+        atomicAdd(out + c, s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void reflect_fold_kernel(const T* __restrict__ gp, const T* __restrict__ mask,
+                                                          T* __restrict__ gx, int B, int H, int W, int C, int p,
+                                                          float slope, long total) {
+    const int Hp = H + 2 * p, Wp = W + 2 * p;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        // padded rows that reflect onto y: y + p, plus p - y (top border) and 2(H-1) - y + p (bottom border)
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = y + p;
+        if (y >= 1 && y <= p) ys[ny++] = p - y;
+        if (y <= H - 2 && y >= H - 1 - p) ys[ny++] = 2 * (H - 1) - y + p;
+        xs[nx++] = x + p;
+        if (x >= 1 && x <= p) xs[nx++] = p - x;
+        if (x <= W - 2 && x >= W - 1 - p) xs[nx++] = 2 * (W - 1) - x + p;
+        float s = 0.f;
+        for (int a = 0; a < ny; ++a)
+            for (int q = 0; q < nx; ++q) s = s + Elt<T>::ld(gp + (((size_t)b * Hp + ys[a]) * Wp + xs[q]) * C + c);
+        if (mask) s = s * (Elt<T>::ld(mask + e) > 0.f ? 1.f : slope);
+        Elt<T>::st(gx + e, s);
+    }
+}
+
+__global__ void zero_kernel(float* p, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+extern "C" {
+
+int msmc_wn_prepare_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream) {
+    if (!items || nitems <= 0 || total_blocks <= 0) return MSMC_E_SHAPE;
+    MSMC_LAUNCH(wn_prepare_kernel, dim3(total_blocks), dim3(256), 0, (msmc_stream_t)stream, items, nitems);
+    return msmc_check_launch();
+}
+
+int msmc_wn_backward_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream) {
+    if (!items || nitems <= 0 || total_blocks <= 0) return MSMC_E_SHAPE;
+    MSMC_LAUNCH(wn_backward_kernel, dim3(total_blocks), dim3(256), 0, (msmc_stream_t)stream, items, nitems);
+    return msmc_check_launch();
+}
+
+int msmc_reflect_fold(const void* gp, const void* mask_src, void* gx, int B, int H, int W, int C, int p, float slope,
+                      int dtype, msmc_stream stream) {
+    if (!gp || !gx || B <= 0 || H <= p || W <= p || C <= 0 || p < 0) return MSMC_E_SHAPE;
+    const long total = (long)B * H * W * C;
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == 0)
+        MSMC_LAUNCH(reflect_fold_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream,
+                    (const float*)gp, (const float*)mask_src, (float*)gx, B, H, W, C, p, slope, total);
+    else if (dtype == 1)
+        MSMC_LAUNCH(reflect_fold_kernel<unsigned short>, dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream,
+                    (const unsigned short*)gp, (const unsigned short*)mask_src, (unsigned short*)gx, B, H, W, C, p,
+                    slope, total);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+
+int msmc_colsum(const void* g, float* out, long rows, int C, int dtype, msmc_stream stream) {
+    if (!g || !out || rows <= 0 || C <= 0) return MSMC_E_SHAPE;
+    MSMC_LAUNCH(zero_kernel, dim3((C + 255) / 256), dim3(256), 0, (msmc_stream_t)stream, out, C);
+    int rpb = 256;
+    while ((rows + rpb - 1) / rpb > 4096) rpb <<= 1;
+    dim3 grid((unsigned)((rows + rpb - 1) / rpb));
+    if (dtype == 0) MSMC_LAUNCH(colsum_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, (const float*)g, out, rows, C, rpb);
+    else if (dtype == 1) MSMC_LAUNCH(colsum_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)g, out, rows, C, rpb);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+
+}  // extern "C"

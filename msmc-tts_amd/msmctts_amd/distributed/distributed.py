@@ -87,7 +87,9 @@ class GradReducer(object):
             self._owner[id(p)] = b
 
     def _on_grad(self, p):
-        b = self._owner[id(p)]
+        b = self._owner.get(id(p))
+        if b is None or p.grad is None:      # e.g. the token edge of a HIP conv: its gradient arrives by hand later
+            return
         if id(p) in b.pending:
             b.pending.discard(id(p))
             b.ready.append(p)
@@ -128,4 +130,6 @@ def apply_gradient_allreduce(module, bucket_bytes=DEFAULT_BUCKET_BYTES):
     with torch.no_grad():
         broadcast_state(module, 0)
     module.grad_reducer = GradReducer(module, bucket_bytes)
+    from ..hip import convnet
+    convnet.GRAD_READY_HOOK = module.grad_reducer._on_grad      # HIP conv stacks deliver their gradients by hand
     return module

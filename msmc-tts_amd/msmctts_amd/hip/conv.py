@@ -37,7 +37,7 @@ class Geometry(object):
 
 
 def _fill(desc, x, w, out, B, Hin, Win, Cin, Hout, Wout, Cout, lattice, taps, pad_mode, bias=None, mask_src=None,
-          res=None, res2=None, in_slope=1.0, mask_slope=1.0, out_div=1.0):
+          res=None, res2=None, in_slope=1.0, mask_slope=1.0, out_div=1.0, out_slope=1.0):
     desc.x, desc.w, desc.out = lib.ptr(x), lib.ptr(w), lib.ptr(out)
     desc.bias = lib.ptr(bias, torch.float32) if bias is not None else None
     desc.mask_src = lib.ptr(mask_src) if mask_src is not None else None
@@ -53,6 +53,7 @@ def _fill(desc, x, w, out, B, Hin, Win, Cin, Hout, Wout, Cout, lattice, taps, pa
         desc.tap_dy[t], desc.tap_dx[t], desc.tap_w[t] = dy, dx, ws
     desc.pad_mode = pad_mode
     desc.in_slope, desc.mask_slope, desc.out_div = float(in_slope), float(mask_slope), float(out_div)
+    desc.out_slope = float(out_slope)
     return desc
 
 
@@ -62,7 +63,7 @@ def _check(x, w, *others):
         assert t is None or (t.dtype == x.dtype and t.is_contiguous()), 'epilogue operands share the activation dtype'
 
 
-def conv_forward(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, out_div=1.0):
+def conv_forward(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, out_div=1.0, out_slope=1.0):
     """x [B,Hin,Win,Cin] -> [B,Hout,Wout,Cout];  w [kh*kw, Cout, Cin]."""
     _check(x, w, res, res2)
     B, Hin, Win, Cin = x.shape
@@ -72,7 +73,8 @@ def conv_forward(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, out_d
     taps = [(ky * geom.dy, kx * geom.dx, ky * geom.kw + kx) for ky in range(geom.kh) for kx in range(geom.kw)]
     lattice = (geom.Hout, geom.Wout, 0, 1, 0, 1, geom.sy, geom.sx, -geom.py, -geom.px)
     d = _fill(lib.ConvDesc(), x, w, out, B, Hin, Win, Cin, geom.Hout, geom.Wout, Cout, lattice, taps,
-              1 if geom.reflect else 0, bias=bias, res=res, res2=res2, in_slope=in_slope, out_div=out_div)
+              1 if geom.reflect else 0, bias=bias, res=res, res2=res2, in_slope=in_slope, out_div=out_div,
+              out_slope=out_slope)
     lib.check(lib.get().msmc_conv_gather(ctypes.byref(d), lib.stream(x)), 'msmc_conv_gather')
     return out
 
@@ -153,4 +155,60 @@ def conv_transpose1d_dgrad(g, wb, k, stride, padding, Lin, mask_src=None, mask_s
     d = _fill(lib.ConvDesc(), g, wb, gx, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, mask_src=mask_src,
               mask_slope=mask_slope)
     lib.check(lib.get().msmc_conv_gather(ctypes.byref(d), lib.stream(g)), 'msmc_conv_gather(convT dgrad)')
+    return gx
+
+
+def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None):
+    """dW [kh*kw, Cout, Cin] fp32 of ``conv_forward`` (x [B,Hin,Win,Cin] pre-activation, g [B,Hout,Wout,Cout])."""
+    _check(x, g)
+    B, Hin, Win, Cin = x.shape
+    Cout = g.shape[3]
+    assert g.shape[1:3] == (geom.Hout, geom.Wout)
+    if dw is None:
+        dw = torch.zeros((n_slices, Cout, Cin), dtype=torch.float32, device=x.device)
+    taps = [(ky * geom.dy, kx * geom.dx, ky * geom.kw + kx) for ky in range(geom.kh) for kx in range(geom.kw)]
+    lattice = (geom.Hout, geom.Wout, 0, 1, 0, 1, geom.sy, geom.sx, -geom.py, -geom.px)
+    d = _fill(lib.ConvDesc(), x, x, x, B, Hin, Win, Cin, geom.Hout, geom.Wout, Cout, lattice, taps,
+              1 if geom.reflect else 0, in_slope=in_slope)
+    lib.check(lib.get().msmc_conv_wgrad(ctypes.byref(d), lib.ptr(g), lib.ptr(dw, torch.float32), lib.stream(x)),
+              'msmc_conv_wgrad')
+    return dw
+
+
+def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None):
+    """dW [k, Cin, Cout] fp32 of ``conv_transpose1d_forward`` (x [B,1,Lin,Cin] pre-activation, g [B,1,Lout,Cout]):
+    dW[k][ci][co] = sum_q act(x[q][ci]) * g[q*stride + k - padding][co]  -- the weight gradient of the strided
+    convolution fine -> coarse with the operand roles swapped (the activation rides on the 'gradient' operand)."""
+    _check(x, g)
+    B, _, Lin, Cin = x.shape
+    Lout, Cout = g.shape[2], g.shape[3]
+    if dw is None:
+        dw = torch.zeros((k, Cin, Cout), dtype=torch.float32, device=x.device)
+    taps = [(0, kk, kk) for kk in range(k)]
+    lattice = (1, Lin, 0, 1, 0, 1, 1, stride, 0, -padding)
+    # kernel roles: "x" = g (fine, channels Cout), "g" = x (coarse, channels Cin) -> dw[k][Cin][Cout]
+    d = _fill(lib.ConvDesc(), g, g, g, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, in_slope=1.0,
+              mask_slope=in_slope)
+    lib.check(lib.get().msmc_conv_wgrad(ctypes.byref(d), lib.ptr(x), lib.ptr(dw, torch.float32), lib.stream(x)),
+              'msmc_conv_wgrad(convT)')
+    return dw
+
+
+def colsum(g2d):
+    """g [rows, C] (fp32 / bf16) -> fp32 [C] column sums (bias gradient)."""
+    rows, C = g2d.shape
+    out = torch.empty(C, dtype=torch.float32, device=g2d.device)
+    lib.check(lib.get().msmc_colsum(lib.ptr(g2d), lib.ptr(out), rows, C, _DT[g2d.dtype], lib.stream(g2d)),
+              'msmc_colsum')
+    return out
+
+
+def reflect_fold(gp, H, W, p=1, mask_src=None, slope=1.0):
+    """Backward of ReflectionPad2d(p) (+ leaky-ReLU' mask): gp [B,H+2p,W+2p,C] -> gx [B,H,W,C]."""
+    B, C = gp.shape[0], gp.shape[3]
+    assert gp.shape[1:3] == (H + 2 * p, W + 2 * p) and gp.is_contiguous()
+    gx = torch.empty((B, H, W, C), dtype=gp.dtype, device=gp.device)
+    lib.check(lib.get().msmc_reflect_fold(lib.ptr(gp), lib.ptr(mask_src) if mask_src is not None else None,
+                                          lib.ptr(gx), B, H, W, C, p, float(slope), _DT[gp.dtype], lib.stream(gp)),
+              'msmc_reflect_fold')
     return gx

@@ -1,0 +1,208 @@
+"""Weight-normalised convolution stacks on the gfx950 implicit-GEMM kernels.
+
+``ConvBank`` owns, for all weight-normalised convolutions of one top-level network (HifiGAN generator,
+UnivNet discriminator):
+  * the kernel-layout weights (forward slices ``[T, Cout, Cin]`` and data-gradient slices
+    ``[T, Cin, Cout]`` in the compute dtype), refreshed from ``weight_v / weight_g`` by ONE
+    ``msmc_wn_prepare_multi`` launch per forward pass of the network;
+  * fp32 weight-gradient accumulators in kernel layout, filled by ``msmc_conv_wgrad`` from each
+    convolution's backward, and turned into ``weight_v.grad / weight_g.grad / bias.grad`` by ONE
+    ``msmc_wn_backward_multi`` launch at the end of the backward pass (autograd engine callback).
+``hip_conv`` is the autograd function of one fused convolution
+    out = lrelu_out( (res2 + ((conv(lrelu_in(x)) + bias) + res)) / div ).
+Activations are channels-last ``[B, H, W, C]`` (1-D signals: H == 1), float32 or bfloat16.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Variable
+
+from . import conv as K
+from . import lib
+
+
+# Set by msmctts_amd.distributed.distributed.apply_gradient_allreduce: callable(param) telling the
+# data-parallel reducer that a parameter gradient produced outside autograd's accumulation is ready.
+GRAD_READY_HOOK = None
+
+
+class ConvLayer(object):
+    """Static description of one weight-normalised convolution inside a bank."""
+
+    def __init__(self, module, kind, kernel, stride=(1, 1), dilation=(1, 1), padding=(0, 0), reflect=False):
+        self.module = module            # owns bias / weight_g / weight_v parameters
+        self.kind = kind                # 'conv' (Conv1d as (1,k) / Conv2d) or 'convT' (ConvTranspose1d)
+        self.kernel, self.stride, self.dilation, self.padding, self.reflect = kernel, stride, dilation, padding, reflect
+        self.taps = kernel[0] * kernel[1]
+        v = module.weight_v
+        if kind == 'conv':
+            self.cout, self.cin = v.shape[0], v.shape[1]
+        else:
+            self.cin, self.cout = v.shape[0], v.shape[1]
+        # filled by the bank
+        self.wf = self.wb = self.dw = self.db = None
+        self.index = -1
+        self._geoms = {}
+
+    def geom(self, H, W):
+        key = (H, W)
+        g = self._geoms.get(key)
+        if g is None:
+            g = self._geoms[key] = K.Geometry(H, W, self.kernel, self.stride, self.dilation, self.padding, self.reflect)
+        return g
+
+
+class ConvBank(object):
+    def __init__(self, layers):
+        self.layers = list(layers)
+        for i, l in enumerate(self.layers):
+            l.index = i
+        self._sig = None
+        self._queued = False
+
+    # -- (re)build device buffers whenever parameters moved / changed dtype ------------------------
+    def _signature(self, dtype):
+        return (dtype,) + tuple(l.module.weight_v.data_ptr() for l in self.layers)
+
+    def _build(self, dtype):
+        dev = self.layers[0].module.weight_v.device
+        pad8 = lambda n: (n + 7) // 8 * 8                 # every layer's slices start 16-byte aligned (vector loads)
+        tot_w = sum(pad8(l.taps * l.cout * l.cin) for l in self.layers)
+        tot_a = sum(l.module.weight_v.shape[0] for l in self.layers)
+        tot_b = sum(l.cout for l in self.layers)
+        self.w1 = torch.empty(tot_w, dtype=dtype, device=dev)            # layout 1 (the layout dW is produced in)
+        self.w2 = torch.empty(tot_w, dtype=dtype, device=dev)            # layout 2
+        self.dw = torch.zeros(tot_w, dtype=torch.float32, device=dev)
+        self.gv = torch.empty(tot_w, dtype=torch.float32, device=dev)
+        self.inv_norm = torch.empty(tot_a, dtype=torch.float32, device=dev)
+        self.gg = torch.empty(tot_a, dtype=torch.float32, device=dev)
+        self.db = torch.zeros(tot_b, dtype=torch.float32, device=dev)
+        items = (lib.WnItem * len(self.layers))()
+        ow = oa = ob = blk = 0
+        esz = self.w1.element_size()
+        for l, it in zip(self.layers, items):
+            v, g = l.module.weight_v, l.module.weight_g
+            n = l.taps * l.cout * l.cin
+            A = v.shape[0]
+            it.v, it.g = v.data_ptr(), g.data_ptr()
+            it.dst1, it.dst2 = self.w1.data_ptr() + ow * esz, self.w2.data_ptr() + ow * esz
+            it.inv_norm = self.inv_norm.data_ptr() + oa * 4
+            it.dw, it.gv, it.gg = self.dw.data_ptr() + ow * 4, self.gv.data_ptr() + ow * 4, self.gg.data_ptr() + oa * 4
+            it.A, it.Bc, it.T = A, v.shape[1], l.taps
+            it.dtype = 0 if dtype == torch.float32 else 1
+            it.block0 = blk
+            w1 = self.w1[ow:ow + n]
+            w2 = self.w2[ow:ow + n]
+            dw = self.dw[ow:ow + n]
+            if l.kind == 'conv':           # v (Cout, Cin, T): a = co, b = ci
+                it.s1[0], it.s1[1], it.s1[2] = l.cout * l.cin, l.cin, 1          # [T][Cout][Cin]  forward + dW
+                it.s2[0], it.s2[1], it.s2[2] = l.cout * l.cin, 1, l.cout          # [T][Cin][Cout]  data gradient
+                l.wf, l.wb = w1.view(l.taps, l.cout, l.cin), w2.view(l.taps, l.cin, l.cout)
+                l.dw = dw.view(l.taps, l.cout, l.cin)
+            else:                          # v (Cin, Cout, T): a = ci, b = co
+                it.s1[0], it.s1[1], it.s1[2] = l.cout * l.cin, l.cout, 1          # [T][Cin][Cout]  data gradient + dW
+                it.s2[0], it.s2[1], it.s2[2] = l.cout * l.cin, 1, l.cin           # [T][Cout][Cin]  forward
+                l.wb, l.wf = w1.view(l.taps, l.cin, l.cout), w2.view(l.taps, l.cout, l.cin)
+                l.dw = dw.view(l.taps, l.cin, l.cout)
+            l.db = self.db[ob:ob + l.cout]
+            l.gv_view = self.gv[ow:ow + n].view_as(v)
+            l.gg_view = self.gg[oa:oa + A].view_as(g)
+            ow, oa, ob, blk = ow + pad8(n), oa + A, ob + l.cout, blk + A
+        self.total_blocks = blk
+        raw = bytes(items)
+        self.items_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.dtype = dtype
+
+    def prepare(self, dtype):
+        """Refresh kernel-layout weights from (weight_v, weight_g): one launch for the whole network."""
+        sig = self._signature(dtype)
+        if sig != self._sig:
+            self._build(dtype)
+            self._sig = sig
+        lib.check(lib.get().msmc_wn_prepare_multi(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
+                                                  lib.stream(self.w1)), 'msmc_wn_prepare_multi')
+
+    # -- end-of-backward: kernel-layout dW -> parameter gradients --------------------------------------
+    def _queue_finish(self):
+        if not self._queued:
+            self._queued = True
+            Variable._execution_engine.queue_callback(self._finish_backward)
+
+    def _finish_backward(self):
+        self._queued = False
+        lib.check(lib.get().msmc_wn_backward_multi(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
+                                                   lib.stream(self.w1)), 'msmc_wn_backward_multi')
+        with torch.no_grad():
+            for l in self.layers:
+                m = l.module
+                if not m.weight_v.requires_grad:
+                    continue
+                for p, gview in ((m.bias, l.db), (m.weight_g, l.gg_view), (m.weight_v, l.gv_view)):
+                    if p.grad is None:
+                        p.grad = gview.clone()
+                    else:
+                        p.grad.add_(gview)
+                    if GRAD_READY_HOOK is not None:
+                        GRAD_READY_HOOK(p)
+            self.dw.zero_()
+            self.db.zero_()
+
+
+class _HipConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, res2, weight_token, bank, layer, in_slope, out_slope, out_div):
+        m = layer.module
+        if layer.kind == 'conv':
+            geom = layer.geom(x.shape[1], x.shape[2])
+            out = K.conv_forward(x, layer.wf, geom, bias=m.bias, in_slope=in_slope, res=res, res2=res2,
+                                 out_div=out_div, out_slope=out_slope)
+        else:
+            assert res is None and res2 is None and out_div == 1.0 and out_slope == 1.0
+            out = K.conv_transpose1d_forward(x, layer.wf, layer.kernel[1], layer.stride[1], layer.padding[1],
+                                             bias=m.bias, in_slope=in_slope)
+        ctx.bank, ctx.layer = bank, layer
+        ctx.in_slope, ctx.out_slope, ctx.out_div = in_slope, out_slope, out_div
+        ctx.has_res, ctx.has_res2 = res is not None, res2 is not None
+        ctx.need_w = m.weight_v.requires_grad
+        ctx.save_for_backward(x, out if out_slope != 1.0 else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, out = ctx.saved_tensors
+        layer, bank = ctx.layer, ctx.bank
+        g = g.contiguous()
+        if ctx.out_slope != 1.0:                       # y = lrelu(z): dz = dy * (y > 0 ? 1 : slope)
+            g = g * torch.where(out > 0, 1.0, ctx.out_slope).to(g.dtype)
+        if ctx.out_div != 1.0:
+            g = g / ctx.out_div
+        gx = None
+        if ctx.needs_input_grad[0]:
+            mask = x if ctx.in_slope != 1.0 else None
+            if layer.kind == 'conv':
+                geom = layer.geom(x.shape[1], x.shape[2])
+                if layer.reflect:
+                    gp = K.conv_dgrad(g, layer.wb, geom)
+                    gx = K.reflect_fold(gp, x.shape[1], x.shape[2], layer.padding[0], mask_src=mask,
+                                        slope=ctx.in_slope)
+                else:
+                    gx = K.conv_dgrad(g, layer.wb, geom, mask_src=mask, mask_slope=ctx.in_slope)
+            else:
+                gx = K.conv_transpose1d_dgrad(g, layer.wb, layer.kernel[1], layer.stride[1], layer.padding[1],
+                                              x.shape[2], mask_src=mask, mask_slope=ctx.in_slope)
+        if ctx.need_w:
+            if layer.kind == 'conv':
+                K.conv_wgrad(x, g, layer.geom(x.shape[1], x.shape[2]), layer.taps, in_slope=ctx.in_slope, dw=layer.dw)
+            else:
+                K.conv_transpose1d_wgrad(x, g, layer.kernel[1], layer.stride[1], layer.padding[1],
+                                         in_slope=ctx.in_slope, dw=layer.dw)
+            layer.db.add_(K.colsum(g.reshape(-1, g.shape[-1])))
+            bank._queue_finish()
+        # weight_token (the layer's weight_v) only ties the output to the parameters in the autograd graph;
+        # parameter gradients are produced in kernel layout and delivered by ConvBank._finish_backward.
+        return gx, (g if ctx.has_res else None), (g if ctx.has_res2 else None), None, None, None, None, None, None
+
+
+def hip_conv(bank, layer, x, res=None, res2=None, in_slope=1.0, out_slope=1.0, out_div=1.0):
+    return _HipConv.apply(x, res, res2, layer.module.weight_v, bank, layer, float(in_slope), float(out_slope),
+                          float(out_div))

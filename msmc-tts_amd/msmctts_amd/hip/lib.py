@@ -39,11 +39,23 @@ class ConvDesc(ctypes.Structure):
                 ('Cout', _i), ('QH', _i), ('QW', _i), ('oy0', _i), ('osy', _i), ('ox0', _i), ('osx', _i),
                 ('isy', _i), ('isx', _i), ('iy0', _i), ('ix0', _i), ('ntaps', _i),
                 ('tap_dy', _i * MAX_TAPS), ('tap_dx', _i * MAX_TAPS), ('tap_w', _i * MAX_TAPS),
-                ('pad_mode', _i), ('in_slope', _f), ('mask_slope', _f), ('out_div', _f)]
+                ('pad_mode', _i), ('in_slope', _f), ('mask_slope', _f), ('out_div', _f), ('out_slope', _f)]
+
+
+class WnItem(ctypes.Structure):
+    """msmc_wn_item of include/msmc_hip.h."""
+    _fields_ = [('v', _vp), ('g', _vp), ('dst1', _vp), ('dst2', _vp), ('inv_norm', _vp), ('dw', _vp), ('gv', _vp),
+                ('gg', _vp), ('s1', ctypes.c_long * 3), ('s2', ctypes.c_long * 3), ('A', _i), ('Bc', _i), ('T', _i),
+                ('dtype', _i), ('block0', _i), ('pad_', _i)]
 
 
 _SIGNATURES.update({
     'msmc_conv_gather': (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    'msmc_conv_wgrad': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp]),
+    'msmc_wn_prepare_multi': (_i, [_vp, _i, _i, _vp]),
+    'msmc_wn_backward_multi': (_i, [_vp, _i, _i, _vp]),
+    'msmc_colsum': (_i, [_vp, _vp, ctypes.c_long, _i, _i, _vp]),
+    'msmc_reflect_fold': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
 })
 
 

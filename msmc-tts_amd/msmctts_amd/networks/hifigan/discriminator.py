@@ -9,9 +9,15 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...hip.convnet import ConvBank, hip_conv
 from ...utils.audio import TorchSTFT
 from ..layers import WNConv2d
 from .common import get_padding
+
+# Arithmetic: channels-last on the gfx950 implicit-GEMM kernels (csrc/conv.hip).  MPD fuses each
+# leaky-ReLU into the consuming convolution's load (its feature maps are the raw outputs); MRD fuses it
+# into the producing convolution's epilogue (its feature maps are the activated outputs) and the
+# ReflectionPad2d into the load; feature maps are handed to the trainer as NCHW-shaped views.
 
 LRELU_SLOPE = 0.2
 
@@ -38,14 +44,19 @@ class DiscriminatorR(nn.Module):
             _Stage(WNConv2d(chans[i], chans[i + 1], (3, 3), (strides[i], strides[i]), reflect_pad=1), i == 0)
             for i in range(7)])
 
-    def forward(self, x):
+    def hip_layers(self):
+        return [st._modules[st.key].hip_layer() for st in self.discriminator]
+
+    def forward_hip(self, bank, layers, img, dtype):
+        """img (B, 2, F, T') -> (score (B, 1, F'', T''), 6 activated feature maps as NCHW-shaped views)."""
+        x = img.permute(0, 2, 3, 1).contiguous().to(dtype)
         fmaps = []
-        for i, stage in enumerate(self.discriminator):
-            if i > 0:
-                x = F.leaky_relu(x, LRELU_SLOPE)
-                fmaps.append(x)                      # aliased post-activation map, see module docstring
-            x = stage(x)
-        return x, fmaps
+        last = len(layers) - 1
+        for i, layer in enumerate(layers):
+            x = hip_conv(bank, layer, x, out_slope=LRELU_SLOPE if i < last else 1.0)
+            if i < last:
+                fmaps.append(x.permute(0, 3, 1, 2))      # aliased post-activation map, see module docstring
+        return x.permute(0, 3, 1, 2), fmaps
 
 
 class MultiResolutionDiscriminator(nn.Module):
@@ -59,12 +70,12 @@ class MultiResolutionDiscriminator(nn.Module):
         self.discriminators = nn.ModuleList([DiscriminatorR(2 if domain == 'double' else 1, c)
                                              for _, c in zip(hop_lengths, hidden_channels)])
 
-    def forward(self, x):
+    def forward_hip(self, bank, layers, x, dtype):
         scores, feats = [], []
-        for stft, disc in zip(self.stfts, self.discriminators):
+        for stft, disc, ls in zip(self.stfts, self.discriminators, layers):
             mag, _ = stft.transform(x.squeeze(1) if x.dim() == 3 else x)
             mag = torch.stack(torch.chunk(mag, 2, dim=1), dim=1) if self.domain == 'double' else mag.unsqueeze(1)
-            s, f = disc(mag)
+            s, f = disc.forward_hip(bank, ls, mag, dtype)
             scores.append(s)
             feats.append(f)
         return scores, feats
@@ -83,19 +94,22 @@ class DiscriminatorP(nn.Module):
             WNConv2d(c4, c4, (5, 1), (1, 1), (2, 0))])
         self.conv_post = WNConv2d(c4, 1, (3, 1), (1, 1), (1, 0))
 
-    def forward(self, x):
+    def hip_layers(self):
+        return [c.hip_layer() for c in self.convs] + [self.conv_post.hip_layer()]
+
+    def forward_hip(self, bank, layers, x, dtype):
+        """x (B, 1, L) -> (flat score, 5 raw feature maps as NCHW-shaped views)."""
         fmap = []
         b, c, t = x.shape
         if t % self.period != 0:
             n_pad = self.period - (t % self.period)
             x = F.pad(x, (0, n_pad), 'reflect')
             t = t + n_pad
-        x = x.view(b, c, t // self.period, self.period)
-        for conv in self.convs:
-            x = conv(x)
-            fmap.append(x)
-            x = F.leaky_relu(x, LRELU_SLOPE)
-        x = self.conv_post(x)
+        x = x.reshape(b, t // self.period, self.period, 1).to(dtype)        # C == 1: NCHW and NHWC coincide
+        for i, layer in enumerate(layers[:-1]):
+            x = hip_conv(bank, layer, x, in_slope=LRELU_SLOPE if i > 0 else 1.0)
+            fmap.append(x.permute(0, 3, 1, 2))
+        x = hip_conv(bank, layers[-1], x, in_slope=LRELU_SLOPE)
         return torch.flatten(x, 1, -1), fmap
 
 
@@ -104,10 +118,10 @@ class MultiPeriodDiscriminator(nn.Module):
         super().__init__()
         self.discriminators = nn.ModuleList([DiscriminatorP(p, channels, max_channels) for p in periods])
 
-    def forward(self, y):
+    def forward_hip(self, bank, layers, y, dtype):
         outs, fmaps = [], []
-        for d in self.discriminators:
-            o, f = d(y)
+        for d, ls in zip(self.discriminators, layers):
+            o, f = d.forward_hip(bank, ls, y, dtype)
             outs.append(o)
             fmaps.append(f)
         return outs, fmaps
@@ -118,10 +132,22 @@ class Discriminator(nn.Module):
         super().__init__()
         self.mrd = MultiResolutionDiscriminator(**mrd_config)
         self.mpd = MultiPeriodDiscriminator(**mpd_config)
+        self.hip_dtype = torch.float32        # compute dtype of the kernels (trainer sets bfloat16 for bf16 runs)
+        self._bank = None
+
+    def _hip(self):
+        if self._bank is None:
+            mrd = [d.hip_layers() for d in self.mrd.discriminators]
+            mpd = [d.hip_layers() for d in self.mpd.discriminators]
+            self._bank = ConvBank([l for ls in mrd + mpd for l in ls])
+            self._layers = (mrd, mpd)
+        return self._bank, self._layers
 
     def forward(self, y):
         if y.dim() == 2:
             y = y.unsqueeze(1)
-        s1, f1 = self.mrd(y)
-        s2, f2 = self.mpd(y)
+        bank, (mrd, mpd) = self._hip()
+        bank.prepare(self.hip_dtype)
+        s1, f1 = self.mrd.forward_hip(bank, mrd, y, self.hip_dtype)
+        s2, f2 = self.mpd.forward_hip(bank, mpd, y, self.hip_dtype)
         return s1 + s2, f1 + f2

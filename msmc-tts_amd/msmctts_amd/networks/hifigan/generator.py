@@ -1,8 +1,15 @@
-"""HifiGAN generator (drop-in for reference msmctts/networks/hifigan/generator.py:10-64)."""
+"""HifiGAN generator (drop-in for reference msmctts/networks/hifigan/generator.py:10-64).
+
+Same constructor, parameter names and numerics; the arithmetic runs channels-last on the gfx950
+implicit-GEMM kernels (csrc/conv.hip): every leaky-ReLU is fused into the consuming convolution's
+load, the residual add, the sum over the three parallel ResBlocks and the ``/ num_kernels`` into
+the producing convolution's epilogue, the transposed convolutions are phase-decomposed gathers and
+weight norm is folded into one weight-preparation launch per forward.
+"""
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
+from ...hip.convnet import ConvBank, hip_conv
 from ..layers import WNConv1d, WNConvTranspose1d
 from .common import LRELU_SLOPE, ResBlock1
 
@@ -26,14 +33,39 @@ class Generator(nn.Module):
                 self.resblocks.append(ResBlock1(ch, k, d))
         self.conv_post = WNConv1d(ch, 1, 7, 1, padding=3)
 
+        self.hip_dtype = torch.float32        # compute dtype of the kernels (trainer sets bfloat16 for bf16 runs)
+        self._bank = None
+
+    def _hip(self):
+        if self._bank is None:
+            L = {'pre': self.conv_pre.hip_layer(), 'post': self.conv_post.hip_layer(),
+                 'ups': [u.hip_layer() for u in self.ups],
+                 'rb': [([c.hip_layer() for c in rb.convs1], [c.hip_layer() for c in rb.convs2])
+                        for rb in self.resblocks]}
+            flat = [L['pre']] + L['ups'] + [c for a, b in L['rb'] for c in a + b] + [L['post']]
+            self._bank, self._layers = ConvBank(flat), L
+        return self._bank, self._layers
+
     def forward(self, mel):
-        x = self.conv_pre(mel)
+        """mel (B, C, T) -> waveform (B, 1, T * prod(upsample_rates)), float32."""
+        bank, L = self._hip()
+        bank.prepare(self.hip_dtype)
+        nk = self.num_kernels
+        x = mel.transpose(1, 2).unsqueeze(1).contiguous().to(self.hip_dtype)          # channels-last [B, 1, T, C]
+        x = hip_conv(bank, L['pre'], x)
         for i in range(self.num_upsamples):
-            x = self.ups[i](F.leaky_relu(x, LRELU_SLOPE))
+            x = hip_conv(bank, L['ups'][i], x, in_slope=LRELU_SLOPE)
             xs = None
-            for j in range(self.num_kernels):
-                y = self.resblocks[i * self.num_kernels + j](x)
-                xs = y if xs is None else xs + y
-            x = xs / self.num_kernels
-        x = self.conv_post(F.leaky_relu(x))          # default slope 0.01, as the reference (generator.py:52)
-        return torch.tanh(x)
+            for j in range(nk):
+                c1s, c2s = L['rb'][i * nk + j]
+                y = x
+                for m in range(len(c1s)):
+                    t = hip_conv(bank, c1s[m], y, in_slope=LRELU_SLOPE)
+                    if m < len(c1s) - 1:
+                        y = hip_conv(bank, c2s[m], t, res=y, in_slope=LRELU_SLOPE)
+                    else:                          # block output, running sum over blocks and the final mean
+                        xs = hip_conv(bank, c2s[m], t, res=y, res2=xs, in_slope=LRELU_SLOPE,
+                                      out_div=float(nk) if j == nk - 1 else 1.0)
+            x = xs
+        x = hip_conv(bank, L['post'], x, in_slope=0.01)       # F.leaky_relu default slope (generator.py:52)
+        return torch.tanh(x.float()).reshape(x.shape[0], 1, x.shape[2])

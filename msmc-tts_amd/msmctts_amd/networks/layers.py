@@ -1,5 +1,10 @@
 """Weight-normalised convolution layers holding the reference's parameter names.
 
+These modules are parameter holders: inside the HifiGAN generator and the discriminators the arithmetic
+runs through ``hip_layer()`` on the gfx950 implicit-GEMM kernels (msmctts_amd/hip/convnet.py).  Their
+``forward`` (stock ATen ops) serves the small prior-predictor stack, which SURVEY.md 8a leaves on
+PyTorch-ROCm operators in this round.
+
 The reference wraps ``torch.nn.Conv*`` in old-style ``torch.nn.utils.weight_norm`` (e.g.
 hifigan/common.py:24-41, generator.py:22-35, discriminator.py:23-25,125-132, vqgantts/modules.py:209-226),
 which stores ``weight_g`` (norm over all dims but 0) and ``weight_v`` next to ``bias`` -- those
@@ -11,6 +16,8 @@ import math
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from ..hip.convnet import ConvLayer
 
 
 def _default_conv_init(weight, bias):
@@ -45,6 +52,10 @@ class WNConv1d(_WNConvNd):
     def forward(self, x):
         return F.conv1d(x, self.weight(), self.bias, self.stride, self.padding, self.dilation)
 
+    def hip_layer(self):
+        return ConvLayer(self, 'conv', (1, self.weight_v.shape[2]), (1, self.stride), (1, self.dilation),
+                         (0, self.padding))
+
 
 class WNConvTranspose1d(_WNConvNd):
     """ConvTranspose1d: weight layout (C_in, C_out, k); weight norm is over dim 0 == C_in."""
@@ -55,6 +66,9 @@ class WNConvTranspose1d(_WNConvNd):
 
     def forward(self, x):
         return F.conv_transpose1d(x, self.weight(), self.bias, self.stride, self.padding)
+
+    def hip_layer(self):
+        return ConvLayer(self, 'convT', (1, self.weight_v.shape[2]), (1, self.stride), (1, 1), (0, self.padding))
 
 
 class WNConv2d(_WNConvNd):
@@ -68,3 +82,8 @@ class WNConv2d(_WNConvNd):
             p = self.reflect_pad
             x = F.pad(x, (p, p, p, p), mode='reflect')
         return F.conv2d(x, self.weight(), self.bias, self.stride, self.padding)
+
+    def hip_layer(self):
+        pad = (self.reflect_pad, self.reflect_pad) if self.reflect_pad else self.padding
+        return ConvLayer(self, 'conv', tuple(self.weight_v.shape[2:]), self.stride, (1, 1), pad,
+                         reflect=bool(self.reflect_pad))

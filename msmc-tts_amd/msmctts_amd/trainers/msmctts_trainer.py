@@ -83,6 +83,7 @@ class VQGANTrainer(BaseTrainer):
         elif stft_loss_func == 'mr_stft':
             self.stft_criterion = MultiResolutionSTFTLoss(**dict(stft_loss_config or {}))
         self.rng = random              # python global RNG, like the reference (:214); tests inject their own
+        self._amp_applied = None
         self.amp_dtype = None          # e.g. torch.bfloat16: autocast for the GEMM/conv bodies (VQ search stays fp32)
 
     def random_select(self, mel_length):
@@ -96,6 +97,11 @@ class VQGANTrainer(BaseTrainer):
         return frame_windows, sample_windows
 
     def _amp(self):
+        if self._amp_applied is not self.amp_dtype:          # tell the HIP conv stacks their compute dtype
+            for m in self.model.modules():
+                if hasattr(m, 'hip_dtype'):
+                    m.hip_dtype = self.amp_dtype or torch.float32
+            self._amp_applied = self.amp_dtype
         if self.amp_dtype is None:
             return contextlib.nullcontext()
         device_type = next(self.model.parameters()).device.type

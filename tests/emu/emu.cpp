@@ -1,14 +1,37 @@
 // tests/emu/emu.cpp -- fiber scheduler behind tests/emu/msmc_rt.hpp.  TEST INFRASTRUCTURE ONLY.
 //
-// One workgroup runs at a time; every work-item is a ucontext fiber.  A fiber runs until it
-// reaches a workgroup barrier or a wave-collective, then yields to the round-robin scheduler,
-// which releases a barrier once every live work-item (of the workgroup / of that wave) is waiting
-// on it.  Divergent barriers and collectives with a partially exited wave abort with a message.
+// One workgroup runs at a time; every work-item is a fiber with its own stack (hand-rolled x86-64
+// context switch: callee-saved registers + stack pointer, no signal-mask syscalls).  A fiber runs
+// until it reaches a workgroup barrier or a wave-collective, then yields to the round-robin
+// scheduler, which releases a barrier once every live work-item (of the workgroup / of that wave)
+// is waiting on it.  Divergent barriers and collectives with a partially exited wave abort.
 #include <msmc_rt.hpp>
 
-#include <ucontext.h>
-
 #include <vector>
+
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch,.-emu_switch
+)");
 
 namespace emu {
 dim3 tid, bid, bdim, gdim;
@@ -17,34 +40,48 @@ char* dyn_lds = nullptr;
 namespace {
 enum { READY = 0, AT_BLOCK = 1, AT_WAVE = 2, DONE = 3 };
 struct Fiber {
-    ucontext_t ctx;
+    void* sp;
     char* stack;
     int state;
+    int ncoll;          // collectives completed by this lane (selects the exchange-slot parity)
     dim3 id;
 };
 const size_t kStack = 256 * 1024;
 std::vector<Fiber> fibers;
-ucontext_t sched_ctx;
+void* sched_sp = nullptr;
 int cur = -1;
 void (*g_body)(void*) = nullptr;
 void* g_closure = nullptr;
-std::vector<uint32_t> slots;        // [waves][64][8]
+std::vector<uint32_t> slots;        // [waves][2 parities][64][32]  (128-byte slots)
+std::vector<int> computed;          // per wave: collective count whose group computation is done
 std::vector<char> lds_buf;
 
 void yield_as(int st) {
     fibers[cur].state = st;
-    swapcontext(&fibers[cur].ctx, &sched_ctx);
+    emu_switch(&fibers[cur].sp, sched_sp);
 }
 void entry() {
     g_body(g_closure);
     fibers[cur].state = DONE;
-    swapcontext(&fibers[cur].ctx, &sched_ctx);
+    emu_switch(&fibers[cur].sp, sched_sp);
+    abort();
 }
 }  // namespace
 
 int lane() { return cur & 63; }
 int wave() { return cur >> 6; }
-uint32_t* slot(int lane_index) { return &slots[((size_t)wave() * 64 + lane_index) * 8]; }
+// Exchange slots are double-buffered per wave: a lane can be at most one collective ahead of the
+// slowest lane of its wave, so one barrier per collective suffices.
+uint32_t* slot(int lane_index) {
+    return &slots[(((size_t)wave() * 2 + (fibers[cur].ncoll & 1)) * 64 + lane_index) * 32];
+}
+void collective_done() { ++fibers[cur].ncoll; }
+bool first_after_barrier() {
+    const int w = wave(), id = fibers[cur].ncoll + 1;
+    if (computed[w] == id) return false;
+    computed[w] = id;
+    return true;
+}
 void block_barrier() { yield_as(AT_BLOCK); }
 void wave_barrier() { yield_as(AT_WAVE); }
 
@@ -56,15 +93,18 @@ static void run_block(dim3 block) {
         fibers.resize(n);
         for (size_t i = old; i < (size_t)n; ++i) fibers[i].stack = (char*)malloc(kStack);
     }
-    slots.assign((size_t)(n / 64) * 64 * 8, 0);
+    slots.assign((size_t)(n / 64) * 2 * 64 * 32, 0);
+    computed.assign(n / 64, 0);
     for (int i = 0; i < n; ++i) {
         Fiber& f = fibers[i];
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = kStack;
-        f.ctx.uc_link = &sched_ctx;
-        makecontext(&f.ctx, (void (*)())entry, 0);
+        // initial frame: 6 callee-saved registers (popped by emu_switch) then the return address
+        uintptr_t top = ((uintptr_t)(f.stack + kStack)) & ~(uintptr_t)15;
+        void** sp = (void**)(top - 8);           // so that rsp % 16 == 8 on entry, as after a call
+        *--sp = (void*)entry;
+        for (int r = 0; r < 6; ++r) *--sp = nullptr;
+        f.sp = sp;
         f.state = READY;
+        f.ncoll = 0;
         f.id = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
     }
     for (;;) {
@@ -74,13 +114,12 @@ static void run_block(dim3 block) {
             if (fibers[i].state == READY) {
                 cur = i;
                 tid = fibers[i].id;
-                swapcontext(&sched_ctx, &fibers[i].ctx);
+                emu_switch(&sched_sp, fibers[i].sp);
                 progressed = true;
             }
             if (fibers[i].state == DONE) ++done;
         }
         if (done == n) break;
-        // wave-level releases
         for (int w = 0; w < n / 64; ++w) {
             int waiting = 0, live = 0;
             for (int l = 0; l < 64; ++l) {
@@ -94,7 +133,6 @@ static void run_block(dim3 block) {
                 progressed = true;
             }
         }
-        // workgroup barrier release
         int at_block = 0, live = 0;
         for (int i = 0; i < n; ++i) {
             if (fibers[i].state != DONE) ++live;

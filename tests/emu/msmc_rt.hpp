@@ -44,7 +44,9 @@ void block_barrier();
 void wave_barrier();
 int lane();
 int wave();
-uint32_t* slot(int lane_index);            // 64 x 32-byte exchange slots of the calling wave
+uint32_t* slot(int lane_index);            // 64 x 32-byte exchange slots of the calling wave (double-buffered)
+bool first_after_barrier();                // true for the first lane of the wave to resume in this collective
+void collective_done();                    // the calling lane has finished reading this collective's slots
 void run_grid(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void* closure);
 }  // namespace emu
 
@@ -71,12 +73,12 @@ static inline void __syncthreads() { emu::block_barrier(); }
 
 template <class T>
 static inline T emu_exchange(T v, int src_lane) {
-    static_assert(sizeof(T) <= 32, "slot too small");
+    static_assert(sizeof(T) <= 128, "slot too small");
     memcpy(emu::slot(emu::lane()), &v, sizeof(T));
     emu::wave_barrier();
     T r;
     memcpy(&r, emu::slot(src_lane & 63), sizeof(T));
-    emu::wave_barrier();
+    emu::collective_done();
     return r;
 }
 MSMC_DEV float wave_xor(float v, int mask) { return emu_exchange(v, emu::lane() ^ mask); }
@@ -90,46 +92,9 @@ MSMC_DEV int wave_bcast(int v, int lane) { return emu_exchange(v, lane); }
 
 MSMC_DEV void wave_sync() { emu::wave_barrier(); }   // fibers are not lock-step: make it a real barrier
 
-// ---- MFMA, by the fragment layouts documented in csrc/gfx950/msmc_rt.hpp ---------------------------------
-struct emu_ab32 { float a, b; };
-MSMC_DEV f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
-    emu_ab32 me = {a, b};
-    memcpy(emu::slot(emu::lane()), &me, sizeof(me));
-    emu::wave_barrier();
-    int l = emu::lane(), col = l & 15;
-    for (int r = 0; r < 4; ++r) {
-        int row = 4 * (l >> 4) + r;
-        float acc = c[r];
-        for (int k = 0; k < 4; ++k) {
-            emu_ab32 pa, pb;
-            memcpy(&pa, emu::slot(row + 16 * k), sizeof(pa));
-            memcpy(&pb, emu::slot(col + 16 * k), sizeof(pb));
-            acc = fmaf(pa.a, pb.b, acc);
-        }
-        c[r] = acc;
-    }
-    emu::wave_barrier();
-    return c;
-}
-MSMC_DEV f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
-    emu_ab32 me = {a, b};
-    memcpy(emu::slot(emu::lane()), &me, sizeof(me));
-    emu::wave_barrier();
-    int l = emu::lane(), col = l & 31;
-    for (int r = 0; r < 16; ++r) {
-        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        float acc = c[r];
-        for (int k = 0; k < 2; ++k) {
-            emu_ab32 pa, pb;
-            memcpy(&pa, emu::slot(row + 32 * k), sizeof(pa));
-            memcpy(&pb, emu::slot(col + 32 * k), sizeof(pb));
-            acc = fmaf(pa.a, pb.b, acc);
-        }
-        c[r] = acc;
-    }
-    emu::wave_barrier();
-    return c;
-}
+// ---- MFMA, by the fragment layouts documented in csrc/gfx950/msmc_rt.hpp --------------------------
+// Every lane deposits (a, b, c) in its slot; after the wave barrier the FIRST lane to resume computes
+// the whole tile D = A.B + C for all 64 lanes (plain loops), the others just read their registers.
 static inline float emu_bf16_f32(__bf16 h) {
     unsigned short s;
     memcpy(&s, &h, 2);
@@ -138,43 +103,91 @@ static inline float emu_bf16_f32(__bf16 h) {
     memcpy(&f, &u, 4);
     return f;
 }
-struct emu_ab16 { bf16x8 a, b; };
-MSMC_DEV f32x16 mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
-    emu_ab16 me = {a, b};
-    memcpy(emu::slot(emu::lane()), &me, sizeof(me));
-    emu::wave_barrier();
-    int l = emu::lane(), col = l & 31;
-    for (int r = 0; r < 16; ++r) {
-        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        float acc = c[r];
-        for (int g = 0; g < 2; ++g) {
-            emu_ab16 pa, pb;
-            memcpy(&pa, emu::slot(row + 32 * g), sizeof(pa));
-            memcpy(&pb, emu::slot(col + 32 * g), sizeof(pb));
-            for (int e = 0; e < 8; ++e) acc += emu_bf16_f32(pa.a[e]) * emu_bf16_f32(pb.b[e]);
-        }
-        c[r] = acc;
+struct emu_f32_slot { float a, b, c[16]; };
+struct emu_b16_slot { bf16x8 a, b; float c[16]; };
+
+template <int M, int KG, int NREG>      // M x M tile, KG lane groups along k, NREG accumulators per lane
+static inline void emu_mfma_f32_all() {
+    float A[32][4], B[4][32];
+    for (int l = 0; l < 64; ++l) {
+        const emu_f32_slot* s = (const emu_f32_slot*)emu::slot(l);
+        A[l % M][l / M] = s->a;
+        B[l / M][l % M] = s->b;
     }
+    for (int l = 0; l < 64; ++l) {
+        emu_f32_slot* s = (emu_f32_slot*)emu::slot(l);
+        const int col = l % M;
+        for (int r = 0; r < NREG; ++r) {
+            const int row = (M == 32) ? (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) : 4 * (l >> 4) + r;
+            float acc = s->c[r];
+            for (int k = 0; k < KG; ++k) acc = fmaf(A[row][k], B[k][col], acc);
+            s->c[r] = acc;
+        }
+    }
+}
+template <int M, int KG, int NREG>
+static inline void emu_mfma_b16_all() {
+    static float A[32][32], B[32][32];
+    for (int l = 0; l < 64; ++l) {
+        const emu_b16_slot* s = (const emu_b16_slot*)emu::slot(l);
+        for (int e = 0; e < 8; ++e) {
+            A[l % M][8 * (l / M) + e] = emu_bf16_f32(s->a[e]);
+            B[8 * (l / M) + e][l % M] = emu_bf16_f32(s->b[e]);
+        }
+    }
+    for (int l = 0; l < 64; ++l) {
+        emu_b16_slot* s = (emu_b16_slot*)emu::slot(l);
+        const int col = l % M;
+        for (int r = 0; r < NREG; ++r) {
+            const int row = (M == 32) ? (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) : 4 * (l >> 4) + r;
+            float acc = s->c[r];
+            for (int k = 0; k < 8 * KG; ++k) acc += A[row][k] * B[k][col];
+            s->c[r] = acc;
+        }
+    }
+}
+MSMC_DEV f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
+    emu_f32_slot* me = (emu_f32_slot*)emu::slot(emu::lane());
+    me->a = a; me->b = b;
+    for (int r = 0; r < 4; ++r) me->c[r] = c[r];
     emu::wave_barrier();
+    if (emu::first_after_barrier()) emu_mfma_f32_all<16, 4, 4>();
+    me = (emu_f32_slot*)emu::slot(emu::lane());
+    for (int r = 0; r < 4; ++r) c[r] = me->c[r];
+    emu::collective_done();
+    return c;
+}
+MSMC_DEV f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
+    emu_f32_slot* me = (emu_f32_slot*)emu::slot(emu::lane());
+    me->a = a; me->b = b;
+    for (int r = 0; r < 16; ++r) me->c[r] = c[r];
+    emu::wave_barrier();
+    if (emu::first_after_barrier()) emu_mfma_f32_all<32, 2, 16>();
+    me = (emu_f32_slot*)emu::slot(emu::lane());
+    for (int r = 0; r < 16; ++r) c[r] = me->c[r];
+    emu::collective_done();
+    return c;
+}
+MSMC_DEV f32x16 mfma_bf16_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    emu_b16_slot* me = (emu_b16_slot*)emu::slot(emu::lane());
+    me->a = a; me->b = b;
+    for (int r = 0; r < 16; ++r) me->c[r] = c[r];
+    emu::wave_barrier();
+    if (emu::first_after_barrier()) emu_mfma_b16_all<32, 2, 16>();
+    me = (emu_b16_slot*)emu::slot(emu::lane());
+    for (int r = 0; r < 16; ++r) c[r] = me->c[r];
+    emu::collective_done();
     return c;
 }
 MSMC_DEV f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
-    emu_ab16 me = {a, b};
-    memcpy(emu::slot(emu::lane()), &me, sizeof(me));
+    emu_b16_slot* me = (emu_b16_slot*)emu::slot(emu::lane());
+    me->a = a; me->b = b;
+    for (int r = 0; r < 4; ++r) me->c[r] = c[r];
     emu::wave_barrier();
-    int l = emu::lane(), col = l & 15;
-    for (int r = 0; r < 4; ++r) {
-        int row = 4 * (l >> 4) + r;
-        float acc = c[r];
-        for (int g = 0; g < 4; ++g) {
-            emu_ab16 pa, pb;
-            memcpy(&pa, emu::slot(row + 16 * g), sizeof(pa));
-            memcpy(&pb, emu::slot(col + 16 * g), sizeof(pb));
-            for (int e = 0; e < 8; ++e) acc += emu_bf16_f32(pa.a[e]) * emu_bf16_f32(pb.b[e]);
-        }
-        c[r] = acc;
-    }
-    emu::wave_barrier();
+    if (emu::first_after_barrier()) emu_mfma_b16_all<16, 4, 4>();
+    me = (emu_b16_slot*)emu::slot(emu::lane());
+    for (int r = 0; r < 4; ++r) c[r] = me->c[r];
+    emu::collective_done();
     return c;
 }
 
