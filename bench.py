@@ -32,6 +32,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}     # dense peaks, same guide
 FLOP_PER_STEP = 3.006e12       # reference GAN step at B=16, T=400 (torch FlopCounter)
 FLOP_PER_STEP_ELIDED = 2.65e12  # without the discarded D weight-gradients of the G step
 
@@ -68,9 +69,9 @@ class KernelTimer(object):
         out = {}
         for label, recs in self.records.items():
             ms = [s.elapsed_time(e) for s, e, _ in recs]
-            byts = [b for _, _, b in recs]
-            out[label] = dict(launches=len(ms), avg_ms=sum(ms) / len(ms), avg_bytes=sum(byts) / len(byts),
-                              total_ms=sum(ms))
+            work = [b for _, _, b in recs]
+            out[label] = dict(launches=len(ms), avg_ms=sum(ms) / len(ms), avg_work=sum(work) / len(work),
+                              total_ms=sum(ms), total_work=sum(work))
         return out
 
 
@@ -173,6 +174,7 @@ def main():
     ap.add_argument('--cpu-batch', type=int, default=4, help='utterances of the batch in the cpu_baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = min(available cores, 32)')
     ap.add_argument('--no-microbench', action='store_true')
+    ap.add_argument('--kernel-timing-steps', type=int, default=3, help='extra steps timed kernel by kernel (rank 0)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -199,9 +201,35 @@ def main():
     trainer.rng = random.Random(1234 + rank)
 
     timer = KernelTimer()
-    D = cfg.task.autoencoder.quantizer_config.embedding_dims
+    from msmctts_amd.hip import conv as hipconv
     timer.wrap(hipvq, 'vq_search', 'vq_search_kernel',
                lambda x, et, en: (x.numel() // x.shape[-1]) * vq_bytes_per_frame(x.shape[-1], et.shape[0]))
+
+    def conv_flops(x, w, geom, *a, **k):                  # 2 * pixels_out * Cout * Cin * taps
+        return 2.0 * x.shape[0] * geom.Hout * geom.Wout * w.shape[1] * w.shape[2] * w.shape[0]
+
+    def dgrad_flops(g, wb, geom, *a, **k):
+        return 2.0 * g.shape[0] * geom.Hout * geom.Wout * wb.shape[1] * wb.shape[2] * wb.shape[0]
+
+    def wgrad_flops(x, g, geom, n_slices, *a, **k):
+        return 2.0 * x.shape[0] * geom.Hout * geom.Wout * g.shape[3] * x.shape[3] * n_slices
+
+    def convt_flops(x, w, kk, stride, padding, *a, **k):   # every input pixel meets every tap once
+        return 2.0 * x.shape[0] * x.shape[2] * w.shape[1] * w.shape[2] * kk
+
+    def convt_dgrad_flops(g, wb, kk, stride, padding, Lin, *a, **k):
+        return 2.0 * g.shape[0] * Lin * wb.shape[1] * wb.shape[2] * kk
+
+    def convt_wgrad_flops(x, g, kk, stride, padding, *a, **k):
+        return 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * g.shape[3] * kk
+
+    for fn, label, work in (('conv_forward', 'conv_gather_kernel[fwd]', conv_flops),
+                            ('conv_dgrad', 'conv_gather_kernel[dgrad]', dgrad_flops),
+                            ('conv_wgrad', 'conv_wgrad_kernel', wgrad_flops),
+                            ('conv_transpose1d_forward', 'conv_gather_kernel[convT]', convt_flops),
+                            ('conv_transpose1d_dgrad', 'conv_gather_kernel[convT dgrad]', convt_dgrad_flops),
+                            ('conv_transpose1d_wgrad', 'conv_wgrad_kernel[convT]', convt_wgrad_flops)):
+        timer.wrap(hipconv, fn, label, work)
 
     def step(i):
         trainer.model.zero_grad()
@@ -216,7 +244,6 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    timer.enabled = True
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -226,7 +253,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    # second pass over the same steps with HIP events around every hand-written launch (the events cost a
+    # few percent of host time, so the headline value above is taken without them)
+    ms_instr = None
+    if rank == 0 and args.kernel_timing_steps > 0:
+        timer.enabled = True
+        t1 = time.perf_counter()
+        for i in range(args.kernel_timing_steps):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        ms_instr = (time.perf_counter() - t1) / args.kernel_timing_steps * 1e3
+        timer.enabled = False
+    if world > 1:
+        dist.barrier()
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -243,14 +282,24 @@ def main():
     if rank != 0:
         return
     ks = timer.summary()
-    roof = None
-    if ks:
-        label, rec = max(ks.items(), key=lambda kv: kv[1]['total_ms'])
-        ach = rec['avg_bytes'] / rec['avg_ms'] / 1e6
-        roof = dict(kernel=label, bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
-                    traffic=None, launches=rec['launches'], avg_us=rec['avg_ms'] * 1e3,
-                    bytes_per_launch=rec['avg_bytes'],
-                    note='training-size launches (N<=B*T frames) are launch-latency bound; see vq_microbench')
+    roof, kernels = None, {}
+    mfma_peak = MFMA_PEAK_TFLOPS[args.dtype]
+    for label, rec in ks.items():
+        if label.startswith('vq_'):
+            ach = rec['total_work'] / rec['total_ms'] / 1e6
+            kernels[label] = dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
+                                  launches=rec['launches'], avg_us=rec['avg_ms'] * 1e3,
+                                  ms_per_step=rec['total_ms'] / max(1, args.kernel_timing_steps))
+        else:
+            ach = rec['total_work'] / rec['total_ms'] / 1e9
+            kernels[label] = dict(bound='mfma', achieved=ach, peak=mfma_peak, unit='TFLOP/s', frac=ach / mfma_peak,
+                                  launches=rec['launches'], avg_us=rec['avg_ms'] * 1e3,
+                                  ms_per_step=rec['total_ms'] / max(1, args.kernel_timing_steps))
+    if kernels:
+        label = max(kernels, key=lambda k: kernels[k]['ms_per_step'])
+        roof = dict(kernel=label, traffic=None, **kernels[label])
+        roof['note'] = ('achieved = algorithmic work of all launches of this kernel in the instrumented steps / their '
+                        'summed HIP-event durations; peak = dense %s MFMA' % args.dtype)
     out = {
         'metric': 'mel-frames/sec MSMC-VQ-GAN train step (GAN phase)', 'value': value, 'unit': 'mel-frames/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
@@ -264,6 +313,8 @@ def main():
         'step_flop_model': 'SURVEY 8d: 3.006 TFLOP/step at B=16,T=400 minus the elided D weight-grads of the G step '
                            '= 2.65 TFLOP',
         'roofline': roof,
+        'kernels': kernels,
+        'ms_per_step_instrumented': ms_instr,
         'losses': {k: float(v) for k, v in log['loss'].items()},
     }
     if not args.no_microbench:
