@@ -104,13 +104,17 @@ typedef struct msmc_conv_desc {
     float out_slope;        /* leaky-ReLU slope applied to v last (1 = identity)                           */
 } msmc_conv_desc;
 
+/* Perf-experiment switch: 0 selects the simple (un-pipelined) gather kernel everywhere; default 1. */
+void msmc_conv_set_pipeline(int on);
+
 /* out[q] = epilogue( sum_t sum_ci w[tap_w[t]][co][ci] * act(x[in(q, t)][ci]) + bias[co] ). */
 int msmc_conv_gather(const msmc_conv_desc* desc, msmc_stream stream);
 
 /* dw[tap_w[t]][co][ci] += sum_{b,q} g[b][out(q)][co] * act(x[b][in(q, t)][ci])   (fp32 atomics; caller zeroes dw).
  * Geometry fields as for the forward convolution it differentiates; desc->x = x, desc->out unused,
- * g has the forward output's shape [B][Hout][Wout][Cout] and dtype. */
-int msmc_conv_wgrad(const msmc_conv_desc* desc, const void* g, float* dw, msmc_stream stream);
+ * g has the forward output's shape [B][Hout][Wout][Cout] and dtype; desc->mask_slope is a leaky-ReLU
+ * slope applied to g on load (1 = identity).  db (may be NULL): db[co] += sum_{b,q} g[b][out(q)][co]. */
+int msmc_conv_wgrad(const msmc_conv_desc* desc, const void* g, float* dw, float* db, msmc_stream stream);
 
 /* Weight-norm (torch weight_norm, dim=0) for MANY convolutions in one launch.
  * Item i: v [A][Bc][T] fp32 contiguous (A = dim 0, the normalised axis; T = taps), g [A] fp32.

@@ -25,6 +25,11 @@
 
 #define CV_BM 128
 
+// A/B switch (msmc_conv_set_pipeline): 0 = simple kernel, 1 = pipelined kernel with automatic M-tile width,
+// 2 / 4 = pipelined kernel forced to 256- / 512-point M tiles (tests).
+static int msmc_conv_pipeline_enabled = 1;
+extern "C" void msmc_conv_set_pipeline(int on) { msmc_conv_pipeline_enabled = on; }
+
 template <typename T> struct Elt;
 template <> struct Elt<float> {
     static constexpr int VEC = 4;       // elements per 16 bytes
@@ -208,7 +213,172 @@ __global__ __launch_bounds__(256) void conv_gather_kernel(msmc_conv_desc d, CvGe
     }
 }
 
-static int cv_geometry(const msmc_conv_desc* d, CvGeom* G, int elt_bytes, int XS, int BN, size_t* lds) {
+// ------------------------------------------------------------------------------------------------
+// Pipelined variant: each work-item owns a fixed list of 16-byte staging slots (computed once, so no
+// index arithmetic in the K loop); the global loads of channel chunk c+1 are issued into registers
+// before the MFMAs of chunk c and written to LDS afterwards, and a wave covers MT 32-row sub-tiles so a
+// staged weight chunk is reused MT times (M tile = 128*MT lattice points).
+// ------------------------------------------------------------------------------------------------
+#define CV_XLD 12
+#define CV_WLD 12
+
+template <typename T, int NT, int MT>
+__global__ __launch_bounds__(256) void conv_gather_pipe_kernel(msmc_conv_desc d, CvGeom G) {
+    MSMC_DYN_LDS(smem);
+    constexpr int VEC = Elt<T>::VEC, CK = Elt<T>::CK, CKV = CK / VEC, XS = CK + VEC, BN = 32 * NT;
+    T* xt = (T*)smem;
+    T* wt = xt + G.xt_elems;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 31, g = lane >> 5;
+    int bt = blockIdx.x;
+    const int tx_ = bt % G.tilesX;
+    bt /= G.tilesX;
+    const int ty_ = bt % G.tilesY;
+    const int b = bt / G.tilesY;
+    const int co0 = blockIdx.y * BN;
+    const int qy0 = ty_ * G.TH, qx0 = tx_ * G.TW;
+    const int iyBase = qy0 * d.isy + d.iy0 + G.dyMin, ixBase = qx0 * d.isx + d.ix0 + G.dxMin;
+    const int IW = G.IW, npix = G.IH * G.IW;
+    const T* xb = (const T*)d.x + (size_t)b * d.Hin * d.Win * d.Cin;
+    const T* wg = (const T*)d.w;
+    const float slope = d.in_slope;
+
+    // ---- staging slots: global element offset (without the chunk base) or -1, and LDS element offset
+    long xsrc[CV_XLD], wsrc[CV_WLD];
+    int xdst[CV_XLD], wdst[CV_WLD], xch[CV_XLD], wch[CV_WLD];
+#pragma unroll
+    for (int j = 0; j < CV_XLD; ++j) {
+        const int e = tid + 256 * j;
+        xsrc[j] = -1; xdst[j] = -1; xch[j] = 0;
+        if (e < npix * CKV) {
+            const int pi = e / CKV, v = e - pi * CKV;
+            const int ry = pi / IW, rx = pi - ry * IW;
+            int iy = iyBase + ry, ix = ixBase + rx;
+            bool inside = true;
+            if (d.pad_mode == 1) {
+                iy = reflect_index(iy, d.Hin);
+                ix = reflect_index(ix, d.Win);
+            } else {
+                inside = (iy >= 0) && (iy < d.Hin) && (ix >= 0) && (ix < d.Win);
+            }
+            xdst[j] = pi * XS + v * VEC;
+            xch[j] = v * VEC;
+            if (inside) xsrc[j] = ((long)iy * d.Win + ix) * d.Cin + v * VEC;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CV_WLD; ++j) {
+        const int e = tid + 256 * j;
+        wsrc[j] = -1; wdst[j] = -1; wch[j] = 0;
+        if (e < d.ntaps * BN * CKV) {
+            const int v = e % CKV, row = e / CKV;
+            const int t = row / BN, col = row - t * BN;
+            wdst[j] = row * XS + v * VEC;
+            wch[j] = v * VEC;
+            if (co0 + col < d.Cout) wsrc[j] = ((long)d.tap_w[t] * d.Cout + co0 + col) * d.Cin + v * VEC;
+        }
+    }
+    int arow[MT];
+#pragma unroll
+    for (int sI = 0; sI < MT; ++sI) {
+        const int m = 32 * (4 * sI + w) + i;
+        const int mty = m / G.TW, mtx = m - mty * G.TW;
+        arow[sI] = (mty < G.TH) ? (mty * d.isy) * IW + mtx * d.isx : 0;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int sI = 0; sI < MT; ++sI)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[sI][n][r] = 0.f;
+
+    u32x4 xreg[CV_XLD], wreg[CV_WLD];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto fetch = [&](int c0) {               // Cin % VEC == 0 is guaranteed by the dispatcher
+#pragma unroll
+        for (int j = 0; j < CV_XLD; ++j) {
+            xreg[j] = zero4;
+            if (xsrc[j] >= 0 && c0 + xch[j] < d.Cin) xreg[j] = *(const u32x4*)(xb + xsrc[j] + c0);
+        }
+#pragma unroll
+        for (int j = 0; j < CV_WLD; ++j) {
+            wreg[j] = zero4;
+            if (wsrc[j] >= 0 && c0 + wch[j] < d.Cin) wreg[j] = *(const u32x4*)(wg + wsrc[j] + c0);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < CV_XLD; ++j) {
+            if (xdst[j] < 0) continue;
+            u32x4 v = xreg[j];
+            if (slope != 1.f) {
+                alignas(16) T vals[VEC];
+                *(u32x4*)vals = v;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    float f = Elt<T>::ld(&vals[q]);
+                    f = f > 0.f ? f : f * slope;
+                    Elt<T>::st(&vals[q], f);
+                }
+                v = *(const u32x4*)vals;
+            }
+            *(u32x4*)(xt + xdst[j]) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < CV_WLD; ++j)
+            if (wdst[j] >= 0) *(u32x4*)(wt + wdst[j]) = wreg[j];
+    };
+
+    fetch(0);
+    for (int c0 = 0; c0 < d.Cin; c0 += CK) {
+        __syncthreads();                     // every wave is done reading the previous chunk
+        commit();
+        __syncthreads();
+        if (c0 + CK < d.Cin) fetch(c0 + CK); // in flight during the MFMAs below
+        for (int t = 0; t < d.ntaps; ++t) {
+            const int toff = (d.tap_dy[t] - G.dyMin) * IW + (d.tap_dx[t] - G.dxMin);
+            const T* bp = wt + (size_t)(t * BN + i) * XS;
+#pragma unroll
+            for (int sI = 0; sI < MT; ++sI) {
+                const T* ap = xt + (size_t)(arow[sI] + toff) * XS;
+#pragma unroll
+                for (int ks = 0; ks < CK / 16; ++ks) mma_chunk16<NT>(ap + ks * 16, bp + ks * 16, 32 * XS, g, acc[sI]);
+            }
+        }
+    }
+
+    const T* mask = (const T*)d.mask_src;
+    const T* res = (const T*)d.res;
+    const T* res2 = (const T*)d.res2;
+    T* out = (T*)d.out;
+#pragma unroll
+    for (int sI = 0; sI < MT; ++sI)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = co0 + n * 32 + i;
+            if (co >= d.Cout) continue;
+            const float bv = d.bias ? d.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = 32 * (4 * sI + w) + (r & 3) + 8 * (r >> 2) + 4 * g;
+                const int mty = m / G.TW, mtx = m - mty * G.TW;
+                const int qy = qy0 + mty, qx = qx0 + mtx;
+                if (mty >= G.TH || qy >= d.QH || qx >= d.QW) continue;
+                const int oy = d.oy0 + qy * d.osy, ox = d.ox0 + qx * d.osx;
+                const size_t o = (((size_t)b * d.Hout + oy) * d.Wout + ox) * d.Cout + co;
+                float v = acc[sI][n][r] + bv;
+                if (mask) v = v * (Elt<T>::ld(mask + o) > 0.f ? 1.f : d.mask_slope);
+                if (res) v = v + Elt<T>::ld(res + o);
+                if (res2) v = Elt<T>::ld(res2 + o) + v;
+                if (d.out_div != 1.f) v = v / d.out_div;
+                if (d.out_slope != 1.f) v = v > 0.f ? v : v * d.out_slope;
+                Elt<T>::st(out + o, v);
+            }
+        }
+}
+
+static int cv_geometry(const msmc_conv_desc* d, CvGeom* G, int elt_bytes, int XS, int BN, size_t* lds,
+                       int bm = CV_BM) {
     if (d->ntaps <= 0 || d->ntaps > MSMC_CONV_MAX_TAPS) return MSMC_E_SHAPE;
     int dyMin = d->tap_dy[0], dyMax = d->tap_dy[0], dxMin = d->tap_dx[0], dxMax = d->tap_dx[0];
     for (int t = 1; t < d->ntaps; ++t) {
@@ -218,9 +388,9 @@ static int cv_geometry(const msmc_conv_desc* d, CvGeom* G, int elt_bytes, int XS
         if (d->tap_dx[t] > dxMax) dxMax = d->tap_dx[t];
     }
     int TH, TW;
-    if (d->QH == 1) { TH = 1; TW = CV_BM; }
-    else if (d->QW <= 16) { TW = d->QW; TH = CV_BM / TW; }
-    else { TW = 16; TH = 8; }
+    if (d->QH == 1) { TH = 1; TW = bm; }
+    else if (d->QW <= 16) { TW = d->QW; TH = bm / TW; if (TH < 1) TH = 1; }
+    else { TW = 16; TH = bm / 16; }
     G->TH = TH; G->TW = TW;
     G->dyMin = dyMin; G->dxMin = dxMin;
     G->IH = (TH - 1) * d->isy + (dyMax - dyMin) + 1;
@@ -232,12 +402,53 @@ static int cv_geometry(const msmc_conv_desc* d, CvGeom* G, int elt_bytes, int XS
     return 0;
 }
 
+template <typename T, int NT, int MT>
+static int cv_try_pipe(const msmc_conv_desc* d, msmc_stream stream, bool* done) {
+    constexpr int XS = Elt<T>::CK + Elt<T>::VEC, CKV = Elt<T>::CK / Elt<T>::VEC;
+    CvGeom G;
+    size_t lds;
+    *done = false;
+    int rc = cv_geometry(d, &G, sizeof(T), XS, 32 * NT, &lds, CV_BM * MT);
+    if (rc) return rc;
+    if (lds > 160 * 1024) return 0;
+    if (G.IH * G.IW * CKV > 256 * CV_XLD || d->ntaps * 32 * NT * CKV > 256 * CV_WLD) return 0;
+    dim3 grid((unsigned)(G.tilesX * G.tilesY * d->B), (unsigned)((d->Cout + 32 * NT - 1) / (32 * NT)));
+    rc = msmc_allow_lds((const void*)conv_gather_pipe_kernel<T, NT, MT>, (int)lds);
+    if (rc) return rc;
+    MSMC_LAUNCH((conv_gather_pipe_kernel<T, NT, MT>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, G);
+    *done = true;
+    return msmc_check_launch();
+}
+
 template <typename T>
 static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
     constexpr int XS = Elt<T>::CK + Elt<T>::VEC;
+    int NT = d->Cout > 32 ? 2 : 1;
+    if ((d->Cin % Elt<T>::VEC) == 0 && msmc_conv_pipeline_enabled) {
+        // widest M tile that still leaves >= ~2 workgroups per CU
+        const long points = (long)d->B * d->QH * d->QW;
+        const long ntile = (d->Cout + 32 * NT - 1) / (32 * NT);
+        int MT = 4;
+        if (msmc_conv_pipeline_enabled == 2 || msmc_conv_pipeline_enabled == 4) MT = msmc_conv_pipeline_enabled;   // tests
+        else while (MT > 1 && (points / (CV_BM * MT)) * ntile < 2 * MSMC_NUM_CU) MT >>= 1;
+        bool done = false;
+        int rc = 0;
+        for (; MT >= 1 && !done; MT >>= 1) {
+            if (NT == 2) {
+                if (MT == 4) rc = cv_try_pipe<T, 2, 4>(d, stream, &done);
+                else if (MT == 2) rc = cv_try_pipe<T, 2, 2>(d, stream, &done);
+                else rc = cv_try_pipe<T, 2, 1>(d, stream, &done);
+            } else {
+                if (MT == 4) rc = cv_try_pipe<T, 1, 4>(d, stream, &done);
+                else if (MT == 2) rc = cv_try_pipe<T, 1, 2>(d, stream, &done);
+                else rc = cv_try_pipe<T, 1, 1>(d, stream, &done);
+            }
+            if (rc) return rc;
+        }
+        if (done) return 0;
+    }
     CvGeom G;
     size_t lds;
-    int NT = d->Cout > 32 ? 2 : 1;
     int rc = cv_geometry(d, &G, sizeof(T), XS, 32 * NT, &lds);
     if (rc) return rc;
     if (lds > 160 * 1024 && NT == 2) {
@@ -269,124 +480,202 @@ extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
 // ================================================================================================
 // weight gradient
 // ================================================================================================
-template <typename T> struct WgTraits;
-template <> struct WgTraits<float> { static constexpr int KP = 64, KSTEP = 2; };
-template <> struct WgTraits<unsigned short> { static constexpr int KP = 128, KSTEP = 16; };
+// dW[t][co][ci] += sum over lattice points p of g[p][co] * act(x[in(p,t)][ci]).  The reduction runs over
+// pixels, so the MFMA K dimension is the pixel axis while LDS holds both operands in their natural
+// channels-last layout ([pixel][channel], staged with the same halo-tile code as the forward kernel):
+//   bf16: fragments come from ds_read_b64_tr_b16 (hardware transpose), every lane addressing the
+//         pixel row it is responsible for -- a tap is again a pure row offset;
+//   fp32: v_mfma_f32_32x32x2_f32 takes one element per lane, read straight from the tile.
+// One workgroup owns a 64(co) x 64(ci) tile of every tap (4 waves x 32x32 fragments x TAPS accumulators)
+// and walks a range of 128-point lattice tiles; partial sums meet in fp32 atomics.
+#define WG_TM 128      // lattice points per tile (upper bound; smaller tiles when the halo would not fit LDS)
 
-struct WgGeom {
-    int P, chunksPerItem, totalChunks, chunksPerWg;
-};
-
-// Stage a [KP points][64 channels] operand TRANSPOSED into lds[ch][KP (+pad)]: each work-item moves
-// 4 points x VEC4 channels through a register transpose (global reads stay 8/16-byte wide along C).
-template <typename T, bool IS_X>
-MSMC_DEV void wg_stage(T* lds, int LS, const msmc_conv_desc& d, const T* base, int C, int c0, int p0, int P, int tap,
-                       float slope, int tid) {
-    constexpr int KP = WgTraits<T>::KP;
-    // 64 channels = 16 groups of 4; KP points = KP/4 groups of 4
-    for (int e = tid; e < 16 * (KP / 4); e += 256) {
-        const int cg = e & 15, pg = e >> 4;
-        const int c = c0 + cg * 4;
-        float v[4][4];                              // [point][channel]
+template <typename T>
+MSMC_DEV void wg_stage_x(T* xt, int XS, const msmc_conv_desc& d, const CvGeom& G, const T* xb, int c0, int iyBase,
+                         int ixBase, int tid) {
+    constexpr int VEC = Elt<T>::VEC, CKV = 64 / VEC;
+    const int npix = G.IH * G.IW;
+    const bool vec_ok = (d.Cin % VEC) == 0;
+    for (int e = tid; e < npix * CKV; e += 256) {
+        const int pi = e / CKV, v = e - pi * CKV;
+        const int ry = pi / G.IW, rx = pi - ry * G.IW;
+        int iy = iyBase + ry, ix = ixBase + rx;
+        bool inside = true;
+        if (d.pad_mode == 1) {
+            iy = reflect_index(iy, d.Hin);
+            ix = reflect_index(ix, d.Win);
+        } else {
+            inside = (iy >= 0) && (iy < d.Hin) && (ix >= 0) && (ix < d.Win);
+        }
+        const int c = c0 + v * VEC;
+        alignas(16) T vals[VEC];
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-            const int p = p0 + pg * 4 + pp;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) v[pp][cc] = 0.f;
-            if (p >= P || c >= C) continue;
-            const int qy = p / d.QW, qx = p - qy * d.QW;
-            size_t off;
-            bool inside = true;
-            if (IS_X) {
-                int iy = qy * d.isy + d.iy0 + d.tap_dy[tap], ix = qx * d.isx + d.ix0 + d.tap_dx[tap];
-                if (d.pad_mode == 1) {
-                    iy = reflect_index(iy, d.Hin);
-                    ix = reflect_index(ix, d.Win);
-                } else {
-                    inside = (iy >= 0) && (iy < d.Hin) && (ix >= 0) && (ix < d.Win);
-                }
-                off = ((size_t)iy * d.Win + ix) * C + c;
+        for (int q = 0; q < VEC; ++q) vals[q] = 0;
+        if (inside && c < d.Cin) {
+            const T* src = xb + ((size_t)iy * d.Win + ix) * d.Cin + c;
+            if (vec_ok) {
+                *(u32x4*)vals = *(const u32x4*)src;
             } else {
-                const int oy = d.oy0 + qy * d.osy, ox = d.ox0 + qx * d.osx;
-                off = ((size_t)oy * d.Wout + ox) * C + c;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q)
+                    if (c + q < d.Cin) vals[q] = src[q];
             }
-            if (!inside) continue;
+            if (d.in_slope != 1.f) {
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
-                if (c + cc < C) {
-                    float f = Elt<T>::ld(base + off + cc);
-                    v[pp][cc] = (slope != 1.f && f <= 0.f) ? f * slope : f;
+                for (int q = 0; q < VEC; ++q) {
+                    float f = Elt<T>::ld(&vals[q]);
+                    f = f > 0.f ? f : f * d.in_slope;
+                    Elt<T>::st(&vals[q], f);
                 }
+            }
         }
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            T* dst = lds + (size_t)(cg * 4 + cc) * LS + pg * 4;
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) Elt<T>::st(dst + pp, v[pp][cc]);
-        }
+        *(u32x4*)(xt + (size_t)pi * XS + v * VEC) = *(const u32x4*)vals;
     }
 }
 
-MSMC_DEV f32x16 wg_mma(const float* ap, const float* bp, int g, f32x16 acc) {
-    // KP = 64 points: lane group g takes points 8t + 4g + e, both operands alike
+template <typename T>
+MSMC_DEV void wg_stage_g(T* gt, int XS, const msmc_conv_desc& d, const CvGeom& G, const T* gb, int c0, int qy0, int qx0,
+                         int tid, int TM) {
+    constexpr int VEC = Elt<T>::VEC, CKV = 64 / VEC;
+    const bool vec_ok = (d.Cout % VEC) == 0;
+    for (int e = tid; e < TM * CKV; e += 256) {
+        const int m = e / CKV, v = e - m * CKV;
+        const int mty = m / G.TW, mtx = m - mty * G.TW;
+        const int qy = qy0 + mty, qx = qx0 + mtx;
+        const int c = c0 + v * VEC;
+        alignas(16) T vals[VEC];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        f32x4 a4 = *(const f32x4*)(ap + 8 * t + 4 * g);
-        f32x4 b4 = *(const f32x4*)(bp + 8 * t + 4 * g);
+        for (int q = 0; q < VEC; ++q) vals[q] = 0;
+        if (mty < G.TH && qy < d.QH && qx < d.QW && c < d.Cout) {
+            const int oy = d.oy0 + qy * d.osy, ox = d.ox0 + qx * d.osx;
+            const T* src = gb + ((size_t)oy * d.Wout + ox) * d.Cout + c;
+            if (vec_ok) {
+                *(u32x4*)vals = *(const u32x4*)src;
+            } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = mfma_f32_32x32x2(a4[e], b4[e], acc);
+                for (int q = 0; q < VEC; ++q)
+                    if (c + q < d.Cout) vals[q] = src[q];
+            }
+            if (d.mask_slope != 1.f) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    float f = Elt<T>::ld(&vals[q]);
+                    f = f > 0.f ? f : f * d.mask_slope;
+                    Elt<T>::st(&vals[q], f);
+                }
+            }
+        }
+        *(u32x4*)(gt + (size_t)m * XS + v * VEC) = *(const u32x4*)vals;
+    }
+}
+
+// One tap, one 128-point tile: acc += G^T . X_t   (per wave: 32 co x 32 ci)
+MSMC_DEV f32x16 wg_tap(const float* gt, const float* xt, int XS, const int* rowtab, int tapoff, int acol, int bcol, int g,
+                       f32x16 acc, int TM) {
+    for (int s = 0; s < TM / 2; ++s) {
+        const int m = 2 * s + g;
+        acc = mfma_f32_32x32x2(gt[(size_t)m * XS + acol], xt[(size_t)(rowtab[m] + tapoff) * XS + bcol], acc);
     }
     return acc;
 }
-MSMC_DEV f32x16 wg_mma(const unsigned short* ap, const unsigned short* bp, int g, f32x16 acc) {
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {               // KP = 128 points, 16 per MFMA
-        bf16x8 a = __builtin_bit_cast(bf16x8, *(const u16x8*)(ap + 16 * t + 8 * g));
-        bf16x8 b = __builtin_bit_cast(bf16x8, *(const u16x8*)(bp + 16 * t + 8 * g));
-        acc = mfma_bf16_32x32x16(a, b, acc);
-    }
-    return acc;
+MSMC_DEV bf16x8 wg_frag(const unsigned short* tile, int XS, int row0, int row1, int col) {
+    u16x4 lo = lds_read_tr16(tile + (size_t)row0 * XS + col);
+    u16x4 hi = lds_read_tr16(tile + (size_t)row1 * XS + col);
+    u16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
 }
 
 template <typename T, int TAPS>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(msmc_conv_desc d, const T* __restrict__ gptr,
-                                                        float* __restrict__ dw, WgGeom G) {
+                                                        float* __restrict__ dw, float* __restrict__ db, CvGeom G,
+                                                        int tilesPerWg, int totalTiles, int TM) {
     MSMC_DYN_LDS(smem);
-    constexpr int KP = WgTraits<T>::KP, LS = KP + Elt<T>::VEC;
-    T* gt = (T*)smem;                   // [64 co][LS]
-    T* xt = gt + 64 * LS;               // [64 ci][LS]
+    constexpr int XS = 64 + Elt<T>::VEC;
+    T* xt = (T*)smem;                                   // [IH*IW][XS]
+    T* gt = xt + (size_t)G.IH * G.IW * XS;              // [TM][XS]
+    int* rowtab = (int*)(gt + (size_t)TM * XS);         // [TM] X-tile pixel row of lattice point m
+    const int nks = TM >> 4;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 31, g = lane >> 5;
-    const int wm = w >> 1, wn = w & 1;  // wave tile: co rows [32*wm, +32), ci cols [32*wn, +32)
+    const int wm = w >> 1, wn = w & 1;
     const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
-    // a wave whose 32x32 tile lies entirely beyond Cout x Cin has nothing to compute (thin layers)
     const bool wave_live = (co0 + 32 * wm < d.Cout) && (ci0 + 32 * wn < d.Cin);
+    for (int m = tid; m < TM; m += 256) {
+        int mty = m / G.TW, mtx = m - mty * G.TW;
+        rowtab[m] = (mty < G.TH) ? (mty * d.isy) * G.IW + mtx * d.isx : 0;
+    }
     f32x16 acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    __syncthreads();
 
-    const int ch0 = blockIdx.x * G.chunksPerWg;
-    int ch1 = ch0 + G.chunksPerWg;
-    if (ch1 > G.totalChunks) ch1 = G.totalChunks;
-    for (int ch = ch0; ch < ch1; ++ch) {
-        const int b = ch / G.chunksPerItem;
-        const int p0 = (ch - b * G.chunksPerItem) * KP;
-        const T* gb = gptr + (size_t)b * d.Hout * d.Wout * d.Cout;
-        const T* xb = (const T*)d.x + (size_t)b * d.Hin * d.Win * d.Cin;
-        __syncthreads();
-        wg_stage<T, false>(gt, LS, d, gb, d.Cout, co0, p0, G.P, 0, d.mask_slope, tid);
+    // bf16: lane L of each 16-lane group addresses row (L>>2) of its 4-row block, 4 channels from (L&3)*4
+    const int L = lane & 15, half = (lane >> 4) & 1;
+    int xrow[16], grow[16];
+    if (sizeof(T) == 2) {
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            if (t < d.ntaps) {
-                if (t > 0) __syncthreads();
-                wg_stage<T, true>(xt, LS, d, xb, d.Cin, ci0, p0, G.P, t, d.in_slope, tid);
-                __syncthreads();
-                if (wave_live)
-                    acc[t] = wg_mma(gt + (size_t)(32 * wm + i) * LS, xt + (size_t)(32 * wn + i) * LS, g, acc[t]);
+        for (int r = 0; r < 16; ++r) {
+            const int m = 16 * (r >> 1) + 8 * g + 4 * (r & 1) + (L >> 2);
+            grow[r] = m < TM ? m : 0;
+            xrow[r] = m < TM ? rowtab[m] : 0;
+        }
+    }
+    const int acol_tr = 32 * wm + 16 * half + 4 * (L & 3), bcol_tr = 32 * wn + 16 * half + 4 * (L & 3);
+
+    const bool do_bias = (db != nullptr) && (blockIdx.z == 0);
+    float bias_acc = 0.f;
+    const int t0 = blockIdx.x * tilesPerWg;
+    int t1 = t0 + tilesPerWg;
+    if (t1 > totalTiles) t1 = totalTiles;
+    for (int tile = t0; tile < t1; ++tile) {
+        int bt = tile;
+        const int tx_ = bt % G.tilesX;
+        bt /= G.tilesX;
+        const int ty_ = bt % G.tilesY;
+        const int b = bt / G.tilesY;
+        const int qy0 = ty_ * G.TH, qx0 = tx_ * G.TW;
+        const int iyBase = qy0 * d.isy + d.iy0 + G.dyMin, ixBase = qx0 * d.isx + d.ix0 + G.dxMin;
+        __syncthreads();
+        wg_stage_x<T>(xt, XS, d, G, (const T*)d.x + (size_t)b * d.Hin * d.Win * d.Cin, ci0, iyBase, ixBase, tid);
+        wg_stage_g<T>(gt, XS, d, G, gptr + (size_t)b * d.Hout * d.Wout * d.Cout, co0, qy0, qx0, tid, TM);
+        __syncthreads();
+        if (do_bias && tid < 64) {                      // bias gradient: column sums of the g tile (fused)
+            float sacc = 0.f;
+            for (int m = 0; m < TM; ++m) sacc = sacc + Elt<T>::ld(gt + (size_t)m * XS + tid);
+            bias_acc = bias_acc + sacc;
+        }
+        if (!wave_live) continue;
+        if (sizeof(T) == 2) {
+            bf16x8 af[8];
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                if (ks < nks) af[ks] = wg_frag((const unsigned short*)gt, XS, grow[2 * ks], grow[2 * ks + 1], acol_tr);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                if (t < d.ntaps) {
+                    const int tapoff = (d.tap_dy[t] - G.dyMin) * G.IW + (d.tap_dx[t] - G.dxMin);
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+                        if (ks >= nks) continue;
+                        bf16x8 bf = wg_frag((const unsigned short*)xt, XS, xrow[2 * ks] + tapoff, xrow[2 * ks + 1] + tapoff,
+                                            bcol_tr);
+                        acc[t] = mfma_bf16_32x32x16(af[ks], bf, acc[t]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                if (t < d.ntaps) {
+                    const int tapoff = (d.tap_dy[t] - G.dyMin) * G.IW + (d.tap_dx[t] - G.dxMin);
+                    acc[t] = wg_tap((const float*)gt, (const float*)xt, XS, rowtab, tapoff, 32 * wm + i, 32 * wn + i, g,
+                                    acc[t], TM);
+                }
             }
         }
     }
+    if (do_bias && tid < 64 && co0 + tid < d.Cout) atomicAdd(db + co0 + tid, bias_acc);
     // D fragment: row (co) = 32*wm + (r&3) + 8*(r>>2) + 4*g, col (ci) = 32*wn + i
     const int ci = ci0 + 32 * wn + i;
     if (!wave_live || ci >= d.Cin) return;
@@ -403,33 +692,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(msmc_conv_desc d, const
 }
 
 template <typename T>
-static int wg_launch(const msmc_conv_desc* d, const void* g, float* dw, msmc_stream stream) {
-    constexpr int KP = WgTraits<T>::KP, LS = KP + Elt<T>::VEC;
-    WgGeom G;
-    G.P = d->QH * d->QW;
-    G.chunksPerItem = (G.P + KP - 1) / KP;
-    G.totalChunks = G.chunksPerItem * d->B;
-    const int tiles = ((d->Cout + 63) / 64) * ((d->Cin + 63) / 64);
-    int nsplit = (2 * MSMC_NUM_CU + tiles - 1) / tiles;
-    if (nsplit > G.totalChunks) nsplit = G.totalChunks;
+static int wg_launch(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream) {
+    constexpr int XS = 64 + Elt<T>::VEC;
+    CvGeom G;
+    size_t lds_unused;
+    int TM = WG_TM, rc;
+    size_t lds;
+    for (;;) {                                     // shrink the lattice tile until halo + g tile fit LDS
+        rc = cv_geometry(d, &G, sizeof(T), XS, 0, &lds_unused, TM);
+        if (rc) return rc;
+        TM = ((G.TH * G.TW + 15) / 16) * 16;       // e.g. 11 x 11 MPD tile -> 128 rows, the tail rows are zero
+        lds = ((size_t)G.IH * G.IW + TM) * XS * sizeof(T) + TM * sizeof(int);
+        if (lds <= 160 * 1024) break;
+        if (G.TH * G.TW <= 16) return MSMC_E_SHAPE;
+        TM = (G.TH * G.TW) / 2;
+    }
+    const int totalTiles = G.tilesX * G.tilesY * d->B;
+    const int ctiles = ((d->Cout + 63) / 64) * ((d->Cin + 63) / 64);
+    int nsplit = (2 * MSMC_NUM_CU + ctiles - 1) / ctiles;
+    if (nsplit > totalTiles) nsplit = totalTiles;
     if (nsplit < 1) nsplit = 1;
-    G.chunksPerWg = (G.totalChunks + nsplit - 1) / nsplit;
-    nsplit = (G.totalChunks + G.chunksPerWg - 1) / G.chunksPerWg;
+    const int tilesPerWg = (totalTiles + nsplit - 1) / nsplit;
+    nsplit = (totalTiles + tilesPerWg - 1) / tilesPerWg;
     dim3 grid((unsigned)nsplit, (unsigned)((d->Cout + 63) / 64), (unsigned)((d->Cin + 63) / 64));
-    const size_t lds = (size_t)2 * 64 * LS * sizeof(T);
     const T* gp = (const T*)g;
-    if (d->ntaps <= 4) MSMC_LAUNCH((conv_wgrad_kernel<T, 4>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, G);
-    else if (d->ntaps <= 8) MSMC_LAUNCH((conv_wgrad_kernel<T, 8>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, G);
-    else if (d->ntaps <= 12) MSMC_LAUNCH((conv_wgrad_kernel<T, 12>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, G);
-    else MSMC_LAUNCH((conv_wgrad_kernel<T, 16>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, G);
+#define WG_GO(TP)                                                                                              \
+    do {                                                                                                       \
+        rc = msmc_allow_lds((const void*)conv_wgrad_kernel<T, TP>, (int)lds);                                  \
+        if (rc) return rc;                                                                                     \
+        MSMC_LAUNCH((conv_wgrad_kernel<T, TP>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, db, G,\
+                    tilesPerWg, totalTiles, TM);                                                               \
+    } while (0)
+    if (d->ntaps <= 4) WG_GO(4);
+    else if (d->ntaps <= 8) WG_GO(8);
+    else if (d->ntaps <= 12) WG_GO(12);
+    else WG_GO(16);
+#undef WG_GO
     return msmc_check_launch();
 }
 
-extern "C" int msmc_conv_wgrad(const msmc_conv_desc* d, const void* g, float* dw, msmc_stream stream) {
+extern "C" int msmc_conv_wgrad(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream) {
     if (!d || !g || !dw || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0) return MSMC_E_SHAPE;
     if (d->ntaps <= 0 || d->ntaps > MSMC_CONV_MAX_TAPS) return MSMC_E_SHAPE;
-    if (d->dtype == 0) return wg_launch<float>(d, g, dw, stream);
-    if (d->dtype == 1) return wg_launch<unsigned short>(d, g, dw, stream);
+    if (d->dtype == 0) return wg_launch<float>(d, g, dw, db, stream);
+    if (d->dtype == 1) return wg_launch<unsigned short>(d, g, dw, db, stream);
     return MSMC_E_SHAPE;
 }
 
@@ -508,14 +814,31 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, float* __restrict__ out, long rows, int C,
                                                     int rows_per_block) {
+    __shared__ float red[256];
     const long r0 = (long)blockIdx.x * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
-        for (long r = r0; r < r1; ++r) s = s + Elt<T>::ld(g + r * C + c);
-        atomicAdd(out + c, s);
+    const int tid = threadIdx.x;
+    if (C >= 256 || (256 % C) != 0) {               // one or more whole columns per work-item
+        for (int c = tid; c < C; c += 256) {
+            float s = 0.f;
+            for (long r = r0; r < r1; ++r) s = s + Elt<T>::ld(g + r * C + c);
+            atomicAdd(out + c, s);
+        }
+        return;
     }
+    // C divides 256: the flat index e = tid + 256*k always lands on column tid % C
+    const long n = (r1 - r0) * C;
+    const T* base = g + r0 * C;
+    float s = 0.f;
+    for (long e = tid; e < n; e += 256) s = s + Elt<T>::ld(base + e);
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 128; st >= C; st >>= 1) {
+        if (tid < st) red[tid] = red[tid] + red[tid + st];
+        __syncthreads();
+    }
+    if (tid < C) atomicAdd(out + tid, red[tid]);
 }
 
 template <typename T>

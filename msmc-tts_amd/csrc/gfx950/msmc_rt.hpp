@@ -62,6 +62,19 @@ MSMC_DEV f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- LDS transpose read (ds_read_b64_tr_b16) ------------------------------------------------------
+// Every lane passes the address of 4 contiguous 16-bit elements (8-byte aligned); within each group of
+// 16 lanes the 16 x 4 elements are transposed: lane l (L = l & 15) receives, for j = 0..3, element
+// (L & 3) of the chunk addressed by lane 16*(l >> 4) + 4*j + (L >> 2).  With lane Ls addressing row
+// (Ls >> 2), columns 4*(Ls & 3).. of a [4][16] block, lane L gets column L of that block: the
+// K-contiguous MFMA fragment of a row-major [k][n] LDS tile.  (Semantics verified on MI355X with
+// tests/probes/tr_probe.hip.)
+MSMC_DEV u16x4 lds_read_tr16(const unsigned short* p) {
+    typedef short s16x4_ __attribute__((ext_vector_type(4)));
+    s16x4_ v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_*)p);
+    return __builtin_bit_cast(u16x4, v);
+}
+
 // ---- bf16 <-> f32 (round to nearest even), bit-level so host and device agree ---------------
 MSMC_DEV unsigned short f32_to_bf16_bits(float f) {
     unsigned int u = __float_as_uint(f);

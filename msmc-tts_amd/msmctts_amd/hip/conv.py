@@ -158,8 +158,9 @@ def conv_transpose1d_dgrad(g, wb, k, stride, padding, Lin, mask_src=None, mask_s
     return gx
 
 
-def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None):
-    """dW [kh*kw, Cout, Cin] fp32 of ``conv_forward`` (x [B,Hin,Win,Cin] pre-activation, g [B,Hout,Wout,Cout])."""
+def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None, db=None):
+    """dW [kh*kw, Cout, Cin] fp32 of ``conv_forward`` (x [B,Hin,Win,Cin] pre-activation, g [B,Hout,Wout,Cout]);
+    when ``db`` (fp32 [Cout]) is given the bias gradient is accumulated into it by the same launch."""
     _check(x, g)
     B, Hin, Win, Cin = x.shape
     Cout = g.shape[3]
@@ -170,7 +171,8 @@ def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None):
     lattice = (geom.Hout, geom.Wout, 0, 1, 0, 1, geom.sy, geom.sx, -geom.py, -geom.px)
     d = _fill(lib.ConvDesc(), x, x, x, B, Hin, Win, Cin, geom.Hout, geom.Wout, Cout, lattice, taps,
               1 if geom.reflect else 0, in_slope=in_slope)
-    lib.check(lib.get().msmc_conv_wgrad(ctypes.byref(d), lib.ptr(g), lib.ptr(dw, torch.float32), lib.stream(x)),
+    lib.check(lib.get().msmc_conv_wgrad(ctypes.byref(d), lib.ptr(g), lib.ptr(dw, torch.float32),
+                                        lib.ptr(db, torch.float32) if db is not None else None, lib.stream(x)),
               'msmc_conv_wgrad')
     return dw
 
@@ -189,7 +191,7 @@ def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None):
     # kernel roles: "x" = g (fine, channels Cout), "g" = x (coarse, channels Cin) -> dw[k][Cin][Cout]
     d = _fill(lib.ConvDesc(), g, g, g, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, in_slope=1.0,
               mask_slope=in_slope)
-    lib.check(lib.get().msmc_conv_wgrad(ctypes.byref(d), lib.ptr(x), lib.ptr(dw, torch.float32), lib.stream(x)),
+    lib.check(lib.get().msmc_conv_wgrad(ctypes.byref(d), lib.ptr(x), lib.ptr(dw, torch.float32), None, lib.stream(x)),
               'msmc_conv_wgrad(convT)')
     return dw
 

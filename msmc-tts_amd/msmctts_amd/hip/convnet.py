@@ -192,11 +192,12 @@ class _HipConv(torch.autograd.Function):
                                               x.shape[2], mask_src=mask, mask_slope=ctx.in_slope)
         if ctx.need_w:
             if layer.kind == 'conv':
-                K.conv_wgrad(x, g, layer.geom(x.shape[1], x.shape[2]), layer.taps, in_slope=ctx.in_slope, dw=layer.dw)
+                K.conv_wgrad(x, g, layer.geom(x.shape[1], x.shape[2]), layer.taps, in_slope=ctx.in_slope, dw=layer.dw,
+                             db=layer.db)
             else:
                 K.conv_transpose1d_wgrad(x, g, layer.kernel[1], layer.stride[1], layer.padding[1],
                                          in_slope=ctx.in_slope, dw=layer.dw)
-            layer.db.add_(K.colsum(g.reshape(-1, g.shape[-1])))
+                layer.db.add_(K.colsum(g.reshape(-1, g.shape[-1])))
             bank._queue_finish()
         # weight_token (the layer's weight_v) only ties the output to the parameters in the autograd graph;
         # parameter gradients are produced in kernel layout and delivered by ConvBank._finish_backward.

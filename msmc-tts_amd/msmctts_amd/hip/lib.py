@@ -51,7 +51,8 @@ class WnItem(ctypes.Structure):
 
 _SIGNATURES.update({
     'msmc_conv_gather': (_i, [ctypes.POINTER(ConvDesc), _vp]),
-    'msmc_conv_wgrad': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp]),
+    'msmc_conv_set_pipeline': (None, [_i]),
+    'msmc_conv_wgrad': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     'msmc_wn_prepare_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_wn_backward_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_colsum': (_i, [_vp, _vp, ctypes.c_long, _i, _i, _vp]),

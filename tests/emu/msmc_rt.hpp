@@ -191,6 +191,23 @@ MSMC_DEV f32x4 mfma_bf16_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
     return c;
 }
 
+// ds_read_b64_tr_b16 by the semantics documented in csrc/gfx950/msmc_rt.hpp (hardware-verified)
+MSMC_DEV u16x4 lds_read_tr16(const unsigned short* p) {
+    u16x4 mine;
+    memcpy(&mine, p, 8);
+    memcpy(emu::slot(emu::lane()), &mine, 8);
+    emu::wave_barrier();
+    const int l = emu::lane(), L = l & 15, grp = l >> 4;
+    u16x4 r;
+    for (int j = 0; j < 4; ++j) {
+        u16x4 src;
+        memcpy(&src, emu::slot(16 * grp + 4 * j + (L >> 2)), 8);
+        r[j] = src[L & 3];
+    }
+    emu::collective_done();
+    return r;
+}
+
 static inline unsigned int __float_as_uint(float f) { unsigned int u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned int u) { float f; memcpy(&f, &u, 4); return f; }
 MSMC_DEV unsigned short f32_to_bf16_bits(float f) {
