@@ -86,7 +86,8 @@ def build(args, device, rank, world):
     torch.manual_seed(cfg.seed)
     task = build_task(cfg, mode='train')
     trainer = build_trainer(cfg, task, num_gpus=world, rank=rank)      # moves to GPU; arms RCCL reducer if world>1
-    trainer.optimizer = build_optimizer(trainer.model, cfg.optimizer)
+    trainer.optimizer = build_optimizer(trainer.model, cfg.optimizer, capturable=not args.no_graph)
+    trainer.use_graphs = not args.no_graph
     trainer.amp_dtype = torch.bfloat16 if args.dtype == 'bf16' else None
     trainer.model.train()
     return cfg, trainer
@@ -138,8 +139,9 @@ def cpu_baseline(cfg, state_dict, batch, windows, steps, threads, sample):
     return timed[len(timed) // 2], float(cb['mel_length'].sum())
 
 
-def vq_microbench(device, H, K, D=256, N=1 << 20, iters=20):
-    from msmctts_amd.hip import vq
+def vq_microbench(device, H, K, D=256, N=1 << 20, iters=20, variant=1):
+    from msmctts_amd.hip import lib, vq
+    lib.get().msmc_vq_set_variant(variant)
     g = torch.Generator(device='cpu').manual_seed(0)
     x = torch.randn(N, D, generator=g).to(device)
     embed = torch.randn(H, D // H, K, generator=g).to(device)
@@ -155,7 +157,8 @@ def vq_microbench(device, H, K, D=256, N=1 << 20, iters=20):
     torch.cuda.synchronize()
     ms = s.elapsed_time(e) / iters          # includes three small output allocations per call (cached allocator)
     byts = N * vq_bytes_per_frame(D, H)
-    return dict(kernel='vq_search_kernel', N=N, D=D, H=H, K=K, ms=ms, GBps=byts / ms / 1e6,
+    lib.get().msmc_vq_set_variant(1)
+    return dict(kernel='vq_search_reg_kernel' if variant else 'vq_search_kernel', N=N, D=D, H=H, K=K, ms=ms, GBps=byts / ms / 1e6,
                 frac_hbm=byts / ms / 1e6 / HBM_PEAK_GBS, Mframes_per_s=N / ms / 1e3,
                 fp32_TFLOPs=2.0 * K * D * N / ms / 1e9)
 
@@ -174,6 +177,7 @@ def main():
     ap.add_argument('--cpu-batch', type=int, default=4, help='utterances of the batch in the cpu_baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = min(available cores, 32)')
     ap.add_argument('--no-microbench', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying hipGraphs')
     ap.add_argument('--kernel-timing-steps', type=int, default=3, help='extra steps timed kernel by kernel (rank 0)')
     args = ap.parse_args()
 
@@ -232,8 +236,9 @@ def main():
         timer.wrap(hipconv, fn, label, work)
 
     def step(i):
-        trainer.model.zero_grad()
-        trainer.optimizer.zero_grad()
+        if not trainer.use_graphs:
+            trainer.model.zero_grad()
+            trainer.optimizer.zero_grad()
         return trainer.train_step(batch, 10 + i)
 
     say('built model; starting warm-up')
@@ -256,7 +261,10 @@ def main():
     # second pass over the same steps with HIP events around every hand-written launch (the events cost a
     # few percent of host time, so the headline value above is taken without them)
     ms_instr = None
-    if rank == 0 and args.kernel_timing_steps > 0:
+    if rank == 0 and world == 1 and args.kernel_timing_steps > 0:
+        graphs_were = trainer.use_graphs
+        trainer.use_graphs = False               # per-launch HIP events need the eager path
+        trainer.model.zero_grad()
         timer.enabled = True
         t1 = time.perf_counter()
         for i in range(args.kernel_timing_steps):
@@ -264,6 +272,7 @@ def main():
         torch.cuda.synchronize()
         ms_instr = (time.perf_counter() - t1) / args.kernel_timing_steps * 1e3
         timer.enabled = False
+        trainer.use_graphs = graphs_were
     if world > 1:
         dist.barrier()
     if world > 1:
@@ -308,7 +317,8 @@ def main():
                                % (args.heads, args.codewords),
                    'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'frames': args.frames,
                    'mel_frames_per_step': frames_per_step, 'parallelism': 'dp%d' % world,
-                   'vq_search': 'fp32 (bit-exact indices)'},
+                   'vq_search': 'fp32 (bit-exact indices)',
+                   'execution': 'eager' if args.no_graph else 'hipGraph replay (3 segments/step)'},
         'step_tflops': FLOP_PER_STEP_ELIDED * (args.batch / 16.0) * world / (elapsed / args.steps) / 1e12,
         'step_flop_model': 'SURVEY 8d: 3.006 TFLOP/step at B=16,T=400 minus the elided D weight-grads of the G step '
                            '= 2.65 TFLOP',
@@ -318,8 +328,10 @@ def main():
         'losses': {k: float(v) for k, v in log['loss'].items()},
     }
     if not args.no_microbench:
-        out['vq_microbench'] = [vq_microbench(device, args.heads, args.codewords),
-                                vq_microbench(device, 4, 64)]
+        out['vq_microbench'] = [vq_microbench(device, args.heads, args.codewords), vq_microbench(device, 4, 64),
+                                vq_microbench(device, 8, 512),
+                                vq_microbench(device, args.heads, args.codewords, variant=0),
+                                vq_microbench(device, 4, 64, variant=0)]
         say('vq microbench done')
     if world == 1 and args.cpu_steps > 0:
         cores = host_cores()

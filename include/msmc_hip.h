@@ -51,6 +51,9 @@ int msmc_vq_prepare(const float* embed, float* embed_t, float* enorm, int H, int
 int msmc_vq_search(const float* x, const float* embed_t, const float* enorm, float* quant, float* diff,
                    int64_t* ind, int N, int D, int H, int K, msmc_stream stream);
 
+/* Perf-experiment switch: 0 selects the LDS-tile search kernel for every shape; default 1. */
+void msmc_vq_set_variant(int v);
+
 /* Bytes of scratch msmc_vq_ema_update needs for these sizes. */
 size_t msmc_vq_ema_workspace(int N, int D, int H, int K);
 

@@ -21,6 +21,10 @@
 #define VQ_TILE 16
 #define VQ_LDS_LIMIT (160 * 1024)
 
+// A/B switch (msmc_vq_set_variant): 1 = register-resident search kernel where d % 16 == 0, 0 = LDS-tile kernel.
+static int vq_use_reg_kernel = 1;
+extern "C" void msmc_vq_set_variant(int v) { vq_use_reg_kernel = v; }
+
 // ------------------------------------------------------------------------------------------------
 // prepare: embed [H][d][K] -> embed_t [H][K][d], enorm [H][K]
 // ------------------------------------------------------------------------------------------------
@@ -255,6 +259,182 @@ __global__ __launch_bounds__(256) void vq_search_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// search, register-resident variant (d % 16 == 0): no frame tile in LDS.  Lane (f, g) of a wave keeps
+// the 4*D4H values x[f][16t + 4g + jj] of the current head in registers (one 16-byte load per t, the
+// next head's / tile's loads are issued before the MFMAs of the current one), feeds them as the MFMA B
+// operand while the A operand streams from the LDS codebook with 16-byte reads (one per 4 MFMAs), and
+// forms quant / diff in registers.  LDS holds only the codebook, so two workgroups share a CU.
+// fp32 summation order: channels are visited as (t, jj, g) -> 16t + 4g + jj; oracle/c/vq_oracle.c mirrors it.
+// ------------------------------------------------------------------------------------------------
+template <int D4H>
+__global__ __launch_bounds__(256, 2) void vq_search_reg_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ embed_t,
+                                                              const float* __restrict__ enorm,
+                                                              float* __restrict__ quant, float* __restrict__ diff,
+                                                              int64_t* __restrict__ ind, int N, int D, int H, int K,
+                                                              int hpg) {
+    MSMC_DYN_LDS(smem);
+    const int d = 16 * D4H;
+    const int ES = d + 4;
+    float* cb = (float*)smem;                        // [hpg*K][ES]
+    float* en = cb + (size_t)hpg * K * ES;           // [hpg*K]
+    const int nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = lane & 15, g = lane >> 4;
+    const int ngroups = (H + hpg - 1) / hpg;
+    const int numTiles = (N + VQ_TILE - 1) / VQ_TILE;
+    const int numIters = (numTiles + nw - 1) / nw;
+
+    auto stage_group = [&](int h0, int cnt) {
+        const int rows = cnt * K, dv = d >> 2;
+        const f32x4* src = (const f32x4*)(embed_t + (size_t)h0 * K * d);
+        for (int e = threadIdx.x; e < rows * dv; e += blockDim.x) {
+            int r = e / dv, c4 = e - r * dv;
+            *(f32x4*)(cb + (size_t)r * ES + c4 * 4) = src[e];
+        }
+        for (int e = threadIdx.x; e < rows; e += blockDim.x) en[e] = enorm[(size_t)h0 * K + e];
+    };
+    if (ngroups == 1) {
+        stage_group(0, H);
+        __syncthreads();
+    }
+
+    f32x4 xb[D4H], xn[D4H], dacc[D4H];
+    auto load_frag = [&](f32x4 (&dst)[D4H], int tile, int h) {
+        const int n = tile * VQ_TILE + f;
+#pragma unroll
+        for (int t = 0; t < D4H; ++t) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (tile < numTiles && n < N) v = *(const f32x4*)(x + (size_t)n * D + h * d + 16 * t + 4 * g);
+            dst[t] = v;
+        }
+    };
+
+    int it = blockIdx.x;
+    if (it < numIters) load_frag(xn, it * nw + w, 0);
+    for (; it < numIters; it += gridDim.x) {
+        const int tile = it * nw + w;
+        const bool active = tile < numTiles;
+        const int n = tile * VQ_TILE + f;
+        for (int grp = 0; grp < ngroups; ++grp) {
+            const int h0 = grp * hpg;
+            const int cnt = (H - h0 < hpg) ? (H - h0) : hpg;
+            if (ngroups > 1) {
+                __syncthreads();
+                stage_group(h0, cnt);
+                __syncthreads();
+            }
+            for (int hl = 0; hl < cnt; ++hl) {
+                const int h = h0 + hl;
+#pragma unroll
+                for (int t = 0; t < D4H; ++t) xb[t] = xn[t];
+                // next fragment in flight: next head of this tile, else head 0 of this wave's next tile
+                if (h + 1 < H) load_frag(xn, tile, h + 1);
+                else if (it + (int)gridDim.x < numIters) load_frag(xn, (it + gridDim.x) * nw + w, 0);
+                if (!active) continue;
+                const float* cbh = cb + (size_t)hl * K * ES;
+                const float* enh = en + hl * K;
+                float xx = 0.f;
+#pragma unroll
+                for (int t = 0; t < D4H; ++t)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        float sq = xb[t][jj] * xb[t][jj];
+                        xx = xx + sq;
+                    }
+                xx = xx + wave_xor(xx, 16);
+                xx = xx + wave_xor(xx, 32);
+
+                float best = __builtin_inff();
+                int bi = 0;
+                const int ntile = K >> 4;
+                int ct = 0;
+                for (; ct + 2 <= ntile; ct += 2) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                    const float* a0 = cbh + (size_t)(ct * 16 + f) * ES + 4 * g;
+                    const float* a1 = a0 + 16 * ES;
+#pragma unroll
+                    for (int t = 0; t < D4H; ++t) {
+                        const f32x4 av0 = *(const f32x4*)(a0 + 16 * t);
+                        const f32x4 av1 = *(const f32x4*)(a1 + 16 * t);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            acc0 = mfma_f32_16x16x4(av0[jj], xb[t][jj], acc0);
+                            acc1 = mfma_f32_16x16x4(av1[jj], xb[t][jj], acc1);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int code = ct * 16 + 4 * g + r;
+                        float t2 = 2.f * acc0[r];
+                        float dist = (xx - t2) + enh[code];
+                        if (dist < best) { best = dist; bi = code; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int code = ct * 16 + 16 + 4 * g + r;
+                        float t2 = 2.f * acc1[r];
+                        float dist = (xx - t2) + enh[code];
+                        if (dist < best) { best = dist; bi = code; }
+                    }
+                }
+                if (ct < ntile) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
+                    const float* a0 = cbh + (size_t)(ct * 16 + f) * ES + 4 * g;
+#pragma unroll
+                    for (int t = 0; t < D4H; ++t) {
+                        const f32x4 av0 = *(const f32x4*)(a0 + 16 * t);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) acc0 = mfma_f32_16x16x4(av0[jj], xb[t][jj], acc0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int code = ct * 16 + 4 * g + r;
+                        float t2 = 2.f * acc0[r];
+                        float dist = (xx - t2) + enh[code];
+                        if (dist < best) { best = dist; bi = code; }
+                    }
+                }
+#pragma unroll
+                for (int m = 16; m <= 32; m <<= 1) {
+                    float od = wave_xor(best, m);
+                    int oi = wave_xor(bi, m);
+                    if (od < best || (od == best && oi < bi)) { best = od; bi = oi; }
+                }
+                const bool row_ok = n < N;
+                if (g == 0 && row_ok) ind[(size_t)n * H + h] = (int64_t)bi;
+                const float* qrow = cbh + (size_t)bi * ES + 4 * g;
+#pragma unroll
+                for (int t = 0; t < D4H; ++t) {
+                    const f32x4 q4 = *(const f32x4*)(qrow + 16 * t);
+                    f32x4 o4, s4;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        float e = q4[jj] - xb[t][jj];
+                        o4[jj] = xb[t][jj] + e;
+                        float sq = e * e;
+                        s4[jj] = (h == 0) ? sq : (dacc[t][jj] + sq);
+                    }
+                    dacc[t] = s4;
+                    if (row_ok) *(f32x4*)(quant + (size_t)n * D + h * d + 16 * t + 4 * g) = o4;
+                }
+            }
+        }
+        if (active && n < N) {
+            const float fh = (float)H;
+#pragma unroll
+            for (int t = 0; t < D4H; ++t) {
+                f32x4 v = dacc[t];
+                if (H > 1) { v[0] = v[0] / fh; v[1] = v[1] / fh; v[2] = v[2] / fh; v[3] = v[3] / fh; }
+                *(f32x4*)(diff + (size_t)n * d + 16 * t + 4 * g) = v;
+            }
+        }
+    }
+}
+
+typedef void (*vq_search_reg_fn)(const float*, const float*, const float*, float*, float*, int64_t*, int, int, int, int,
+                                 int);
+
 typedef void (*vq_search_fn)(const float*, const float*, const float*, float*, float*, int64_t*, int, int, int, int,
                              int, VqLds);
 
@@ -412,6 +592,37 @@ int msmc_vq_search(const float* x, const float* embed_t, const float* enorm, flo
     const int d = D / H;
     if (d % 4 || K % 16 || K <= 0) return MSMC_E_SHAPE;
     if (N == 0) return 0;
+    if (d % 16 == 0 && vq_use_reg_kernel) {
+        const int d4h = d / 16;
+        vq_search_reg_fn rf = nullptr;
+        if (d4h == 1) rf = vq_search_reg_kernel<1>;
+        else if (d4h == 2) rf = vq_search_reg_kernel<2>;
+        else if (d4h == 4) rf = vq_search_reg_kernel<4>;
+        else if (d4h == 8) rf = vq_search_reg_kernel<8>;
+        else if (d4h == 16) rf = vq_search_reg_kernel<16>;
+        if (rf) {
+            // most resident heads with <= 80 KiB (two workgroups per CU); at least one head must fit 160 KiB
+            int hpg = H;
+            size_t lds;
+            for (;;) {
+                lds = ((size_t)hpg * K * (d + 4) + (size_t)hpg * K) * sizeof(float);
+                if (lds <= 80 * 1024 || hpg == 1) break;
+                hpg = (hpg + 1) / 2;
+            }
+            if (lds <= VQ_LDS_LIMIT) {
+                int rc = msmc_allow_lds((const void*)rf, (int)lds);
+                if (rc) return rc;
+                const int nw = 4;
+                const int numTiles = (N + VQ_TILE - 1) / VQ_TILE;
+                const int numIters = (numTiles + nw - 1) / nw;
+                const int wgs = (lds <= 80 * 1024 ? 2 : 1) * MSMC_NUM_CU;
+                const int grid = numIters < wgs ? numIters : wgs;
+                MSMC_LAUNCH(rf, dim3(grid), dim3(64 * nw), lds, (msmc_stream_t)stream, x, embed_t, enorm, quant, diff,
+                            ind, N, D, H, K, hpg);
+                return msmc_check_launch();
+            }
+        }
+    }
     // pick the widest workgroup and the most resident heads that fit LDS
     int nw = 4, hpg = H;
     VqLds L;

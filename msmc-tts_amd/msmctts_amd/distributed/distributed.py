@@ -105,6 +105,25 @@ class GradReducer(object):
         b.ready = []
         b.pending = set(id(p) for p in b.params)
 
+    def allreduce_child(self, child):
+        """Synchronous exchange of every existing gradient of one child (used between hipGraph replays, where
+        the hooks do not fire): one flat all-reduce, averaged, written back in place."""
+        ps = [p for p in child.parameters() if p.requires_grad and p.grad is not None]
+        if not ps:
+            return
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        dist.all_reduce(flat, group=self.group)
+        flat.div_(self.world)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            p.grad.copy_(flat[off:off + n].view_as(p.grad))
+            off += n
+        for b in self.buckets:                      # drop hook state recorded while capturing
+            b.ready = []
+            b.pending = set(id(q) for q in b.params)
+        self._inflight = []
+
     def finish(self):
         """Flush partial buckets, wait for the collectives, write back grad / world_size."""
         for b in self.buckets:

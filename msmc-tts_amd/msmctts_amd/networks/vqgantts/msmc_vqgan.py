@@ -13,9 +13,9 @@ from ..hifigan.generator import Generator as HifiGANGenerator
 from .modules import MultiHeadQuantize, Quantize, ResStack
 
 
-def _positions(lengths, device):
-    """1..len per utterance, 0 on padding (msmc_vqgan.py:56-58)."""
-    width = int(lengths.max())
+def _positions(lengths, device, width):
+    """1..len per utterance, 0 on padding (msmc_vqgan.py:56-58).  The reference takes the width from
+    ``lengths.max()`` (a host sync); the batch contract guarantees it equals the padded length."""
     pos = torch.arange(1, width + 1, device=device).unsqueeze(0).repeat(lengths.shape[0], 1)
     return pos.masked_fill(get_mask_from_lengths(lengths.to(device), width), 0)
 
@@ -41,7 +41,7 @@ class MultiStageEncoder(nn.Module):
                 feat = F.avg_pool1d(feat.transpose(1, 2), kernel_size=scale, stride=scale,
                                     ceil_mode=True).transpose(1, 2)
                 flen = torch.ceil(flen / scale).int()
-            feat, _ = enc(feat, _positions(flen, feat.device))
+            feat, _ = enc(feat, _positions(flen, feat.device, feat.shape[1]))
             outputs.append((feat, flen))
         return outputs
 
@@ -96,7 +96,7 @@ class MultiStageQuantizer(nn.Module):
             if residual is None:
                 pred_q = None
             else:
-                residual = residual[:, :int(length.max())]
+                residual = residual[:, :(emb.shape[1] if emb is not None else int(length.max()))]
                 hid, pred_q = self.predictor[i](residual, length)
                 residual = residual + F.dropout(hid, p=self.dropout, training=self.training)
             if emb is None:
@@ -172,7 +172,7 @@ class MSMCVQGAN(nn.Module):
 
     def _decode_frames(self, x, lengths):
         if hasattr(self, 'frame_decoder'):
-            x, _ = self.frame_decoder(x, _positions(lengths, x.device))
+            x, _ = self.frame_decoder(x, _positions(lengths, x.device, x.shape[1]))
         return x
 
     def forward(self, mel, mel_length, warmup=False, window=None):
@@ -186,7 +186,9 @@ class MSMCVQGAN(nn.Module):
         if hasattr(self, 'mel_predictor'):
             out['mel_outputs'] = self.mel_predictor(dec_in)
         if not warmup:
-            if window is not None:
+            if torch.is_tensor(window):            # (B, n_frames) frame indices on the device: graph-replayable
+                dec_in = torch.gather(dec_in, 1, window.unsqueeze(-1).expand(-1, -1, dec_in.shape[-1]))
+            elif window is not None:
                 assert len(window) == dec_in.shape[0]
                 dec_in = torch.stack([dec_in[i, s:e] for i, (s, e) in enumerate(window)], dim=0)
             out['decoder_outputs'] = self.decoder(dec_in.transpose(1, 2)).transpose(1, 2)

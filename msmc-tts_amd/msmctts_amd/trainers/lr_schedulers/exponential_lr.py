@@ -17,4 +17,7 @@ class ExponentialDecayLRScheduler(object):
         for key, opt in optimizer.optimizers.items():
             lr = max(self.final_learning_rate, scale * optimizer.config[key].learning_rate)
             for group in opt.param_groups:
-                group['lr'] = lr
+                if hasattr(group['lr'], 'fill_'):       # capturable optimizers keep lr in a device tensor
+                    group['lr'].fill_(lr)
+                else:
+                    group['lr'] = lr

@@ -84,6 +84,8 @@ class VQGANTrainer(BaseTrainer):
             self.stft_criterion = MultiResolutionSTFTLoss(**dict(stft_loss_config or {}))
         self.rng = random              # python global RNG, like the reference (:214); tests inject their own
         self._amp_applied = None
+        self.use_graphs = False        # replay the GAN-phase step as three hipGraphs (static shapes)
+        self._graphs = None
         self.amp_dtype = None          # e.g. torch.bfloat16: autocast for the GEMM/conv bodies (VQ search stays fp32)
 
     def random_select(self, mel_length):
@@ -107,72 +109,180 @@ class VQGANTrainer(BaseTrainer):
         device_type = next(self.model.parameters()).device.type
         return torch.autocast(device_type=device_type, dtype=self.amp_dtype)
 
-    def train_step(self, batch, iteration):
-        losses = {}
-        mel, mel_length, wav = batch['mel'], batch['mel_length'], batch['wav']
+    # ------------------------------------------------------------------------------------------
+    # The step is three segments separated by the two gradient exchanges of the data-parallel path:
+    #   A  autoencoder forward, losses, D(fake.detach) / D(real), d_loss.backward()
+    #   B  D optimizer step, D(fake) / D(real) against the updated D, g_loss.backward()
+    #   C  gradient clipping, autoencoder optimizer step
+    # Eagerly they run back to back; ``use_graphs`` captures each into a hipGraph (static batch buffers,
+    # window indices on the device) and replays them with the RCCL all-reduces in between.
+    # ------------------------------------------------------------------------------------------
+    def _segment_a(self, st):
+        losses = st.losses = {}
+        mel, mel_length = st.mel, st.mel_length
         ae, disc = self.model.autoencoder, getattr(self.model, 'discriminator', None)
-        if iteration < self.warmup_steps:
-            with self._amp():
-                out = ae(mel, mel_length, warmup=True)
-        else:
-            frame_windows, sample_windows = self.random_select(batch.get('mel_length_host', mel_length))
-            target = torch.stack([wav[i, s:e] for i, (s, e) in enumerate(sample_windows)], dim=0)
-            with self._amp():
-                out = ae(mel, mel_length, warmup=False, window=frame_windows)
-
+        with self._amp():
+            out = ae(mel, mel_length, warmup=st.phase == 0, window=st.frame_window)
         vq = self.vq_criterion(out)
         losses.update(vq)
         g_loss = vq['vq_loss']
-
         if 'mel_outputs' in out:
             ml = F.mse_loss(mel, out['mel_outputs'].float(), reduction='none')
             ml = ml.masked_fill(get_mask_from_lengths(mel_length, ml.shape[1]).unsqueeze(-1), 0)
             ml = ml.sum() / mel_length.sum() / ml.shape[2]
             losses['frame_loss'] = ml
             g_loss = g_loss + self.lambda_frame * ml
+        st.g_loss = g_loss
+        if st.phase < 2:
+            return
+        st.predict = predict = out['decoder_outputs'].squeeze(-1).float()
+        target = st.target
+        stl = self.stft_criterion(predict, target)
+        if isinstance(stl, dict):
+            for name, term in stl.items():
+                losses[name] = term
+            stl = sum(stl.values())
+        losses['stft_loss'] = stl
+        st.g_loss = g_loss + self.lambda_stft * stl
+        with self._amp():
+            fake_scores, _ = disc(predict.detach())
+            real_scores, _ = disc(target)
+        d_real = sum(F.mse_loss(r.float(), torch.ones_like(r, dtype=torch.float32)) for r in real_scores)
+        d_fake = sum(F.mse_loss(f.float(), torch.zeros_like(f, dtype=torch.float32)) for f in fake_scores)
+        d_loss = d_real + d_fake
+        losses['d_loss_real'], losses['d_loss_fake'], losses['d_loss'] = d_real, d_fake, d_loss
+        self.optimizer.zero_grad(['discriminator'])
+        d_loss.backward()
 
-        if iteration > self.warmup_steps:
-            predict = out['decoder_outputs'].squeeze(-1).float()
-            target = target.squeeze(-1)
-            st = self.stft_criterion(predict, target)
-            if isinstance(st, dict):
-                for name, term in st.items():
-                    losses[name] = term
-                st = sum(st.values())
-            losses['stft_loss'] = st
-            g_loss = g_loss + self.lambda_stft * st
-
-            # ---- discriminator step
-            with self._amp():
-                fake_scores, _ = disc(predict.detach())
-                real_scores, _ = disc(target)
-            d_real = sum(F.mse_loss(r.float(), torch.ones_like(r, dtype=torch.float32)) for r in real_scores)
-            d_fake = sum(F.mse_loss(f.float(), torch.zeros_like(f, dtype=torch.float32)) for f in fake_scores)
-            d_loss = d_real + d_fake
-            losses['d_loss_real'], losses['d_loss_fake'], losses['d_loss'] = d_real, d_fake, d_loss
-            self.optimizer.zero_grad(['discriminator'])
-            d_loss.backward()
-            self._sync_grads()
+    def _segment_b(self, st):
+        losses, disc = st.losses, getattr(self.model, 'discriminator', None)
+        if st.phase == 2:
             self.optimizer.step(['discriminator'])
-
-            # ---- generator step (against the updated D; D's own gradients are not needed)
+            # generator step against the updated D; D's own gradients are not needed
             with _frozen(disc), self._amp():
-                fake_scores, fake_feats = disc(predict)
+                fake_scores, fake_feats = disc(st.predict)
                 with torch.no_grad():
-                    _, real_feats = disc(target)
+                    _, real_feats = disc(st.target)
             adv = sum(F.mse_loss(f.float(), torch.ones_like(f, dtype=torch.float32)) for f in fake_scores)
             fm = 0
             for fa, fb in zip(fake_feats, real_feats):
                 for a, b in zip(fa, fb):
                     fm = fm + F.l1_loss(a.float(), b.float())
-            lam = self.lambda_fm if self.lambda_fm != 'auto' else (g_loss / fm).detach()
+            lam = self.lambda_fm if self.lambda_fm != 'auto' else (st.g_loss / fm).detach()
             adv = adv + fm * lam
-            g_loss = g_loss + adv
-            losses['fm_loss'], losses['adv_loss'], losses['g_loss'] = fm, adv, g_loss
-
+            st.g_loss = st.g_loss + adv
+            losses['fm_loss'], losses['adv_loss'], losses['g_loss'] = fm, adv, st.g_loss
         self.optimizer.zero_grad(['autoencoder'])
-        g_loss.backward()
-        self._sync_grads()
-        self.grad_norm = nn.utils.clip_grad_norm_(ae.parameters(), self.grad_clip_thresh)
+        st.g_loss.backward()
+
+    def _segment_c(self, st):
+        self.grad_norm = nn.utils.clip_grad_norm_(self.model.autoencoder.parameters(), self.grad_clip_thresh)
         self.optimizer.step(['autoencoder'])
-        return {'loss': {k: (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()}}
+
+    def _phase(self, iteration):
+        """0 = warm-up (no vocoder), 1 = vocoder runs but no GAN/STFT loss (iteration == warmup_steps), 2 = GAN."""
+        if iteration < self.warmup_steps:
+            return 0
+        return 2 if iteration > self.warmup_steps else 1
+
+    def train_step(self, batch, iteration):
+        phase = self._phase(iteration)
+        if self.use_graphs and phase == 2:
+            return self._train_step_graphed(batch)
+        st = _StepState()
+        st.phase, st.mel, st.mel_length = phase, batch['mel'], batch['mel_length']
+        st.frame_window = st.target = None
+        if phase > 0:
+            frame_windows, sample_windows = self.random_select(batch.get('mel_length_host', batch['mel_length']))
+            st.frame_window = frame_windows
+            st.target = torch.stack([batch['wav'][i, s:e] for i, (s, e) in enumerate(sample_windows)], dim=0).squeeze(-1)
+        self._segment_a(st)
+        if phase == 2:
+            self._sync_grads()
+        self._segment_b(st)
+        self._sync_grads()
+        self._segment_c(st)
+        return {'loss': {k: (v.detach() if torch.is_tensor(v) else v) for k, v in st.losses.items()}}
+
+    # -- hipGraph replay of the GAN-phase step -----------------------------------------------------
+    def _train_step_graphed(self, batch):
+        g = self._graphs
+        if g is None:
+            g = self._graphs = self._capture(batch)
+        st = g['state']
+        lengths = batch.get('mel_length_host')
+        if lengths is None:
+            lengths = batch['mel_length'].tolist()
+        starts = [self.rng.randrange(max(1, int(n) - self.frame_lengths)) for n in lengths]
+        g['starts_host'].copy_(torch.tensor(starts, dtype=torch.int64))
+        g['starts'].copy_(g['starts_host'], non_blocking=True)
+        if batch['mel'].data_ptr() != st.mel.data_ptr():
+            st.mel.copy_(batch['mel'], non_blocking=True)
+            st.mel_length.copy_(batch['mel_length'], non_blocking=True)
+            g['wav'].copy_(batch['wav'].reshape(g['wav'].shape), non_blocking=True)
+        g['a'].replay()
+        self._sync_grads_static('discriminator')
+        g['b'].replay()
+        self._sync_grads_static('autoencoder')
+        g['c'].replay()
+        return {'loss': dict(g['losses'])}
+
+    def _sync_grads_static(self, child):
+        reducer = getattr(self.model, 'grad_reducer', None)
+        if reducer is not None:
+            reducer.allreduce_child(getattr(self.model, child))
+
+    def _build_windows(self, g, st):
+        """Frame / sample index tensors from the per-utterance window starts (device arithmetic only)."""
+        starts = g['starts']
+        fl = self.frame_lengths
+        st.frame_window = starts.unsqueeze(1) + torch.arange(fl, device=starts.device).unsqueeze(0)
+        sidx = (starts * self.frameshift).unsqueeze(1) + torch.arange(fl * self.frameshift,
+                                                                      device=starts.device).unsqueeze(0)
+        st.target = torch.gather(g['wav'], 1, sidx)
+
+    def _capture(self, batch):
+        """Warm up eagerly on a side stream, then record segments A, B, C into three graphs sharing one pool."""
+        dev = batch['mel'].device
+        B = batch['mel'].shape[0]
+        st = _StepState()
+        st.phase = 2
+        st.mel, st.mel_length = batch['mel'].clone(), batch['mel_length'].clone()
+        g = {'state': st, 'wav': batch['wav'].reshape(B, -1).clone(),
+             'starts': torch.zeros(B, dtype=torch.int64, device=dev),
+             'starts_host': torch.zeros(B, dtype=torch.int64).pin_memory()}
+
+        def run_eager():
+            self._build_windows(g, st)
+            self._segment_a(st)
+            self._sync_grads_static('discriminator')
+            self._segment_b(st)
+            self._sync_grads_static('autoencoder')
+            self._segment_c(st)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.model.zero_grad(set_to_none=True)
+                run_eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.model.zero_grad(set_to_none=True)          # gradients get (static) graph-pool storage during capture
+        ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            self._build_windows(g, st)
+            self._segment_a(st)
+        self._sync_grads_static('discriminator')
+        with torch.cuda.graph(gb, pool=ga.pool()):
+            self._segment_b(st)
+        self._sync_grads_static('autoencoder')
+        with torch.cuda.graph(gc, pool=ga.pool()):
+            self._segment_c(st)
+        torch.cuda.synchronize()
+        g.update(a=ga, b=gb, c=gc, losses={k: v.detach() for k, v in st.losses.items() if torch.is_tensor(v)})
+        return g
+
+
+class _StepState(object):
+    pass

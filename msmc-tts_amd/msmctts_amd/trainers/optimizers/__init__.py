@@ -12,7 +12,7 @@ from torch.optim import Adam, AdamW
 from .radam import RAdam
 
 
-def get_optimizer(parameters, config):
+def get_optimizer(parameters, config, capturable=False):
     parameters = list(parameters)
     name = config._name
     args = (config.learning_rate, tuple(config.betas), config.eps, config.weight_decay)
@@ -20,10 +20,14 @@ def get_optimizer(parameters, config):
         return RAdam(parameters, *args)
     cls = {'Adam': Adam, 'AdamW': AdamW}[name]
     fused = any(p.is_cuda for p in parameters)
+    if fused and capturable:         # hipGraph replay: step counters and lr live on the device
+        dev = next(p.device for p in parameters if p.is_cuda)
+        return cls(parameters, torch.tensor(float(config.learning_rate), device=dev), tuple(config.betas), config.eps,
+                   config.weight_decay, fused=True, capturable=True)
     return cls(parameters, *args, fused=True) if fused else cls(parameters, *args)
 
 
-def build_optimizer(model, config):
+def build_optimizer(model, config, capturable=False):
     optimizers, configs = {}, {}
     for child_name, child in model.named_children():
         if child_name in config:
@@ -40,7 +44,7 @@ def build_optimizer(model, config):
                     params.append(p)
                 else:
                     p.requires_grad = False
-        optimizers[child_name] = get_optimizer(params, cfg)
+        optimizers[child_name] = get_optimizer(params, cfg, capturable)
     return Optimizer(optimizers, configs)
 
 

@@ -33,10 +33,24 @@ int vq_oracle_search(const float* x, const float* embed, int64_t* ind, float* qu
     for (long n = 0; n < N; ++n) {
         for (int h = 0; h < H; ++h) {
             const float* xh = x + (size_t)n * D + (size_t)h * d;
+            /* channel visiting order of the kernel: natural for the LDS-tile kernel (d % 16 != 0), and
+             * (t, jj, g) -> 16t + 4g + jj for the register-resident kernel (d % 16 == 0); the four
+             * partial sums of |x|^2 belong to the lane groups g */
+            const int perm = (d % 16) == 0;
             float p[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int j = 0; j < d; ++j) {
-                float sq = xh[j] * xh[j];
-                p[j & 3] = p[j & 3] + sq;
+            if (perm) {
+                for (int g = 0; g < 4; ++g)
+                    for (int t = 0; t < d / 16; ++t)
+                        for (int jj = 0; jj < 4; ++jj) {
+                            float v = xh[16 * t + 4 * g + jj];
+                            float sq = v * v;
+                            p[g] = p[g] + sq;
+                        }
+            } else {
+                for (int j = 0; j < d; ++j) {
+                    float sq = xh[j] * xh[j];
+                    p[j & 3] = p[j & 3] + sq;
+                }
             }
             /* lane group g combines as (p_g + p_{g^1}) + (p_{g^2} + p_{g^3}); addition commutes */
             float xx = (p[0] + p[1]) + (p[2] + p[3]);
@@ -44,7 +58,16 @@ int vq_oracle_search(const float* x, const float* embed, int64_t* ind, float* qu
             int bi = 0;
             for (int k = 0; k < K; ++k) {
                 float dot = 0.f;
-                for (int j = 0; j < d; ++j) dot = fmaf(embed[((size_t)h * d + j) * K + k], xh[j], dot);
+                if (perm) {
+                    for (int t = 0; t < d / 16; ++t)
+                        for (int jj = 0; jj < 4; ++jj)
+                            for (int g = 0; g < 4; ++g) {
+                                int j = 16 * t + 4 * g + jj;
+                                dot = fmaf(embed[((size_t)h * d + j) * K + k], xh[j], dot);
+                            }
+                } else {
+                    for (int j = 0; j < d; ++j) dot = fmaf(embed[((size_t)h * d + j) * K + k], xh[j], dot);
+                }
                 float t2 = 2.f * dot;
                 float dist = (xx - t2) + enorm[h * K + k];
                 if (dist < best) { best = dist; bi = k; }

@@ -144,3 +144,47 @@ def test_no_cpu_fallback():
     from msmctts_amd.hip import vq
     with pytest.raises(RuntimeError):
         vq.vq_prepare(torch.randn(1, 4, 16))
+
+
+def test_graphed_step_matches_eager():
+    """hipGraph replay of the GAN-phase step (three captured segments) against the eager step: same
+    weights, batch and windows -> same losses and parameters (the small model has no dropout)."""
+    import random
+    from msmctts_amd.synthetic import make_batch
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    batch = make_batch(3, 24, 80, 300, seed=5, device=DEV)
+    batch['mel_length_host'] = batch['mel_length'].tolist()
+    results = []
+    for graphed in (False, True):
+        cfg, task = _parity.build_small(DEV)
+        tr = build_trainer(cfg, task, num_gpus=0, rank=0)
+        tr.model = task
+        tr.optimizer = build_optimizer(task, cfg.optimizer, capturable=True)
+        tr.use_graphs = graphed
+        tr.rng = random.Random(3)
+        if graphed:
+            log = tr.train_step(batch, 6)                      # 2 eager warm-up steps (window start 0) + capture + replay
+            log2 = tr.train_step(batch, 7)
+        else:
+            zero = lambda ml: ([(0, 8)] * 3, [(0, 2400)] * 3)
+            rs = tr.random_select
+            tr.random_select = zero
+            for it in (6, 6):
+                task.zero_grad()
+                tr.train_step(batch, it)
+            tr.random_select = rs
+            task.zero_grad()
+            log = tr.train_step(batch, 6)
+            task.zero_grad()
+            log2 = tr.train_step(batch, 7)
+        results.append(({k: float(v) for k, v in log['loss'].items()}, {k: float(v) for k, v in log2['loss'].items()},
+                        {k: v.detach().clone() for k, v in task.state_dict().items()}))
+    (e1, e2, es), (g1, g2, gs) = results
+    assert set(e1) == set(g1)
+    for a, b in ((e1, g1), (e2, g2)):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    for k in es:
+        if es[k].dtype.is_floating_point:
+            _parity.close(gs[k], es[k], 2e-3, 1e-3, k)
