@@ -124,7 +124,8 @@ int msmc_conv_wgrad(const msmc_conv_desc* desc, const void* g, float* dw, float*
  *   prepare : w = v * (g / ||v||) written to up to two kernel layouts
  *             dst_k[tap*s_k[0] + a*s_k[1] + b*s_k[2]]  (dtype: 0 fp32, 1 bf16), inv_norm[a] = 1/||v||
  *   backward: from dw (fp32, layout s_1):  gg[a] = sum(dw*v)*inv_norm,
- *             gv = (g*inv_norm) * (dw - v * sum(dw*v) * inv_norm^2)
+ *             gv = (g*inv_norm) * (dw - v * sum(dw*v) * inv_norm^2);  gb = db;
+ *             dw and db are ZEROED as they are consumed (ready for the next accumulation)
  * ``items`` is a DEVICE array; item i owns blocks [block0, block0 + A) of the grid of total_blocks. */
 typedef struct msmc_wn_item {
     const float* v;
@@ -137,7 +138,9 @@ typedef struct msmc_wn_item {
     float* gg;              /* backward: [A] */
     long s1[3];
     long s2[3];
-    int A, Bc, T, dtype, block0, pad_;
+    int A, Bc, T, dtype, block0, nbias;
+    float* db;              /* backward: [nbias] bias-gradient accumulator (consumed and zeroed), may be NULL */
+    float* gb;              /* backward: [nbias] bias gradient out */
 } msmc_wn_item;
 
 int msmc_wn_prepare_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream);
@@ -149,8 +152,34 @@ int msmc_wn_backward_multi(const msmc_wn_item* items, int nitems, int total_bloc
 int msmc_reflect_fold(const void* gp, const void* mask_src, void* gx, int B, int H, int W, int C, int p, float slope,
                       int dtype, msmc_stream stream);
 
+/* gx = g * (y > 0 ? 1 : slope): backward of a leaky ReLU from its OUTPUT y (sign-preserving), n elements. */
+int msmc_lrelu_bwd(const void* g, const void* y, void* gx, long n, float slope, int dtype, msmc_stream stream);
+
 /* Column sums: out[c] = sum_rows g[row][c] (bias gradients); g dtype as above, out fp32 (overwritten). */
 int msmc_colsum(const void* g, float* out, long rows, int C, int dtype, msmc_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * T2  GAN loss terms over MANY tensors in one launch (feature matching has 55 map pairs, the LSGAN terms
+ * 10 score tensors): replaces the per-tensor l1_loss / MSELoss loops of
+ *   VQGANTrainer.train_step, reference msmctts/trainers/msmctts_trainer.py:165-171,187-193.
+ * Tensors are dense (any permutation of a contiguous layout; a and b share it); dtype 0 fp32 / 1 bf16.
+ * ------------------------------------------------------------------------------------------- */
+#define MSMC_MAX_TENSORS 64
+typedef struct msmc_tensor_table {
+    const void* a[MSMC_MAX_TENSORS];
+    const void* b[MSMC_MAX_TENSORS];      /* second operand (L1) or unused */
+    void* ga[MSMC_MAX_TENSORS];           /* backward: gradient wrt a */
+    long n[MSMC_MAX_TENSORS];
+    int count, dtype;
+} msmc_tensor_table;
+
+/* out[0] = sum_i mean_e |a_i[e] - b_i[e]| */
+int msmc_l1_multi_fwd(const msmc_tensor_table* t, float* out, msmc_stream stream);
+/* ga_i[e] = gout[0] * sign(a_i[e] - b_i[e]) / n_i */
+int msmc_l1_multi_bwd(const msmc_tensor_table* t, const float* gout, msmc_stream stream);
+/* out[0] = sum_i mean_e (a_i[e] - target)^2 ;  ga_i[e] = gout[0] * 2 (a_i[e] - target) / n_i */
+int msmc_mse_const_multi_fwd(const msmc_tensor_table* t, float target, float* out, msmc_stream stream);
+int msmc_mse_const_multi_bwd(const msmc_tensor_table* t, float target, const float* gout, msmc_stream stream);
 
 #ifdef __cplusplus
 }

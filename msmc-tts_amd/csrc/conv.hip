@@ -795,10 +795,11 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     const int a = blockIdx.x - it.block0;
     const int n = it.Bc * it.T;
     const float* v = it.v + (size_t)a * n;
+    float* dw = (float*)it.dw;
     float dot = 0.f;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int b = e / it.T, t = e - b * it.T;
-        dot = fmaf(it.dw[t * it.s1[0] + a * it.s1[1] + b * it.s1[2]], v[e], dot);
+        dot = fmaf(dw[t * it.s1[0] + a * it.s1[1] + b * it.s1[2]], v[e], dot);
     }
     dot = block_sum(dot, red);
     const float inv = it.inv_norm[a], gval = it.g[a];
@@ -807,7 +808,23 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     float* gv = it.gv + (size_t)a * n;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int b = e / it.T, t = e - b * it.T;
-        gv[e] = k1 * (it.dw[t * it.s1[0] + a * it.s1[1] + b * it.s1[2]] - v[e] * k2);
+        const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
+        gv[e] = k1 * (dw[o] - v[e] * k2);
+        dw[o] = 0.f;                                  // each accumulator element has exactly this one reader
+    }
+    if (it.db && threadIdx.x == 0)
+        for (int c = a; c < it.nbias; c += it.A) {
+            it.gb[c] = it.db[c];
+            it.db[c] = 0.f;
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                       T* __restrict__ gx, long n, float slope) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float gv = Elt<T>::ld(g + e);
+        Elt<T>::st(gx + e, Elt<T>::ld(y + e) > 0.f ? gv : gv * slope);
     }
 }
 
@@ -901,6 +918,20 @@ int msmc_reflect_fold(const void* gp, const void* mask_src, void* gx, int B, int
         MSMC_LAUNCH(reflect_fold_kernel<unsigned short>, dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream,
                     (const unsigned short*)gp, (const unsigned short*)mask_src, (unsigned short*)gx, B, H, W, C, p,
                     slope, total);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+
+int msmc_lrelu_bwd(const void* g, const void* y, void* gx, long n, float slope, int dtype, msmc_stream stream) {
+    if (!g || !y || !gx || n <= 0) return MSMC_E_SHAPE;
+    long blocks = (n + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    if (dtype == 0)
+        MSMC_LAUNCH(lrelu_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream,
+                    (const float*)g, (const float*)y, (float*)gx, n, slope);
+    else if (dtype == 1)
+        MSMC_LAUNCH(lrelu_bwd_kernel<unsigned short>, dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream,
+                    (const unsigned short*)g, (const unsigned short*)y, (unsigned short*)gx, n, slope);
     else return MSMC_E_SHAPE;
     return msmc_check_launch();
 }

@@ -214,3 +214,12 @@ def reflect_fold(gp, H, W, p=1, mask_src=None, slope=1.0):
                                           lib.ptr(gx), B, H, W, C, p, float(slope), _DT[gp.dtype], lib.stream(gp)),
               'msmc_reflect_fold')
     return gx
+
+
+def lrelu_bwd(g, y, slope):
+    """g * (y > 0 ? 1 : slope) -- leaky-ReLU backward from the activation's output."""
+    assert g.shape == y.shape and g.dtype == y.dtype and g.is_contiguous() and y.is_contiguous()
+    gx = torch.empty_like(g)
+    lib.check(lib.get().msmc_lrelu_bwd(lib.ptr(g), lib.ptr(y), lib.ptr(gx), g.numel(), float(slope), _DT[g.dtype],
+                                       lib.stream(g)), 'msmc_lrelu_bwd')
+    return gx

@@ -77,6 +77,7 @@ class ConvBank(object):
         self.inv_norm = torch.empty(tot_a, dtype=torch.float32, device=dev)
         self.gg = torch.empty(tot_a, dtype=torch.float32, device=dev)
         self.db = torch.zeros(tot_b, dtype=torch.float32, device=dev)
+        self.gb = torch.empty(tot_b, dtype=torch.float32, device=dev)
         items = (lib.WnItem * len(self.layers))()
         ow = oa = ob = blk = 0
         esz = self.w1.element_size()
@@ -91,6 +92,8 @@ class ConvBank(object):
             it.A, it.Bc, it.T = A, v.shape[1], l.taps
             it.dtype = 0 if dtype == torch.float32 else 1
             it.block0 = blk
+            it.nbias = l.cout
+            it.db, it.gb = self.db.data_ptr() + ob * 4, self.gb.data_ptr() + ob * 4
             w1 = self.w1[ow:ow + n]
             w2 = self.w2[ow:ow + n]
             dw = self.dw[ow:ow + n]
@@ -105,6 +108,7 @@ class ConvBank(object):
                 l.wb, l.wf = w1.view(l.taps, l.cin, l.cout), w2.view(l.taps, l.cout, l.cin)
                 l.dw = dw.view(l.taps, l.cin, l.cout)
             l.db = self.db[ob:ob + l.cout]
+            l.gb_view = self.gb[ob:ob + l.cout]
             l.gv_view = self.gv[ow:ow + n].view_as(v)
             l.gg_view = self.gg[oa:oa + A].view_as(g)
             ow, oa, ob, blk = ow + pad8(n), oa + A, ob + l.cout, blk + A
@@ -137,15 +141,15 @@ class ConvBank(object):
                 m = l.module
                 if not m.weight_v.requires_grad:
                     continue
-                for p, gview in ((m.bias, l.db), (m.weight_g, l.gg_view), (m.weight_v, l.gv_view)):
+                # gradients ARE the bank's output buffers (no copies): they stay valid until the next backward
+                # of this network, i.e. past the optimizer step that consumes them
+                for p, gview in ((m.bias, l.gb_view), (m.weight_g, l.gg_view), (m.weight_v, l.gv_view)):
                     if p.grad is None:
-                        p.grad = gview.clone()
-                    else:
+                        p.grad = gview
+                    elif p.grad.data_ptr() != gview.data_ptr():
                         p.grad.add_(gview)
                     if GRAD_READY_HOOK is not None:
                         GRAD_READY_HOOK(p)
-            self.dw.zero_()
-            self.db.zero_()
 
 
 class _HipConv(torch.autograd.Function):
@@ -173,7 +177,7 @@ class _HipConv(torch.autograd.Function):
         layer, bank = ctx.layer, ctx.bank
         g = g.contiguous()
         if ctx.out_slope != 1.0:                       # y = lrelu(z): dz = dy * (y > 0 ? 1 : slope)
-            g = g * torch.where(out > 0, 1.0, ctx.out_slope).to(g.dtype)
+            g = K.lrelu_bwd(g, out, ctx.out_slope)
         if ctx.out_div != 1.0:
             g = g / ctx.out_div
         gx = None

@@ -47,16 +47,30 @@ class WnItem(ctypes.Structure):
     """msmc_wn_item of include/msmc_hip.h."""
     _fields_ = [('v', _vp), ('g', _vp), ('dst1', _vp), ('dst2', _vp), ('inv_norm', _vp), ('dw', _vp), ('gv', _vp),
                 ('gg', _vp), ('s1', ctypes.c_long * 3), ('s2', ctypes.c_long * 3), ('A', _i), ('Bc', _i), ('T', _i),
-                ('dtype', _i), ('block0', _i), ('pad_', _i)]
+                ('dtype', _i), ('block0', _i), ('nbias', _i), ('db', _vp), ('gb', _vp)]
+
+
+MAX_TENSORS = 64
+
+
+class TensorTable(ctypes.Structure):
+    """msmc_tensor_table of include/msmc_hip.h."""
+    _fields_ = [('a', _vp * MAX_TENSORS), ('b', _vp * MAX_TENSORS), ('ga', _vp * MAX_TENSORS),
+                ('n', ctypes.c_long * MAX_TENSORS), ('count', _i), ('dtype', _i)]
 
 
 _SIGNATURES.update({
+    'msmc_l1_multi_fwd': (_i, [ctypes.POINTER(TensorTable), _vp, _vp]),
+    'msmc_l1_multi_bwd': (_i, [ctypes.POINTER(TensorTable), _vp, _vp]),
+    'msmc_mse_const_multi_fwd': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp]),
+    'msmc_mse_const_multi_bwd': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp]),
     'msmc_conv_gather': (_i, [ctypes.POINTER(ConvDesc), _vp]),
     'msmc_conv_set_pipeline': (None, [_i]),
     'msmc_conv_wgrad': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     'msmc_wn_prepare_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_wn_backward_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_colsum': (_i, [_vp, _vp, ctypes.c_long, _i, _i, _vp]),
+    'msmc_lrelu_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _f, _i, _vp]),
     'msmc_reflect_fold': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
 })
 

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..hip import losses as hiploss
 from ..utils.utils import get_mask_from_lengths
 from .base_trainer import BaseTrainer
 from .criterions.stft_loss import MelLoss, MultiResolutionSTFTLoss
@@ -147,8 +148,8 @@ class VQGANTrainer(BaseTrainer):
         with self._amp():
             fake_scores, _ = disc(predict.detach())
             real_scores, _ = disc(target)
-        d_real = sum(F.mse_loss(r.float(), torch.ones_like(r, dtype=torch.float32)) for r in real_scores)
-        d_fake = sum(F.mse_loss(f.float(), torch.zeros_like(f, dtype=torch.float32)) for f in fake_scores)
+        d_real = hiploss.mse_const_sum(real_scores, 1.0)         # LSGAN, summed over the 10 sub-discriminators
+        d_fake = hiploss.mse_const_sum(fake_scores, 0.0)
         d_loss = d_real + d_fake
         losses['d_loss_real'], losses['d_loss_fake'], losses['d_loss'] = d_real, d_fake, d_loss
         self.optimizer.zero_grad(['discriminator'])
@@ -163,11 +164,8 @@ class VQGANTrainer(BaseTrainer):
                 fake_scores, fake_feats = disc(st.predict)
                 with torch.no_grad():
                     _, real_feats = disc(st.target)
-            adv = sum(F.mse_loss(f.float(), torch.ones_like(f, dtype=torch.float32)) for f in fake_scores)
-            fm = 0
-            for fa, fb in zip(fake_feats, real_feats):
-                for a, b in zip(fa, fb):
-                    fm = fm + F.l1_loss(a.float(), b.float())
+            adv = hiploss.mse_const_sum(fake_scores, 1.0)
+            fm = hiploss.l1_sum([a for fa in fake_feats for a in fa], [b for fb in real_feats for b in fb])
             lam = self.lambda_fm if self.lambda_fm != 'auto' else (st.g_loss / fm).detach()
             adv = adv + fm * lam
             st.g_loss = st.g_loss + adv
@@ -268,16 +266,24 @@ class VQGANTrainer(BaseTrainer):
                 run_eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # Drop every reference to the warm-up autograd graphs (their AccumulateGrad nodes are bound to a
+        # stream) and capture on the SAME side stream the warm-up ran on, so that gradient accumulation is
+        # recorded into the graphs instead of running on another stream.
+        for name in ('losses', 'g_loss', 'predict', 'target', 'frame_window'):
+            setattr(st, name, None)
+        self.grad_norm = None
+        import gc as _gc
+        _gc.collect()
         self.model.zero_grad(set_to_none=True)          # gradients get (static) graph-pool storage during capture
         ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
+        with torch.cuda.graph(ga, stream=side):
             self._build_windows(g, st)
             self._segment_a(st)
         self._sync_grads_static('discriminator')
-        with torch.cuda.graph(gb, pool=ga.pool()):
+        with torch.cuda.graph(gb, pool=ga.pool(), stream=side):
             self._segment_b(st)
         self._sync_grads_static('autoencoder')
-        with torch.cuda.graph(gc, pool=ga.pool()):
+        with torch.cuda.graph(gc, pool=ga.pool(), stream=side):
             self._segment_c(st)
         torch.cuda.synchronize()
         g.update(a=ga, b=gb, c=gc, losses={k: v.detach() for k, v in st.losses.items() if torch.is_tensor(v)})
