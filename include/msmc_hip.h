@@ -159,6 +159,41 @@ int msmc_lrelu_bwd(const void* g, const void* y, void* gx, long n, float slope, 
 int msmc_colsum(const void* g, float* out, long rows, int C, int dtype, msmc_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * D3/L1  spectral front-ends as framed-DFT GEMMs on the matrix cores (exact-fp32 MFMA through
+ * msmc_conv_gather with one tap) plus three fused element-wise kernels.  Replaces torch.stft (cuFFT/hipFFT)
+ * and the surrounding glue of
+ *   TorchSTFT.transform / MelScale.forward   reference msmctts/utils/audio.py:398-419, 348-376
+ *   MelLoss.mel_spectrogram                  reference msmctts/trainers/criterions/stft_loss.py:76-108
+ * All fp32.
+ * ------------------------------------------------------------------------------------------- */
+
+/* frames[b][t][j] = x[b][reflect(t*hop + j - pad)] for j < n_fft, 0 for n_fft <= j < NP (row pitch NP).
+ * pad = n_fft/2 (centred STFT) or (n_fft-hop)/2 (MelLoss); x [B][L], frames [B][T][NP]. */
+int msmc_stft_frames_fwd(const float* x, float* frames, int B, int L, int T, int n_fft, int NP, int hop, int pad,
+                         msmc_stream stream);
+/* overlap-add adjoint: gx[b][l] = sum of gframes over every (t, j) that read sample l (reflections included). */
+int msmc_stft_frames_bwd(const float* gframes, float* gx, int B, int L, int T, int n_fft, int NP, int hop, int pad,
+                         msmc_stream stream);
+
+/* spec [R][CP] holds re in columns [0,F) and im in [F,2F) -> mag[r][f] = sqrt(clamp(re^2+im^2, lo)) when
+ * clamp_mode = 1 (audio.py:403-404) or sqrt(re^2+im^2+lo) when clamp_mode = 0 (stft_loss.py:104);
+ * mag [R][FP], columns F..FP zeroed. */
+int msmc_spec_mag_fwd(const float* spec, float* mag, long R, int F, int CP, int FP, float lo, int clamp_mode,
+                      msmc_stream stream);
+int msmc_spec_mag_bwd(const float* spec, const float* mag, const float* gmag, float* gspec, long R, int F, int CP,
+                      int FP, float lo, int clamp_mode, msmc_stream stream);
+
+/* MRD image, channels-last [B][F][T][2] from mel [B*T][FP]: ch0 = mel, ch1 = clamp((20 log10(mel) - ref + 100)/100, 0, 1)
+ * (audio.py:411-419 'double' domain, ref_level_db = 20, min_level_db = -100). */
+int msmc_mrd_image_fwd(const float* mel, float* img, int B, int T, int F, int FP, msmc_stream stream);
+int msmc_mrd_image_bwd(const float* mel, const float* gimg, float* gmel, int B, int T, int F, int FP,
+                       msmc_stream stream);
+
+/* y = log(max(x, lo)) and its backward gx = g * (x > lo ? 1/x : 0) over n elements (stft_loss.py:110-114). */
+int msmc_log_clamp_fwd(const float* x, float* y, long n, float lo, msmc_stream stream);
+int msmc_log_clamp_bwd(const float* x, const float* g, float* gx, long n, float lo, msmc_stream stream);
+
+/* ---------------------------------------------------------------------------------------------
  * T2  GAN loss terms over MANY tensors in one launch (feature matching has 55 map pairs, the LSGAN terms
  * 10 score tensors): replaces the per-tensor l1_loss / MSELoss loops of
  *   VQGANTrainer.train_step, reference msmctts/trainers/msmctts_trainer.py:165-171,187-193.

@@ -1,0 +1,210 @@
+// spectral.hip -- STFT framing and magnitude / log / mel glue kernels for gfx950.
+//
+// The DFT itself and the mel projections run as one-tap channels-last "convolutions" (plain GEMMs) on the
+// fp32 matrix cores through msmc_conv_gather; these kernels are the memory-bound pieces around them:
+// reflect-padded framing and its overlap-add adjoint, magnitude, the MRD two-channel image with the
+// transposition to the channels-last [B][F][T][2] layout the discriminator stack consumes, and log-clamp.
+// Replaces torch.stft + glue of TorchSTFT.transform (reference msmctts/utils/audio.py:398-419),
+// MelScale.forward (:348-376) and MelLoss.mel_spectrogram (reference criterions/stft_loss.py:76-108).
+#include <msmc_rt.hpp>
+#include <msmc_hip.h>
+
+MSMC_DEV int sp_reflect(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * n - 2 - i;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void stft_frames_fwd_kernel(const float* __restrict__ x, float* __restrict__ fr, int L,
+                                                             int T, int n_fft, int NP, int hop, int pad, long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int j = (int)(e % NP);
+        const long r = e / NP;
+        const int t = (int)(r % T);
+        const long b = r / T;
+        float v = 0.f;
+        if (j < n_fft) v = x[b * L + sp_reflect(t * hop + j - pad, L)];
+        fr[e] = v;
+    }
+}
+
+// gx[b][l]: frames read padded position p = t*hop + j; sample l is read at p = l + pad and, through the
+// reflection, at p = pad - l (l >= 1, left border) and p = 2(L-1) - l + pad (l <= L-2, right border).
+__global__ __launch_bounds__(256) void stft_frames_bwd_kernel(const float* __restrict__ gfr, float* __restrict__ gx,
+                                                             int L, int T, int n_fft, int NP, int hop, int pad,
+                                                             long total) {
+    const int Lp = (T - 1) * hop + n_fft;           // padded positions actually covered by frames
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int l = (int)(e % L);
+        const long b = e / L;
+        int ps[3], np = 0;
+        ps[np++] = l + pad;
+        if (l >= 1 && l <= pad) ps[np++] = pad - l;
+        if (l <= L - 2 && 2 * (L - 1) - l + pad < Lp) ps[np++] = 2 * (L - 1) - l + pad;
+        float s = 0.f;
+        for (int q = 0; q < np; ++q) {
+            const int p = ps[q];
+            if (p < 0 || p >= Lp) continue;
+            int t_hi = p / hop;
+            if (t_hi > T - 1) t_hi = T - 1;
+            int t_lo = (p - n_fft + hop) / hop;      // ceil((p - n_fft + 1) / hop)
+            if (p - n_fft + 1 <= 0) t_lo = 0;
+            for (int t = t_lo; t <= t_hi; ++t) {
+                const int j = p - t * hop;
+                if (j >= 0 && j < n_fft) s = s + gfr[(b * T + t) * NP + j];
+            }
+        }
+        gx[e] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void spec_mag_fwd_kernel(const float* __restrict__ spec, float* __restrict__ mag, int F,
+                                                          int CP, int FP, float lo, int clamp_mode, long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int f = (int)(e % FP);
+        const long r = e / FP;
+        float v = 0.f;
+        if (f < F) {
+            const float re = spec[r * CP + f], im = spec[r * CP + F + f];
+            float s = re * re + im * im;
+            s = clamp_mode ? (s < lo ? lo : s) : (s + lo);
+            v = sqrtf(s);
+        }
+        mag[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void spec_mag_bwd_kernel(const float* __restrict__ spec, const float* __restrict__ mag,
+                                                          const float* __restrict__ gmag, float* __restrict__ gspec,
+                                                          int F, int CP, int FP, float lo, int clamp_mode, long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % CP);
+        const long r = e / CP;
+        float g = 0.f;
+        if (c < 2 * F) {
+            const int f = c < F ? c : c - F;
+            const float re = spec[r * CP + f], im = spec[r * CP + F + f];
+            const float s = re * re + im * im;
+            if (!clamp_mode || s > lo) g = gmag[r * FP + f] * (c < F ? re : im) / mag[r * FP + f];
+        }
+        gspec[e] = g;
+    }
+}
+
+// img[b][f][t][0..1] <- mel[(b*T + t)][f]   (transposed write; reads are the strided side, tiny tensors)
+__global__ __launch_bounds__(256) void mrd_image_fwd_kernel(const float* __restrict__ mel, float* __restrict__ img, int T,
+                                                           int F, int FP, long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int t = (int)(e % T);
+        long r = e / T;
+        const int f = (int)(r % F);
+        const long b = r / F;
+        const float m = mel[(b * T + t) * FP + f];
+        float lg = (20.f * log10f(m) - 20.f + 100.f) / 100.f;
+        lg = lg < 0.f ? 0.f : (lg > 1.f ? 1.f : lg);
+        f32x2 o = {m, lg};
+        *(f32x2*)(img + e * 2) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void mrd_image_bwd_kernel(const float* __restrict__ mel, const float* __restrict__ gimg,
+                                                           float* __restrict__ gmel, int T, int F, int FP, long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int f = (int)(e % FP);
+        const long r = e / FP;              // b*T + t
+        const int t = (int)(r % T);
+        const long b = r / T;
+        float g = 0.f;
+        if (f < F) {
+            const float m = mel[e];
+            const f32x2 gi = *(const f32x2*)(gimg + (((b * F + f) * (long)T) + t) * 2);
+            const float lg = (20.f * log10f(m) - 20.f + 100.f) / 100.f;
+            g = gi[0];
+            if (lg > 0.f && lg < 1.f) g = g + gi[1] * (0.2f / (2.302585092994046f * m));
+        }
+        gmel[e] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void log_clamp_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                           float lo) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float v = x[e];
+        y[e] = logf(v < lo ? lo : v);
+    }
+}
+__global__ __launch_bounds__(256) void log_clamp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                           float* __restrict__ gx, long n, float lo) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float v = x[e];
+        gx[e] = v > lo ? g[e] / v : 0.f;
+    }
+}
+
+static inline dim3 sp_grid(long total) {
+    long b = (total + 1023) / 1024;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return dim3((unsigned)b);
+}
+
+extern "C" {
+
+int msmc_stft_frames_fwd(const float* x, float* frames, int B, int L, int T, int n_fft, int NP, int hop, int pad,
+                         msmc_stream stream) {
+    if (!x || !frames || B <= 0 || L <= pad || T <= 0 || NP < n_fft || hop <= 0 || pad < 0) return MSMC_E_SHAPE;
+    const long total = (long)B * T * NP;
+    MSMC_LAUNCH(stft_frames_fwd_kernel, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, x, frames, L, T, n_fft, NP,
+                hop, pad, total);
+    return msmc_check_launch();
+}
+int msmc_stft_frames_bwd(const float* gframes, float* gx, int B, int L, int T, int n_fft, int NP, int hop, int pad,
+                         msmc_stream stream) {
+    if (!gframes || !gx || B <= 0 || L <= pad || T <= 0 || NP < n_fft || hop <= 0 || pad < 0) return MSMC_E_SHAPE;
+    const long total = (long)B * L;
+    MSMC_LAUNCH(stft_frames_bwd_kernel, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, gframes, gx, L, T, n_fft, NP,
+                hop, pad, total);
+    return msmc_check_launch();
+}
+int msmc_spec_mag_fwd(const float* spec, float* mag, long R, int F, int CP, int FP, float lo, int clamp_mode,
+                      msmc_stream stream) {
+    if (!spec || !mag || R <= 0 || F <= 0 || CP < 2 * F || FP < F) return MSMC_E_SHAPE;
+    const long total = R * FP;
+    MSMC_LAUNCH(spec_mag_fwd_kernel, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, spec, mag, F, CP, FP, lo,
+                clamp_mode, total);
+    return msmc_check_launch();
+}
+int msmc_spec_mag_bwd(const float* spec, const float* mag, const float* gmag, float* gspec, long R, int F, int CP,
+                      int FP, float lo, int clamp_mode, msmc_stream stream) {
+    if (!spec || !mag || !gmag || !gspec || R <= 0 || F <= 0 || CP < 2 * F || FP < F) return MSMC_E_SHAPE;
+    const long total = R * CP;
+    MSMC_LAUNCH(spec_mag_bwd_kernel, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, spec, mag, gmag, gspec, F, CP,
+                FP, lo, clamp_mode, total);
+    return msmc_check_launch();
+}
+int msmc_mrd_image_fwd(const float* mel, float* img, int B, int T, int F, int FP, msmc_stream stream) {
+    if (!mel || !img || B <= 0 || T <= 0 || F <= 0 || FP < F) return MSMC_E_SHAPE;
+    const long total = (long)B * F * T;
+    MSMC_LAUNCH(mrd_image_fwd_kernel, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, mel, img, T, F, FP, total);
+    return msmc_check_launch();
+}
+int msmc_mrd_image_bwd(const float* mel, const float* gimg, float* gmel, int B, int T, int F, int FP,
+                       msmc_stream stream) {
+    if (!mel || !gimg || !gmel || B <= 0 || T <= 0 || F <= 0 || FP < F) return MSMC_E_SHAPE;
+    const long total = (long)B * T * FP;
+    MSMC_LAUNCH(mrd_image_bwd_kernel, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, mel, gimg, gmel, T, F, FP,
+                total);
+    return msmc_check_launch();
+}
+int msmc_log_clamp_fwd(const float* x, float* y, long n, float lo, msmc_stream stream) {
+    if (!x || !y || n <= 0) return MSMC_E_SHAPE;
+    MSMC_LAUNCH(log_clamp_fwd_kernel, sp_grid(n), dim3(256), 0, (msmc_stream_t)stream, x, y, n, lo);
+    return msmc_check_launch();
+}
+int msmc_log_clamp_bwd(const float* x, const float* g, float* gx, long n, float lo, msmc_stream stream) {
+    if (!x || !g || !gx || n <= 0) return MSMC_E_SHAPE;
+    MSMC_LAUNCH(log_clamp_bwd_kernel, sp_grid(n), dim3(256), 0, (msmc_stream_t)stream, x, g, gx, n, lo);
+    return msmc_check_launch();
+}
+
+}  // extern "C"

@@ -60,6 +60,14 @@ class TensorTable(ctypes.Structure):
 
 
 _SIGNATURES.update({
+    'msmc_stft_frames_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'msmc_stft_frames_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'msmc_spec_mag_fwd': (_i, [_vp, _vp, ctypes.c_long, _i, _i, _i, _f, _i, _vp]),
+    'msmc_spec_mag_bwd': (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _i, _i, _i, _f, _i, _vp]),
+    'msmc_mrd_image_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'msmc_mrd_image_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'msmc_log_clamp_fwd': (_i, [_vp, _vp, ctypes.c_long, _f, _vp]),
+    'msmc_log_clamp_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _f, _vp]),
     'msmc_l1_multi_fwd': (_i, [ctypes.POINTER(TensorTable), _vp, _vp]),
     'msmc_l1_multi_bwd': (_i, [ctypes.POINTER(TensorTable), _vp, _vp]),
     'msmc_mse_const_multi_fwd': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp]),

@@ -1,0 +1,171 @@
+"""Spectral front-ends on the gfx950 kernels: framed-DFT GEMMs (csrc/conv.hip, exact-fp32 MFMA, one tap) between
+the framing / magnitude / image / log kernels of csrc/spectral.hip.
+
+Replaces ``torch.stft`` + glue of ``TorchSTFT.transform`` / ``MelScale.forward``
+(reference msmctts/utils/audio.py:398-419, 348-376) and ``MelLoss.mel_spectrogram``
+(reference msmctts/trainers/criterions/stft_loss.py:76-108).  Everything is fp32 (also in bf16 runs).
+"""
+import math
+
+import torch
+
+from . import conv as K
+from . import lib
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class _Frames(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, T, n_fft, NP, hop, pad):
+        B, L = x.shape
+        xc = x.contiguous().float()
+        fr = torch.empty((B, 1, T, NP), dtype=torch.float32, device=x.device)
+        lib.check(lib.get().msmc_stft_frames_fwd(lib.ptr(xc), lib.ptr(fr), B, L, T, n_fft, NP, hop, pad, lib.stream(xc)),
+                  'msmc_stft_frames_fwd')
+        ctx.args = (B, L, T, n_fft, NP, hop, pad)
+        return fr
+
+    @staticmethod
+    def backward(ctx, g):
+        B, L, T, n_fft, NP, hop, pad = ctx.args
+        g = g.contiguous()
+        gx = torch.empty((B, L), dtype=torch.float32, device=g.device)
+        lib.check(lib.get().msmc_stft_frames_bwd(lib.ptr(g), lib.ptr(gx), B, L, T, n_fft, NP, hop, pad, lib.stream(g)),
+                  'msmc_stft_frames_bwd')
+        return gx, None, None, None, None, None
+
+
+class _ConstGemm(torch.autograd.Function):
+    """y[b,1,t,:] = W x[b,1,t,:] with a constant matrix (DFT basis / filter bank): one-tap conv on the fp32 MFMA."""
+
+    @staticmethod
+    def forward(ctx, x, wf, wb):
+        geom = K.Geometry(1, x.shape[2], (1, 1))
+        ctx.save_for_backward(wb)
+        ctx.geom = geom
+        return K.conv_forward(x, wf, geom)
+
+    @staticmethod
+    def backward(ctx, g):
+        (wb,) = ctx.saved_tensors
+        return K.conv_dgrad(g.contiguous(), wb, ctx.geom), None, None
+
+
+class _SpecMag(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, F, FP, lo, clamp_mode):
+        CP = spec.shape[-1]
+        R = spec.numel() // CP
+        mag = torch.empty(spec.shape[:-1] + (FP,), dtype=torch.float32, device=spec.device)
+        lib.check(lib.get().msmc_spec_mag_fwd(lib.ptr(spec), lib.ptr(mag), R, F, CP, FP, lo, clamp_mode, lib.stream(spec)),
+                  'msmc_spec_mag_fwd')
+        ctx.save_for_backward(spec, mag)
+        ctx.args = (R, F, CP, FP, lo, clamp_mode)
+        return mag
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, mag = ctx.saved_tensors
+        R, F, CP, FP, lo, clamp_mode = ctx.args
+        g = g.contiguous()
+        gs = torch.empty_like(spec)
+        lib.check(lib.get().msmc_spec_mag_bwd(lib.ptr(spec), lib.ptr(mag), lib.ptr(g), lib.ptr(gs), R, F, CP, FP, lo,
+                                              clamp_mode, lib.stream(g)), 'msmc_spec_mag_bwd')
+        return gs, None, None, None, None
+
+
+class _MrdImage(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mel, F):
+        B, _, T, FP = mel.shape
+        img = torch.empty((B, F, T, 2), dtype=torch.float32, device=mel.device)
+        lib.check(lib.get().msmc_mrd_image_fwd(lib.ptr(mel), lib.ptr(img), B, T, F, FP, lib.stream(mel)),
+                  'msmc_mrd_image_fwd')
+        ctx.save_for_backward(mel)
+        ctx.F = F
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        (mel,) = ctx.saved_tensors
+        B, _, T, FP = mel.shape
+        g = g.contiguous()
+        gm = torch.empty_like(mel)
+        lib.check(lib.get().msmc_mrd_image_bwd(lib.ptr(mel), lib.ptr(g), lib.ptr(gm), B, T, ctx.F, FP, lib.stream(g)),
+                  'msmc_mrd_image_bwd')
+        return gm, None
+
+
+class _LogClamp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, lo):
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        lib.check(lib.get().msmc_log_clamp_fwd(lib.ptr(xc), lib.ptr(y), xc.numel(), lo, lib.stream(xc)),
+                  'msmc_log_clamp_fwd')
+        ctx.save_for_backward(xc)
+        ctx.lo = lo
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (xc,) = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(xc)
+        lib.check(lib.get().msmc_log_clamp_bwd(lib.ptr(xc), lib.ptr(g), lib.ptr(gx), xc.numel(), ctx.lo, lib.stream(g)),
+                  'msmc_log_clamp_bwd')
+        return gx, None
+
+
+def dft_basis(n_fft, win, normalized, device):
+    """Windowed real-DFT basis as one-tap conv slices: forward [1, CP, NP] (rows: re 0..F-1 | im F..2F-1),
+    data-gradient [1, NP, CP].  ``win`` is the analysis window already centred / zero-padded to n_fft."""
+    F = n_fft // 2 + 1
+    NP, CP = _pad4(n_fft), _pad4(2 * F)
+    j = torch.arange(n_fft, dtype=torch.float64)
+    f = torch.arange(F, dtype=torch.float64)
+    ang = 2.0 * math.pi * torch.outer(f, j) / n_fft
+    scale = (1.0 / math.sqrt(n_fft)) if normalized else 1.0
+    w = win.double().cpu() * scale
+    W = torch.zeros((CP, NP), dtype=torch.float64)
+    W[:F, :n_fft] = torch.cos(ang) * w
+    W[F:2 * F, :n_fft] = -torch.sin(ang) * w
+    W = W.float()
+    return W.unsqueeze(0).contiguous().to(device), W.t().unsqueeze(0).contiguous().to(device)
+
+
+def projection(mat, device):
+    """out[:, o] = sum_i in[:, i] * mat[i, o] as one-tap conv slices with both sides padded to multiples of 4."""
+    I, O = mat.shape
+    W = torch.zeros((_pad4(O), _pad4(I)), dtype=torch.float32)
+    W[:O, :I] = mat.t().float().cpu()
+    return W.unsqueeze(0).contiguous().to(device), W.t().unsqueeze(0).contiguous().to(device)
+
+
+def mrd_image(x, n_fft, hop, dft, fb):
+    """x (B, L) -> MRD input image, channels-last [B, F, T', 2] (ch0 mel-scaled magnitude, ch1 normalised log)."""
+    B, L = x.shape
+    F = n_fft // 2 + 1
+    T = L // hop + 1
+    fr = _Frames.apply(x, T, n_fft, _pad4(n_fft), hop, n_fft // 2)
+    spec = _ConstGemm.apply(fr, dft[0], dft[1])
+    mag = _SpecMag.apply(spec, F, _pad4(F), 1e-7, 1)
+    if fb is not None:
+        mag = _ConstGemm.apply(mag, fb[0], fb[1])
+    return _MrdImage.apply(mag, F)
+
+
+def log_mel(y, n_fft, hop, dft, mel, num_mels):
+    """y (B, L) -> log-mel [B, 1, T', pad4(num_mels)] per MelLoss.mel_spectrogram (manual reflect pad, no centring)."""
+    B, L = y.shape
+    F = n_fft // 2 + 1
+    pad = int((n_fft - hop) / 2)
+    T = (L + 2 * pad - n_fft) // hop + 1
+    fr = _Frames.apply(y, T, n_fft, _pad4(n_fft), hop, pad)
+    spec = _ConstGemm.apply(fr, dft[0], dft[1])
+    mag = _SpecMag.apply(spec, F, _pad4(F), 1e-9, 0)
+    m = _ConstGemm.apply(mag, mel[0], mel[1])
+    return _LogClamp.apply(m, 1e-5)[..., :num_mels]

@@ -48,8 +48,8 @@ class DiscriminatorR(nn.Module):
         return [st._modules[st.key].hip_layer() for st in self.discriminator]
 
     def forward_hip(self, bank, layers, img, dtype):
-        """img (B, 2, F, T') -> (score (B, 1, F'', T''), 6 activated feature maps as NCHW-shaped views)."""
-        x = img.permute(0, 2, 3, 1).contiguous().to(dtype)
+        """img channels-last [B, F, T', 2] -> (score (B, 1, F'', T''), 6 activated feature maps as NCHW-shaped views)."""
+        x = img.to(dtype)
         fmaps = []
         last = len(layers) - 1
         for i, layer in enumerate(layers):
@@ -73,9 +73,9 @@ class MultiResolutionDiscriminator(nn.Module):
     def forward_hip(self, bank, layers, x, dtype):
         scores, feats = [], []
         for stft, disc, ls in zip(self.stfts, self.discriminators, layers):
-            mag, _ = stft.transform(x.squeeze(1) if x.dim() == 3 else x)
-            mag = torch.stack(torch.chunk(mag, 2, dim=1), dim=1) if self.domain == 'double' else mag.unsqueeze(1)
-            s, f = disc.forward_hip(bank, ls, mag, dtype)
+            assert self.domain == 'double', 'every shipped config uses the two-channel (mag, log-mag) image'
+            img = stft.image_cl(x.squeeze(1) if x.dim() == 3 else x)
+            s, f = disc.forward_hip(bank, ls, img, dtype)
             scores.append(s)
             feats.append(f)
         return scores, feats

@@ -38,6 +38,9 @@ def mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
 
 
 class MelLoss(nn.Module):
+    """L1 between log-mel spectrograms (reference stft_loss.py:55-114) on the gfx950 kernels: reflect-padded
+    framing, windowed DFT and the Slaney mel projection as fp32 matrix-core GEMMs, fused magnitude and log."""
+
     def __init__(self, fft_size, hop_size, win_size, sample_rate, num_mels):
         super().__init__()
         self.sample_rate, self.fft_size, self.hop_size = sample_rate, fft_size, hop_size
@@ -46,25 +49,28 @@ class MelLoss(nn.Module):
         self._basis = torch.from_numpy(mel_filterbank(sample_rate, fft_size, num_mels, self.fmin, self.fmax))
         self._cache = {}
 
-    def _consts(self, like):
-        key = (str(like.device), like.dtype)
+    def _consts(self, device):
+        key = str(device)
         if key not in self._cache:
-            self._cache[key] = (self._basis.to(like), torch.hann_window(self.win_size, dtype=like.dtype,
-                                                                        device=like.device))
+            from ...hip import spectral
+            win = torch.hann_window(self.win_size)
+            left = (self.fft_size - self.win_size) // 2
+            win = F.pad(win, (left, self.fft_size - self.win_size - left))
+            self._cache[key] = (spectral.dft_basis(self.fft_size, win, False, device),
+                                spectral.projection(self._basis.t(), device))
         return self._cache[key]
 
     def mel_spectrogram(self, y, center=False):
-        basis, window = self._consts(y)
-        pad = int((self.fft_size - self.hop_size) / 2)
-        y = F.pad(y.unsqueeze(1), (pad, pad), mode='reflect').squeeze(1)
-        spec = torch.stft(y, self.fft_size, hop_length=self.hop_size, win_length=self.win_size, window=window,
-                          center=center, pad_mode='reflect', normalized=False, onesided=True, return_complex=True)
-        spec = torch.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-9)
-        return torch.log(torch.clamp(torch.matmul(basis, spec), min=1e-5))
+        """y (B, L) -> (B, num_mels, T') log-mel."""
+        from ...hip import spectral
+        assert not center
+        dft, mel = self._consts(y.device)
+        lm = spectral.log_mel(y.float(), self.fft_size, self.hop_size, dft, mel, self.num_mels)   # [B, 1, T', M]
+        return lm.squeeze(1).transpose(1, 2)
 
     def forward(self, predicts, targets):
         with torch.autocast(device_type=predicts.device.type, enabled=False):
-            return F.l1_loss(self.mel_spectrogram(predicts.float()), self.mel_spectrogram(targets.float()))
+            return F.l1_loss(self.mel_spectrogram(predicts), self.mel_spectrogram(targets))
 
 
 class STFTLoss(nn.Module):

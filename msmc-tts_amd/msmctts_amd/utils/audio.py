@@ -48,35 +48,54 @@ class MelScale(nn.Module):
 
 
 class TorchSTFT(nn.Module):
+    """STFT magnitude front-end of the MRD discriminators (reference audio.py:379-419).
+
+    The transform runs on the gfx950 kernels (msmctts_amd/hip/spectral.py): reflect-padded framing, the
+    windowed DFT and the HTK-mel projection as fp32 GEMMs on the matrix cores, fused magnitude / log image.
+    ``image_cl`` hands the discriminator its channels-last input directly; ``transform`` keeps the reference's
+    (B, 2F, T') return layout.  The unused ``atan2`` phase of the reference (:405) is not computed.
+    """
+
     def __init__(self, fft_size, hop_size, win_size, normalized=False, domain='linear', mel_scale=False,
                  sample_rate=24000, ref_level_db=20, min_level_db=-100):
         super().__init__()
         self.fft_size, self.hop_size, self.win_size = fft_size, hop_size, win_size
         self.ref_level_db, self.min_level_db = ref_level_db, min_level_db
         self.normalized, self.domain = normalized, domain
+        assert (ref_level_db, min_level_db) == (20, -100), 'the image kernel fixes the reference levels'
         self.mel_scale = MelScale(n_mels=fft_size // 2 + 1, sample_rate=sample_rate,
                                   n_stft=fft_size // 2 + 1) if mel_scale else None
-        self._win = {}
+        self._consts = {}
 
-    def window(self, like):
-        key = (str(like.device), like.dtype)
-        if key not in self._win:
-            self._win[key] = torch.hann_window(self.win_size, dtype=like.dtype, device=like.device)
-        return self._win[key]
+    def consts(self, device):
+        key = str(device)
+        if key not in self._consts:
+            from ..hip import spectral
+            win = torch.hann_window(self.win_size)
+            if self.win_size < self.fft_size:
+                left = (self.fft_size - self.win_size) // 2
+                win = torch.nn.functional.pad(win, (left, self.fft_size - self.win_size - left))
+            dft = spectral.dft_basis(self.fft_size, win, self.normalized, device)
+            fb = None
+            if self.mel_scale is not None:
+                F = self.fft_size // 2 + 1
+                fb = spectral.projection(create_fb_matrix(F, self.mel_scale.f_min, self.mel_scale.f_max, F,
+                                                          self.mel_scale.sample_rate), device)
+            self._consts[key] = (dft, fb)
+        return self._consts[key]
+
+    def image_cl(self, x):
+        """x (B, L) -> channels-last [B, F, T', 2]: ch0 (mel-scaled) magnitude, ch1 normalised log-magnitude."""
+        from ..hip import spectral
+        dft, fb = self.consts(x.device)
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            return spectral.mrd_image(x.float(), self.fft_size, self.hop_size, dft, fb)
 
     def transform(self, x):
-        """x (B, L) -> (magnitude image, None); 'double' domain returns cat(mag, norm-log-mag) on dim 1."""
-        with torch.autocast(device_type=x.device.type, enabled=False):      # spectra stay fp32 under bf16 autocast
-            x = x.float()
-            spec = torch.stft(x, self.fft_size, self.hop_size, self.win_size, self.window(x),
-                              normalized=self.normalized, return_complex=True)
-            mag = torch.sqrt(torch.clamp(spec.real ** 2 + spec.imag ** 2, min=1e-7))
-            if self.mel_scale is not None:
-                mag = self.mel_scale(mag)
-            if self.domain == 'linear':
-                return mag, None
-            log_mag = 20 * torch.log10(mag) - self.ref_level_db
-            log_mag = torch.clamp((log_mag - self.min_level_db) / -self.min_level_db, 0, 1)
-            if self.domain == 'log':
-                return log_mag, None
-            return torch.cat((mag, log_mag), dim=1), None
+        img = self.image_cl(x)                       # [B, F, T, 2]
+        B, F, T, _ = img.shape
+        if self.domain == 'linear':
+            return img[..., 0], None
+        if self.domain == 'log':
+            return img[..., 1], None
+        return img.permute(0, 3, 1, 2).reshape(B, 2 * F, T), None

@@ -126,3 +126,38 @@ def test_generator_and_discriminator_full_size_vs_oracle_ops():
     for fa, fb in zip(fmaps, rf):
         for a, b in zip(fa, fb):
             assert a.shape == b.shape and (a.float() - b).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize('hop', [15, 30, 50, 120, 240])
+def test_mrd_spectral_front_end_full_size(hop):
+    """HIP framed-DFT front-end (B=16, L=12000) against the torch.stft-based oracle on the same device:
+    image within 1e-4, gradient wrt the waveform within 1e-3 of its scale."""
+    from msmctts_amd.utils.audio import TorchSTFT
+    from oracle import audio
+    g = torch.Generator().manual_seed(hop)
+    x = (torch.rand(16, 12000, generator=g) * 2 - 1).to(DEV).requires_grad_(True)
+    st = TorchSTFT(fft_size=4 * hop, hop_size=hop, win_size=4 * hop, normalized=True, domain='double', mel_scale=True)
+    img = st.image_cl(x)
+    xo = x.detach().clone().requires_grad_(True)
+    ref = audio.mrd_spectrogram(xo, hop)                       # (B, 2, F, T)
+    assert (img.permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-4
+    go = torch.randn(ref.shape, generator=g).to(DEV)
+    ref.backward(go)
+    img.backward(go.permute(0, 2, 3, 1).contiguous())
+    assert (x.grad - xo.grad).abs().max().item() < 1e-3 * max(1.0, xo.grad.abs().max().item())
+
+
+def test_mel_loss_full_size():
+    from msmctts_amd.trainers.criterions.stft_loss import MelLoss
+    from oracle import audio
+    g = torch.Generator().manual_seed(1)
+    a = (torch.rand(16, 12000, generator=g) * 2 - 1).to(DEV).requires_grad_(True)
+    b = (torch.rand(16, 12000, generator=g) * 2 - 1).to(DEV)
+    ml = MelLoss(fft_size=2048, hop_size=300, win_size=1200, sample_rate=24000, num_mels=128)
+    loss = ml(a, b)
+    ao = a.detach().clone().requires_grad_(True)
+    ref = audio.mel_loss(ao, b)
+    assert abs(loss.item() - ref.item()) < 1e-4
+    loss.backward()
+    ref.backward()
+    assert (a.grad - ao.grad).abs().max().item() < 1e-3 * max(1e-6, ao.grad.abs().max().item()) + 1e-9
