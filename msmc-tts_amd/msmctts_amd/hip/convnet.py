@@ -26,6 +26,46 @@ from . import lib
 GRAD_READY_HOOK = None
 
 
+def fork_join(streams, thunks, inputs=()):
+    """Run independent launch sequences on side HIP streams and join them back (hipGraph-capturable).
+
+    The sub-discriminators / parallel ResBlocks are chains of small kernels (tens of workgroups): run back to
+    back they leave most of the 256 CUs idle, concurrently they fill the chip.  ``inputs`` are tensors produced
+    on the calling stream and read by the side streams; every tensor returned by a thunk is produced on a side
+    stream and consumed by the caller -- both directions are registered with the caching allocator.
+    Autograd replays each backward node on the stream of its forward, so the backward pass forks the same way.
+    """
+    if not streams:
+        return [t() for t in thunks]
+    main = torch.cuda.current_stream()
+    outs = []
+    for i, thunk in enumerate(thunks):
+        st = streams[i % len(streams)]
+        st.wait_stream(main)
+        for x in inputs:
+            x.record_stream(st)
+        with torch.cuda.stream(st):
+            outs.append(thunk())
+    for st in streams[:len(thunks)]:
+        main.wait_stream(st)
+
+    def mark(o):
+        if torch.is_tensor(o):
+            o.record_stream(main)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                mark(v)
+    mark(outs)
+    return outs
+
+
+def make_streams(device, n):
+    """n side streams on a CUDA/HIP device; [] on the CPU (kernel-interpreter tests run sequentially)."""
+    if device.type != 'cuda' or n <= 1:
+        return []
+    return [torch.cuda.Stream(device=device) for _ in range(n)]
+
+
 class ConvLayer(object):
     """Static description of one weight-normalised convolution inside a bank."""
 
@@ -59,6 +99,7 @@ class ConvBank(object):
             l.index = i
         self._sig = None
         self._queued = False
+        self.streams = []               # side streams whose backward launches write this bank's accumulators
 
     # -- (re)build device buffers whenever parameters moved / changed dtype ------------------------
     def _signature(self, dtype):
@@ -134,6 +175,10 @@ class ConvBank(object):
 
     def _finish_backward(self):
         self._queued = False
+        if self.streams:                # weight-gradient launches ran on the side streams of their forward
+            cur = torch.cuda.current_stream()
+            for st in self.streams:
+                cur.wait_stream(st)
         lib.check(lib.get().msmc_wn_backward_multi(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
                                                    lib.stream(self.w1)), 'msmc_wn_backward_multi')
         with torch.no_grad():

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ...hip.convnet import ConvBank, hip_conv
+from ...hip.convnet import ConvBank, fork_join, hip_conv, make_streams
 from ...utils.audio import TorchSTFT
 from ..layers import WNConv2d
 from .common import get_padding
@@ -70,15 +70,11 @@ class MultiResolutionDiscriminator(nn.Module):
         self.discriminators = nn.ModuleList([DiscriminatorR(2 if domain == 'double' else 1, c)
                                              for _, c in zip(hop_lengths, hidden_channels)])
 
-    def forward_hip(self, bank, layers, x, dtype):
-        scores, feats = [], []
-        for stft, disc, ls in zip(self.stfts, self.discriminators, layers):
-            assert self.domain == 'double', 'every shipped config uses the two-channel (mag, log-mag) image'
-            img = stft.image_cl(x.squeeze(1) if x.dim() == 3 else x)
-            s, f = disc.forward_hip(bank, ls, img, dtype)
-            scores.append(s)
-            feats.append(f)
-        return scores, feats
+    def thunks(self, bank, layers, x, dtype):
+        assert self.domain == 'double', 'every shipped config uses the two-channel (mag, log-mag) image'
+        wav = x.squeeze(1) if x.dim() == 3 else x
+        return [lambda stft=stft, disc=disc, ls=ls: disc.forward_hip(bank, ls, stft.image_cl(wav), dtype)
+                for stft, disc, ls in zip(self.stfts, self.discriminators, layers)]
 
 
 class DiscriminatorP(nn.Module):
@@ -118,13 +114,8 @@ class MultiPeriodDiscriminator(nn.Module):
         super().__init__()
         self.discriminators = nn.ModuleList([DiscriminatorP(p, channels, max_channels) for p in periods])
 
-    def forward_hip(self, bank, layers, y, dtype):
-        outs, fmaps = [], []
-        for d, ls in zip(self.discriminators, layers):
-            o, f = d.forward_hip(bank, ls, y, dtype)
-            outs.append(o)
-            fmaps.append(f)
-        return outs, fmaps
+    def thunks(self, bank, layers, y, dtype):
+        return [lambda d=d, ls=ls: d.forward_hip(bank, ls, y, dtype) for d, ls in zip(self.discriminators, layers)]
 
 
 class Discriminator(nn.Module):
@@ -141,6 +132,8 @@ class Discriminator(nn.Module):
             mpd = [d.hip_layers() for d in self.mpd.discriminators]
             self._bank = ConvBank([l for ls in mrd + mpd for l in ls])
             self._layers = (mrd, mpd)
+            self._streams = make_streams(next(self.parameters()).device, len(mrd) + len(mpd))
+            self._bank.streams = self._streams
         return self._bank, self._layers
 
     def forward(self, y):
@@ -148,6 +141,7 @@ class Discriminator(nn.Module):
             y = y.unsqueeze(1)
         bank, (mrd, mpd) = self._hip()
         bank.prepare(self.hip_dtype)
-        s1, f1 = self.mrd.forward_hip(bank, mrd, y, self.hip_dtype)
-        s2, f2 = self.mpd.forward_hip(bank, mpd, y, self.hip_dtype)
-        return s1 + s2, f1 + f2
+        # the ten sub-discriminators are independent chains of small launches: one HIP stream each
+        outs = fork_join(self._streams, self.mrd.thunks(bank, mrd, y, self.hip_dtype) +
+                         self.mpd.thunks(bank, mpd, y, self.hip_dtype), inputs=(y,))
+        return [o[0] for o in outs], [o[1] for o in outs]

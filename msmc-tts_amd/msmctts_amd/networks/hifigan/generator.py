@@ -9,7 +9,7 @@ weight norm is folded into one weight-preparation launch per forward.
 import torch
 import torch.nn as nn
 
-from ...hip.convnet import ConvBank, hip_conv
+from ...hip.convnet import ConvBank, fork_join, hip_conv, make_streams
 from ..layers import WNConv1d, WNConvTranspose1d
 from .common import LRELU_SLOPE, ResBlock1
 
@@ -44,6 +44,8 @@ class Generator(nn.Module):
                         for rb in self.resblocks]}
             flat = [L['pre']] + L['ups'] + [c for a, b in L['rb'] for c in a + b] + [L['post']]
             self._bank, self._layers = ConvBank(flat), L
+            self._streams = make_streams(self.conv_pre.weight_v.device, self.num_kernels)
+            self._bank.streams = self._streams
         return self._bank, self._layers
 
     def forward(self, mel):
@@ -55,17 +57,20 @@ class Generator(nn.Module):
         x = hip_conv(bank, L['pre'], x)
         for i in range(self.num_upsamples):
             x = hip_conv(bank, L['ups'][i], x, in_slope=LRELU_SLOPE)
-            xs = None
-            for j in range(nk):
+            def block_body(j, x=x):
+                """all but the last convolution of parallel ResBlock j (independent of the other blocks)"""
                 c1s, c2s = L['rb'][i * nk + j]
                 y = x
-                for m in range(len(c1s)):
+                for m in range(len(c1s) - 1):
                     t = hip_conv(bank, c1s[m], y, in_slope=LRELU_SLOPE)
-                    if m < len(c1s) - 1:
-                        y = hip_conv(bank, c2s[m], t, res=y, in_slope=LRELU_SLOPE)
-                    else:                          # block output, running sum over blocks and the final mean
-                        xs = hip_conv(bank, c2s[m], t, res=y, res2=xs, in_slope=LRELU_SLOPE,
-                                      out_div=float(nk) if j == nk - 1 else 1.0)
+                    y = hip_conv(bank, c2s[m], t, res=y, in_slope=LRELU_SLOPE)
+                return y, hip_conv(bank, c1s[-1], y, in_slope=LRELU_SLOPE)
+
+            parts = fork_join(self._streams, [lambda j=j: block_body(j) for j in range(nk)], inputs=(x,))
+            xs = None
+            for j, (y, t) in enumerate(parts):    # block outputs, running sum over blocks and the final mean
+                xs = hip_conv(bank, L['rb'][i * nk + j][1][-1], t, res=y, res2=xs, in_slope=LRELU_SLOPE,
+                              out_div=float(nk) if j == nk - 1 else 1.0)
             x = xs
         x = hip_conv(bank, L['post'], x, in_slope=0.01)       # F.leaky_relu default slope (generator.py:52)
         return torch.tanh(x.float()).reshape(x.shape[0], 1, x.shape[2])

@@ -223,7 +223,8 @@ class VQGANTrainer(BaseTrainer):
         g['b'].replay()
         self._sync_grads_static('autoencoder')
         g['c'].replay()
-        return {'loss': dict(g['losses'])}
+        vec = g['loss_vec'].clone()                  # the graph's outputs are static buffers: hand out a snapshot
+        return {'loss': {k: vec[i] for i, k in enumerate(g['loss_keys'])}}
 
     def _sync_grads_static(self, child):
         reducer = getattr(self.model, 'grad_reducer', None)
@@ -283,10 +284,12 @@ class VQGANTrainer(BaseTrainer):
         with torch.cuda.graph(gb, pool=ga.pool(), stream=side):
             self._segment_b(st)
         self._sync_grads_static('autoencoder')
+        keys = [k for k, v in st.losses.items() if torch.is_tensor(v)]
         with torch.cuda.graph(gc, pool=ga.pool(), stream=side):
             self._segment_c(st)
+            loss_vec = torch.stack([st.losses[k].detach().float().reshape(()) for k in keys])
         torch.cuda.synchronize()
-        g.update(a=ga, b=gb, c=gc, losses={k: v.detach() for k, v in st.losses.items() if torch.is_tensor(v)})
+        g.update(a=ga, b=gb, c=gc, loss_vec=loss_vec, loss_keys=keys)
         return g
 
 

@@ -165,6 +165,7 @@ def test_graphed_step_matches_eager():
         tr.rng = random.Random(3)
         if graphed:
             log = tr.train_step(batch, 6)                      # 2 eager warm-up steps (window start 0) + capture + replay
+            log = {'loss': {k: float(v) for k, v in log['loss'].items()}}
             log2 = tr.train_step(batch, 7)
         else:
             zero = lambda ml: ([(0, 8)] * 3, [(0, 2400)] * 3)
