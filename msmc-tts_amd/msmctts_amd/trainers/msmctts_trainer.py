@@ -13,6 +13,7 @@ Differences that change no result:
 * loss values stay on the device (0-dim tensors, ``float(v)`` to read) instead of ~15 host syncs.
 """
 import contextlib
+import os
 import random
 
 import torch
@@ -85,6 +86,7 @@ class VQGANTrainer(BaseTrainer):
             self.stft_criterion = MultiResolutionSTFTLoss(**dict(stft_loss_config or {}))
         self.rng = random              # python global RNG, like the reference (:214); tests inject their own
         self._amp_applied = None
+        self.batch_g_step = os.environ.get('MSMC_BATCH_G_STEP', '1') != '0'
         self.use_graphs = False        # replay the GAN-phase step as three hipGraphs (static shapes)
         self._graphs = None
         self.amp_dtype = None          # e.g. torch.bfloat16: autocast for the GEMM/conv bodies (VQ search stays fp32)
@@ -145,11 +147,13 @@ class VQGANTrainer(BaseTrainer):
             stl = sum(stl.values())
         losses['stft_loss'] = stl
         st.g_loss = g_loss + self.lambda_stft * stl
+        # D(fake.detach()) and D(real) as ONE pass over the concatenated batch (every layer is per-sample, so
+        # the scores are those of two separate passes): half the launches, twice the work per launch
+        B = predict.shape[0]
         with self._amp():
-            fake_scores, _ = disc(predict.detach())
-            real_scores, _ = disc(target)
-        d_real = hiploss.mse_const_sum(real_scores, 1.0)         # LSGAN, summed over the 10 sub-discriminators
-        d_fake = hiploss.mse_const_sum(fake_scores, 0.0)
+            both_scores, _ = disc(torch.cat((predict.detach(), target), dim=0))
+        d_fake = hiploss.mse_const_sum([s_[:B] for s_ in both_scores], 0.0)   # LSGAN, summed over the 10 sub-discriminators
+        d_real = hiploss.mse_const_sum([s_[B:] for s_ in both_scores], 1.0)
         d_loss = d_real + d_fake
         losses['d_loss_real'], losses['d_loss_fake'], losses['d_loss'] = d_real, d_fake, d_loss
         self.optimizer.zero_grad(['discriminator'])
@@ -160,10 +164,19 @@ class VQGANTrainer(BaseTrainer):
         if st.phase == 2:
             self.optimizer.step(['discriminator'])
             # generator step against the updated D; D's own gradients are not needed
-            with _frozen(disc), self._amp():
-                fake_scores, fake_feats = disc(st.predict)
-                with torch.no_grad():
-                    _, real_feats = disc(st.target)
+            if self.batch_g_step:
+                # one pass over [fake; real]: the real half only feeds the (detached) feature-matching targets
+                B = st.predict.shape[0]
+                with _frozen(disc), self._amp():
+                    scores, feats = disc(torch.cat((st.predict, st.target), dim=0))
+                fake_scores = [s_[:B] for s_ in scores]
+                fake_feats = [[f_[:B] for f_ in fl] for fl in feats]
+                real_feats = [[f_[B:].detach() for f_ in fl] for fl in feats]
+            else:
+                with _frozen(disc), self._amp():
+                    fake_scores, fake_feats = disc(st.predict)
+                    with torch.no_grad():
+                        _, real_feats = disc(st.target)
             adv = hiploss.mse_const_sum(fake_scores, 1.0)
             fm = hiploss.l1_sum([a for fa in fake_feats for a in fa], [b for fb in real_feats for b in fb])
             lam = self.lambda_fm if self.lambda_fm != 'auto' else (st.g_loss / fm).detach()
