@@ -31,19 +31,67 @@ class Geometry(object):
         self.Hout = (Hin + 2 * self.py - self.dy * (self.kh - 1) - 1) // self.sy + 1
         self.Wout = (Win + 2 * self.px - self.dx * (self.kw - 1) - 1) // self.sx + 1
 
-    @property
-    def ntaps(self):
-        return self.kh * self.kw
+        self.ntaps = self.kh * self.kw
+        # launch tables, built once per geometry
+        self.fwd_taps = tuple((ky * self.dy, kx * self.dx, ky * self.kw + kx)
+                              for ky in range(self.kh) for kx in range(self.kw))
+        self.fwd_lattice = (self.Hout, self.Wout, 0, 1, 0, 1, self.sy, self.sx, -self.py, -self.px)
+        self._dgrad_plan = None
+        self.plans = {}
+
+    def dgrad_plan(self):
+        """[(lattice, taps)] per stride phase of the data gradient (None taps: no kernel tap reaches the phase)."""
+        if self._dgrad_plan is None:
+            if self.reflect:
+                Hx, Wx, py, px = self.Hin + 2 * self.py, self.Win + 2 * self.px, 0, 0
+            else:
+                Hx, Wx, py, px = self.Hin, self.Win, self.py, self.px
+            plan = []
+            for ry, ny, ty in _phases(Hx, self.kh, self.sy, self.dy, py):
+                for rx, nx, tx in _phases(Wx, self.kw, self.sx, self.dx, px):
+                    if ny == 0 or nx == 0:
+                        continue
+                    taps = tuple((oy, ox, ky * self.kw + kx) for oy, ky in ty for ox, kx in tx)
+                    plan.append(((ny, nx, ry, self.sy, rx, self.sx, 1, 1, 0, 0), taps, ry, rx))
+            self._dgrad_plan = (Hx, Wx, plan)
+        return self._dgrad_plan
 
 
-def _fill(desc, x, w, out, B, Hin, Win, Cin, Hout, Wout, Cout, lattice, taps, pad_mode, bias=None, mask_src=None,
+_PLANS = {}
+
+
+def _ptr(t):
+    """data pointer of a tensor the caller has validated (dtype, contiguity); GPU-only unless the kernel
+    interpreter is bound."""
+    if t is None:
+        return None
+    if not (t.is_cuda or lib._host_pointers_ok):
+        raise RuntimeError('msmc HIP ops run on the GPU only (got a %s tensor); there is no CPU path' % t.device)
+    if not t.is_contiguous():
+        raise ValueError('msmc HIP ops take contiguous tensors')
+    return t.data_ptr()
+
+
+def _fill(desc_unused, x, w, out, B, Hin, Win, Cin, Hout, Wout, Cout, lattice, taps, pad_mode, bias=None, mask_src=None,
           res=None, res2=None, in_slope=1.0, mask_slope=1.0, out_div=1.0, out_slope=1.0):
-    desc.x, desc.w, desc.out = lib.ptr(x), lib.ptr(w), lib.ptr(out)
-    desc.bias = lib.ptr(bias, torch.float32) if bias is not None else None
-    desc.mask_src = lib.ptr(mask_src) if mask_src is not None else None
-    desc.res = lib.ptr(res) if res is not None else None
-    desc.res2 = lib.ptr(res2) if res2 is not None else None
-    desc.dtype = _DT[x.dtype]
+    """Descriptor for one launch.  The geometry part is built once per distinct (shape, lattice, taps, flags) and
+    cached -- per call only the seven pointers change (the step issues ~2000 convolution launches, so the
+    host cost of a launch matters as much as its GPU time)."""
+    key = (x.dtype, B, Hin, Win, Cin, Hout, Wout, Cout, lattice, tuple(taps), pad_mode, in_slope, mask_slope, out_div,
+           out_slope)
+    desc = _PLANS.get(key)
+    if desc is None:
+        desc = _PLANS[key] = _build_desc(x.dtype, B, Hin, Win, Cin, Hout, Wout, Cout, lattice, taps, pad_mode,
+                                         in_slope, mask_slope, out_div, out_slope)
+    desc.x, desc.w, desc.out = _ptr(x), _ptr(w), _ptr(out)
+    desc.bias, desc.mask_src, desc.res, desc.res2 = _ptr(bias), _ptr(mask_src), _ptr(res), _ptr(res2)
+    return desc
+
+
+def _build_desc(dtype, B, Hin, Win, Cin, Hout, Wout, Cout, lattice, taps, pad_mode, in_slope, mask_slope, out_div,
+                out_slope):
+    desc = lib.ConvDesc()
+    desc.dtype = _DT[dtype]
     desc.B, desc.Hin, desc.Win, desc.Cin = B, Hin, Win, Cin
     desc.Hout, desc.Wout, desc.Cout = Hout, Wout, Cout
     (desc.QH, desc.QW, desc.oy0, desc.osy, desc.ox0, desc.osx, desc.isy, desc.isx, desc.iy0, desc.ix0) = lattice
@@ -63,19 +111,40 @@ def _check(x, w, *others):
         assert t is None or (t.dtype == x.dtype and t.is_contiguous()), 'epilogue operands share the activation dtype'
 
 
+def _dev_ok(t):
+    if not (t.is_cuda or lib._host_pointers_ok):
+        raise RuntimeError('msmc HIP ops run on the GPU only (got a %s tensor); there is no CPU path' % t.device)
+    if not t.is_contiguous():
+        raise ValueError('msmc HIP ops take contiguous tensors')
+
+
+def _opt_ptr(t, like):
+    if t is None:
+        return None
+    if t.dtype != like.dtype or not t.is_contiguous():
+        raise ValueError('epilogue operands share the activation dtype and are contiguous')
+    return t.data_ptr()
+
+
 def conv_forward(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, out_div=1.0, out_slope=1.0):
     """x [B,Hin,Win,Cin] -> [B,Hout,Wout,Cout];  w [kh*kw, Cout, Cin]."""
-    _check(x, w, res, res2)
-    B, Hin, Win, Cin = x.shape
-    T, Cout, _ = w.shape
-    assert (Hin, Win) == (geom.Hin, geom.Win) and T == geom.ntaps and w.shape[2] == Cin
-    out = torch.empty((B, geom.Hout, geom.Wout, Cout), dtype=x.dtype, device=x.device)
-    taps = [(ky * geom.dy, kx * geom.dx, ky * geom.kw + kx) for ky in range(geom.kh) for kx in range(geom.kw)]
-    lattice = (geom.Hout, geom.Wout, 0, 1, 0, 1, geom.sy, geom.sx, -geom.py, -geom.px)
-    d = _fill(lib.ConvDesc(), x, w, out, B, Hin, Win, Cin, geom.Hout, geom.Wout, Cout, lattice, taps,
-              1 if geom.reflect else 0, bias=bias, res=res, res2=res2, in_slope=in_slope, out_div=out_div,
-              out_slope=out_slope)
-    lib.check(lib.get().msmc_conv_gather(ctypes.byref(d), lib.stream(x)), 'msmc_conv_gather')
+    key = (x.dtype, x.shape[0], w.shape[1], w.shape[2], in_slope, out_div, out_slope)
+    plan = geom.plans.get(key)
+    if plan is None:
+        _check(x, w, res, res2)
+        B, Hin, Win, Cin = x.shape
+        T, Cout, _ = w.shape
+        assert (Hin, Win) == (geom.Hin, geom.Win) and T == geom.ntaps and w.shape[2] == Cin
+        desc = _build_desc(x.dtype, B, Hin, Win, Cin, geom.Hout, geom.Wout, Cout, geom.fwd_lattice, geom.fwd_taps,
+                           1 if geom.reflect else 0, in_slope, 1.0, out_div, out_slope)
+        plan = geom.plans[key] = (desc, (B, geom.Hout, geom.Wout, Cout))
+    desc, oshape = plan
+    _dev_ok(x)
+    out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    desc.x, desc.w, desc.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    desc.bias = bias.data_ptr() if bias is not None else None
+    desc.res, desc.res2, desc.mask_src = _opt_ptr(res, x), _opt_ptr(res2, x), None
+    lib.check(lib.get().msmc_conv_gather(ctypes.byref(desc), lib.stream(x)), 'msmc_conv_gather')
     return out
 
 
@@ -101,28 +170,33 @@ def conv_dgrad(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
     returned on the PADDED grid (Hin+2py, Win+2px); the caller folds the border back.
     Epilogue: gx = gx * lrelu'(mask_src) + res.
     """
-    _check(g, wb, mask_src, res)
-    B, Hout, Wout, Cout = g.shape
-    T, Cin, _ = wb.shape
-    assert (Hout, Wout) == (geom.Hout, geom.Wout) and T == geom.ntaps and wb.shape[2] == Cout
-    if geom.reflect:
-        Hx, Wx, py, px = geom.Hin + 2 * geom.py, geom.Win + 2 * geom.px, 0, 0
-    else:
-        Hx, Wx, py, px = geom.Hin, geom.Win, geom.py, geom.px
-    gx = torch.empty((B, Hx, Wx, Cin), dtype=g.dtype, device=g.device)
-    L = lib.get()
-    for ry, ny, ty in _phases(Hx, geom.kh, geom.sy, geom.dy, py):
-        for rx, nx, tx in _phases(Wx, geom.kw, geom.sx, geom.dx, px):
-            if ny == 0 or nx == 0:
-                continue
-            taps = [(oy, ox, ky * geom.kw + kx) for oy, ky in ty for ox, kx in tx]
-            lattice = (ny, nx, ry, geom.sy, rx, geom.sx, 1, 1, 0, 0)
-            if not taps:                      # phase that no kernel tap reaches: gradient is the epilogue of zero
-                gx[:, ry::geom.sy, rx::geom.sx] = 0 if res is None else res[:, ry::geom.sy, rx::geom.sx]
-                continue
-            d = _fill(lib.ConvDesc(), g, wb, gx, B, Hout, Wout, Cout, Hx, Wx, Cin, lattice, taps, 0,
-                      mask_src=mask_src, mask_slope=mask_slope, res=res)
-            lib.check(L.msmc_conv_gather(ctypes.byref(d), lib.stream(g)), 'msmc_conv_gather(dgrad)')
+    key = ('d', g.dtype, g.shape[0], wb.shape[1], wb.shape[2], mask_slope)
+    plan = geom.plans.get(key)
+    if plan is None:
+        _check(g, wb, mask_src, res)
+        B, Hout, Wout, Cout = g.shape
+        T, Cin, _ = wb.shape
+        assert (Hout, Wout) == (geom.Hout, geom.Wout) and T == geom.ntaps and wb.shape[2] == Cout
+        Hx, Wx, phases = geom.dgrad_plan()
+        descs = []
+        for lattice, taps, ry, rx in phases:
+            descs.append((None, ry, rx) if not taps else
+                         (_build_desc(g.dtype, B, Hout, Wout, Cout, Hx, Wx, Cin, lattice, taps, 0, 1.0, mask_slope, 1.0,
+                                      1.0), ry, rx))
+        plan = geom.plans[key] = (descs, (B, Hx, Wx, Cin))
+    descs, oshape = plan
+    _dev_ok(g)
+    gx = torch.empty(oshape, dtype=g.dtype, device=g.device)
+    gp, wp, op = g.data_ptr(), wb.data_ptr(), gx.data_ptr()
+    mp, rp = _opt_ptr(mask_src, g), _opt_ptr(res, g)
+    fn, stream = lib.get().msmc_conv_gather, lib.stream(g)
+    for desc, ry, rx in descs:
+        if desc is None:                      # phase that no kernel tap reaches: gradient is the epilogue of zero
+            gx[:, ry::geom.sy, rx::geom.sx] = 0 if res is None else res[:, ry::geom.sy, rx::geom.sx]
+            continue
+        desc.x, desc.w, desc.out, desc.mask_src, desc.res = gp, wp, op, mp, rp
+        desc.bias = desc.res2 = None
+        lib.check(fn(ctypes.byref(desc), stream), 'msmc_conv_gather(dgrad)')
     return gx
 
 
@@ -138,7 +212,7 @@ def conv_transpose1d_forward(x, w, k, stride, padding, bias=None, in_slope=1.0):
         assert taps1, 'kernel_size >= stride expected'
         taps = [(0, off, kk) for off, kk in taps1]
         lattice = (1, n, 0, 1, r, stride, 1, 1, 0, 0)
-        d = _fill(lib.ConvDesc(), x, w, out, B, 1, Lin, Cin, 1, Lout, Cout, lattice, taps, 0, bias=bias,
+        d = _fill(None, x, w, out, B, 1, Lin, Cin, 1, Lout, Cout, lattice, taps, 0, bias=bias,
                   in_slope=in_slope)
         lib.check(L.msmc_conv_gather(ctypes.byref(d), lib.stream(x)), 'msmc_conv_gather(convT)')
     return out
@@ -152,7 +226,7 @@ def conv_transpose1d_dgrad(g, wb, k, stride, padding, Lin, mask_src=None, mask_s
     gx = torch.empty((B, 1, Lin, Cin), dtype=g.dtype, device=g.device)
     taps = [(0, kk, kk) for kk in range(k)]
     lattice = (1, Lin, 0, 1, 0, 1, 1, stride, 0, -padding)
-    d = _fill(lib.ConvDesc(), g, wb, gx, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, mask_src=mask_src,
+    d = _fill(None, g, wb, gx, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, mask_src=mask_src,
               mask_slope=mask_slope)
     lib.check(lib.get().msmc_conv_gather(ctypes.byref(d), lib.stream(g)), 'msmc_conv_gather(convT dgrad)')
     return gx
@@ -161,19 +235,23 @@ def conv_transpose1d_dgrad(g, wb, k, stride, padding, Lin, mask_src=None, mask_s
 def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None, db=None):
     """dW [kh*kw, Cout, Cin] fp32 of ``conv_forward`` (x [B,Hin,Win,Cin] pre-activation, g [B,Hout,Wout,Cout]);
     when ``db`` (fp32 [Cout]) is given the bias gradient is accumulated into it by the same launch."""
-    _check(x, g)
-    B, Hin, Win, Cin = x.shape
-    Cout = g.shape[3]
-    assert g.shape[1:3] == (geom.Hout, geom.Wout)
+    key = ('w', x.dtype, x.shape[0], x.shape[3], g.shape[3], in_slope)
+    desc = geom.plans.get(key)
+    if desc is None:
+        _check(x, g)
+        B, Hin, Win, Cin = x.shape
+        assert g.shape[1:3] == (geom.Hout, geom.Wout)
+        desc = geom.plans[key] = _build_desc(x.dtype, B, Hin, Win, Cin, geom.Hout, geom.Wout, g.shape[3],
+                                             geom.fwd_lattice, geom.fwd_taps, 1 if geom.reflect else 0, in_slope, 1.0,
+                                             1.0, 1.0)
+    _dev_ok(x)
+    _dev_ok(g)
     if dw is None:
-        dw = torch.zeros((n_slices, Cout, Cin), dtype=torch.float32, device=x.device)
-    taps = [(ky * geom.dy, kx * geom.dx, ky * geom.kw + kx) for ky in range(geom.kh) for kx in range(geom.kw)]
-    lattice = (geom.Hout, geom.Wout, 0, 1, 0, 1, geom.sy, geom.sx, -geom.py, -geom.px)
-    d = _fill(lib.ConvDesc(), x, x, x, B, Hin, Win, Cin, geom.Hout, geom.Wout, Cout, lattice, taps,
-              1 if geom.reflect else 0, in_slope=in_slope)
-    lib.check(lib.get().msmc_conv_wgrad(ctypes.byref(d), lib.ptr(g), lib.ptr(dw, torch.float32),
-                                        lib.ptr(db, torch.float32) if db is not None else None, lib.stream(x)),
-              'msmc_conv_wgrad')
+        dw = torch.zeros((n_slices, g.shape[3], x.shape[3]), dtype=torch.float32, device=x.device)
+    desc.x = desc.w = desc.out = x.data_ptr()
+    desc.bias = desc.mask_src = desc.res = desc.res2 = None
+    lib.check(lib.get().msmc_conv_wgrad(ctypes.byref(desc), g.data_ptr(), dw.data_ptr(),
+                                        db.data_ptr() if db is not None else None, lib.stream(x)), 'msmc_conv_wgrad')
     return dw
 
 
@@ -189,7 +267,7 @@ def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None):
     taps = [(0, kk, kk) for kk in range(k)]
     lattice = (1, Lin, 0, 1, 0, 1, 1, stride, 0, -padding)
     # kernel roles: "x" = g (fine, channels Cout), "g" = x (coarse, channels Cin) -> dw[k][Cin][Cout]
-    d = _fill(lib.ConvDesc(), g, g, g, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, in_slope=1.0,
+    d = _fill(None, g, g, g, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, in_slope=1.0,
               mask_slope=in_slope)
     lib.check(lib.get().msmc_conv_wgrad(ctypes.byref(d), lib.ptr(x), lib.ptr(dw, torch.float32), None, lib.stream(x)),
               'msmc_conv_wgrad(convT)')

@@ -86,7 +86,7 @@ class VQGANTrainer(BaseTrainer):
             self.stft_criterion = MultiResolutionSTFTLoss(**dict(stft_loss_config or {}))
         self.rng = random              # python global RNG, like the reference (:214); tests inject their own
         self._amp_applied = None
-        self.batch_g_step = os.environ.get('MSMC_BATCH_G_STEP', '1') != '0'
+        self.batch_g_step = os.environ.get('MSMC_BATCH_G_STEP', '0') != '0'
         self.use_graphs = False        # replay the GAN-phase step as three hipGraphs (static shapes)
         self._graphs = None
         self.amp_dtype = None          # e.g. torch.bfloat16: autocast for the GEMM/conv bodies (VQ search stays fp32)
