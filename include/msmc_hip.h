@@ -109,6 +109,9 @@ typedef struct msmc_conv_desc {
 
 /* Perf-experiment switch: 0 selects the simple (un-pipelined) gather kernel everywhere; default 1. */
 void msmc_conv_set_pipeline(int on);
+/* Perf-sweep switches: force the weight-gradient pixel split (0 = model), allow 32-channel N tiles for small grids. */
+void msmc_conv_set_wgrad_split(int n);
+void msmc_conv_set_narrow(int on);
 
 /* out[q] = epilogue( sum_t sum_ci w[tap_w[t]][co][ci] * act(x[in(q, t)][ci]) + bias[co] ). */
 int msmc_conv_gather(const msmc_conv_desc* desc, msmc_stream stream);

@@ -29,6 +29,10 @@
 // 2 / 4 = pipelined kernel forced to 256- / 512-point M tiles (tests).
 static int msmc_conv_pipeline_enabled = 1;
 extern "C" void msmc_conv_set_pipeline(int on) { msmc_conv_pipeline_enabled = on; }
+static int msmc_conv_narrow_when_small = 1;
+extern "C" void msmc_conv_set_narrow(int on) { msmc_conv_narrow_when_small = on; }
+static int msmc_wgrad_split_override = 0;       // tests / perf sweeps: force the pixel-split factor
+extern "C" void msmc_conv_set_wgrad_split(int n) { msmc_wgrad_split_override = n; }
 
 template <typename T> struct Elt;
 template <> struct Elt<float> {
@@ -424,6 +428,12 @@ template <typename T>
 static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
     constexpr int XS = Elt<T>::CK + Elt<T>::VEC;
     int NT = d->Cout > 32 ? 2 : 1;
+    if (NT == 2 && msmc_conv_narrow_when_small) {
+        // few output pixels: 32-channel N tiles double the workgroup count (two co-resident workgroups per CU
+        // hide each other's global-load latency, which dominates at this size)
+        const long mt = ((long)d->QH * d->QW + CV_BM - 1) / CV_BM * d->B;
+        if (mt * ((d->Cout + 63) / 64) < 2 * MSMC_NUM_CU) NT = 1;
+    }
     if ((d->Cin % Elt<T>::VEC) == 0 && msmc_conv_pipeline_enabled) {
         // widest M tile that still leaves >= ~2 workgroups per CU
         const long points = (long)d->B * d->QH * d->QW;
@@ -709,7 +719,15 @@ static int wg_launch(const msmc_conv_desc* d, const void* g, float* dw, float* d
     }
     const int totalTiles = G.tilesX * G.tilesY * d->B;
     const int ctiles = ((d->Cout + 63) / 64) * ((d->Cin + 63) / 64);
-    int nsplit = (2 * MSMC_NUM_CU + ctiles - 1) / ctiles;
+    // Split of the pixel reduction over workgroups: each split costs one fp32 atomic per dW element, each
+    // tile ~3 us of staging + MFMA, so  t(n) = (tiles/n) * t_tile + n * |dW| / atomic_rate  is minimised at
+    // n* = sqrt(tiles * t_tile * rate / |dW|)  (rate ~0.3e6 atomics/us measured on MI355X); never more
+    // workgroups than ~2 per CU.
+    const double elems = (double)d->ntaps * d->Cout * d->Cin;
+    int nsplit = (int)(sqrt((double)totalTiles * 3.0 * 0.3e6 / elems) + 0.5);
+    const int cap = (2 * MSMC_NUM_CU + ctiles - 1) / ctiles;
+    if (msmc_wgrad_split_override > 0) nsplit = msmc_wgrad_split_override;
+    else if (nsplit > cap) nsplit = cap;
     if (nsplit > totalTiles) nsplit = totalTiles;
     if (nsplit < 1) nsplit = 1;
     const int tilesPerWg = (totalTiles + nsplit - 1) / nsplit;

@@ -52,7 +52,15 @@ def main():
             r['fwd_' + tag] = timeit(lambda: conv.conv_forward(x, wf, geom, bias=bias, in_slope=slope))
             r['dgrad_' + tag] = timeit(lambda: conv.conv_dgrad(g, wb, geom))
         L.msmc_conv_set_pipeline(1)
+        L.msmc_conv_set_narrow(0)
+        r['fwd_wide'] = timeit(lambda: conv.conv_forward(x, wf, geom, bias=bias, in_slope=slope))
+        L.msmc_conv_set_narrow(1)
         r['wgrad'] = timeit(lambda: conv.conv_wgrad(x, g, geom, T, in_slope=slope, dw=dw, db=db))
+        r['wgrad_sweep'] = {}
+        for ns in (1, 2, 4, 8, 16, 32, 64, 128, 512):
+            L.msmc_conv_set_wgrad_split(ns)
+            r['wgrad_sweep'][ns] = timeit(lambda: conv.conv_wgrad(x, g, geom, T, in_slope=slope, dw=dw, db=db), iters=10)
+        L.msmc_conv_set_wgrad_split(0)
         # PyTorch-ROCm reference timing (NCHW bf16, MIOpen)
         xn = x.permute(0, 3, 1, 2).contiguous().requires_grad_(True)
         wn = wf.permute(1, 2, 0).reshape(Cout, Cin, *k).contiguous().requires_grad_(True)
@@ -69,10 +77,11 @@ def main():
         except Exception as ex:          # noqa
             r['torch_fwd'] = r['torch_bwd'] = float('nan')
         rows.append(r)
-        print('%-28s %7.2f GF | fwd %7.1f -> %7.1f us (%6.1f TF/s) | dgrad %7.1f -> %7.1f | wgrad %7.1f (%6.1f TF/s) | '
-              'torch fwd %7.1f bwd %7.1f' % (name, r['gflop'], r['fwd_simple'], r['fwd_pipe'],
-                                             flops / r['fwd_pipe'] / 1e6, r['dgrad_simple'], r['dgrad_pipe'], r['wgrad'],
-                                             flops / r['wgrad'] / 1e6, r['torch_fwd'], r['torch_bwd']), flush=True)
+        print('%-28s %7.2f GF | fwd %7.1f -> %7.1f us (wide %7.1f) | dgrad %7.1f -> %7.1f | wgrad %7.1f | '
+              'torch fwd %7.1f bwd %7.1f | wgrad split sweep %s' % (
+                  name, r['gflop'], r['fwd_simple'], r['fwd_pipe'], r['fwd_wide'], r['dgrad_simple'], r['dgrad_pipe'],
+                  r['wgrad'], r['torch_fwd'], r['torch_bwd'],
+                  ' '.join('%d:%.0f' % kv for kv in r['wgrad_sweep'].items())), flush=True)
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     with open(os.path.join(ROOT, 'gpurun_out', 'perf_conv.json'), 'w') as f:
         json.dump(rows, f, indent=1)
