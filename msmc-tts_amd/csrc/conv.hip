@@ -432,9 +432,12 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
         // few output pixels: 32-channel N tiles double the workgroup count (two co-resident workgroups per CU
         // hide each other's global-load latency, which dominates at this size)
         const long mt = ((long)d->QH * d->QW + CV_BM - 1) / CV_BM * d->B;
-        if (mt * ((d->Cout + 63) / 64) < 2 * MSMC_NUM_CU) NT = 1;
+        const long wide = mt * ((d->Cout + 63) / 64);
+        if (wide < MSMC_NUM_CU || (wide < 2 * MSMC_NUM_CU && d->Cin >= 256)) NT = 1;
     }
-    if ((d->Cin % Elt<T>::VEC) == 0 && msmc_conv_pipeline_enabled) {
+    // the pipelined kernel pays a slot-table prologue: worth it from ~4 channel chunks on (measured per layer)
+    const bool deep = d->Cin >= 4 * Elt<T>::CK || msmc_conv_pipeline_enabled >= 2;
+    if ((d->Cin % Elt<T>::VEC) == 0 && msmc_conv_pipeline_enabled && deep) {
         // widest M tile that still leaves >= ~2 workgroups per CU
         const long points = (long)d->B * d->QH * d->QW;
         const long ntile = (d->Cout + 32 * NT - 1) / (32 * NT);
@@ -595,7 +598,13 @@ MSMC_DEV bf16x8 wg_frag(const unsigned short* tile, int XS, int row0, int row1, 
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <typename T, int TAPS>
+// staging slots per work-item of the FAST weight-gradient path: 64 channels are 8 (bf16) / 16 (fp32) 16-byte
+// vectors per pixel, so the fp32 kernel needs twice the slots for the same tile
+template <typename T, int TAPS> struct WgSlots {
+    static constexpr int X = sizeof(T) == 2 ? (TAPS > 8 ? 6 : 12) : 12, G = sizeof(T) == 2 ? 4 : 8;
+};
+
+template <typename T, int TAPS, bool FAST>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(msmc_conv_desc d, const T* __restrict__ gptr,
                                                         float* __restrict__ dw, float* __restrict__ db, CvGeom G,
                                                         int tilesPerWg, int totalTiles, int TM) {
@@ -638,7 +647,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(msmc_conv_desc d, const
     const int t0 = blockIdx.x * tilesPerWg;
     int t1 = t0 + tilesPerWg;
     if (t1 > totalTiles) t1 = totalTiles;
-    for (int tile = t0; tile < t1; ++tile) {
+
+    // FAST: every work-item owns fixed 16-byte staging slots (tile-relative coordinates computed once); the
+    // loads of tile t+1 are issued before the MFMAs of tile t and written to LDS afterwards.
+    constexpr int VEC = Elt<T>::VEC, CKV = 64 / VEC, WG_XLD = WgSlots<T, TAPS>::X, WG_GLD = WgSlots<T, TAPS>::G;
+    int x_ry[WG_XLD], x_rx[WG_XLD], x_dst[WG_XLD], g_m[WG_GLD], g_dst[WG_GLD];
+    u32x4 xreg[WG_XLD], greg[WG_GLD];
+    if (FAST) {
+        const int npix = G.IH * G.IW;
+#pragma unroll
+        for (int j = 0; j < WG_XLD; ++j) {
+            const int e = tid + 256 * j;
+            x_dst[j] = -1; x_ry[j] = x_rx[j] = 0;
+            if (e < npix * CKV) {
+                const int pi = e / CKV, v = e - pi * CKV;
+                x_ry[j] = pi / G.IW;
+                x_rx[j] = pi - x_ry[j] * G.IW;
+                x_dst[j] = pi * XS + v * VEC;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WG_GLD; ++j) {
+            const int e = tid + 256 * j;
+            g_dst[j] = -1; g_m[j] = 0;
+            if (e < TM * CKV) {
+                g_m[j] = e / CKV;
+                g_dst[j] = g_m[j] * XS + (e - g_m[j] * CKV) * VEC;
+            }
+        }
+    }
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto fetch = [&](int tile) {
         int bt = tile;
         const int tx_ = bt % G.tilesX;
         bt /= G.tilesX;
@@ -646,10 +685,76 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(msmc_conv_desc d, const
         const int b = bt / G.tilesY;
         const int qy0 = ty_ * G.TH, qx0 = tx_ * G.TW;
         const int iyBase = qy0 * d.isy + d.iy0 + G.dyMin, ixBase = qx0 * d.isx + d.ix0 + G.dxMin;
+        const T* xb = (const T*)d.x + (size_t)b * d.Hin * d.Win * d.Cin;
+        const T* gb = gptr + (size_t)b * d.Hout * d.Wout * d.Cout;
+#pragma unroll
+        for (int j = 0; j < WG_XLD; ++j) {
+            xreg[j] = zero4;
+            if (x_dst[j] < 0) continue;
+            int iy = iyBase + x_ry[j], ix = ixBase + x_rx[j];
+            bool inside = true;
+            if (d.pad_mode == 1) {
+                iy = reflect_index(iy, d.Hin);
+                ix = reflect_index(ix, d.Win);
+            } else {
+                inside = (iy >= 0) && (iy < d.Hin) && (ix >= 0) && (ix < d.Win);
+            }
+            const int c = ci0 + (x_dst[j] % XS);
+            if (inside && c < d.Cin) xreg[j] = *(const u32x4*)(xb + ((size_t)iy * d.Win + ix) * d.Cin + c);
+        }
+#pragma unroll
+        for (int j = 0; j < WG_GLD; ++j) {
+            greg[j] = zero4;
+            if (g_dst[j] < 0) continue;
+            const int m = g_m[j];
+            const int mty = m / G.TW, mtx = m - mty * G.TW;
+            const int qy = qy0 + mty, qx = qx0 + mtx;
+            const int c = co0 + (g_dst[j] % XS);
+            if (mty < G.TH && qy < d.QH && qx < d.QW && c < d.Cout) {
+                const int oy = d.oy0 + qy * d.osy, ox = d.ox0 + qx * d.osx;
+                greg[j] = *(const u32x4*)(gb + ((size_t)oy * d.Wout + ox) * d.Cout + c);
+            }
+        }
+    };
+    auto act = [&](u32x4 v, float slope) {
+        if (slope == 1.f) return v;
+        alignas(16) T vals[VEC];
+        *(u32x4*)vals = v;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            float f = Elt<T>::ld(&vals[q]);
+            f = f > 0.f ? f : f * slope;
+            Elt<T>::st(&vals[q], f);
+        }
+        return *(const u32x4*)vals;
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < WG_XLD; ++j)
+            if (x_dst[j] >= 0) *(u32x4*)(xt + x_dst[j]) = act(xreg[j], d.in_slope);
+#pragma unroll
+        for (int j = 0; j < WG_GLD; ++j)
+            if (g_dst[j] >= 0) *(u32x4*)(gt + g_dst[j]) = act(greg[j], d.mask_slope);
+    };
+
+    if (FAST && t0 < t1) fetch(t0);
+    for (int tile = t0; tile < t1; ++tile) {
         __syncthreads();
-        wg_stage_x<T>(xt, XS, d, G, (const T*)d.x + (size_t)b * d.Hin * d.Win * d.Cin, ci0, iyBase, ixBase, tid);
-        wg_stage_g<T>(gt, XS, d, G, gptr + (size_t)b * d.Hout * d.Wout * d.Cout, co0, qy0, qx0, tid, TM);
+        if (FAST) {
+            commit();
+        } else {
+            int bt = tile;
+            const int tx_ = bt % G.tilesX;
+            bt /= G.tilesX;
+            const int ty_ = bt % G.tilesY;
+            const int b = bt / G.tilesY;
+            const int qy0 = ty_ * G.TH, qx0 = tx_ * G.TW;
+            const int iyBase = qy0 * d.isy + d.iy0 + G.dyMin, ixBase = qx0 * d.isx + d.ix0 + G.dxMin;
+            wg_stage_x<T>(xt, XS, d, G, (const T*)d.x + (size_t)b * d.Hin * d.Win * d.Cin, ci0, iyBase, ixBase, tid);
+            wg_stage_g<T>(gt, XS, d, G, gptr + (size_t)b * d.Hout * d.Wout * d.Cout, co0, qy0, qx0, tid, TM);
+        }
         __syncthreads();
+        if (FAST && tile + 1 < t1) fetch(tile + 1);
         if (do_bias && tid < 64) {                      // bias gradient: column sums of the g tile (fused)
             float sacc = 0.f;
             for (int m = 0; m < TM; ++m) sacc = sacc + Elt<T>::ld(gt + (size_t)m * XS + tid);
@@ -657,20 +762,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(msmc_conv_desc d, const
         }
         if (!wave_live) continue;
         if (sizeof(T) == 2) {
-            bf16x8 af[8];
+            // K-step outer, taps inner: one A fragment (g tile) live at a time, reused by every tap
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                if (ks < nks) af[ks] = wg_frag((const unsigned short*)gt, XS, grow[2 * ks], grow[2 * ks + 1], acol_tr);
+            for (int ks = 0; ks < 8; ++ks) {
+                if (ks >= nks) continue;
+                const bf16x8 af = wg_frag((const unsigned short*)gt, XS, grow[2 * ks], grow[2 * ks + 1], acol_tr);
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                if (t < d.ntaps) {
-                    const int tapoff = (d.tap_dy[t] - G.dyMin) * G.IW + (d.tap_dx[t] - G.dxMin);
-#pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) {
-                        if (ks >= nks) continue;
-                        bf16x8 bf = wg_frag((const unsigned short*)xt, XS, xrow[2 * ks] + tapoff, xrow[2 * ks + 1] + tapoff,
-                                            bcol_tr);
-                        acc[t] = mfma_bf16_32x32x16(af[ks], bf, acc[t]);
+                for (int t = 0; t < TAPS; ++t) {
+                    if (t < d.ntaps) {
+                        const int tapoff = (d.tap_dy[t] - G.dyMin) * G.IW + (d.tap_dx[t] - G.dxMin);
+                        const bf16x8 bf = wg_frag((const unsigned short*)xt, XS, xrow[2 * ks] + tapoff,
+                                                  xrow[2 * ks + 1] + tapoff, bcol_tr);
+                        acc[t] = mfma_bf16_32x32x16(af, bf, acc[t]);
                     }
                 }
             }
@@ -734,12 +837,24 @@ static int wg_launch(const msmc_conv_desc* d, const void* g, float* dw, float* d
     nsplit = (totalTiles + tilesPerWg - 1) / tilesPerWg;
     dim3 grid((unsigned)nsplit, (unsigned)((d->Cout + 63) / 64), (unsigned)((d->Cin + 63) / 64));
     const T* gp = (const T*)g;
+    constexpr int CKVh = 64 / Elt<T>::VEC;
+    const int xslots = d->ntaps <= 4 ? WgSlots<T, 4>::X : d->ntaps <= 8 ? WgSlots<T, 8>::X : WgSlots<T, 12>::X;
+    const bool fast = (d->Cin % Elt<T>::VEC) == 0 && (d->Cout % Elt<T>::VEC) == 0 && d->ntaps <= 12 &&
+                      (long)G.IH * G.IW * CKVh <= 256L * xslots && (long)TM * CKVh <= 256L * WgSlots<T, 4>::G &&
+                      msmc_conv_pipeline_enabled;
 #define WG_GO(TP)                                                                                              \
     do {                                                                                                       \
-        rc = msmc_allow_lds((const void*)conv_wgrad_kernel<T, TP>, (int)lds);                                  \
-        if (rc) return rc;                                                                                     \
-        MSMC_LAUNCH((conv_wgrad_kernel<T, TP>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, db, G,\
-                    tilesPerWg, totalTiles, TM);                                                               \
+        if (fast) {                                                                                            \
+            rc = msmc_allow_lds((const void*)conv_wgrad_kernel<T, TP, true>, (int)lds);                        \
+            if (rc) return rc;                                                                                 \
+            MSMC_LAUNCH((conv_wgrad_kernel<T, TP, true>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, \
+                        dw, db, G, tilesPerWg, totalTiles, TM);                                                \
+        } else {                                                                                               \
+            rc = msmc_allow_lds((const void*)conv_wgrad_kernel<T, TP, false>, (int)lds);                       \
+            if (rc) return rc;                                                                                 \
+            MSMC_LAUNCH((conv_wgrad_kernel<T, TP, false>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp,\
+                        dw, db, G, tilesPerWg, totalTiles, TM);                                                \
+        }                                                                                                      \
     } while (0)
     if (d->ntaps <= 4) WG_GO(4);
     else if (d->ntaps <= 8) WG_GO(8);
