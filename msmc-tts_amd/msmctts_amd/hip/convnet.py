@@ -99,6 +99,7 @@ class ConvBank(object):
             l.index = i
         self._sig = None
         self._queued = False
+        self._hold = []                 # gradients shared by several consumers, pinned until the backward ends
         self.streams = []               # side streams whose backward launches write this bank's accumulators
 
     # -- (re)build device buffers whenever parameters moved / changed dtype ------------------------
@@ -175,6 +176,7 @@ class ConvBank(object):
 
     def _finish_backward(self):
         self._queued = False
+        del self._hold[:]
         if self.streams:                # weight-gradient launches ran on the side streams of their forward
             cur = torch.cuda.current_stream()
             for st in self.streams:
@@ -247,6 +249,13 @@ class _HipConv(torch.autograd.Function):
                 K.conv_transpose1d_wgrad(x, g, layer.kernel[1], layer.stride[1], layer.padding[1],
                                          in_slope=ctx.in_slope, dw=layer.dw)
                 layer.db.add_(K.colsum(g.reshape(-1, g.shape[-1])))
+            bank._queue_finish()
+        if ctx.has_res or ctx.has_res2:
+            # g goes to several consumers that may replay on different streams.  The autograd engine accumulates
+            # IN PLACE into a gradient it holds the only reference to, while other streams may still be reading
+            # that same tensor (their out-of-place sums are ordered only against the producer).  Keeping a
+            # reference until the end of the backward pass rules the in-place path out for this tensor.
+            bank._hold.append(g)
             bank._queue_finish()
         # weight_token (the layer's weight_v) only ties the output to the parameters in the autograd graph;
         # parameter gradients are produced in kernel layout and delivered by ConvBank._finish_backward.

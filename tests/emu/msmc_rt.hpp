@@ -224,6 +224,9 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p 
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 #define MSMC_BACKEND_NAME "emu"
-#define MSMC_NUM_CU 3                // tiny on purpose: exercises the persistent grid-stride loops
+// tiny by default (exercises the persistent grid-stride loops); MSMC_EMU_CUS=256 reproduces the launch
+// heuristics of the real chip
+static inline int msmc_emu_num_cu() { const char* e = getenv("MSMC_EMU_CUS"); return e ? atoi(e) : 3; }
+#define MSMC_NUM_CU (msmc_emu_num_cu())
 static inline int msmc_check_launch() { return 0; }
 static inline int msmc_allow_lds(const void*, int) { return 0; }
