@@ -86,8 +86,8 @@ def build(args, device, rank, world):
     torch.manual_seed(cfg.seed)
     task = build_task(cfg, mode='train')
     trainer = build_trainer(cfg, task, num_gpus=world, rank=rank)      # moves to GPU; arms RCCL reducer if world>1
-    trainer.optimizer = build_optimizer(trainer.model, cfg.optimizer, capturable=not args.no_graph)
-    trainer.use_graphs = not args.no_graph
+    trainer.optimizer = build_optimizer(trainer.model, cfg.optimizer, capturable=args.graph)
+    trainer.use_graphs = args.graph
     trainer.amp_dtype = torch.bfloat16 if args.dtype == 'bf16' else None
     trainer.model.train()
     return cfg, trainer
@@ -177,7 +177,8 @@ def main():
     ap.add_argument('--cpu-batch', type=int, default=4, help='utterances of the batch in the cpu_baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = min(available cores, 32)')
     ap.add_argument('--no-microbench', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying hipGraphs')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the step from three hipGraphs (measured slower than the multi-stream eager step)')
     ap.add_argument('--kernel-timing-steps', type=int, default=3, help='extra steps timed kernel by kernel (rank 0)')
     args = ap.parse_args()
 
@@ -318,7 +319,7 @@ def main():
                    'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'frames': args.frames,
                    'mel_frames_per_step': frames_per_step, 'parallelism': 'dp%d' % world,
                    'vq_search': 'fp32 (bit-exact indices)',
-                   'execution': 'eager' if args.no_graph else 'hipGraph replay (3 segments/step)'},
+                   'execution': 'hipGraph replay (3 segments/step)' if args.graph else 'eager, multi-stream'},
         'step_tflops': FLOP_PER_STEP_ELIDED * (args.batch / 16.0) * world / (elapsed / args.steps) / 1e12,
         'step_flop_model': 'SURVEY 8d: 3.006 TFLOP/step at B=16,T=400 minus the elided D weight-grads of the G step '
                            '= 2.65 TFLOP',

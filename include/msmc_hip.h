@@ -111,6 +111,8 @@ typedef struct msmc_conv_desc {
 void msmc_conv_set_pipeline(int on);
 /* Perf-sweep switches: force the weight-gradient pixel split (0 = model), allow 32-channel N tiles for small grids. */
 void msmc_conv_set_wgrad_split(int n);
+/* 2 (default) = second-generation bf16 weight-gradient kernel, 1 = first generation (A/B tests) */
+void msmc_conv_set_wgrad_generation(int n);
 void msmc_conv_set_narrow(int on);
 
 /* out[q] = epilogue( sum_t sum_ci w[tap_w[t]][co][ci] * act(x[in(q, t)][ci]) + bias[co] ). */

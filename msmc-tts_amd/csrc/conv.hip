@@ -31,6 +31,8 @@ static int msmc_conv_pipeline_enabled = 1;
 extern "C" void msmc_conv_set_pipeline(int on) { msmc_conv_pipeline_enabled = on; }
 static int msmc_conv_narrow_when_small = 1;
 extern "C" void msmc_conv_set_narrow(int on) { msmc_conv_narrow_when_small = on; }
+static int msmc_wgrad_generation = 2;           // 1 = first-generation bf16 weight-gradient kernel (A/B tests)
+extern "C" void msmc_conv_set_wgrad_generation(int n) { msmc_wgrad_generation = n; }
 static int msmc_wgrad_split_override = 0;       // tests / perf sweeps: force the pixel-split factor
 extern "C" void msmc_conv_set_wgrad_split(int n) { msmc_wgrad_split_override = n; }
 
@@ -822,12 +824,10 @@ static int wg_launch(const msmc_conv_desc* d, const void* g, float* dw, float* d
     }
     const int totalTiles = G.tilesX * G.tilesY * d->B;
     const int ctiles = ((d->Cout + 63) / 64) * ((d->Cin + 63) / 64);
-    // Split of the pixel reduction over workgroups: each split costs one fp32 atomic per dW element, each
-    // tile ~3 us of staging + MFMA, so  t(n) = (tiles/n) * t_tile + n * |dW| / atomic_rate  is minimised at
-    // n* = sqrt(tiles * t_tile * rate / |dW|)  (rate ~0.3e6 atomics/us measured on MI355X); never more
-    // workgroups than ~2 per CU.
-    const double elems = (double)d->ntaps * d->Cout * d->Cin;
-    int nsplit = (int)(sqrt((double)totalTiles * 3.0 * 0.3e6 / elems) + 0.5);
+    // Split of the pixel reduction over workgroups: each split costs one fp32 atomic per dW element, and atomics
+    // on ONE address retire serially at ~0.1 us each, so  t(n) = (tiles/n) * t_tile + n * 0.1 us  (t_tile ~3 us)
+    // is minimal at n = sqrt(30 * tiles); never more workgroups than ~2 per CU.
+    int nsplit = (int)(sqrt(30.0 * totalTiles) + 0.5);
     const int cap = (2 * MSMC_NUM_CU + ctiles - 1) / ctiles;
     if (msmc_wgrad_split_override > 0) nsplit = msmc_wgrad_split_override;
     else if (nsplit > cap) nsplit = cap;
@@ -864,11 +864,351 @@ static int wg_launch(const msmc_conv_desc* d, const void* g, float* dw, float* d
     return msmc_check_launch();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 weight gradient, second generation.  Same math and LDS operand layout as conv_wgrad_kernel, but
+//   * a wave owns one 32-channel block of output channels (its A fragment, read once per 16 pixels) and up
+//     to TPW (input-channel block, tap) units of it -- with 32 or fewer channels the taps are spread over
+//     all four waves instead of leaving three idle, and taps beyond the per-wave budget go to another
+//     workgroup (grid.z), so no wave carries more than 5 accumulators and two or three workgroups fit a CU;
+//   * staging vectors are as wide as the channel count allows (2..16 bytes), and the LDS rows hold only
+//     the real channels: thin layers (2, 4, 8 channels) stage kilobytes, not 64-channel padded rows;
+//   * the bias gradient is accumulated from the staged registers (no LDS pass);
+//   * tile coordinates come from LDS tables built once per workgroup.
+// ------------------------------------------------------------------------------------------------
+struct Wg2Params {
+    int TM, tilesPerWg, totalTiles;
+    int XSx, XSg;            // LDS row strides (elements)
+    int vex, veg;            // elements per staging vector (1, 2, 4, 8)
+    int shx, shg;            // log2(staging vectors per pixel)
+    int TG, ntg;             // taps per workgroup, tap groups
+};
+
+template <int VE> struct WgVec;
+template <> struct WgVec<8> { typedef u32x4 type; };
+template <> struct WgVec<4> { typedef u32x2 type; };
+template <> struct WgVec<2> { typedef unsigned int type; };
+template <> struct WgVec<1> { typedef unsigned short type; };
+
+template <int VE, bool SUM>
+MSMC_DEV typename WgVec<VE>::type wg2_act(typename WgVec<VE>::type v, float slope, float (&sums)[8]) {
+    typedef typename WgVec<VE>::type V;
+    if (slope == 1.f && !SUM) return v;
+    alignas(16) unsigned short vals[VE];
+    *(V*)vals = v;
+#pragma unroll
+    for (int q = 0; q < VE; ++q) {
+        float f = bf16_bits_to_f32(vals[q]);
+        if (slope != 1.f) {
+            f = f > 0.f ? f : f * slope;
+            vals[q] = f32_to_bf16_bits(f);
+        }
+        if (SUM) sums[q] = sums[q] + f;
+    }
+    return *(const V*)vals;
+}
+
+// input halo tile -> LDS rows [pixel][channel]; padding rule and input activation applied here
+template <int VE>
+MSMC_DEV void wg2_stage_x(unsigned short* xt, const int* xmeta, const msmc_conv_desc& d, const unsigned short* xb,
+                          int ci0, int iyBase, int ixBase, int npix, int sh, int XS, int tid) {
+    typedef typename WgVec<VE>::type V;
+    float unused[8];
+    const int nvec = npix << sh, vmask = (1 << sh) - 1;
+    for (int e0 = tid; e0 < nvec; e0 += 1024) {
+        V vals[4];
+        int dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            dst[u] = -1;
+            vals[u] = V();
+            if (e < nvec) {
+                const int pi = e >> sh, c = (e & vmask) * VE;
+                const int meta = xmeta[pi];
+                int iy = iyBase + (meta >> 16), ix = ixBase + (meta & 0xffff);
+                bool inside = true;
+                if (d.pad_mode == 1) {
+                    iy = reflect_index(iy, d.Hin);
+                    ix = reflect_index(ix, d.Win);
+                } else {
+                    inside = (iy >= 0) && (iy < d.Hin) && (ix >= 0) && (ix < d.Win);
+                }
+                if (ci0 + c < d.Cin) {
+                    dst[u] = pi * XS + c;
+                    if (inside) vals[u] = *(const V*)(xb + ((size_t)iy * d.Win + ix) * d.Cin + ci0 + c);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) *(V*)(xt + dst[u]) = wg2_act<VE, false>(vals[u], d.in_slope, unused);
+    }
+}
+
+// output-gradient tile -> LDS rows [lattice point][channel]; per-thread column sums feed the bias gradient
+template <int VE, bool SUM>
+MSMC_DEV void wg2_stage_g(unsigned short* gt, const int* gmeta, const msmc_conv_desc& d, const unsigned short* gb,
+                          int co0, int qy0, int qx0, int TM, int sh, int XS, int tid, float (&sums)[8]) {
+    typedef typename WgVec<VE>::type V;
+    const int nvec = TM << sh, vmask = (1 << sh) - 1;
+    for (int e0 = tid; e0 < nvec; e0 += 1024) {
+        V vals[4];
+        int dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            dst[u] = -1;
+            vals[u] = V();
+            if (e < nvec) {
+                const int m = e >> sh, c = (e & vmask) * VE;
+                const int meta = gmeta[m];
+                if (co0 + c < d.Cout) {
+                    dst[u] = m * XS + c;
+                    const int qy = qy0 + (meta >> 16), qx = qx0 + (meta & 0xffff);
+                    if (meta >= 0 && qy < d.QH && qx < d.QW) {
+                        const int oy = d.oy0 + qy * d.osy, ox = d.ox0 + qx * d.osx;
+                        vals[u] = *(const V*)(gb + ((size_t)oy * d.Wout + ox) * d.Cout + co0 + c);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) *(V*)(gt + dst[u]) = wg2_act<VE, SUM>(vals[u], d.mask_slope, sums);
+    }
+}
+
+template <int TPW>
+__global__ __launch_bounds__(256, 2) void conv_wgrad2_kernel(msmc_conv_desc d, const unsigned short* __restrict__ gptr,
+                                                            float* __restrict__ dw, float* __restrict__ db, CvGeom G,
+                                                            Wg2Params P) {
+    MSMC_DYN_LDS(smem);
+    const int npix = G.IH * G.IW, TM = P.TM, XSx = P.XSx, XSg = P.XSg;
+    unsigned short* xt = (unsigned short*)smem;                  // [npix][XSx]
+    unsigned short* gt = xt + (((size_t)npix * XSx + 7) & ~(size_t)7);   // [TM][XSg], 16-byte aligned
+    int* xmeta = (int*)(gt + (size_t)TM * XSg);                  // [npix] (ry << 16) | rx
+    int* gmeta = xmeta + npix;                                   // [TM]   (mty << 16) | mtx, -1 past the tile
+    const int tid = threadIdx.x, w = wave_uniform(tid >> 6), lane = tid & 63, L = lane & 15, half = (lane >> 4) & 1;
+    const int g = lane >> 5;
+    const int co0 = blockIdx.y * 64;
+    const int ciTile = blockIdx.z / P.ntg, tg = blockIdx.z - ciTile * P.ntg;
+    const int ci0 = ciTile * 64;
+    for (int pi = tid; pi < npix; pi += 256) {
+        const int ry = pi / G.IW;
+        xmeta[pi] = (ry << 16) | (pi - ry * G.IW);
+    }
+    for (int m = tid; m < TM; m += 256) {
+        const int mty = m / G.TW;
+        gmeta[m] = (mty < G.TH) ? ((mty << 16) | (m - mty * G.TW)) : -1;
+    }
+    __syncthreads();
+
+    // ---- this wave's units: output-channel block cb, then (input-channel block, tap) pairs
+    const int coLeft = d.Cout - co0, ciLeft = d.Cin - ci0;
+    const int n_cb = coLeft > 32 ? 2 : 1, n_ib = ciLeft > 32 ? 2 : 1;
+    const int wpc = 4 / n_cb, cb = w % n_cb, slot = w / n_cb;
+    const int tap0 = tg * P.TG;
+    int ntl = d.ntaps - tap0;
+    if (ntl > P.TG) ntl = P.TG;
+    const int nunits = n_ib * ntl;
+    const int cpx = ((ciLeft > 64 ? 64 : ciLeft) + 3) & ~3, cpg = ((coLeft > 64 ? 64 : coLeft) + 3) & ~3;
+    int boff[TPW], utap[TPW], uib[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        const int u = slot + wpc * j;
+        utap[j] = -1; uib[j] = 0; boff[j] = 0;
+        if (u < nunits) {
+            const int ib = u % n_ib, t = tap0 + u / n_ib;
+            int col = 32 * ib + 16 * half + 4 * (L & 3);
+            if (col > cpx - 4) col = cpx - 4;           // thin tiles: surplus lanes re-read the last real chunk
+            utap[j] = t; uib[j] = ib;
+            boff[j] = ((d.tap_dy[t] - G.dyMin) * G.IW + (d.tap_dx[t] - G.dxMin)) * XSx + col;
+        }
+    }
+    int acol = 32 * cb + 16 * half + 4 * (L & 3);
+    if (acol > cpg - 4) acol = cpg - 4;
+    // fragment rows: lane L of each 16-lane group addresses pixel row (L >> 2) of its 4-row block
+    int xrow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = 16 * (r >> 1) + 8 * g + 4 * (r & 1) + (L >> 2);
+        int meta = m < TM ? gmeta[m] : -1;
+        xrow[r] = meta >= 0 ? ((meta >> 16) * d.isy * G.IW + (meta & 0xffff) * d.isx) * XSx : 0;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const bool do_bias = (db != nullptr) && (blockIdx.z == 0);
+    float bsum[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bsum[q] = 0.f;
+    const int nks = TM >> 4;
+    const int t0 = blockIdx.x * P.tilesPerWg;
+    int t1 = t0 + P.tilesPerWg;
+    if (t1 > P.totalTiles) t1 = P.totalTiles;
+
+    for (int tile = t0; tile < t1; ++tile) {
+        int bt = tile;
+        const int tx_ = bt % G.tilesX;
+        bt /= G.tilesX;
+        const int ty_ = bt % G.tilesY;
+        const int b = bt / G.tilesY;
+        const int qy0 = ty_ * G.TH, qx0 = tx_ * G.TW;
+        const int iyBase = qy0 * d.isy + d.iy0 + G.dyMin, ixBase = qx0 * d.isx + d.ix0 + G.dxMin;
+        const unsigned short* xb = (const unsigned short*)d.x + (size_t)b * d.Hin * d.Win * d.Cin;
+        const unsigned short* gb = gptr + (size_t)b * d.Hout * d.Wout * d.Cout;
+        __syncthreads();
+        switch (P.vex) {
+            case 8: wg2_stage_x<8>(xt, xmeta, d, xb, ci0, iyBase, ixBase, npix, P.shx, XSx, tid); break;
+            case 4: wg2_stage_x<4>(xt, xmeta, d, xb, ci0, iyBase, ixBase, npix, P.shx, XSx, tid); break;
+            case 2: wg2_stage_x<2>(xt, xmeta, d, xb, ci0, iyBase, ixBase, npix, P.shx, XSx, tid); break;
+            default: wg2_stage_x<1>(xt, xmeta, d, xb, ci0, iyBase, ixBase, npix, P.shx, XSx, tid); break;
+        }
+#define WG2_STAGE_G(VE_)                                                                                      \
+    do {                                                                                                      \
+        if (do_bias) wg2_stage_g<VE_, true>(gt, gmeta, d, gb, co0, qy0, qx0, TM, P.shg, XSg, tid, bsum);      \
+        else wg2_stage_g<VE_, false>(gt, gmeta, d, gb, co0, qy0, qx0, TM, P.shg, XSg, tid, bsum);             \
+    } while (0)
+        switch (P.veg) {
+            case 8: WG2_STAGE_G(8); break;
+            case 4: WG2_STAGE_G(4); break;
+            case 2: WG2_STAGE_G(2); break;
+            default: WG2_STAGE_G(1); break;
+        }
+#undef WG2_STAGE_G
+        __syncthreads();
+        if (utap[0] < 0) continue;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            if (ks >= nks) continue;
+            const int m0 = 16 * ks + 8 * g + (L >> 2);
+            const bf16x8 af = wg_frag(gt, 1, m0 * XSg, (m0 + 4) * XSg, acol);
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                if (utap[j] >= 0) {
+                    const bf16x8 bf = wg_frag(xt, 1, xrow[2 * ks] + boff[j], xrow[2 * ks + 1] + boff[j], 0);
+                    acc[j] = mfma_bf16_32x32x16(af, bf, acc[j]);
+                }
+            }
+        }
+    }
+
+    if (do_bias) {
+        // every work-item staged the same channel vector of each pixel it touched: combine the lanes that
+        // share it, then the four waves through LDS -- ONE atomic per channel and workgroup (atomics on one
+        // address retire at ~10 per microsecond on MI355X, whoever issues them)
+        const int nv = 1 << P.shg, ve = P.veg;
+        for (int mask = nv; mask < 64; mask <<= 1)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bsum[q] = bsum[q] + wave_xor(bsum[q], mask);
+        float* red = (float*)smem;                      // [4][64]; the tiles are dead by now
+        __syncthreads();
+        if (lane < nv) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < ve) red[w * 64 + lane * ve + q] = bsum[q];
+        }
+        __syncthreads();
+        if (tid < nv * ve && co0 + tid < d.Cout)
+            atomicAdd(db + co0 + tid, ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid]);
+    }
+    // D fragment: row (co) = 32*cb + (r&3) + 8*(r>>2) + 4*g, col (ci) = 32*ib + (lane & 31)
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        if (utap[j] < 0) continue;
+        const int ci = ci0 + 32 * uib[j] + (lane & 31);
+        if (ci >= d.Cin) continue;
+        float* dst = dw + (size_t)d.tap_w[utap[j]] * d.Cout * d.Cin;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (co < d.Cout) atomicAdd(dst + (size_t)co * d.Cin + ci, acc[j][r]);
+        }
+    }
+}
+
+static int wg2_vec_elems(int channels, const void* base) {
+    int ve = 8;                                   // largest power of two dividing the pixel pitch and the base
+    while (ve > 1 && ((channels % ve) != 0 || (((size_t)base) % (2 * ve)) != 0)) ve >>= 1;
+    return ve;
+}
+static int wg2_row_stride(int cp) { return cp == 32 ? 48 : cp + 8; }   // rows of a 4-row transpose read on disjoint banks
+
+static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream) {
+    Wg2Params P;
+    const int cx = d->Cin > 64 ? 64 : d->Cin, cg = d->Cout > 64 ? 64 : d->Cout;
+    P.vex = wg2_vec_elems(d->Cin, d->x);
+    P.veg = wg2_vec_elems(d->Cout, g);
+    P.shx = 0;
+    while ((P.vex << P.shx) < cx) ++P.shx;
+    P.shg = 0;
+    while ((P.veg << P.shg) < cg) ++P.shg;
+    P.XSx = wg2_row_stride((cx + 3) & ~3);
+    P.XSg = wg2_row_stride((cg + 3) & ~3);
+    CvGeom G;
+    size_t lds_unused, lds;
+    int TM = WG_TM, rc;
+    for (;;) {                                     // shrink the lattice tile until two workgroups fit a CU
+        rc = cv_geometry(d, &G, 2, P.XSx, 0, &lds_unused, TM);
+        if (rc) return rc;
+        TM = ((G.TH * G.TW + 15) / 16) * 16;
+        lds = ((((size_t)G.IH * G.IW * P.XSx + 7) & ~(size_t)7) + (size_t)TM * P.XSg) * 2 +
+              ((size_t)G.IH * G.IW + TM) * sizeof(int);
+        if (lds <= 64 * 1024 && G.IH < 32768 && G.IW < 65536) break;
+        if (G.TH * G.TW <= 16) {
+            if (lds <= 160 * 1024) break;
+            return MSMC_E_SHAPE;
+        }
+        TM = (G.TH * G.TW) / 2;
+    }
+    P.TM = TM;
+    if (lds < 1024) lds = 1024;                  // the bias reduction reuses the first KiB
+    // taps per workgroup: a wave carries at most 5 accumulators (6 would spill at two waves per SIMD)
+    const int ncb = d->Cout > 32 ? 2 : 1, nib = d->Cin > 32 ? 2 : 1, wpc = 4 / ncb;
+    int tgmax = 5 * wpc / nib;
+    P.ntg = (d->ntaps + tgmax - 1) / tgmax;
+    P.TG = (d->ntaps + P.ntg - 1) / P.ntg;
+    const int tpw = (P.TG * nib + wpc - 1) / wpc;
+    P.totalTiles = G.tilesX * G.tilesY * d->B;
+    const int cols = ((d->Cout + 63) / 64) * ((d->Cin + 63) / 64) * P.ntg;
+    // pixel split: every split adds one fp32 atomic per dW element, and atomics on ONE address retire serially at
+    // ~0.1 us each (measured: 4096 per address -> 430 us), so  t(n) = (tiles/n) * t_tile + n * 0.1 us  with
+    // t_tile ~3 us is minimal at n = sqrt(30 * tiles), whatever the size of dW
+    int nsplit = (int)(sqrt(30.0 * P.totalTiles) + 0.5);
+    const int cap = (4 * MSMC_NUM_CU + cols - 1) / cols;
+    if (msmc_wgrad_split_override > 0) nsplit = msmc_wgrad_split_override;
+    else if (nsplit > cap) nsplit = cap;
+    if (nsplit > P.totalTiles) nsplit = P.totalTiles;
+    if (nsplit < 1) nsplit = 1;
+    P.tilesPerWg = (P.totalTiles + nsplit - 1) / nsplit;
+    nsplit = (P.totalTiles + P.tilesPerWg - 1) / P.tilesPerWg;
+    dim3 grid((unsigned)nsplit, (unsigned)((d->Cout + 63) / 64), (unsigned)(((d->Cin + 63) / 64) * P.ntg));
+    const unsigned short* gp = (const unsigned short*)g;
+#define WG2_GO(TP)                                                                                           \
+    do {                                                                                                     \
+        rc = msmc_allow_lds((const void*)conv_wgrad2_kernel<TP>, (int)lds);                                  \
+        if (rc) return rc;                                                                                   \
+        MSMC_LAUNCH((conv_wgrad2_kernel<TP>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, db, G, P); \
+    } while (0)
+    if (tpw <= 1) WG2_GO(1);
+    else if (tpw <= 2) WG2_GO(2);
+    else if (tpw <= 3) WG2_GO(3);
+    else if (tpw <= 4) WG2_GO(4);
+    else WG2_GO(5);
+#undef WG2_GO
+    return msmc_check_launch();
+}
+
 extern "C" int msmc_conv_wgrad(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream) {
     if (!d || !g || !dw || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0) return MSMC_E_SHAPE;
     if (d->ntaps <= 0 || d->ntaps > MSMC_CONV_MAX_TAPS) return MSMC_E_SHAPE;
     if (d->dtype == 0) return wg_launch<float>(d, g, dw, db, stream);
-    if (d->dtype == 1) return wg_launch<unsigned short>(d, g, dw, db, stream);
+    if (d->dtype == 1) return msmc_wgrad_generation == 1 ? wg_launch<unsigned short>(d, g, dw, db, stream)
+                                                         : wg2_launch(d, g, dw, db, stream);
     return MSMC_E_SHAPE;
 }
 

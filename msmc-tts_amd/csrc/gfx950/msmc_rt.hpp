@@ -16,6 +16,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define MSMC_WAVE 64
 #define MSMC_DEV static __device__ __forceinline__
@@ -27,6 +28,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef hipStream_t msmc_stream_t;
 
 // ---- 64-lane cross-lane moves ------------------------------------------------------------
+// value known to be identical in every lane of the wave -> scalar register
+MSMC_DEV int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 MSMC_DEV float wave_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 MSMC_DEV int wave_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
 MSMC_DEV float wave_down(float v, int delta) { return __shfl_down(v, delta, 64); }

@@ -69,6 +69,8 @@ def _ptr(t):
         raise RuntimeError('msmc HIP ops run on the GPU only (got a %s tensor); there is no CPU path' % t.device)
     if not t.is_contiguous():
         raise ValueError('msmc HIP ops take contiguous tensors')
+    if t.data_ptr() % 16:
+        raise ValueError('msmc HIP ops take 16-byte aligned operands (got an offset view)')
     return t.data_ptr()
 
 
@@ -116,13 +118,15 @@ def _dev_ok(t):
         raise RuntimeError('msmc HIP ops run on the GPU only (got a %s tensor); there is no CPU path' % t.device)
     if not t.is_contiguous():
         raise ValueError('msmc HIP ops take contiguous tensors')
+    if t.data_ptr() % 16:
+        raise ValueError('msmc HIP ops take 16-byte aligned operands (got an offset view)')
 
 
 def _opt_ptr(t, like):
     if t is None:
         return None
-    if t.dtype != like.dtype or not t.is_contiguous():
-        raise ValueError('epilogue operands share the activation dtype and are contiguous')
+    if t.dtype != like.dtype or not t.is_contiguous() or t.data_ptr() % 16:
+        raise ValueError('epilogue operands share the activation dtype, are contiguous and 16-byte aligned')
     return t.data_ptr()
 
 

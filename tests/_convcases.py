@@ -1,0 +1,109 @@
+"""Convolution layer cases shared by the GPU tests (full CSMSC sizes) and the kernel-interpreter tests
+(same layer geometry, fewer pixels): every check compares the HIP kernels with PyTorch's own convolution."""
+import torch
+import torch.nn.functional as F
+
+
+def cl(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def rel(a, b):
+    return (a.float() - b.float()).abs().max().item() / max(1e-6, b.float().abs().max().item())
+
+
+# (name, B, Cin, Cout, H, W, kernel, stride, dilation, padding, reflect, in_slope)
+CONVS = [
+    ('gen conv_pre k7', 16, 256, 512, 1, 40, (1, 7), (1, 1), (1, 1), (0, 3), False, 1.0),
+    ('gen rb0 k11 d5 C256', 16, 256, 256, 1, 240, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
+    ('gen rb1 k7 d3 C128', 16, 128, 128, 1, 1200, (1, 7), (1, 1), (1, 3), (0, 9), False, 0.1),
+    ('gen rb2 k3 d1 C64', 16, 64, 64, 1, 6000, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
+    ('gen rb3 k11 d1 C32', 8, 32, 32, 1, 12000, (1, 11), (1, 1), (1, 1), (0, 5), False, 0.1),
+    ('gen conv_post k7 C32->1', 16, 32, 1, 1, 12000, (1, 7), (1, 1), (1, 1), (0, 3), False, 0.01),
+    ('mpd p2 conv0 1->16', 16, 1, 16, 6000, 2, (5, 1), (3, 1), (1, 1), (2, 0), False, 1.0),
+    ('mpd p3 conv1 16->64', 16, 16, 64, 1334, 3, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
+    ('mpd p11 conv2 64->256', 16, 64, 256, 122, 11, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
+    ('mpd p5 conv3 256->512', 16, 256, 512, 89, 5, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
+    ('mpd p7 conv4 512->512 s1', 16, 512, 512, 22, 7, (5, 1), (1, 1), (1, 1), (2, 0), False, 0.2),
+    ('mpd p2 post 512->1', 16, 512, 1, 75, 2, (3, 1), (1, 1), (1, 1), (1, 0), False, 0.2),
+    ('mrd h15 conv0 2->4 s1', 16, 2, 4, 31, 801, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
+    ('mrd h15 conv1 4->8 s2', 16, 4, 8, 31, 801, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
+    ('mrd h240 conv3 64->128 s2', 16, 64, 128, 241, 26, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
+    ('mrd h240 conv4 128->256 s1', 16, 128, 256, 121, 13, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
+    ('mrd h240 conv6 512->1', 16, 512, 1, 61, 7, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
+]
+
+# the same geometries with few pixels / channels (the interpreter runs one work-item at a time), plus the
+# thin and odd channel counts of the first discriminator layers
+SMALL = [
+    ('gen k11 d5 C64', 2, 64, 64, 1, 70, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
+    ('gen k7 d3 C32', 2, 32, 32, 1, 150, (1, 7), (1, 1), (1, 3), (0, 9), False, 0.1),
+    ('gen k3 C96->40', 1, 96, 40, 1, 40, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
+    ('gen post C32->1', 2, 32, 1, 1, 140, (1, 7), (1, 1), (1, 1), (0, 3), False, 0.01),
+    ('mpd 1->16', 2, 1, 16, 61, 2, (5, 1), (3, 1), (1, 1), (2, 0), False, 1.0),
+    ('mpd 16->64 p3', 2, 16, 64, 40, 3, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
+    ('mpd 64->1 p5', 1, 64, 1, 9, 5, (3, 1), (1, 1), (1, 1), (1, 0), False, 0.2),
+    ('mrd 2->4 s1', 2, 2, 4, 9, 37, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
+    ('mrd 4->8 s2', 2, 4, 8, 9, 37, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
+    ('mrd 8->16 s1', 1, 8, 16, 11, 21, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
+    ('mrd 64->72 s2', 1, 64, 72, 13, 18, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
+]
+
+
+def check_conv_case(case, dtype, tol, dev, parts=('fwd', 'dgrad', 'wgrad'), batch_offset=0):
+    """forward / data gradient / weight + bias gradient of one layer against PyTorch on ``dev``."""
+    from msmctts_amd.hip import conv
+    name, B, Cin, Cout, H, W, k, s, dil, pad, reflect, slope = case
+    g = torch.Generator(device='cpu').manual_seed(sum(ord(c) for c in name))
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, *k, generator=g) / (Cin * k[0] * k[1]) ** 0.5).to(dev).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).to(dev).requires_grad_(True)
+    xa = F.leaky_relu(x, slope) if slope != 1.0 else x
+    if reflect:
+        ref = F.conv2d(F.pad(xa, (pad[1], pad[1], pad[0], pad[0]), mode='reflect'), w, b, s, 0, dil)
+    else:
+        ref = F.conv2d(xa, w, b, s, pad, dil)
+    go = torch.randn(ref.shape, generator=g).to(dev)
+    ref.backward(go)
+    geom = conv.Geometry(H, W, k, s, dil, pad, reflect)
+    T = k[0] * k[1]
+    wf = w.detach().permute(2, 3, 0, 1).reshape(T, Cout, Cin).contiguous().to(dtype)
+    wb = w.detach().permute(2, 3, 1, 0).reshape(T, Cin, Cout).contiguous().to(dtype)
+    xc, gc = cl(x.detach()).to(dtype), cl(go).to(dtype)
+    if batch_offset:
+        # operands that start in the middle of a larger allocation at an element-aligned address are refused
+        # loudly (the kernels use 16-byte vector accesses), not mis-read
+        import pytest
+        buf = torch.empty(xc.numel() + batch_offset, dtype=xc.dtype, device=xc.device)
+        xo = buf[batch_offset:].view(xc.shape)
+        xo.copy_(xc)
+        with pytest.raises(ValueError, match='16-byte aligned'):
+            conv.conv_forward(xo, wf, geom, bias=b.detach(), in_slope=slope)
+        with pytest.raises(ValueError, match='16-byte aligned'):
+            conv.conv_wgrad(xo, gc, geom, T, in_slope=slope)
+    if 'fwd' in parts:
+        out = conv.conv_forward(xc, wf, geom, bias=b.detach(), in_slope=slope)
+        assert rel(nchw(out), ref) < tol, 'forward'
+    if 'dgrad' in parts:
+        if reflect:
+            gx = conv.reflect_fold(conv.conv_dgrad(gc, wb, geom), H, W, pad[0],
+                                   mask_src=xc if slope != 1.0 else None, slope=slope)
+        else:
+            gx = conv.conv_dgrad(gc, wb, geom, mask_src=xc if slope != 1.0 else None, mask_slope=slope)
+        assert rel(nchw(gx), x.grad) < tol, 'dgrad'
+    if 'wgrad' in parts:
+        db = torch.zeros(Cout, device=dev)
+        dw = conv.conv_wgrad(xc, gc, geom, T, in_slope=slope, db=db)
+        want = w.grad.permute(2, 3, 0, 1).reshape(T, Cout, Cin)
+        wtol = max(tol, 1e-3 if dtype == torch.float32 else tol)
+        assert rel(dw, want) < wtol, ('wgrad', rel(dw, want))
+        # the fused bias gradient sums exactly the (rounded) operand the kernel was given
+        bref = gc.float().reshape(-1, Cout).sum(0)
+        bscale = gc.float().reshape(-1, Cout).abs().sum(0).max().item()
+        assert (db - bref).abs().max().item() < 1e-5 * bscale + 1e-6, ('fused bias grad', db, bref)
+        cs = conv.colsum(gc.reshape(-1, Cout))
+        assert (cs - bref).abs().max().item() < 1e-5 * bscale + 1e-6, ('bias grad', cs, bref)

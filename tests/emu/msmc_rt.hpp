@@ -22,6 +22,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 #define __global__
 #define __device__
@@ -81,6 +82,7 @@ static inline T emu_exchange(T v, int src_lane) {
     emu::collective_done();
     return r;
 }
+static inline int wave_uniform(int v) { return v; }
 MSMC_DEV float wave_xor(float v, int mask) { return emu_exchange(v, emu::lane() ^ mask); }
 MSMC_DEV int wave_xor(int v, int mask) { return emu_exchange(v, emu::lane() ^ mask); }
 MSMC_DEV float wave_down(float v, int delta) {

@@ -9,73 +9,32 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def cl(x):
-    return x.permute(0, 2, 3, 1).contiguous()
-
-
-def nchw(x):
-    return x.permute(0, 3, 1, 2)
-
-
-def rel(a, b):
-    return (a.float() - b.float()).abs().max().item() / max(1e-6, b.float().abs().max().item())
-
-
-# (name, B, Cin, Cout, H, W, kernel, stride, dilation, padding, reflect, in_slope)
-CONVS = [
-    ('gen conv_pre k7', 16, 256, 512, 1, 40, (1, 7), (1, 1), (1, 1), (0, 3), False, 1.0),
-    ('gen rb0 k11 d5 C256', 16, 256, 256, 1, 240, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
-    ('gen rb1 k7 d3 C128', 16, 128, 128, 1, 1200, (1, 7), (1, 1), (1, 3), (0, 9), False, 0.1),
-    ('gen rb2 k3 d1 C64', 16, 64, 64, 1, 6000, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
-    ('gen rb3 k11 d1 C32', 8, 32, 32, 1, 12000, (1, 11), (1, 1), (1, 1), (0, 5), False, 0.1),
-    ('gen conv_post k7 C32->1', 16, 32, 1, 1, 12000, (1, 7), (1, 1), (1, 1), (0, 3), False, 0.01),
-    ('mpd p2 conv0 1->16', 16, 1, 16, 6000, 2, (5, 1), (3, 1), (1, 1), (2, 0), False, 1.0),
-    ('mpd p3 conv1 16->64', 16, 16, 64, 1334, 3, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
-    ('mpd p11 conv2 64->256', 16, 64, 256, 122, 11, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
-    ('mpd p5 conv3 256->512', 16, 256, 512, 89, 5, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
-    ('mpd p7 conv4 512->512 s1', 16, 512, 512, 22, 7, (5, 1), (1, 1), (1, 1), (2, 0), False, 0.2),
-    ('mpd p2 post 512->1', 16, 512, 1, 75, 2, (3, 1), (1, 1), (1, 1), (1, 0), False, 0.2),
-    ('mrd h15 conv0 2->4 s1', 16, 2, 4, 31, 801, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
-    ('mrd h15 conv1 4->8 s2', 16, 4, 8, 31, 801, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
-    ('mrd h240 conv3 64->128 s2', 16, 64, 128, 241, 26, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
-    ('mrd h240 conv4 128->256 s1', 16, 128, 256, 121, 13, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
-    ('mrd h240 conv6 512->1', 16, 512, 1, 61, 7, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
-]
+from _convcases import CONVS, SMALL, check_conv_case, cl, nchw, rel
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize('case', CONVS, ids=[c[0] for c in CONVS])
 def test_conv_forward_dgrad_wgrad(case, dtype, tol):
-    from msmctts_amd.hip import conv
-    name, B, Cin, Cout, H, W, k, s, dil, pad, reflect, slope = case
-    g = torch.Generator(device='cpu').manual_seed(sum(ord(c) for c in name))
-    x = torch.randn(B, Cin, H, W, generator=g).to(DEV).requires_grad_(True)
-    w = (torch.randn(Cout, Cin, *k, generator=g) / (Cin * k[0] * k[1]) ** 0.5).to(DEV).requires_grad_(True)
-    b = torch.randn(Cout, generator=g).to(DEV).requires_grad_(True)
-    xa = F.leaky_relu(x, slope) if slope != 1.0 else x
-    if reflect:
-        ref = F.conv2d(F.pad(xa, (pad[1], pad[1], pad[0], pad[0]), mode='reflect'), w, b, s, 0, dil)
-    else:
-        ref = F.conv2d(xa, w, b, s, pad, dil)
-    go = torch.randn(ref.shape, generator=g).to(DEV)
-    ref.backward(go)
-    geom = conv.Geometry(H, W, k, s, dil, pad, reflect)
-    T = k[0] * k[1]
-    wf = w.detach().permute(2, 3, 0, 1).reshape(T, Cout, Cin).contiguous().to(dtype)
-    wb = w.detach().permute(2, 3, 1, 0).reshape(T, Cin, Cout).contiguous().to(dtype)
-    xc, gc = cl(x.detach()).to(dtype), cl(go).to(dtype)
-    out = conv.conv_forward(xc, wf, geom, bias=b.detach(), in_slope=slope)
-    assert rel(nchw(out), ref) < tol, 'forward'
-    if reflect:
-        gx = conv.reflect_fold(conv.conv_dgrad(gc, wb, geom), H, W, pad[0], mask_src=xc if slope != 1.0 else None,
-                               slope=slope)
-    else:
-        gx = conv.conv_dgrad(gc, wb, geom, mask_src=xc if slope != 1.0 else None, mask_slope=slope)
-    assert rel(nchw(gx), x.grad) < tol, 'dgrad'
-    dw = conv.conv_wgrad(xc, gc, geom, T, in_slope=slope)
-    want = w.grad.permute(2, 3, 0, 1).reshape(T, Cout, Cin)
-    assert rel(dw, want) < max(tol, 1e-3 if dtype == torch.float32 else tol), 'wgrad'
-    assert rel(conv.colsum(gc.reshape(-1, Cout)), b.grad) < max(tol, 1e-3), 'bias grad'
+    check_conv_case(case, dtype, tol, DEV)
+
+
+@pytest.mark.parametrize('case', SMALL, ids=[c[0] for c in SMALL])
+def test_conv_small_and_thin_shapes(case):
+    """odd / thin channel counts, ragged tiles; offset (not 16-byte aligned) operands are refused"""
+    check_conv_case(case, torch.bfloat16, 2e-2, DEV, batch_offset=1)
+    check_conv_case(case, torch.float32, 2e-4, DEV)
+
+
+@pytest.mark.parametrize('gen', [1, 2])
+def test_wgrad_generations_agree(gen):
+    """A/B switch of the bf16 weight-gradient kernels: both generations against PyTorch on a mid-size layer"""
+    from msmctts_amd.hip import lib
+    lib.get().msmc_conv_set_wgrad_generation(gen)
+    try:
+        for case in (CONVS[2], CONVS[8], CONVS[14]):
+            check_conv_case(case, torch.bfloat16, 2e-2, DEV, parts=('wgrad',))
+    finally:
+        lib.get().msmc_conv_set_wgrad_generation(2)
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])

@@ -78,3 +78,14 @@ def test_train_step_runs_under_bf16_autocast():
         task.zero_grad()
         log = tr.train_step(batch, it)
         assert all(torch.isfinite(torch.as_tensor(float(v))) for v in log['loss'].values())
+
+
+import _convcases
+
+
+@pytest.mark.parametrize('case', _convcases.SMALL, ids=[c[0] for c in _convcases.SMALL])
+def test_conv_kernels_small_and_thin_shapes(case):
+    """forward / data gradient / weight + bias gradient kernels (bf16 and fp32 code paths) on the interpreter:
+    thin and odd channel counts, ragged tiles, strided and reflect-padded 2-D layers, against PyTorch."""
+    _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', batch_offset=1)
+    _convcases.check_conv_case(case, torch.float32, 2e-4, 'cpu')
