@@ -126,7 +126,7 @@ def check_modules(device):
                 close(fmap_digest(f), z['disc.%s.fmap.%d.%d' % (tag, i, j)], what='fmap %d %d' % (i, j))
 
 
-def check_train_steps(device):
+def check_train_steps(device, arm_reducer=False):
     from msmctts_amd.trainers import build_trainer
     from msmctts_amd.trainers.optimizers import build_optimizer
     z = load_npz('small_steps.npz')
@@ -134,6 +134,9 @@ def check_train_steps(device):
         cfg, task = build_small(device)
         tr = build_trainer(cfg, task, num_gpus=0, rank=0)
         tr.model = task
+        if arm_reducer:      # data-parallel plumbing (hooks, buckets, collectives) with whatever group is initialised
+            from msmctts_amd.distributed.distributed import apply_gradient_allreduce
+            apply_gradient_allreduce(task)
         tr.optimizer = build_optimizer(task, cfg.optimizer)
         fw = [tuple(int(v) for v in r) for r in z['windows']]
         sw = [(s * 300, e * 300) for s, e in fw]

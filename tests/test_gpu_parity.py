@@ -189,3 +189,27 @@ def test_graphed_step_matches_eager():
     for k in es:
         if es[k].dtype.is_floating_point:
             _parity.close(gs[k], es[k], 2e-3, 1e-3, k)
+
+
+def test_rccl_gradient_reducer_single_rank_matches_reference():
+    """The data-parallel path on the real backend: RCCL process group of one rank, bucketed reducer armed
+    (autograd hooks + the HIP conv banks' hand-delivered gradients, collectives on RCCL's stream next to the
+    multi-stream backward).  Averaging over one rank is the identity, so the golden step must still match."""
+    import subprocess, sys, os, socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, torch.distributed as dist\n"
+        "sys.path[:0] = [%r, %r, %r]\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d', world_size=1, rank=0)\n"
+        "import _parity\n"
+        "_parity.check_train_steps('cuda:0', arm_reducer=True)\n"
+        "dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()\n"
+        "print('REDUCER-OK')\n" % (root, os.path.join(root, 'msmc-tts_amd'), os.path.join(root, 'tests'), port))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and 'REDUCER-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
