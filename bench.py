@@ -43,7 +43,8 @@ def vq_bytes_per_frame(D, H):
 
 
 class KernelTimer(object):
-    """HIP-event timing of named C-ABI launches on the current (launch) stream."""
+    """HIP-event timing of the hand-written launches on the stream they are launched on, attributed to the kernel
+    symbol the C library reports (the names rocprofv3 prints), with the algorithmic flops and bytes of each call."""
 
     def __init__(self):
         self.records = {}
@@ -60,7 +61,7 @@ class KernelTimer(object):
             s.record()
             out = inner(*args, **kw)
             e.record()
-            timer.records.setdefault(label, []).append((s, e, work(*args, **kw)))
+            timer.records.setdefault(label(), []).append((s, e) + tuple(work(*args, **kw)))
             return out
 
         setattr(module, fn_name, timed)
@@ -68,10 +69,9 @@ class KernelTimer(object):
     def summary(self):
         out = {}
         for label, recs in self.records.items():
-            ms = [s.elapsed_time(e) for s, e, _ in recs]
-            work = [b for _, _, b in recs]
-            out[label] = dict(launches=len(ms), avg_ms=sum(ms) / len(ms), avg_work=sum(work) / len(work),
-                              total_ms=sum(ms), total_work=sum(work))
+            ms = [s.elapsed_time(e) for s, e, _, _ in recs]
+            out[label] = dict(launches=len(ms), total_ms=sum(ms), flops=sum(r[2] for r in recs),
+                              bytes=sum(r[3] for r in recs))
         return out
 
 
@@ -89,6 +89,7 @@ def build(args, device, rank, world):
     trainer.optimizer = build_optimizer(trainer.model, cfg.optimizer, capturable=args.graph)
     trainer.use_graphs = args.graph
     trainer.amp_dtype = torch.bfloat16 if args.dtype == 'bf16' else None
+    trainer.amp_autocast = not args.no_autocast
     trainer.model.train()
     return cfg, trainer
 
@@ -177,6 +178,8 @@ def main():
     ap.add_argument('--cpu-batch', type=int, default=4, help='utterances of the batch in the cpu_baseline sample')
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = min(available cores, 32)')
     ap.add_argument('--no-microbench', action='store_true')
+    ap.add_argument('--no-autocast', action='store_true',
+                    help='bf16 only inside the HIP conv stacks; the transformer encoder/decoder stay fp32')
     ap.add_argument('--graph', action='store_true',
                     help='replay the step from three hipGraphs (measured slower than the multi-stream eager step)')
     ap.add_argument('--kernel-timing-steps', type=int, default=3, help='extra steps timed kernel by kernel (rank 0)')
@@ -207,34 +210,55 @@ def main():
 
     timer = KernelTimer()
     from msmctts_amd.hip import conv as hipconv
-    timer.wrap(hipvq, 'vq_search', 'vq_search_kernel',
-               lambda x, et, en: (x.numel() // x.shape[-1]) * vq_bytes_per_frame(x.shape[-1], et.shape[0]))
+    def esz(t):
+        return t.element_size()
 
-    def conv_flops(x, w, geom, *a, **k):                  # 2 * pixels_out * Cout * Cin * taps
-        return 2.0 * x.shape[0] * geom.Hout * geom.Wout * w.shape[1] * w.shape[2] * w.shape[0]
+    def vq_work(x, et, en):
+        n = x.numel() // x.shape[-1]
+        return 2.0 * n * x.shape[-1] * et.shape[1], n * vq_bytes_per_frame(x.shape[-1], et.shape[0])
 
-    def dgrad_flops(g, wb, geom, *a, **k):
-        return 2.0 * g.shape[0] * geom.Hout * geom.Wout * wb.shape[1] * wb.shape[2] * wb.shape[0]
+    timer.wrap(hipvq, 'vq_search', lambda: 'vq_search_reg_kernel', vq_work)
 
-    def wgrad_flops(x, g, geom, n_slices, *a, **k):
-        return 2.0 * x.shape[0] * geom.Hout * geom.Wout * g.shape[3] * x.shape[3] * n_slices
+    # algorithmic work of one call: flops = 2 * output points * Cout * Cin * taps; bytes = every operand once
+    def conv_work(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, **k):
+        pts = x.shape[0] * geom.Hout * geom.Wout
+        extra = sum(1 for t in (res, res2) if t is not None)
+        return (2.0 * pts * w.shape[1] * w.shape[2] * w.shape[0],
+                (x.numel() + pts * w.shape[1] * (1 + extra) + w.numel()) * esz(x))
 
-    def convt_flops(x, w, kk, stride, padding, *a, **k):   # every input pixel meets every tap once
-        return 2.0 * x.shape[0] * x.shape[2] * w.shape[1] * w.shape[2] * kk
+    def dgrad_work(g, wb, geom, mask_src=None, mask_slope=1.0, res=None, **k):
+        pts = g.shape[0] * geom.Hout * geom.Wout
+        Hx, Wx = geom.dgrad_plan()[:2]
+        nx = g.shape[0] * Hx * Wx * wb.shape[1]
+        return (2.0 * pts * wb.shape[1] * wb.shape[2] * wb.shape[0],
+                (g.numel() + nx * (2 if mask_src is not None else 1) + wb.numel()) * esz(g))
 
-    def convt_dgrad_flops(g, wb, kk, stride, padding, Lin, *a, **k):
-        return 2.0 * g.shape[0] * Lin * wb.shape[1] * wb.shape[2] * kk
+    def wgrad_work(x, g, geom, n_slices, *a, **k):
+        pts = x.shape[0] * geom.Hout * geom.Wout
+        return (2.0 * pts * g.shape[3] * x.shape[3] * n_slices,
+                (x.numel() + g.numel()) * esz(x) + 8.0 * n_slices * g.shape[3] * x.shape[3])
 
-    def convt_wgrad_flops(x, g, kk, stride, padding, *a, **k):
-        return 2.0 * x.shape[0] * x.shape[2] * x.shape[3] * g.shape[3] * kk
+    def convt_work(x, w, kk, stride, padding, *a, **k):   # every input pixel meets every tap once
+        Lout = (x.shape[2] - 1) * stride - 2 * padding + kk
+        return (2.0 * x.shape[0] * x.shape[2] * w.shape[1] * w.shape[2] * kk,
+                (x.numel() + x.shape[0] * Lout * w.shape[1] + w.numel()) * esz(x))
 
-    for fn, label, work in (('conv_forward', 'conv_gather_kernel[fwd]', conv_flops),
-                            ('conv_dgrad', 'conv_gather_kernel[dgrad]', dgrad_flops),
-                            ('conv_wgrad', 'conv_wgrad_kernel', wgrad_flops),
-                            ('conv_transpose1d_forward', 'conv_gather_kernel[convT]', convt_flops),
-                            ('conv_transpose1d_dgrad', 'conv_gather_kernel[convT dgrad]', convt_dgrad_flops),
-                            ('conv_transpose1d_wgrad', 'conv_wgrad_kernel[convT]', convt_wgrad_flops)):
-        timer.wrap(hipconv, fn, label, work)
+    def convt_dgrad_work(g, wb, kk, stride, padding, Lin, mask_src=None, **k):
+        nx = g.shape[0] * Lin * wb.shape[1]
+        return (2.0 * g.shape[0] * Lin * wb.shape[1] * wb.shape[2] * kk,
+                (g.numel() + nx * (2 if mask_src is not None else 1) + wb.numel()) * esz(g))
+
+    def convt_wgrad_work(x, g, kk, stride, padding, *a, **k):
+        return (2.0 * x.shape[0] * x.shape[2] * x.shape[3] * g.shape[3] * kk,
+                (x.numel() + g.numel()) * esz(x) + 8.0 * kk * x.shape[3] * g.shape[3])
+
+    def last_kernel():
+        return lib.get().msmc_conv_last_kernel().decode()
+
+    for fn, work in (('conv_forward', conv_work), ('conv_dgrad', dgrad_work), ('conv_wgrad', wgrad_work),
+                     ('conv_transpose1d_forward', convt_work), ('conv_transpose1d_dgrad', convt_dgrad_work),
+                     ('conv_transpose1d_wgrad', convt_wgrad_work)):
+        timer.wrap(hipconv, fn, last_kernel, work)
 
     def step(i):
         if not trainer.use_graphs:
@@ -294,22 +318,40 @@ def main():
     ks = timer.summary()
     roof, kernels = None, {}
     mfma_peak = MFMA_PEAK_TFLOPS[args.dtype]
+    nst = max(1, args.kernel_timing_steps)
     for label, rec in ks.items():
-        if label.startswith('vq_'):
-            ach = rec['total_work'] / rec['total_ms'] / 1e6
-            kernels[label] = dict(bound='hbm', achieved=ach, peak=HBM_PEAK_GBS, unit='GB/s', frac=ach / HBM_PEAK_GBS,
-                                  launches=rec['launches'], avg_us=rec['avg_ms'] * 1e3,
-                                  ms_per_step=rec['total_ms'] / max(1, args.kernel_timing_steps))
-        else:
-            ach = rec['total_work'] / rec['total_ms'] / 1e9
-            kernels[label] = dict(bound='mfma', achieved=ach, peak=mfma_peak, unit='TFLOP/s', frac=ach / mfma_peak,
-                                  launches=rec['launches'], avg_us=rec['avg_ms'] * 1e3,
-                                  ms_per_step=rec['total_ms'] / max(1, args.kernel_timing_steps))
+        # fp32 kernels (spectral DFT projections, VQ search) are priced against the fp32 MFMA peak
+        peak = MFMA_PEAK_TFLOPS['fp32'] if ('float' in label or label.startswith('vq_')) else mfma_peak
+        t_mfma, t_hbm = rec['flops'] / (peak * 1e12), rec['bytes'] / (HBM_PEAK_GBS * 1e9)
+        sec = rec['total_ms'] * 1e-3
+        kernels[label] = dict(launches=rec['launches'], avg_us=rec['total_ms'] * 1e3 / rec['launches'],
+                              ms_per_step=rec['total_ms'] / nst, tflops=rec['flops'] / sec / 1e12,
+                              gbps=rec['bytes'] / sec / 1e9, bound='mfma' if t_mfma >= t_hbm else 'hbm',
+                              mfma_peak_tflops=peak, frac_mfma=t_mfma / sec, frac_hbm=t_hbm / sec,
+                              bytes_per_launch=rec['bytes'] / rec['launches'],
+                              flops_per_launch=rec['flops'] / rec['launches'])
     if kernels:
         label = max(kernels, key=lambda k: kernels[k]['ms_per_step'])
-        roof = dict(kernel=label, traffic=None, **kernels[label])
-        roof['note'] = ('achieved = algorithmic work of all launches of this kernel in the instrumented steps / their '
-                        'summed HIP-event durations; peak = dense %s MFMA' % args.dtype)
+        k = kernels[label]
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            traffic = pmc['kernels'][label]['hbm_bytes_per_launch']
+        except Exception:
+            pass
+        if k['bound'] == 'mfma':
+            roof = dict(bound='mfma', achieved=k['tflops'], peak=k['mfma_peak_tflops'], unit='TFLOP/s',
+                        frac=k['frac_mfma'], traffic=traffic)
+        else:
+            roof = dict(bound='hbm', achieved=k['gbps'], peak=HBM_PEAK_GBS, unit='GB/s', frac=k['frac_hbm'],
+                        traffic=traffic)
+        roof.update(kernel=label, launches=k['launches'], avg_us=k['avg_us'], ms_per_step=k['ms_per_step'],
+                    bytes_per_launch=k['bytes_per_launch'], flops_per_launch=k['flops_per_launch'])
+        roof['note'] = ('dominant hand-written kernel by summed HIP-event time over %d instrumented steps; achieved = '
+                        'algorithmic flops (or bytes) of its launches / their summed durations; bound = the roofline '
+                        'that prices those launches higher; traffic = PMC HBM bytes per launch from '
+                        'profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command), null if not collected'
+                        % nst)
     out = {
         'metric': 'mel-frames/sec MSMC-VQ-GAN train step (GAN phase)', 'value': value, 'unit': 'mel-frames/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,

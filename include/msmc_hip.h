@@ -113,7 +113,11 @@ void msmc_conv_set_pipeline(int on);
 void msmc_conv_set_wgrad_split(int n);
 /* 2 (default) = second-generation bf16 weight-gradient kernel, 1 = first generation (A/B tests) */
 void msmc_conv_set_wgrad_generation(int n);
+/* 2 (default) = second-generation forward / data-gradient gather kernel, 1 = first generation (A/B tests) */
+void msmc_conv_set_gather_generation(int n);
 void msmc_conv_set_narrow(int on);
+/* Symbol of the kernel the calling thread's most recent msmc_conv_gather / msmc_conv_wgrad launched (profiling aid). */
+const char* msmc_conv_last_kernel(void);
 
 /* out[q] = epilogue( sum_t sum_ci w[tap_w[t]][co][ci] * act(x[in(q, t)][ci]) + bias[co] ). */
 int msmc_conv_gather(const msmc_conv_desc* desc, msmc_stream stream);

@@ -20,6 +20,7 @@
 // conv_wgrad_kernel<T>: dW[t][co][ci] += sum_{b,q} g[q][co] * act(x[in(q,t)][ci]); the reduction runs
 //   over pixels, so both operands are transposed on their way into LDS (4x4 register transposes,
 //   8-byte LDS writes) and every tap accumulates into its own fragment of the same wave.
+#include <cstdio>
 #include <msmc_rt.hpp>
 #include <msmc_hip.h>
 
@@ -31,6 +32,22 @@ static int msmc_conv_pipeline_enabled = 1;
 extern "C" void msmc_conv_set_pipeline(int on) { msmc_conv_pipeline_enabled = on; }
 static int msmc_conv_narrow_when_small = 1;
 extern "C" void msmc_conv_set_narrow(int on) { msmc_conv_narrow_when_small = on; }
+// name of the kernel the most recent msmc_conv_gather / msmc_conv_wgrad call of this thread launched (profiling aid:
+// bench.py attributes its per-launch HIP-event timings to the same symbols rocprofv3 reports)
+static thread_local const char* msmc_conv_last = "";
+extern "C" const char* msmc_conv_last_kernel(void) { return msmc_conv_last; }
+template <typename T> struct EltName;
+template <> struct EltName<float> { static constexpr const char* v = "float"; };
+template <> struct EltName<unsigned short> { static constexpr const char* v = "unsigned short"; };
+static const char* msmc_kname(const char* base, const char* elt, int a, int b) {
+    static thread_local char buf[96];
+    if (b >= 0) snprintf(buf, sizeof(buf), "%s<%s, %d, %d>", base, elt, a, b);
+    else if (elt) snprintf(buf, sizeof(buf), "%s<%s, %d>", base, elt, a);
+    else snprintf(buf, sizeof(buf), "%s<%d>", base, a);
+    return buf;
+}
+static int msmc_gather_generation = 2;          // 1 = first-generation forward / data-gradient kernels (A/B tests)
+extern "C" void msmc_conv_set_gather_generation(int n) { msmc_gather_generation = n; }
 static int msmc_wgrad_generation = 2;           // 1 = first-generation bf16 weight-gradient kernel (A/B tests)
 extern "C" void msmc_conv_set_wgrad_generation(int n) { msmc_wgrad_generation = n; }
 static int msmc_wgrad_split_override = 0;       // tests / perf sweeps: force the pixel-split factor
@@ -383,6 +400,222 @@ __global__ __launch_bounds__(256) void conv_gather_pipe_kernel(msmc_conv_desc d,
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second-generation gather kernel.  Same tiling and MFMA schedule as conv_gather_kernel; what changed is
+// everything around the matrix cores, which is where the time went (the first generation executed
+// ~2000-6000 scalar/vector ALU instructions per work-item around 2-16 MFMAs):
+//   * pixel -> global-offset tables for the input halo tile and the output tile are built ONCE per workgroup
+//     in LDS (padding rule, reflect, lattice stride and tile raggedness folded in); the channel-chunk loop
+//     and the epilogue index them instead of dividing;
+//   * the accumulators leave through an fp32 LDS tile, so bias / mask / residual / activation / store
+//     run on 16-byte vectors of consecutive channels (one load and one store instruction per 8 bf16)
+//     instead of one 2-byte access per element.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NT>
+__global__ __launch_bounds__(256, 2) void conv_gather2_kernel(msmc_conv_desc d, CvGeom G) {
+    MSMC_DYN_LDS(smem);
+    constexpr int VEC = Elt<T>::VEC, CK = Elt<T>::CK, CKV = CK / VEC, XS = CK + VEC, BN = 32 * NT, OS = BN + 4;
+    constexpr int BNV = BN / VEC;
+    const int npix = G.IH * G.IW, IW = G.IW;
+    int* in_off = (int*)smem;                                   // [npix] element offset of halo pixel, -1 = zero
+    int* out_off = in_off + npix;                               // [128]  pixel index of lattice point, -1 = none
+    int* tapw = out_off + 128;                                  // [16]   weight slice of tap t
+    char* region = smem + (((size_t)(npix + 128 + 16) * sizeof(int) + 15) & ~(size_t)15);
+    T* xt = (T*)region;                                         // [npix][XS]
+    T* wt = xt + G.xt_elems;                                    // [ntaps][BN][XS]
+    float* ot = (float*)region;                                 // [128][OS] epilogue tile (aliases xt / wt)
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 31, g = lane >> 5;
+    int bt = blockIdx.x;
+    const int tx_ = bt % G.tilesX;
+    bt /= G.tilesX;
+    const int ty_ = bt % G.tilesY;
+    const int b = bt / G.tilesY;
+    const int co0 = blockIdx.y * BN;
+    const int qy0 = ty_ * G.TH, qx0 = tx_ * G.TW;
+    const int iyBase = qy0 * d.isy + d.iy0 + G.dyMin, ixBase = qx0 * d.isx + d.ix0 + G.dxMin;
+
+    for (int pi = tid; pi < npix; pi += 256) {
+        const int ry = pi / IW, rx = pi - ry * IW;
+        int iy = iyBase + ry, ix = ixBase + rx;
+        bool inside = true;
+        if (d.pad_mode == 1) {
+            iy = reflect_index(iy, d.Hin);
+            ix = reflect_index(ix, d.Win);
+        } else {
+            inside = (iy >= 0) && (iy < d.Hin) && (ix >= 0) && (ix < d.Win);
+        }
+        in_off[pi] = inside ? (iy * d.Win + ix) * d.Cin : -1;
+    }
+    if (tid < 128) {
+        const int mty = tid / G.TW, mtx = tid - mty * G.TW;
+        const int qy = qy0 + mty, qx = qx0 + mtx;
+        const bool valid = mty < G.TH && qy < d.QH && qx < d.QW;
+        out_off[tid] = valid ? (d.oy0 + qy * d.osy) * d.Wout + (d.ox0 + qx * d.osx) : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < MSMC_CONV_MAX_TAPS; ++t)
+        if (tid == 128 + t) tapw[t] = t < d.ntaps ? d.tap_w[t] : 0;
+
+    int arow;
+    {
+        const int m = 32 * w + i;
+        const int mty = m / G.TW, mtx = m - mty * G.TW;
+        arow = (mty < G.TH) ? (mty * d.isy) * IW + mtx * d.isx : 0;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+    const T* xb = (const T*)d.x + (size_t)b * d.Hin * d.Win * d.Cin;
+    const T* wg = (const T*)d.w;
+    const bool vec_ok = (d.Cin % VEC) == 0;
+    const float slope = d.in_slope;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const int nxv = npix * CKV, nwv = d.ntaps * BN * CKV;
+
+    for (int c0 = 0; c0 < d.Cin; c0 += CK) {
+        __syncthreads();                      // tables ready (first pass) / previous chunk's fragments consumed
+        // ---- input halo tile: padding rule folded into in_off, input activation applied once per element
+        for (int e0 = tid; e0 < nxv; e0 += 1024) {
+            u32x4 vals[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 256 * u;
+                dst[u] = -1;
+                vals[u] = zero4;
+                if (e < nxv) {
+                    const int pi = e / CKV, v = e - pi * CKV;
+                    const int off = in_off[pi], c = c0 + v * VEC;
+                    dst[u] = pi * XS + v * VEC;
+                    if (off >= 0 && c < d.Cin) {
+                        const T* src = xb + off + c;
+                        if (vec_ok) {
+                            vals[u] = *(const u32x4*)src;
+                        } else {
+                            alignas(16) T tmp[VEC];
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) tmp[q] = (c + q < d.Cin) ? src[q] : (T)0;
+                            vals[u] = *(const u32x4*)tmp;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (dst[u] < 0) continue;
+                if (slope != 1.f) {
+                    alignas(16) T tmp[VEC];
+                    *(u32x4*)tmp = vals[u];
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        float f = Elt<T>::ld(&tmp[q]);
+                        f = f > 0.f ? f : f * slope;
+                        Elt<T>::st(&tmp[q], f);
+                    }
+                    vals[u] = *(const u32x4*)tmp;
+                }
+                *(u32x4*)(xt + dst[u]) = vals[u];
+            }
+        }
+        // ---- weight slices of every tap for this channel chunk
+        for (int e0 = tid; e0 < nwv; e0 += 1024) {
+            u32x4 vals[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + 256 * u;
+                dst[u] = -1;
+                vals[u] = zero4;
+                if (e < nwv) {
+                    const int row = e / CKV, v = e - row * CKV;       // row = t * BN + output channel
+                    const int t = row / BN, col = row - t * BN;
+                    const int co = co0 + col, c = c0 + v * VEC;
+                    dst[u] = row * XS + v * VEC;
+                    if (co < d.Cout && c < d.Cin) {
+                        const T* src = wg + ((size_t)tapw[t] * d.Cout + co) * d.Cin + c;
+                        if (vec_ok) {
+                            vals[u] = *(const u32x4*)src;
+                        } else {
+                            alignas(16) T tmp[VEC];
+#pragma unroll
+                            for (int q = 0; q < VEC; ++q) tmp[q] = (c + q < d.Cin) ? src[q] : (T)0;
+                            vals[u] = *(const u32x4*)tmp;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0) *(u32x4*)(wt + dst[u]) = vals[u];
+        }
+        __syncthreads();
+        for (int t = 0; t < d.ntaps; ++t) {
+            const T* ap = xt + (size_t)(arow + (d.tap_dy[t] - G.dyMin) * IW + (d.tap_dx[t] - G.dxMin)) * XS;
+            const T* bp = wt + (size_t)(t * BN + i) * XS;
+#pragma unroll
+            for (int ks = 0; ks < CK / 16; ++ks) mma_chunk16<NT>(ap + ks * 16, bp + ks * 16, 32 * XS, g, acc);
+        }
+    }
+
+    // ---- epilogue: accumulators -> fp32 LDS tile -> vectors of VEC consecutive output channels
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            ot[(32 * w + (r & 3) + 8 * (r >> 2) + 4 * g) * OS + n * 32 + i] = acc[n][r];
+    __syncthreads();
+    const T* mask = (const T*)d.mask_src;
+    const T* res = (const T*)d.res;
+    const T* res2 = (const T*)d.res2;
+    T* out = (T*)d.out;
+    const bool ovec = (d.Cout % VEC) == 0;
+    const size_t img = (size_t)b * d.Hout * d.Wout;
+    for (int e = tid; e < 128 * BNV; e += 256) {
+        const int m = e / BNV, vcol = (e - m * BNV) * VEC;
+        const int po = out_off[m], co = co0 + vcol;
+        if (po < 0 || co >= d.Cout) continue;
+        const size_t o = (img + po) * d.Cout + co;
+        float v[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) v[q] = ot[m * OS + vcol + q] + ((d.bias && co + q < d.Cout) ? d.bias[co + q] : 0.f);
+        alignas(16) T mk[VEC], r1[VEC], r2[VEC], ov[VEC];
+        if (ovec) {
+            if (mask) *(u32x4*)mk = *(const u32x4*)(mask + o);
+            if (res) *(u32x4*)r1 = *(const u32x4*)(res + o);
+            if (res2) *(u32x4*)r2 = *(const u32x4*)(res2 + o);
+        } else {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const bool in = co + q < d.Cout;
+                if (mask) mk[q] = in ? mask[o + q] : (T)0;
+                if (res) r1[q] = in ? res[o + q] : (T)0;
+                if (res2) r2[q] = in ? res2[o + q] : (T)0;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            float x = v[q];
+            if (mask) x = x * (Elt<T>::ld(&mk[q]) > 0.f ? 1.f : d.mask_slope);
+            if (res) x = x + Elt<T>::ld(&r1[q]);
+            if (res2) x = Elt<T>::ld(&r2[q]) + x;
+            if (d.out_div != 1.f) x = x / d.out_div;
+            if (d.out_slope != 1.f) x = x > 0.f ? x : x * d.out_slope;
+            Elt<T>::st(&ov[q], x);
+        }
+        if (ovec) {
+            *(u32x4*)(out + o) = *(const u32x4*)ov;
+        } else {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q)
+                if (co + q < d.Cout) out[o + q] = ov[q];
+        }
+    }
+}
+
 static int cv_geometry(const msmc_conv_desc* d, CvGeom* G, int elt_bytes, int XS, int BN, size_t* lds,
                        int bm = CV_BM) {
     if (d->ntaps <= 0 || d->ntaps > MSMC_CONV_MAX_TAPS) return MSMC_E_SHAPE;
@@ -422,6 +655,7 @@ static int cv_try_pipe(const msmc_conv_desc* d, msmc_stream stream, bool* done) 
     rc = msmc_allow_lds((const void*)conv_gather_pipe_kernel<T, NT, MT>, (int)lds);
     if (rc) return rc;
     MSMC_LAUNCH((conv_gather_pipe_kernel<T, NT, MT>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, G);
+    msmc_conv_last = msmc_kname("conv_gather_pipe_kernel", EltName<T>::v, NT, MT);
     *done = true;
     return msmc_check_launch();
 }
@@ -436,6 +670,44 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
         const long mt = ((long)d->QH * d->QW + CV_BM - 1) / CV_BM * d->B;
         const long wide = mt * ((d->Cout + 63) / 64);
         if (wide < MSMC_NUM_CU || (wide < 2 * MSMC_NUM_CU && d->Cin >= 256)) NT = 1;
+    }
+    // second generation for shallow reductions (fewer than 4 channel chunks); deep ones keep the register-prefetching
+    // pipelined kernel, which hides the per-chunk global-load latency better (measured per layer on MI355X)
+    const bool shallow = d->Cin < 4 * Elt<T>::CK || (d->Cin % Elt<T>::VEC) != 0 || msmc_gather_generation == 3;
+    if (msmc_gather_generation >= 2 && shallow && (long)d->Hin * d->Win * d->Cin < (1L << 31) &&
+        (long)d->Hout * d->Wout < (1L << 31)) {
+        constexpr int OS2 = 64 + 4;
+        CvGeom G2;
+        size_t stage;
+        int nt = NT;
+        int rc2 = cv_geometry(d, &G2, sizeof(T), XS, 32 * nt, &stage);
+        if (rc2) return rc2;
+        auto total = [&](int n_) {
+            const size_t tables = (((size_t)(G2.IH * G2.IW + 128 + 16) * sizeof(int)) + 15) & ~(size_t)15;
+            const size_t epi = (size_t)128 * (32 * n_ + 4) * sizeof(float);
+            return tables + (stage > epi ? stage : epi);
+        };
+        (void)OS2;
+        if (total(nt) > 160 * 1024 && nt == 2) {
+            nt = 1;
+            rc2 = cv_geometry(d, &G2, sizeof(T), XS, 32, &stage);
+            if (rc2) return rc2;
+        }
+        const size_t lds2 = total(nt);
+        if (lds2 <= 160 * 1024) {
+            dim3 grid((unsigned)(G2.tilesX * G2.tilesY * d->B), (unsigned)((d->Cout + 32 * nt - 1) / (32 * nt)));
+            if (nt == 2) {
+                rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, 2>, (int)lds2);
+                if (rc2) return rc2;
+                MSMC_LAUNCH((conv_gather2_kernel<T, 2>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d, G2);
+            } else {
+                rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, 1>, (int)lds2);
+                if (rc2) return rc2;
+                MSMC_LAUNCH((conv_gather2_kernel<T, 1>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d, G2);
+            }
+            msmc_conv_last = msmc_kname("conv_gather2_kernel", EltName<T>::v, nt, -1);
+            return msmc_check_launch();
+        }
     }
     // the pipelined kernel pays a slot-table prologue: worth it from ~4 channel chunks on (measured per layer)
     const bool deep = d->Cin >= 4 * Elt<T>::CK || msmc_conv_pipeline_enabled >= 2;
@@ -477,10 +749,12 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
         rc = msmc_allow_lds((const void*)conv_gather_kernel<T, 2>, (int)lds);
         if (rc) return rc;
         MSMC_LAUNCH((conv_gather_kernel<T, 2>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, G);
+        msmc_conv_last = msmc_kname("conv_gather_kernel", EltName<T>::v, 2, -1);
     } else {
         rc = msmc_allow_lds((const void*)conv_gather_kernel<T, 1>, (int)lds);
         if (rc) return rc;
         MSMC_LAUNCH((conv_gather_kernel<T, 1>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, G);
+        msmc_conv_last = msmc_kname("conv_gather_kernel", EltName<T>::v, 1, -1);
     }
     return msmc_check_launch();
 }
@@ -861,6 +1135,8 @@ static int wg_launch(const msmc_conv_desc* d, const void* g, float* dw, float* d
     else if (d->ntaps <= 12) WG_GO(12);
     else WG_GO(16);
 #undef WG_GO
+    msmc_conv_last = msmc_kname("conv_wgrad_kernel", EltName<T>::v, d->ntaps <= 4 ? 4 : d->ntaps <= 8 ? 8 : d->ntaps <= 12 ? 12 : 16,
+                                fast ? 1 : 0);
     return msmc_check_launch();
 }
 
@@ -1200,6 +1476,7 @@ static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* 
     else if (tpw <= 4) WG2_GO(4);
     else WG2_GO(5);
 #undef WG2_GO
+    msmc_conv_last = msmc_kname("conv_wgrad2_kernel", nullptr, tpw <= 4 ? (tpw < 1 ? 1 : tpw) : 5, -1);
     return msmc_check_launch();
 }
 

@@ -14,6 +14,8 @@ Activations are channels-last ``[B, H, W, C]`` (1-D signals: H == 1), float32 or
 """
 import ctypes
 
+import os
+
 import torch
 from torch.autograd import Variable
 
@@ -61,7 +63,7 @@ def fork_join(streams, thunks, inputs=()):
 
 def make_streams(device, n):
     """n side streams on a CUDA/HIP device; [] on the CPU (kernel-interpreter tests run sequentially)."""
-    if device.type != 'cuda' or n <= 1:
+    if device.type != 'cuda' or n <= 1 or os.environ.get('MSMC_STREAMS', '1') == '0':
         return []
     return [torch.cuda.Stream(device=device) for _ in range(n)]
 

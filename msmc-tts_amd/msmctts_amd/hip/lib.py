@@ -76,6 +76,8 @@ _SIGNATURES.update({
     'msmc_conv_set_pipeline': (None, [_i]),
     'msmc_conv_set_wgrad_split': (None, [_i]),
     'msmc_conv_set_wgrad_generation': (None, [_i]),
+    'msmc_conv_set_gather_generation': (None, [_i]),
+    'msmc_conv_last_kernel': (ctypes.c_char_p, []),
     'msmc_conv_set_narrow': (None, [_i]),
     'msmc_conv_wgrad': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     'msmc_wn_prepare_multi': (_i, [_vp, _i, _i, _vp]),

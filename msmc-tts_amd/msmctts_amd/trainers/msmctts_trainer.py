@@ -89,6 +89,7 @@ class VQGANTrainer(BaseTrainer):
         self.batch_g_step = os.environ.get('MSMC_BATCH_G_STEP', '0') != '0'
         self.use_graphs = False        # replay the GAN-phase step as three hipGraphs (static shapes)
         self._graphs = None
+        self.amp_autocast = True       # False: only the HIP conv stacks compute in amp_dtype, stock operators stay fp32
         self.amp_dtype = None          # e.g. torch.bfloat16: autocast for the GEMM/conv bodies (VQ search stays fp32)
 
     def random_select(self, mel_length):
@@ -107,7 +108,7 @@ class VQGANTrainer(BaseTrainer):
                 if hasattr(m, 'hip_dtype'):
                     m.hip_dtype = self.amp_dtype or torch.float32
             self._amp_applied = self.amp_dtype
-        if self.amp_dtype is None:
+        if self.amp_dtype is None or not self.amp_autocast:
             return contextlib.nullcontext()
         device_type = next(self.model.parameters()).device.type
         return torch.autocast(device_type=device_type, dtype=self.amp_dtype)

@@ -9,7 +9,7 @@ from msmctts_amd.synthetic import make_batch
 
 
 class A(object):
-    codewords, heads, batch, frames, graph, dtype = 256, 4, 16, 400, False, 'bf16'
+    codewords, heads, batch, frames, graph, dtype, no_autocast = 256, 4, 16, 400, False, 'bf16', False
 
 
 dev = torch.device('cuda:0')

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs ON the GPU box (via gpurun): rocprofv3 kernel stats of the default bench command, then the two PMC passes
+# (counters in their own runs, kernel-trace only).  Summaries land in gpurun_out/ (copied to profiles/ by hand).
+set -u
+REPO=$(pwd)
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+TAG=${1:-r01}
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $REPO/bench.py > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.log
+cp $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
+SHORT="--steps 2 --warmup 2 --no-microbench --cpu-steps 0 --kernel-timing-steps 0"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python $REPO/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- python $REPO/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_write.log
+python $REPO/tools/pmc_summary.py $OUT/${TAG}_pmc_traffic.json FETCH=/tmp/prof_fetch WRITE=/tmp/prof_write > $OUT/${TAG}_pmc_summary.txt 2>&1
+cd $REPO
+python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.log
+tail -c 1500 $OUT/${TAG}_bench.json
+head -12 $OUT/${TAG}_pmc_summary.txt

@@ -16,7 +16,7 @@ if os.environ.get('SERIAL', '1') == '1':
 
 
 class A(object):
-    codewords, heads, batch, frames, graph, dtype = 256, 4, 16, 400, False, 'bf16'
+    codewords, heads, batch, frames, graph, dtype, no_autocast = 256, 4, 16, 400, False, 'bf16', False
 
 
 dev = torch.device('cuda:0')

@@ -10,7 +10,7 @@ from torch.profiler import profile, ProfilerActivity, record_function
 
 
 class A(object):
-    codewords, heads, batch, frames, graph, dtype = 256, 4, 16, 400, False, 'bf16'
+    codewords, heads, batch, frames, graph, dtype, no_autocast = 256, 4, 16, 400, False, 'bf16', False
 
 
 dev = torch.device('cuda:0')
