@@ -288,7 +288,9 @@ def main():
     ms_instr = None
     if rank == 0 and world == 1 and args.kernel_timing_steps > 0:
         graphs_were = trainer.use_graphs
-        trainer.use_graphs = False               # per-launch HIP events need the eager path
+        trainer.use_graphs = False               # per-launch HIP events need the eager path ...
+        from msmctts_amd.hip import convnet
+        convnet.STREAMS_ENABLED = False          # ... and one stream, so that an event pair brackets exactly one kernel
         trainer.model.zero_grad()
         timer.enabled = True
         t1 = time.perf_counter()
@@ -297,6 +299,7 @@ def main():
         torch.cuda.synchronize()
         ms_instr = (time.perf_counter() - t1) / args.kernel_timing_steps * 1e3
         timer.enabled = False
+        convnet.STREAMS_ENABLED = True
         trainer.use_graphs = graphs_were
     if world > 1:
         dist.barrier()
@@ -347,7 +350,7 @@ def main():
                         traffic=traffic)
         roof.update(kernel=label, launches=k['launches'], avg_us=k['avg_us'], ms_per_step=k['ms_per_step'],
                     bytes_per_launch=k['bytes_per_launch'], flops_per_launch=k['flops_per_launch'])
-        roof['note'] = ('dominant hand-written kernel by summed HIP-event time over %d instrumented steps; achieved = '
+        roof['note'] = ('dominant hand-written kernel by summed HIP-event time over %d instrumented single-stream steps; achieved = '
                         'algorithmic flops (or bytes) of its launches / their summed durations; bound = the roofline '
                         'that prices those launches higher; traffic = PMC HBM bytes per launch from '
                         'profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command), null if not collected'

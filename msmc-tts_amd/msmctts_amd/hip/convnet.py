@@ -27,6 +27,9 @@ from . import lib
 # data-parallel reducer that a parameter gradient produced outside autograd's accumulation is ready.
 GRAD_READY_HOOK = None
 
+# False: fork_join runs its branches back to back on the calling stream (bench.py's per-kernel timing pass)
+STREAMS_ENABLED = True
+
 
 def fork_join(streams, thunks, inputs=()):
     """Run independent launch sequences on side HIP streams and join them back (hipGraph-capturable).
@@ -37,7 +40,7 @@ def fork_join(streams, thunks, inputs=()):
     stream and consumed by the caller -- both directions are registered with the caching allocator.
     Autograd replays each backward node on the stream of its forward, so the backward pass forks the same way.
     """
-    if not streams:
+    if not streams or not STREAMS_ENABLED:
         return [t() for t in thunks]
     main = torch.cuda.current_stream()
     outs = []

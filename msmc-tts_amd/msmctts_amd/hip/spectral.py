@@ -122,19 +122,24 @@ class _LogClamp(torch.autograd.Function):
 
 def dft_basis(n_fft, win, normalized, device):
     """Windowed real-DFT basis as one-tap conv slices: forward [1, CP, NP] (rows: re 0..F-1 | im F..2F-1),
-    data-gradient [1, NP, CP].  ``win`` is the analysis window already centred / zero-padded to n_fft."""
+    data-gradient [1, NP, CP].  ``win`` is the analysis window already centred / zero-padded to n_fft; samples the
+    window zeroes (``win_length < n_fft``: MelLoss frames 1200 of 2048) are dropped from the reduction, so the
+    basis covers only ``n_eff`` samples starting ``lo`` into each frame.  Returns (forward, backward, lo, n_eff)."""
     F = n_fft // 2 + 1
-    NP, CP = _pad4(n_fft), _pad4(2 * F)
-    j = torch.arange(n_fft, dtype=torch.float64)
+    nz = torch.nonzero(win.detach().cpu() != 0).flatten()
+    lo, hi = (int(nz[0]), int(nz[-1]) + 1) if nz.numel() else (0, n_fft)
+    n_eff = hi - lo
+    NP, CP = _pad4(n_eff), _pad4(2 * F)
+    j = torch.arange(lo, hi, dtype=torch.float64)
     f = torch.arange(F, dtype=torch.float64)
     ang = 2.0 * math.pi * torch.outer(f, j) / n_fft
     scale = (1.0 / math.sqrt(n_fft)) if normalized else 1.0
-    w = win.double().cpu() * scale
+    w = win.double().cpu()[lo:hi] * scale
     W = torch.zeros((CP, NP), dtype=torch.float64)
-    W[:F, :n_fft] = torch.cos(ang) * w
-    W[F:2 * F, :n_fft] = -torch.sin(ang) * w
+    W[:F, :n_eff] = torch.cos(ang) * w
+    W[F:2 * F, :n_eff] = -torch.sin(ang) * w
     W = W.float()
-    return W.unsqueeze(0).contiguous().to(device), W.t().unsqueeze(0).contiguous().to(device)
+    return W.unsqueeze(0).contiguous().to(device), W.t().unsqueeze(0).contiguous().to(device), lo, n_eff
 
 
 def projection(mat, device):
@@ -150,7 +155,8 @@ def mrd_image(x, n_fft, hop, dft, fb):
     B, L = x.shape
     F = n_fft // 2 + 1
     T = L // hop + 1
-    fr = _Frames.apply(x, T, n_fft, _pad4(n_fft), hop, n_fft // 2)
+    lo, n_eff = dft[2], dft[3]
+    fr = _Frames.apply(x, T, n_eff, _pad4(n_eff), hop, n_fft // 2 - lo)
     spec = _ConstGemm.apply(fr, dft[0], dft[1])
     mag = _SpecMag.apply(spec, F, _pad4(F), 1e-7, 1)
     if fb is not None:
@@ -164,7 +170,8 @@ def log_mel(y, n_fft, hop, dft, mel, num_mels):
     F = n_fft // 2 + 1
     pad = int((n_fft - hop) / 2)
     T = (L + 2 * pad - n_fft) // hop + 1
-    fr = _Frames.apply(y, T, n_fft, _pad4(n_fft), hop, pad)
+    lo, n_eff = dft[2], dft[3]
+    fr = _Frames.apply(y, T, n_eff, _pad4(n_eff), hop, pad - lo)
     spec = _ConstGemm.apply(fr, dft[0], dft[1])
     mag = _SpecMag.apply(spec, F, _pad4(F), 1e-9, 0)
     m = _ConstGemm.apply(mag, mel[0], mel[1])
