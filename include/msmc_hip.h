@@ -105,6 +105,11 @@ typedef struct msmc_conv_desc {
     float mask_slope;
     float out_div;          /* v = v / out_div when != 1                                                   */
     float out_slope;        /* leaky-ReLU slope applied to v last (1 = identity)                           */
+    int variant;            /* kernel choice, 0 = library heuristic.  msmc_conv_gather: 1 = first-generation dispatch
+                               (pipelined / simple kernel), 2 = second generation with 128-byte channel chunks where
+                               they fit, 3 = second generation, 64-byte chunks.  msmc_conv_wgrad (bf16): 1 = first,
+                               2 = second generation.  The host layer times the candidates once per layer shape.       */
+    int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative)                */
 } msmc_conv_desc;
 
 /* Perf-experiment switch: 0 selects the simple (un-pipelined) gather kernel everywhere; default 1. */

@@ -4,5 +4,5 @@
 
 extern "C" {
 const char* msmc_backend(void) { return MSMC_BACKEND_NAME; }
-int msmc_abi_version(void) { return 1; }
+int msmc_abi_version(void) { return 2; }
 }

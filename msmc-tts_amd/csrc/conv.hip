@@ -411,10 +411,11 @@ __global__ __launch_bounds__(256) void conv_gather_pipe_kernel(msmc_conv_desc d,
 //     run on 16-byte vectors of consecutive channels (one load and one store instruction per 8 bf16)
 //     instead of one 2-byte access per element.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NT>
+template <typename T, int NT, int CKM>
 __global__ __launch_bounds__(256, 2) void conv_gather2_kernel(msmc_conv_desc d, CvGeom G) {
     MSMC_DYN_LDS(smem);
-    constexpr int VEC = Elt<T>::VEC, CK = Elt<T>::CK, CKV = CK / VEC, XS = CK + VEC, BN = 32 * NT, OS = BN + 4;
+    // CKM = 2: 128-byte channel chunks (half the load -> LDS -> MFMA round trips of a deep reduction)
+    constexpr int VEC = Elt<T>::VEC, CK = Elt<T>::CK * CKM, CKV = CK / VEC, XS = CK + VEC, BN = 32 * NT, OS = BN + 4;
     constexpr int BNV = BN / VEC;
     const int npix = G.IH * G.IW, IW = G.IW;
     int* in_off = (int*)smem;                                   // [npix] element offset of halo pixel, -1 = zero
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather2_kernel(msmc_conv_desc d, 
     int* tapw = out_off + 128;                                  // [16]   weight slice of tap t
     char* region = smem + (((size_t)(npix + 128 + 16) * sizeof(int) + 15) & ~(size_t)15);
     T* xt = (T*)region;                                         // [npix][XS]
-    T* wt = xt + G.xt_elems;                                    // [ntaps][BN][XS]
+    T* wt = xt + (size_t)npix * XS;                             // [ntaps][BN][XS]
     float* ot = (float*)region;                                 // [128][OS] epilogue tile (aliases xt / wt)
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 31, g = lane >> 5;
     int bt = blockIdx.x;
@@ -672,40 +673,49 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
         if (wide < MSMC_NUM_CU || (wide < 2 * MSMC_NUM_CU && d->Cin >= 256)) NT = 1;
     }
     // second generation for shallow reductions (fewer than 4 channel chunks); deep ones keep the register-prefetching
-    // pipelined kernel, which hides the per-chunk global-load latency better (measured per layer on MI355X)
-    const bool shallow = d->Cin < 4 * Elt<T>::CK || (d->Cin % Elt<T>::VEC) != 0 || msmc_gather_generation == 3;
-    if (msmc_gather_generation >= 2 && shallow && (long)d->Hin * d->Win * d->Cin < (1L << 31) &&
+    // pipelined kernel unless generation 3 is forced (A/B): measured per layer on MI355X
+    const int gen = d->variant > 0 ? d->variant : msmc_gather_generation;
+    bool shallow = d->Cin < 4 * Elt<T>::CK || (d->Cin % Elt<T>::VEC) != 0 || gen >= 3 || d->variant == 2;
+    if (!shallow && gen == 2) {
+        // heuristic without a tuned variant: deep reductions go to the pipelined kernel only where it would use
+        // 256-point (or wider) M tiles, i.e. where it amortises the weight staging over a large grid
+        const long points = (long)d->B * d->QH * d->QW;
+        const long ntile = (d->Cout + 32 * NT - 1) / (32 * NT);
+        shallow = (points / (CV_BM * 2)) * ntile < 2 * MSMC_NUM_CU;
+    }
+    if (gen >= 2 && shallow && (long)d->Hin * d->Win * d->Cin < (1L << 31) &&
         (long)d->Hout * d->Wout < (1L << 31)) {
-        constexpr int OS2 = 64 + 4;
         CvGeom G2;
-        size_t stage;
-        int nt = NT;
-        int rc2 = cv_geometry(d, &G2, sizeof(T), XS, 32 * nt, &stage);
+        size_t unused;
+        int rc2 = cv_geometry(d, &G2, sizeof(T), XS, 32, &unused);
         if (rc2) return rc2;
-        auto total = [&](int n_) {
-            const size_t tables = (((size_t)(G2.IH * G2.IW + 128 + 16) * sizeof(int)) + 15) & ~(size_t)15;
-            const size_t epi = (size_t)128 * (32 * n_ + 4) * sizeof(float);
+        const long npix = (long)G2.IH * G2.IW;
+        const size_t tables = (((size_t)(npix + 128 + 16) * sizeof(int)) + 15) & ~(size_t)15;
+        auto lds_of = [&](int nt, int ckm) {
+            const size_t xs = (size_t)Elt<T>::CK * ckm + Elt<T>::VEC;
+            const size_t stage = ((size_t)npix + (size_t)d->ntaps * 32 * nt) * xs * sizeof(T);
+            const size_t epi = (size_t)128 * (32 * nt + 4) * sizeof(float);
             return tables + (stage > epi ? stage : epi);
         };
-        (void)OS2;
-        if (total(nt) > 160 * 1024 && nt == 2) {
-            nt = 1;
-            rc2 = cv_geometry(d, &G2, sizeof(T), XS, 32, &stage);
-            if (rc2) return rc2;
-        }
-        const size_t lds2 = total(nt);
+        int nt = NT;
+        int ckm = (d->Cin >= 2 * Elt<T>::CK && (d->Cin % Elt<T>::VEC) == 0 && lds_of(nt, 2) <= 64 * 1024 &&
+                   gen != 3) ? 2 : 1;
+        if (lds_of(nt, ckm) > 160 * 1024 && nt == 2) nt = 1;
+        const size_t lds2 = lds_of(nt, ckm);
         if (lds2 <= 160 * 1024) {
             dim3 grid((unsigned)(G2.tilesX * G2.tilesY * d->B), (unsigned)((d->Cout + 32 * nt - 1) / (32 * nt)));
-            if (nt == 2) {
-                rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, 2>, (int)lds2);
-                if (rc2) return rc2;
-                MSMC_LAUNCH((conv_gather2_kernel<T, 2>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d, G2);
-            } else {
-                rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, 1>, (int)lds2);
-                if (rc2) return rc2;
-                MSMC_LAUNCH((conv_gather2_kernel<T, 1>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d, G2);
-            }
-            msmc_conv_last = msmc_kname("conv_gather2_kernel", EltName<T>::v, nt, -1);
+#define CV2_GO(NT_, CKM_)                                                                                          \
+    do {                                                                                                           \
+        rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, NT_, CKM_>, (int)lds2);                           \
+        if (rc2) return rc2;                                                                                       \
+        MSMC_LAUNCH((conv_gather2_kernel<T, NT_, CKM_>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d, G2);    \
+    } while (0)
+            if (nt == 2 && ckm == 2) CV2_GO(2, 2);
+            else if (nt == 2) CV2_GO(2, 1);
+            else if (ckm == 2) CV2_GO(1, 2);
+            else CV2_GO(1, 1);
+#undef CV2_GO
+            msmc_conv_last = msmc_kname("conv_gather2_kernel", EltName<T>::v, nt, ckm);
             return msmc_check_launch();
         }
     }
@@ -1102,6 +1112,8 @@ static int wg_launch(const msmc_conv_desc* d, const void* g, float* dw, float* d
     // on ONE address retire serially at ~0.1 us each, so  t(n) = (tiles/n) * t_tile + n * 0.1 us  (t_tile ~3 us)
     // is minimal at n = sqrt(30 * tiles); never more workgroups than ~2 per CU.
     int nsplit = (int)(sqrt(30.0 * totalTiles) + 0.5);
+    if (d->split_shift > 0) nsplit <<= d->split_shift;
+    else if (d->split_shift < 0) nsplit >>= -d->split_shift;
     const int cap = (2 * MSMC_NUM_CU + ctiles - 1) / ctiles;
     if (msmc_wgrad_split_override > 0) nsplit = msmc_wgrad_split_override;
     else if (nsplit > cap) nsplit = cap;
@@ -1455,6 +1467,8 @@ static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* 
     // ~0.1 us each (measured: 4096 per address -> 430 us), so  t(n) = (tiles/n) * t_tile + n * 0.1 us  with
     // t_tile ~3 us is minimal at n = sqrt(30 * tiles), whatever the size of dW
     int nsplit = (int)(sqrt(30.0 * P.totalTiles) + 0.5);
+    if (d->split_shift > 0) nsplit <<= d->split_shift;
+    else if (d->split_shift < 0) nsplit >>= -d->split_shift;
     const int cap = (4 * MSMC_NUM_CU + cols - 1) / cols;
     if (msmc_wgrad_split_override > 0) nsplit = msmc_wgrad_split_override;
     else if (nsplit > cap) nsplit = cap;
@@ -1484,8 +1498,10 @@ extern "C" int msmc_conv_wgrad(const msmc_conv_desc* d, const void* g, float* dw
     if (!d || !g || !dw || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0) return MSMC_E_SHAPE;
     if (d->ntaps <= 0 || d->ntaps > MSMC_CONV_MAX_TAPS) return MSMC_E_SHAPE;
     if (d->dtype == 0) return wg_launch<float>(d, g, dw, db, stream);
-    if (d->dtype == 1) return msmc_wgrad_generation == 1 ? wg_launch<unsigned short>(d, g, dw, db, stream)
-                                                         : wg2_launch(d, g, dw, db, stream);
+    if (d->dtype == 1) {
+        const int gen = d->variant > 0 ? d->variant : msmc_wgrad_generation;
+        return gen == 1 ? wg_launch<unsigned short>(d, g, dw, db, stream) : wg2_launch(d, g, dw, db, stream);
+    }
     return MSMC_E_SHAPE;
 }
 

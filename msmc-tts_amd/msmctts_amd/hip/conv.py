@@ -10,6 +10,7 @@ Activations are channels-last ``[B, H, W, C]`` tensors (1-D signals use H = 1); 
 Weights are "slices" ``[n_taps, C_out, C_in]`` in the activation dtype.
 """
 import ctypes
+import os
 
 import torch
 
@@ -58,6 +59,67 @@ class Geometry(object):
 
 
 _PLANS = {}
+
+# Per-layer-shape kernel selection: the first launch of a descriptor on the GPU times the candidate kernels
+# (msmc_conv_desc.variant / .split_shift) once and keeps the fastest -- tile heuristics cannot see L2 / LDS effects
+# that differ by 2x between layers of equal arithmetic.  Off inside hipGraph capture and on the interpreter.
+AUTOTUNE = os.environ.get('MSMC_AUTOTUNE', '1') != '0'
+_GATHER_CANDIDATES = ((1, 0), (2, 0), (3, 0))
+_WGRAD_CANDIDATES = ((2, 0), (2, -1), (2, 1), (1, 0))
+TUNED = {}                                    # (kind, shape signature) -> (variant, split_shift, {candidate: ms})
+
+
+def _signature(desc):
+    return (desc.dtype, desc.B, desc.Hin, desc.Win, desc.Cin, desc.Hout, desc.Wout, desc.Cout, desc.QH, desc.QW,
+            desc.osy, desc.osx, desc.isy, desc.isx, desc.ntaps, tuple(desc.tap_dy[:desc.ntaps]),
+            tuple(desc.tap_dx[:desc.ntaps]), desc.pad_mode, bool(desc.res), bool(desc.res2), bool(desc.mask_src))
+
+
+def _tune(kind, desc, launch, candidates):
+    """Time ``launch()`` under every candidate (variant, split_shift); leave the fastest in the descriptor."""
+    desc._tuned = True
+    if not AUTOTUNE or lib._host_pointers_ok or torch.cuda.is_current_stream_capturing():
+        return
+    sig = (kind,) + _signature(desc)
+    hit = TUNED.get(sig)
+    if hit is None:
+        times = {}
+        for variant, shift in candidates:
+            desc.variant, desc.split_shift = variant, shift
+            if launch() != 0:
+                continue
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(3):
+                launch()
+            e.record()
+            e.synchronize()
+            times[(variant, shift)] = s.elapsed_time(e) / 3.0
+        best = min(times, key=times.get) if times else (0, 0)
+        hit = TUNED[sig] = (best[0], best[1], times)
+    desc.variant, desc.split_shift = hit[0], hit[1]
+
+
+def _gather(desc, stream, what):
+    fn = lib.get().msmc_conv_gather
+    if not getattr(desc, '_tuned', False):
+        _tune('gather', desc, lambda: fn(ctypes.byref(desc), stream), _GATHER_CANDIDATES)
+    lib.check(fn(ctypes.byref(desc), stream), what)
+
+
+def _wgrad(desc, g_ptr, dw, db, stream, what):
+    fn = lib.get().msmc_conv_wgrad
+    dbp = db.data_ptr() if db is not None else None
+    if not getattr(desc, '_tuned', False):
+        if AUTOTUNE and not lib._host_pointers_ok and not torch.cuda.is_current_stream_capturing():
+            sdw = torch.zeros_like(dw)                       # candidates accumulate into scratch, not into dW
+            sdb = torch.zeros_like(db) if db is not None else None
+            sdbp = sdb.data_ptr() if sdb is not None else None
+            _tune('wgrad', desc, lambda: fn(ctypes.byref(desc), g_ptr, sdw.data_ptr(), sdbp, stream), _WGRAD_CANDIDATES)
+        else:
+            desc._tuned = True
+    lib.check(fn(ctypes.byref(desc), g_ptr, dw.data_ptr(), dbp, stream), what)
+
 
 
 def _ptr(t):
@@ -148,7 +210,7 @@ def conv_forward(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, out_d
     desc.x, desc.w, desc.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
     desc.bias = bias.data_ptr() if bias is not None else None
     desc.res, desc.res2, desc.mask_src = _opt_ptr(res, x), _opt_ptr(res2, x), None
-    lib.check(lib.get().msmc_conv_gather(ctypes.byref(desc), lib.stream(x)), 'msmc_conv_gather')
+    _gather(desc, lib.stream(x), 'msmc_conv_gather')
     return out
 
 
@@ -193,14 +255,14 @@ def conv_dgrad(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
     gx = torch.empty(oshape, dtype=g.dtype, device=g.device)
     gp, wp, op = g.data_ptr(), wb.data_ptr(), gx.data_ptr()
     mp, rp = _opt_ptr(mask_src, g), _opt_ptr(res, g)
-    fn, stream = lib.get().msmc_conv_gather, lib.stream(g)
+    stream = lib.stream(g)
     for desc, ry, rx in descs:
         if desc is None:                      # phase that no kernel tap reaches: gradient is the epilogue of zero
             gx[:, ry::geom.sy, rx::geom.sx] = 0 if res is None else res[:, ry::geom.sy, rx::geom.sx]
             continue
         desc.x, desc.w, desc.out, desc.mask_src, desc.res = gp, wp, op, mp, rp
         desc.bias = desc.res2 = None
-        lib.check(fn(ctypes.byref(desc), stream), 'msmc_conv_gather(dgrad)')
+        _gather(desc, stream, 'msmc_conv_gather(dgrad)')
     return gx
 
 
@@ -218,7 +280,7 @@ def conv_transpose1d_forward(x, w, k, stride, padding, bias=None, in_slope=1.0):
         lattice = (1, n, 0, 1, r, stride, 1, 1, 0, 0)
         d = _fill(None, x, w, out, B, 1, Lin, Cin, 1, Lout, Cout, lattice, taps, 0, bias=bias,
                   in_slope=in_slope)
-        lib.check(L.msmc_conv_gather(ctypes.byref(d), lib.stream(x)), 'msmc_conv_gather(convT)')
+        _gather(d, lib.stream(x), 'msmc_conv_gather(convT)')
     return out
 
 
@@ -232,7 +294,7 @@ def conv_transpose1d_dgrad(g, wb, k, stride, padding, Lin, mask_src=None, mask_s
     lattice = (1, Lin, 0, 1, 0, 1, 1, stride, 0, -padding)
     d = _fill(None, g, wb, gx, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, mask_src=mask_src,
               mask_slope=mask_slope)
-    lib.check(lib.get().msmc_conv_gather(ctypes.byref(d), lib.stream(g)), 'msmc_conv_gather(convT dgrad)')
+    _gather(d, lib.stream(g), 'msmc_conv_gather(convT dgrad)')
     return gx
 
 
@@ -254,8 +316,7 @@ def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None, db=None):
         dw = torch.zeros((n_slices, g.shape[3], x.shape[3]), dtype=torch.float32, device=x.device)
     desc.x = desc.w = desc.out = x.data_ptr()
     desc.bias = desc.mask_src = desc.res = desc.res2 = None
-    lib.check(lib.get().msmc_conv_wgrad(ctypes.byref(desc), g.data_ptr(), dw.data_ptr(),
-                                        db.data_ptr() if db is not None else None, lib.stream(x)), 'msmc_conv_wgrad')
+    _wgrad(desc, g.data_ptr(), dw, db, lib.stream(x), 'msmc_conv_wgrad')
     return dw
 
 
@@ -273,8 +334,8 @@ def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None):
     # kernel roles: "x" = g (fine, channels Cout), "g" = x (coarse, channels Cin) -> dw[k][Cin][Cout]
     d = _fill(None, g, g, g, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, in_slope=1.0,
               mask_slope=in_slope)
-    lib.check(lib.get().msmc_conv_wgrad(ctypes.byref(d), lib.ptr(x), lib.ptr(dw, torch.float32), None, lib.stream(x)),
-              'msmc_conv_wgrad(convT)')
+    lib.ptr(dw, torch.float32)
+    _wgrad(d, lib.ptr(x), dw, None, lib.stream(x), 'msmc_conv_wgrad(convT)')
     return dw
 
 

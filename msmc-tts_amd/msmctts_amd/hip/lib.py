@@ -40,7 +40,8 @@ class ConvDesc(ctypes.Structure):
                 ('Cout', _i), ('QH', _i), ('QW', _i), ('oy0', _i), ('osy', _i), ('ox0', _i), ('osx', _i),
                 ('isy', _i), ('isx', _i), ('iy0', _i), ('ix0', _i), ('ntaps', _i),
                 ('tap_dy', _i * MAX_TAPS), ('tap_dx', _i * MAX_TAPS), ('tap_w', _i * MAX_TAPS),
-                ('pad_mode', _i), ('in_slope', _f), ('mask_slope', _f), ('out_div', _f), ('out_slope', _f)]
+                ('pad_mode', _i), ('in_slope', _f), ('mask_slope', _f), ('out_div', _f), ('out_slope', _f),
+                ('variant', _i), ('split_shift', _i)]
 
 
 class WnItem(ctypes.Structure):

@@ -120,3 +120,29 @@ def test_mel_loss_full_size():
     loss.backward()
     ref.backward()
     assert (a.grad - ao.grad).abs().max().item() < 1e-3 * max(1e-6, ao.grad.abs().max().item()) + 1e-9
+
+
+def test_autotune_picks_a_variant_and_every_variant_is_correct():
+    """first launch of a layer shape times the candidate kernels (descriptor.variant / split_shift) and keeps one;
+    every candidate, forced, matches PyTorch"""
+    from msmctts_amd.hip import conv
+    case = CONVS[2]                                   # gen rb1 k7 d3 C128
+    check_conv_case(case, torch.bfloat16, 2e-2, DEV)
+    kinds = {k[0] for k in conv.TUNED}
+    assert {'gather', 'wgrad'} <= kinds
+    assert all(v[0] in (1, 2, 3) and len(v[2]) >= 2 for v in conv.TUNED.values())
+    saved = (conv._GATHER_CANDIDATES, conv._WGRAD_CANDIDATES, dict(conv.TUNED))
+    try:
+        for gv in conv._GATHER_CANDIDATES:
+            for wv in conv._WGRAD_CANDIDATES:
+                conv.TUNED.clear()
+                conv._GATHER_CANDIDATES, conv._WGRAD_CANDIDATES = (gv,), (wv,)
+                name, B, Cin, Cout, H, W, k, s, dil, pad, reflect, slope = case
+                fresh = (name + ' %s %s' % (gv, wv), B, Cin, Cout, H + 0, W, k, s, dil, pad, reflect, slope)
+                conv_geom_cache_reset = getattr(conv, '_PLANS')
+                conv_geom_cache_reset.clear()
+                check_conv_case(fresh, torch.bfloat16, 2e-2, DEV)
+    finally:
+        conv._GATHER_CANDIDATES, conv._WGRAD_CANDIDATES = saved[0], saved[1]
+        conv.TUNED.clear()
+        conv.TUNED.update(saved[2])

@@ -19,6 +19,9 @@ class A(object):
     codewords, heads, batch, frames, graph, dtype, no_autocast = 256, 4, 16, 400, False, 'bf16', False
 
 
+from msmctts_amd.hip import lib as _lib
+if os.environ.get('GATHER_GEN'):
+    _lib.get().msmc_conv_set_gather_generation(int(os.environ['GATHER_GEN']))
 dev = torch.device('cuda:0')
 torch.cuda.set_device(0)
 cfg, trainer = bench.build(A, dev, 0, 1)
@@ -88,7 +91,7 @@ for key, ev in recs.items():
     rows.append((sum(us) / N, len(us) / N, sum(us) / len(us), key))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
-with open(os.path.join(ROOT, 'gpurun_out', 'step_breakdown.txt'), 'w') as f:
+with open(os.path.join(ROOT, 'gpurun_out', os.environ.get('BREAKDOWN_OUT', 'step_breakdown.txt')), 'w') as f:
     f.write('step (no events) %.2f ms; hand-written conv-family launches: %.2f ms/step over %d launches\n'
             % (plain, tot / 1e3, sum(r[1] for r in rows)))
     by = collections.defaultdict(float)
@@ -97,4 +100,10 @@ with open(os.path.join(ROOT, 'gpurun_out', 'step_breakdown.txt'), 'w') as f:
     f.write('  '.join('%s %.2f ms' % kv for kv in sorted(by.items(), key=lambda kv: -kv[1])) + '\n')
     for tot_us, n, avg, key in rows:
         f.write('%8.1f us/step  n=%5.1f  avg %7.1f us  %s\n' % (tot_us, n, avg, ' '.join(key)))
-print(open(os.path.join(ROOT, 'gpurun_out', 'step_breakdown.txt')).read()[:6000])
+print(open(os.path.join(ROOT, 'gpurun_out', os.environ.get('BREAKDOWN_OUT', 'step_breakdown.txt'))).read()[:400])
+from msmctts_amd.hip import conv as _c
+import json as _json
+with open(os.path.join(ROOT, 'gpurun_out', 'tuned.json'), 'w') as f:
+    _json.dump([dict(kind=k[0], sig=list(map(str, k[1:])), variant=v[0], shift=v[1], times={str(c): t for c, t in v[2].items()}) for k, v in _c.TUNED.items()], f, indent=0)
+wins = collections.Counter((k[0], v[0], v[1]) for k, v in _c.TUNED.items())
+print('tuned choices (kind, variant, split_shift): count', dict(wins))
