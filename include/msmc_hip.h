@@ -107,9 +107,13 @@ typedef struct msmc_conv_desc {
     float out_slope;        /* leaky-ReLU slope applied to v last (1 = identity)                           */
     int variant;            /* kernel choice, 0 = library heuristic.  msmc_conv_gather: 1 = first-generation dispatch
                                (pipelined / simple kernel), 2 = second generation with 128-byte channel chunks where
-                               they fit, 3 = second generation, 64-byte chunks.  msmc_conv_wgrad (bf16): 1 = first,
+                               they fit, 3 = second generation, 64-byte chunks, 4 / 5 = as 2 / 3 with eight instead of
+                               four weight vectors in flight per work-item.  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation.  The host layer times the candidates once per layer shape.       */
     int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative)                */
+    int dw_copies;          /* msmc_conv_wgrad: R > 1 = dw is [R][ntaps][Cout][Cin] and db [R][Cout]; workgroup i adds
+                               into copy i % R (same-address atomics retire serially; R copies shorten the chain R
+                               times); the consumer sums the copies (msmc_wn_backward_multi does)                      */
 } msmc_conv_desc;
 
 /* Perf-experiment switch: 0 selects the simple (un-pipelined) gather kernel everywhere; default 1. */
@@ -143,7 +147,7 @@ int msmc_conv_wgrad(const msmc_conv_desc* desc, const void* g, float* dw, float*
  * ``items`` is a DEVICE array; item i owns blocks [block0, block0 + A) of the grid of total_blocks. */
 typedef struct msmc_wn_item {
     const float* v;
-    const float* g;
+    const float* g;         /* NULL: plain (not weight-normalised) layer -- w = v, gv = dW, gg / inv_norm unused */
     void* dst1;
     void* dst2;             /* may be NULL */
     float* inv_norm;        /* [A] */
@@ -155,6 +159,10 @@ typedef struct msmc_wn_item {
     int A, Bc, T, dtype, block0, nbias;
     float* db;              /* backward: [nbias] bias-gradient accumulator (consumed and zeroed), may be NULL */
     float* gb;              /* backward: [nbias] bias gradient out */
+    int copies;             /* backward: dw / db hold this many privatised copies (0 or 1 = one), summed here */
+    int pad_;
+    long dw_copy_stride;    /* elements between copies of dw */
+    long db_copy_stride;    /* elements between copies of db */
 } msmc_wn_item;
 
 int msmc_wn_prepare_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream);

@@ -39,6 +39,11 @@ extern "C" const char* msmc_conv_last_kernel(void) { return msmc_conv_last; }
 template <typename T> struct EltName;
 template <> struct EltName<float> { static constexpr const char* v = "float"; };
 template <> struct EltName<unsigned short> { static constexpr const char* v = "unsigned short"; };
+static const char* msmc_kname2(const char* base, const char* elt, int a, int b, int c) {
+    static thread_local char buf[96];
+    snprintf(buf, sizeof(buf), "%s<%s, %d, %d, %d>", base, elt, a, b, c);
+    return buf;
+}
 static const char* msmc_kname(const char* base, const char* elt, int a, int b) {
     static thread_local char buf[96];
     if (b >= 0) snprintf(buf, sizeof(buf), "%s<%s, %d, %d>", base, elt, a, b);
@@ -411,10 +416,11 @@ __global__ __launch_bounds__(256) void conv_gather_pipe_kernel(msmc_conv_desc d,
 //     run on 16-byte vectors of consecutive channels (one load and one store instruction per 8 bf16)
 //     instead of one 2-byte access per element.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NT, int CKM>
+template <typename T, int NT, int CKM, int SB>
 __global__ __launch_bounds__(256, 2) void conv_gather2_kernel(msmc_conv_desc d, CvGeom G) {
     MSMC_DYN_LDS(smem);
-    // CKM = 2: 128-byte channel chunks (half the load -> LDS -> MFMA round trips of a deep reduction)
+    // CKM = 2: 128-byte channel chunks (half the load -> LDS -> MFMA round trips of a deep reduction);
+    // SB: weight-slice vectors a work-item keeps in flight per batch (4 or 8)
     constexpr int VEC = Elt<T>::VEC, CK = Elt<T>::CK * CKM, CKV = CK / VEC, XS = CK + VEC, BN = 32 * NT, OS = BN + 4;
     constexpr int BNV = BN / VEC;
     const int npix = G.IH * G.IW, IW = G.IW;
@@ -476,81 +482,102 @@ __global__ __launch_bounds__(256, 2) void conv_gather2_kernel(msmc_conv_desc d, 
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     const int nxv = npix * CKV, nwv = d.ntaps * BN * CKV;
 
-    for (int c0 = 0; c0 < d.Cin; c0 += CK) {
-        __syncthreads();                      // tables ready (first pass) / previous chunk's fragments consumed
-        // ---- input halo tile: padding rule folded into in_off, input activation applied once per element
-        for (int e0 = tid; e0 < nxv; e0 += 1024) {
-            u32x4 vals[4];
-            int dst[4];
+    // staging helpers: loads of a batch are all issued before its LDS stores (one global-load latency per batch)
+    auto load_x = [&](int c0, int e0, u32x4 (&vals)[4], int (&dst)[4]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + 256 * u;
-                dst[u] = -1;
-                vals[u] = zero4;
-                if (e < nxv) {
-                    const int pi = e / CKV, v = e - pi * CKV;
-                    const int off = in_off[pi], c = c0 + v * VEC;
-                    dst[u] = pi * XS + v * VEC;
-                    if (off >= 0 && c < d.Cin) {
-                        const T* src = xb + off + c;
-                        if (vec_ok) {
-                            vals[u] = *(const u32x4*)src;
-                        } else {
-                            alignas(16) T tmp[VEC];
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            dst[u] = -1;
+            vals[u] = zero4;
+            if (e < nxv) {
+                const int pi = e / CKV, v = e - pi * CKV;
+                const int off = in_off[pi], c = c0 + v * VEC;
+                dst[u] = pi * XS + v * VEC;
+                if (off >= 0 && c < d.Cin) {
+                    const T* src = xb + off + c;
+                    if (vec_ok) {
+                        vals[u] = *(const u32x4*)src;
+                    } else {
+                        alignas(16) T tmp[VEC];
 #pragma unroll
-                            for (int q = 0; q < VEC; ++q) tmp[q] = (c + q < d.Cin) ? src[q] : (T)0;
-                            vals[u] = *(const u32x4*)tmp;
-                        }
+                        for (int q = 0; q < VEC; ++q) tmp[q] = (c + q < d.Cin) ? src[q] : (T)0;
+                        vals[u] = *(const u32x4*)tmp;
                     }
                 }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (dst[u] < 0) continue;
-                if (slope != 1.f) {
-                    alignas(16) T tmp[VEC];
-                    *(u32x4*)tmp = vals[u];
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) {
-                        float f = Elt<T>::ld(&tmp[q]);
-                        f = f > 0.f ? f : f * slope;
-                        Elt<T>::st(&tmp[q], f);
-                    }
-                    vals[u] = *(const u32x4*)tmp;
-                }
-                *(u32x4*)(xt + dst[u]) = vals[u];
             }
         }
-        // ---- weight slices of every tap for this channel chunk
-        for (int e0 = tid; e0 < nwv; e0 += 1024) {
-            u32x4 vals[4];
-            int dst[4];
+    };
+    auto store_x = [&](u32x4 (&vals)[4], int (&dst)[4]) {   // input activation applied once per element
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + 256 * u;
-                dst[u] = -1;
-                vals[u] = zero4;
-                if (e < nwv) {
-                    const int row = e / CKV, v = e - row * CKV;       // row = t * BN + output channel
-                    const int t = row / BN, col = row - t * BN;
-                    const int co = co0 + col, c = c0 + v * VEC;
-                    dst[u] = row * XS + v * VEC;
-                    if (co < d.Cout && c < d.Cin) {
-                        const T* src = wg + ((size_t)tapw[t] * d.Cout + co) * d.Cin + c;
-                        if (vec_ok) {
-                            vals[u] = *(const u32x4*)src;
-                        } else {
-                            alignas(16) T tmp[VEC];
+        for (int u = 0; u < 4; ++u) {
+            if (dst[u] < 0) continue;
+            if (slope != 1.f) {
+                alignas(16) T tmp[VEC];
+                *(u32x4*)tmp = vals[u];
 #pragma unroll
-                            for (int q = 0; q < VEC; ++q) tmp[q] = (c + q < d.Cin) ? src[q] : (T)0;
-                            vals[u] = *(const u32x4*)tmp;
-                        }
+                for (int q = 0; q < VEC; ++q) {
+                    float f = Elt<T>::ld(&tmp[q]);
+                    f = f > 0.f ? f : f * slope;
+                    Elt<T>::st(&tmp[q], f);
+                }
+                vals[u] = *(const u32x4*)tmp;
+            }
+            *(u32x4*)(xt + dst[u]) = vals[u];
+        }
+    };
+    auto load_w = [&](int c0, int e0, u32x4 (&vals)[SB], int (&dst)[SB]) {
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int e = e0 + 256 * u;
+            dst[u] = -1;
+            vals[u] = zero4;
+            if (e < nwv) {
+                const int row = e / CKV, v = e - row * CKV;       // row = t * BN + output channel
+                const int t = row / BN, col = row - t * BN;
+                const int co = co0 + col, c = c0 + v * VEC;
+                dst[u] = row * XS + v * VEC;
+                if (co < d.Cout && c < d.Cin) {
+                    const T* src = wg + ((size_t)tapw[t] * d.Cout + co) * d.Cin + c;
+                    if (vec_ok) {
+                        vals[u] = *(const u32x4*)src;
+                    } else {
+                        alignas(16) T tmp[VEC];
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) tmp[q] = (c + q < d.Cin) ? src[q] : (T)0;
+                        vals[u] = *(const u32x4*)tmp;
                     }
                 }
             }
+        }
+    };
+    auto store_w = [&](u32x4 (&vals)[SB], int (&dst)[SB]) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (dst[u] >= 0) *(u32x4*)(wt + dst[u]) = vals[u];
+        for (int u = 0; u < SB; ++u)
+            if (dst[u] >= 0) *(u32x4*)(wt + dst[u]) = vals[u];
+    };
+
+    for (int c0 = 0; c0 < d.Cin; c0 += CK) {
+        __syncthreads();                      // tables ready (first pass) / previous chunk's fragments consumed
+        {
+            // first batch of the halo tile and of the weight slices share one global-load latency
+            u32x4 xv[4], wv[SB];
+            int xd[4], wd[SB];
+            load_x(c0, tid, xv, xd);
+            load_w(c0, tid, wv, wd);
+            store_x(xv, xd);
+            store_w(wv, wd);
+        }
+        for (int e0 = tid + 1024; e0 < nxv; e0 += 1024) {
+            u32x4 xv[4];
+            int xd[4];
+            load_x(c0, e0, xv, xd);
+            store_x(xv, xd);
+        }
+        for (int e0 = tid + 256 * SB; e0 < nwv; e0 += 256 * SB) {
+            u32x4 wv[SB];
+            int wd[SB];
+            load_w(c0, e0, wv, wd);
+            store_w(wv, wd);
         }
         __syncthreads();
         for (int t = 0; t < d.ntaps; ++t) {
@@ -675,6 +702,8 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
     // second generation for shallow reductions (fewer than 4 channel chunks); deep ones keep the register-prefetching
     // pipelined kernel unless generation 3 is forced (A/B): measured per layer on MI355X
     const int gen = d->variant > 0 ? d->variant : msmc_gather_generation;
+    const bool sb8 = gen == 4 || gen == 5 || (d->variant == 0 && (long)d->ntaps * 32 * NT * (Elt<T>::CK / Elt<T>::VEC) > 1024);
+    const bool ck1 = gen == 3 || gen == 5;
     bool shallow = d->Cin < 4 * Elt<T>::CK || (d->Cin % Elt<T>::VEC) != 0 || gen >= 3 || d->variant == 2;
     if (!shallow && gen == 2) {
         // heuristic without a tuned variant: deep reductions go to the pipelined kernel only where it would use
@@ -699,23 +728,31 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
         };
         int nt = NT;
         int ckm = (d->Cin >= 2 * Elt<T>::CK && (d->Cin % Elt<T>::VEC) == 0 && lds_of(nt, 2) <= 64 * 1024 &&
-                   gen != 3) ? 2 : 1;
+                   !ck1) ? 2 : 1;
         if (lds_of(nt, ckm) > 160 * 1024 && nt == 2) nt = 1;
         const size_t lds2 = lds_of(nt, ckm);
         if (lds2 <= 160 * 1024) {
             dim3 grid((unsigned)(G2.tilesX * G2.tilesY * d->B), (unsigned)((d->Cout + 32 * nt - 1) / (32 * nt)));
 #define CV2_GO(NT_, CKM_)                                                                                          \
     do {                                                                                                           \
-        rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, NT_, CKM_>, (int)lds2);                           \
-        if (rc2) return rc2;                                                                                       \
-        MSMC_LAUNCH((conv_gather2_kernel<T, NT_, CKM_>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d, G2);    \
+        if (sb8) {                                                                                                 \
+            rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, NT_, CKM_, 8>, (int)lds2);                    \
+            if (rc2) return rc2;                                                                                   \
+            MSMC_LAUNCH((conv_gather2_kernel<T, NT_, CKM_, 8>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d,  \
+                        G2);                                                                                       \
+        } else {                                                                                                   \
+            rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, NT_, CKM_, 4>, (int)lds2);                    \
+            if (rc2) return rc2;                                                                                   \
+            MSMC_LAUNCH((conv_gather2_kernel<T, NT_, CKM_, 4>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d,  \
+                        G2);                                                                                       \
+        }                                                                                                          \
     } while (0)
             if (nt == 2 && ckm == 2) CV2_GO(2, 2);
             else if (nt == 2) CV2_GO(2, 1);
             else if (ckm == 2) CV2_GO(1, 2);
             else CV2_GO(1, 1);
 #undef CV2_GO
-            msmc_conv_last = msmc_kname("conv_gather2_kernel", EltName<T>::v, nt, ckm);
+            msmc_conv_last = msmc_kname2("conv_gather2_kernel", EltName<T>::v, nt, ckm, sb8 ? 8 : 4);
             return msmc_check_launch();
         }
     }
@@ -928,6 +965,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(msmc_conv_desc d, const
     }
     const int acol_tr = 32 * wm + 16 * half + 4 * (L & 3), bcol_tr = 32 * wn + 16 * half + 4 * (L & 3);
 
+    if (d.dw_copies > 1) {                              // privatised accumulators: copy (split index mod R)
+        const int copy = blockIdx.x % d.dw_copies;
+        dw += (size_t)copy * d.ntaps * d.Cout * d.Cin;
+        if (db) db += (size_t)copy * d.Cout;
+    }
     const bool do_bias = (db != nullptr) && (blockIdx.z == 0);
     float bias_acc = 0.f;
     const int t0 = blockIdx.x * tilesPerWg;
@@ -1111,7 +1153,7 @@ static int wg_launch(const msmc_conv_desc* d, const void* g, float* dw, float* d
     // Split of the pixel reduction over workgroups: each split costs one fp32 atomic per dW element, and atomics
     // on ONE address retire serially at ~0.1 us each, so  t(n) = (tiles/n) * t_tile + n * 0.1 us  (t_tile ~3 us)
     // is minimal at n = sqrt(30 * tiles); never more workgroups than ~2 per CU.
-    int nsplit = (int)(sqrt(30.0 * totalTiles) + 0.5);
+    int nsplit = (int)(sqrt(30.0 * totalTiles * (d->dw_copies > 1 ? d->dw_copies : 1)) + 0.5);
     if (d->split_shift > 0) nsplit <<= d->split_shift;
     else if (d->split_shift < 0) nsplit >>= -d->split_shift;
     const int cap = (2 * MSMC_NUM_CU + ctiles - 1) / ctiles;
@@ -1330,6 +1372,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad2_kernel(msmc_conv_desc d, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
+    if (d.dw_copies > 1) {                              // privatised accumulators: copy (split index mod R)
+        const int copy = blockIdx.x % d.dw_copies;
+        dw += (size_t)copy * d.ntaps * d.Cout * d.Cin;
+        if (db) db += (size_t)copy * d.Cout;
+    }
     const bool do_bias = (db != nullptr) && (blockIdx.z == 0);
     float bsum[8];
 #pragma unroll
@@ -1466,7 +1513,7 @@ static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* 
     // pixel split: every split adds one fp32 atomic per dW element, and atomics on ONE address retire serially at
     // ~0.1 us each (measured: 4096 per address -> 430 us), so  t(n) = (tiles/n) * t_tile + n * 0.1 us  with
     // t_tile ~3 us is minimal at n = sqrt(30 * tiles), whatever the size of dW
-    int nsplit = (int)(sqrt(30.0 * P.totalTiles) + 0.5);
+    int nsplit = (int)(sqrt(30.0 * P.totalTiles * (d->dw_copies > 1 ? d->dw_copies : 1)) + 0.5);
     if (d->split_shift > 0) nsplit <<= d->split_shift;
     else if (d->split_shift < 0) nsplit >>= -d->split_shift;
     const int cap = (4 * MSMC_NUM_CU + cols - 1) / cols;
@@ -1541,12 +1588,15 @@ __global__ __launch_bounds__(256) void wn_prepare_kernel(const msmc_wn_item* __r
     const int a = blockIdx.x - it.block0;
     const int n = it.Bc * it.T;
     const float* v = it.v + (size_t)a * n;
-    float ss = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) ss = fmaf(v[e], v[e], ss);
-    ss = block_sum(ss, red);
-    const float norm = sqrtf(ss);
-    const float scale = it.g[a] / norm;
-    if (threadIdx.x == 0) it.inv_norm[a] = 1.f / norm;
+    float scale = 1.f;
+    if (it.g) {                                        // weight norm; g == NULL: plain weight, layout conversion only
+        float ss = 0.f;
+        for (int e = threadIdx.x; e < n; e += 256) ss = fmaf(v[e], v[e], ss);
+        ss = block_sum(ss, red);
+        const float norm = sqrtf(ss);
+        scale = it.g[a] / norm;
+        if (threadIdx.x == 0) it.inv_norm[a] = 1.f / norm;
+    }
     for (int e = threadIdx.x; e < n; e += 256) {
         const int b = e / it.T, t = e - b * it.T;
         const float wv = v[e] * scale;
@@ -1562,15 +1612,27 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     const int n = it.Bc * it.T;
     const float* v = it.v + (size_t)a * n;
     float* dw = (float*)it.dw;
+    const int R = it.copies > 1 ? it.copies : 1;
     float dot = 0.f;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int b = e / it.T, t = e - b * it.T;
-        dot = fmaf(dw[t * it.s1[0] + a * it.s1[1] + b * it.s1[2]], v[e], dot);
+        const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
+        float sum = dw[o];
+        for (int r = 1; r < R; ++r) {                 // privatised copies: fold into copy 0, leave the others zeroed
+            sum = sum + dw[o + r * it.dw_copy_stride];
+            dw[o + r * it.dw_copy_stride] = 0.f;
+        }
+        if (R > 1) dw[o] = sum;
+        dot = fmaf(sum, v[e], dot);
     }
-    dot = block_sum(dot, red);
-    const float inv = it.inv_norm[a], gval = it.g[a];
-    if (threadIdx.x == 0) it.gg[a] = dot * inv;
-    const float k1 = gval * inv, k2 = dot * inv * inv;
+    float k1 = 1.f, k2 = 0.f;                          // plain weight: gv = dW
+    if (it.g) {
+        dot = block_sum(dot, red);
+        const float inv = it.inv_norm[a], gval = it.g[a];
+        if (threadIdx.x == 0) it.gg[a] = dot * inv;
+        k1 = gval * inv;
+        k2 = dot * inv * inv;
+    }
     float* gv = it.gv + (size_t)a * n;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int b = e / it.T, t = e - b * it.T;
@@ -1580,8 +1642,13 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     }
     if (it.db && threadIdx.x == 0)
         for (int c = a; c < it.nbias; c += it.A) {
-            it.gb[c] = it.db[c];
+            float sum = it.db[c];
             it.db[c] = 0.f;
+            for (int r = 1; r < R; ++r) {
+                sum = sum + it.db[c + r * it.db_copy_stride];
+                it.db[c + r * it.db_copy_stride] = 0.f;
+            }
+            it.gb[c] = sum;
         }
 }
 

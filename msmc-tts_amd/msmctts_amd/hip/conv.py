@@ -64,7 +64,7 @@ _PLANS = {}
 # (msmc_conv_desc.variant / .split_shift) once and keeps the fastest -- tile heuristics cannot see L2 / LDS effects
 # that differ by 2x between layers of equal arithmetic.  Off inside hipGraph capture and on the interpreter.
 AUTOTUNE = os.environ.get('MSMC_AUTOTUNE', '1') != '0'
-_GATHER_CANDIDATES = ((1, 0), (2, 0), (3, 0))
+_GATHER_CANDIDATES = tuple((int(v), 0) for v in os.environ.get('MSMC_GATHER_VARIANTS', '1,2,3').split(','))
 _WGRAD_CANDIDATES = ((2, 0), (2, -1), (2, 1), (1, 0))
 TUNED = {}                                    # (kind, shape signature) -> (variant, split_shift, {candidate: ms})
 
@@ -112,8 +112,9 @@ def _wgrad(desc, g_ptr, dw, db, stream, what):
     dbp = db.data_ptr() if db is not None else None
     if not getattr(desc, '_tuned', False):
         if AUTOTUNE and not lib._host_pointers_ok and not torch.cuda.is_current_stream_capturing():
-            sdw = torch.zeros_like(dw)                       # candidates accumulate into scratch, not into dW
-            sdb = torch.zeros_like(db) if db is not None else None
+            R = max(1, desc.dw_copies)                       # candidates accumulate into scratch, not into dW
+            sdw = torch.zeros(R * desc.ntaps * desc.Cout * desc.Cin, dtype=torch.float32, device=dw.device)
+            sdb = torch.zeros(R * desc.Cout, dtype=torch.float32, device=dw.device) if db is not None else None
             sdbp = sdb.data_ptr() if sdb is not None else None
             _tune('wgrad', desc, lambda: fn(ctypes.byref(desc), g_ptr, sdw.data_ptr(), sdbp, stream), _WGRAD_CANDIDATES)
         else:
@@ -298,7 +299,7 @@ def conv_transpose1d_dgrad(g, wb, k, stride, padding, Lin, mask_src=None, mask_s
     return gx
 
 
-def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None, db=None):
+def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None, db=None, copies=1):
     """dW [kh*kw, Cout, Cin] fp32 of ``conv_forward`` (x [B,Hin,Win,Cin] pre-activation, g [B,Hout,Wout,Cout]);
     when ``db`` (fp32 [Cout]) is given the bias gradient is accumulated into it by the same launch."""
     key = ('w', x.dtype, x.shape[0], x.shape[3], g.shape[3], in_slope)
@@ -316,11 +317,12 @@ def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None, db=None):
         dw = torch.zeros((n_slices, g.shape[3], x.shape[3]), dtype=torch.float32, device=x.device)
     desc.x = desc.w = desc.out = x.data_ptr()
     desc.bias = desc.mask_src = desc.res = desc.res2 = None
+    desc.dw_copies = copies              # dw / db then hold ``copies`` privatised accumulators back to back
     _wgrad(desc, g.data_ptr(), dw, db, lib.stream(x), 'msmc_conv_wgrad')
     return dw
 
 
-def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None):
+def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None, copies=1):
     """dW [k, Cin, Cout] fp32 of ``conv_transpose1d_forward`` (x [B,1,Lin,Cin] pre-activation, g [B,1,Lout,Cout]):
     dW[k][ci][co] = sum_q act(x[q][ci]) * g[q*stride + k - padding][co]  -- the weight gradient of the strided
     convolution fine -> coarse with the operand roles swapped (the activation rides on the 'gradient' operand)."""
@@ -335,6 +337,7 @@ def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None):
     d = _fill(None, g, g, g, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, in_slope=1.0,
               mask_slope=in_slope)
     lib.ptr(dw, torch.float32)
+    d.dw_copies = copies
     _wgrad(d, lib.ptr(x), dw, None, lib.stream(x), 'msmc_conv_wgrad(convT)')
     return dw
 

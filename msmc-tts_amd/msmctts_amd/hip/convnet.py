@@ -27,6 +27,9 @@ from . import lib
 # data-parallel reducer that a parameter gradient produced outside autograd's accumulation is ready.
 GRAD_READY_HOOK = None
 
+DW_COPIES = int(os.environ.get('MSMC_DW_COPIES', '8'))
+DW_COPIES_MAX_ELEMS = 256 * 1024
+
 # False: fork_join runs its branches back to back on the calling stream (bench.py's per-kernel timing pass)
 STREAMS_ENABLED = True
 
@@ -72,14 +75,17 @@ def make_streams(device, n):
 
 
 class ConvLayer(object):
-    """Static description of one weight-normalised convolution inside a bank."""
+    """Static description of one convolution inside a bank: weight-normalised (``weight_g`` / ``weight_v``) or, with
+    ``plain=True``, an ordinary ``nn.Conv1d`` whose ``weight`` is used as it is."""
 
-    def __init__(self, module, kind, kernel, stride=(1, 1), dilation=(1, 1), padding=(0, 0), reflect=False):
-        self.module = module            # owns bias / weight_g / weight_v parameters
+    def __init__(self, module, kind, kernel, stride=(1, 1), dilation=(1, 1), padding=(0, 0), reflect=False,
+                 plain=False):
+        self.module = module            # owns bias / weight_g / weight_v (or bias / weight) parameters
+        self.plain = plain
         self.kind = kind                # 'conv' (Conv1d as (1,k) / Conv2d) or 'convT' (ConvTranspose1d)
         self.kernel, self.stride, self.dilation, self.padding, self.reflect = kernel, stride, dilation, padding, reflect
         self.taps = kernel[0] * kernel[1]
-        v = module.weight_v
+        v = self.weight
         if kind == 'conv':
             self.cout, self.cin = v.shape[0], v.shape[1]
         else:
@@ -88,6 +94,11 @@ class ConvLayer(object):
         self.wf = self.wb = self.dw = self.db = None
         self.index = -1
         self._geoms = {}
+
+    @property
+    def weight(self):
+        """the parameter the kernel-layout weights are derived from (weight_v under weight norm)"""
+        return self.module.weight if self.plain else self.module.weight_v
 
     def geom(self, H, W):
         key = (H, W)
@@ -109,41 +120,49 @@ class ConvBank(object):
 
     # -- (re)build device buffers whenever parameters moved / changed dtype ------------------------
     def _signature(self, dtype):
-        return (dtype,) + tuple(l.module.weight_v.data_ptr() for l in self.layers)
+        return (dtype,) + tuple(l.weight.data_ptr() for l in self.layers)
 
     def _build(self, dtype):
-        dev = self.layers[0].module.weight_v.device
+        dev = self.layers[0].weight.device
         pad8 = lambda n: (n + 7) // 8 * 8                 # every layer's slices start 16-byte aligned (vector loads)
         tot_w = sum(pad8(l.taps * l.cout * l.cin) for l in self.layers)
-        tot_a = sum(l.module.weight_v.shape[0] for l in self.layers)
+        tot_a = sum(l.weight.shape[0] for l in self.layers)
         tot_b = sum(l.cout for l in self.layers)
+        # privatised dW / db accumulators: atomics on one address retire serially (~0.1 us each), so layers with
+        # small weights (= many pixel tiles per weight) spread their workgroups over DW_COPIES copies
+        copies = lambda l: DW_COPIES if l.taps * l.cout * l.cin <= DW_COPIES_MAX_ELEMS else 1
+        tot_dw = sum(pad8(l.taps * l.cout * l.cin) * copies(l) for l in self.layers)
+        tot_db = sum(pad8(l.cout) * copies(l) for l in self.layers)
         self.w1 = torch.empty(tot_w, dtype=dtype, device=dev)            # layout 1 (the layout dW is produced in)
         self.w2 = torch.empty(tot_w, dtype=dtype, device=dev)            # layout 2
-        self.dw = torch.zeros(tot_w, dtype=torch.float32, device=dev)
+        self.dw = torch.zeros(tot_dw, dtype=torch.float32, device=dev)
         self.gv = torch.empty(tot_w, dtype=torch.float32, device=dev)
         self.inv_norm = torch.empty(tot_a, dtype=torch.float32, device=dev)
         self.gg = torch.empty(tot_a, dtype=torch.float32, device=dev)
-        self.db = torch.zeros(tot_b, dtype=torch.float32, device=dev)
+        self.db = torch.zeros(tot_db, dtype=torch.float32, device=dev)
         self.gb = torch.empty(tot_b, dtype=torch.float32, device=dev)
         items = (lib.WnItem * len(self.layers))()
-        ow = oa = ob = blk = 0
+        ow = oa = ob = blk = odw = odb = 0
         esz = self.w1.element_size()
         for l, it in zip(self.layers, items):
-            v, g = l.module.weight_v, l.module.weight_g
+            v, g = l.weight, (None if l.plain else l.module.weight_g)
             n = l.taps * l.cout * l.cin
             A = v.shape[0]
-            it.v, it.g = v.data_ptr(), g.data_ptr()
+            it.v, it.g = v.data_ptr(), (g.data_ptr() if g is not None else None)
             it.dst1, it.dst2 = self.w1.data_ptr() + ow * esz, self.w2.data_ptr() + ow * esz
             it.inv_norm = self.inv_norm.data_ptr() + oa * 4
-            it.dw, it.gv, it.gg = self.dw.data_ptr() + ow * 4, self.gv.data_ptr() + ow * 4, self.gg.data_ptr() + oa * 4
+            R = copies(l)
+            it.dw, it.gv, it.gg = self.dw.data_ptr() + odw * 4, self.gv.data_ptr() + ow * 4, self.gg.data_ptr() + oa * 4
+            it.copies, it.dw_copy_stride, it.db_copy_stride = R, n, l.cout
+            l.dw_copies = R
             it.A, it.Bc, it.T = A, v.shape[1], l.taps
             it.dtype = 0 if dtype == torch.float32 else 1
             it.block0 = blk
             it.nbias = l.cout
-            it.db, it.gb = self.db.data_ptr() + ob * 4, self.gb.data_ptr() + ob * 4
+            it.db, it.gb = self.db.data_ptr() + odb * 4, self.gb.data_ptr() + ob * 4
             w1 = self.w1[ow:ow + n]
             w2 = self.w2[ow:ow + n]
-            dw = self.dw[ow:ow + n]
+            dw = self.dw[odw:odw + n]                      # copy 0; copies 1..R-1 follow at stride n
             if l.kind == 'conv':           # v (Cout, Cin, T): a = co, b = ci
                 it.s1[0], it.s1[1], it.s1[2] = l.cout * l.cin, l.cin, 1          # [T][Cout][Cin]  forward + dW
                 it.s2[0], it.s2[1], it.s2[2] = l.cout * l.cin, 1, l.cout          # [T][Cin][Cout]  data gradient
@@ -154,11 +173,12 @@ class ConvBank(object):
                 it.s2[0], it.s2[1], it.s2[2] = l.cout * l.cin, 1, l.cin           # [T][Cout][Cin]  forward
                 l.wb, l.wf = w1.view(l.taps, l.cin, l.cout), w2.view(l.taps, l.cout, l.cin)
                 l.dw = dw.view(l.taps, l.cin, l.cout)
-            l.db = self.db[ob:ob + l.cout]
+            l.db = self.db[odb:odb + l.cout]
             l.gb_view = self.gb[ob:ob + l.cout]
             l.gv_view = self.gv[ow:ow + n].view_as(v)
-            l.gg_view = self.gg[oa:oa + A].view_as(g)
+            l.gg_view = self.gg[oa:oa + A].view_as(g) if g is not None else None
             ow, oa, ob, blk = ow + pad8(n), oa + A, ob + l.cout, blk + A
+            odw, odb = odw + pad8(n * R), odb + pad8(l.cout * R)
         self.total_blocks = blk
         raw = bytes(items)
         self.items_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
@@ -191,11 +211,13 @@ class ConvBank(object):
         with torch.no_grad():
             for l in self.layers:
                 m = l.module
-                if not m.weight_v.requires_grad:
+                if not l.weight.requires_grad:
                     continue
                 # gradients ARE the bank's output buffers (no copies): they stay valid until the next backward
                 # of this network, i.e. past the optimizer step that consumes them
-                for p, gview in ((m.bias, l.gb_view), (m.weight_g, l.gg_view), (m.weight_v, l.gv_view)):
+                pairs = (((m.bias, l.gb_view), (m.weight, l.gv_view)) if l.plain else
+                         ((m.bias, l.gb_view), (m.weight_g, l.gg_view), (m.weight_v, l.gv_view)))
+                for p, gview in pairs:
                     if p.grad is None:
                         p.grad = gview
                     elif p.grad.data_ptr() != gview.data_ptr():
@@ -219,7 +241,7 @@ class _HipConv(torch.autograd.Function):
         ctx.bank, ctx.layer = bank, layer
         ctx.in_slope, ctx.out_slope, ctx.out_div = in_slope, out_slope, out_div
         ctx.has_res, ctx.has_res2 = res is not None, res2 is not None
-        ctx.need_w = m.weight_v.requires_grad
+        ctx.need_w = layer.weight.requires_grad
         ctx.save_for_backward(x, out if out_slope != 1.0 else None)
         return out
 
@@ -249,10 +271,10 @@ class _HipConv(torch.autograd.Function):
         if ctx.need_w:
             if layer.kind == 'conv':
                 K.conv_wgrad(x, g, layer.geom(x.shape[1], x.shape[2]), layer.taps, in_slope=ctx.in_slope, dw=layer.dw,
-                             db=layer.db)
+                             db=layer.db, copies=layer.dw_copies)
             else:
                 K.conv_transpose1d_wgrad(x, g, layer.kernel[1], layer.stride[1], layer.padding[1],
-                                         in_slope=ctx.in_slope, dw=layer.dw)
+                                         in_slope=ctx.in_slope, dw=layer.dw, copies=layer.dw_copies)
                 layer.db.add_(K.colsum(g.reshape(-1, g.shape[-1])))
             bank._queue_finish()
         if ctx.has_res or ctx.has_res2:
@@ -268,5 +290,5 @@ class _HipConv(torch.autograd.Function):
 
 
 def hip_conv(bank, layer, x, res=None, res2=None, in_slope=1.0, out_slope=1.0, out_div=1.0):
-    return _HipConv.apply(x, res, res2, layer.module.weight_v, bank, layer, float(in_slope), float(out_slope),
+    return _HipConv.apply(x, res, res2, layer.weight, bank, layer, float(in_slope), float(out_slope),
                           float(out_div))

@@ -41,14 +41,15 @@ class ConvDesc(ctypes.Structure):
                 ('isy', _i), ('isx', _i), ('iy0', _i), ('ix0', _i), ('ntaps', _i),
                 ('tap_dy', _i * MAX_TAPS), ('tap_dx', _i * MAX_TAPS), ('tap_w', _i * MAX_TAPS),
                 ('pad_mode', _i), ('in_slope', _f), ('mask_slope', _f), ('out_div', _f), ('out_slope', _f),
-                ('variant', _i), ('split_shift', _i)]
+                ('variant', _i), ('split_shift', _i), ('dw_copies', _i)]
 
 
 class WnItem(ctypes.Structure):
     """msmc_wn_item of include/msmc_hip.h."""
     _fields_ = [('v', _vp), ('g', _vp), ('dst1', _vp), ('dst2', _vp), ('inv_norm', _vp), ('dw', _vp), ('gv', _vp),
                 ('gg', _vp), ('s1', ctypes.c_long * 3), ('s2', ctypes.c_long * 3), ('A', _i), ('Bc', _i), ('T', _i),
-                ('dtype', _i), ('block0', _i), ('nbias', _i), ('db', _vp), ('gb', _vp)]
+                ('dtype', _i), ('block0', _i), ('nbias', _i), ('db', _vp), ('gb', _vp), ('copies', _i), ('pad_', _i),
+                ('dw_copy_stride', ctypes.c_long), ('db_copy_stride', ctypes.c_long)]
 
 
 MAX_TENSORS = 64

@@ -8,11 +8,14 @@ and numerics follow the reference: fused QKV projection, post-LayerNorm, key-pad
 -inf, conv feed-forward, output zeroed on padding after both sub-layers.
 """
 import math
+import os
 
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from ...hip.convnet import ConvBank, ConvLayer, hip_conv
 
 
 def get_sinusoid_encoding_table(n_position, d_hid, padding_idx=None):
@@ -86,8 +89,19 @@ class PositionwiseFeedForward(nn.Module):
         self.layer_norm = nn.LayerNorm(d_in)
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, x, acts=None):
-        h = self.w_2(F.relu(self.w_1(x.transpose(1, 2)))).transpose(1, 2)
+    def hip_layers(self):
+        k, p = self.w_1.kernel_size[0], self.w_1.padding[0]
+        return [ConvLayer(m, 'conv', (1, k), (1, 1), (1, 1), (0, p), plain=True) for m in (self.w_1, self.w_2)]
+
+    def forward(self, x, acts=None, hip=None):
+        if hip is None:         # stock operators (stand-alone use of the block)
+            h = self.w_2(F.relu(self.w_1(x.transpose(1, 2)))).transpose(1, 2)
+        else:
+            # [B, T, C] IS the channels-last layout of a 1-D convolution: no transposes; the ReLU between the two
+            # convolutions is the second one's input activation (leaky slope 0)
+            bank, (l1, l2), dtype = hip
+            x4 = x.unsqueeze(1).to(dtype)
+            h = hip_conv(bank, l2, hip_conv(bank, l1, x4), in_slope=0.0).squeeze(1)
         return self.layer_norm(self.dropout(h) + x)
 
 
@@ -99,10 +113,10 @@ class FFTBlock(nn.Module):
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, fft_conv1d_kernel, fft_conv1d_padding, dropout,
                                                name + '.pos_ffn')
 
-    def forward(self, input, non_pad_mask=None, slf_attn_mask=None, acts=None):
+    def forward(self, input, non_pad_mask=None, slf_attn_mask=None, acts=None, hip=None):
         keep = non_pad_mask.to(input.dtype)
         out, attn = self.slf_attn(input, mask=slf_attn_mask)
-        out = self.pos_ffn(out * keep) * keep
+        out = self.pos_ffn(out * keep, hip=hip) * keep
         return out, attn
 
 
@@ -117,10 +131,26 @@ class FFTBlocks(nn.Module):
             FFTBlock(d_model, d_inner, n_head, d_k, d_v, fft_conv1d_kernel, fft_conv1d_padding, dropout,
                      '%s.layer_stack.%d' % (name, i), attn_dropout, fused_layernorm) for i in range(n_layers)])
 
+        self.hip_dtype = torch.float32        # compute dtype of the HIP convolutions (trainer: bfloat16 in bf16 runs)
+        # position-wise convolutions on the gfx950 kernels (csrc/conv.hip); MSMC_FFT_HIP=0 keeps the stock operators (A/B)
+        self.use_hip = os.environ.get('MSMC_FFT_HIP', '1') != '0'
+        self._bank = None
+
+    def _hip(self):
+        if self._bank is None:
+            self._layers = [blk.pos_ffn.hip_layers() for blk in self.layer_stack]
+            self._bank = ConvBank([l for pair in self._layers for l in pair])
+        return self._bank, self._layers
+
     def forward(self, seq, pos, return_attns=False, acts=None):
         mask = get_attn_key_pad_mask(pos, pos)
         keep = get_non_pad_mask(pos)
         out = seq + self.position(pos)
-        for layer in self.layer_stack:
-            out, _ = layer(out, non_pad_mask=keep, slf_attn_mask=mask)
+        hips = [None] * len(self.layer_stack)
+        if self.use_hip:
+            bank, layers = self._hip()
+            bank.prepare(self.hip_dtype)          # one launch: kernel-layout weights of the 2 x n_layers convolutions
+            hips = [(bank, pair, self.hip_dtype) for pair in layers]
+        for layer, hip in zip(self.layer_stack, hips):
+            out, _ = layer(out, non_pad_mask=keep, slf_attn_mask=mask, hip=hip)
         return out, keep

@@ -105,5 +105,12 @@ def check_conv_case(case, dtype, tol, dev, parts=('fwd', 'dgrad', 'wgrad'), batc
         bref = gc.float().reshape(-1, Cout).sum(0)
         bscale = gc.float().reshape(-1, Cout).abs().sum(0).max().item()
         assert (db - bref).abs().max().item() < 1e-5 * bscale + 1e-6, ('fused bias grad', db, bref)
+        # privatised accumulators: R copies back to back, workgroup i adds into copy i % R; their sum is dW
+        R = 4
+        dwR = torch.zeros(R, T, Cout, Cin, device=dev)
+        dbR = torch.zeros(R, Cout, device=dev)
+        conv.conv_wgrad(xc, gc, geom, T, in_slope=slope, dw=dwR.view(-1), db=dbR.view(-1), copies=R)
+        assert rel(dwR.sum(0), want) < wtol, ('wgrad copies', rel(dwR.sum(0), want))
+        assert (dbR.sum(0) - bref).abs().max().item() < 1e-5 * bscale + 1e-6, 'bias grad copies'
         cs = conv.colsum(gc.reshape(-1, Cout))
         assert (cs - bref).abs().max().item() < 1e-5 * bscale + 1e-6, ('bias grad', cs, bref)

@@ -13,7 +13,7 @@ class A(object):
     codewords, heads, batch, frames, graph, dtype, no_autocast = 256, 4, 16, 400, False, 'bf16', False
 
 
-os.environ['MSMC_STREAMS'] = '0'
+os.environ['MSMC_STREAMS'] = '0'; os.environ['MSMC_AUTOTUNE'] = '0'
 dev = torch.device('cuda:0')
 torch.cuda.set_device(0)
 cfg, trainer = bench.build(A, dev, 0, 1)
@@ -33,7 +33,8 @@ def step(i):
 for i in range(4):
     step(i)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True,
+             experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     step(20)
     torch.cuda.synchronize()
 agg = collections.defaultdict(lambda: [0, 0.0, collections.Counter()])
@@ -60,3 +61,19 @@ with open(os.path.join(ROOT, 'gpurun_out', 'torch_ops_by_source.txt'), 'w') as f
     for src, (n, dt, names) in rows[:70]:
         f.write('%7.1f us  n=%4d  %-70s %s\n' % (dt, n, src[:70], dict(names.most_common(3))))
 print(open(os.path.join(ROOT, 'gpurun_out', 'torch_ops_by_source.txt')).read()[:9000])
+
+want = ('aten::copy_', 'aten::add_', 'aten::sum', 'aten::fill_', 'aten::mul', 'aten::add', 'aten::div')
+agg2 = collections.defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    ks = getattr(ev, 'kernels', None) or []
+    dt = sum(k.duration for k in ks)
+    if dt <= 0 or ev.name not in want:
+        continue
+    frames = [fr for fr in (ev.stack or []) if '/msmc-tts_amd/' in fr or 'bench.py' in fr or '/torch/optim' in fr or 'clip_grad' in fr or 'autograd' in fr]
+    key = (ev.name, frames[0].split('/')[-1][:80] if frames else (ev.stack[0][-60:] if ev.stack else '?'))
+    agg2[key][0] += 1
+    agg2[key][1] += dt
+with open(os.path.join(ROOT, 'gpurun_out', 'torch_small_ops_by_line.txt'), 'w') as f:
+    for key, (n, dt) in sorted(agg2.items(), key=lambda kv: -kv[1][1])[:80]:
+        f.write('%7.1f us  n=%4d  %-12s %s\n' % (dt, n, key[0], key[1]))
+print(open(os.path.join(ROOT, 'gpurun_out', 'torch_small_ops_by_line.txt')).read()[:7000])
