@@ -180,12 +180,16 @@ def main():
     ap.add_argument('--no-microbench', action='store_true')
     ap.add_argument('--no-autocast', action='store_true',
                     help='bf16 only inside the HIP conv stacks; the transformer encoder/decoder stay fp32')
-    ap.add_argument('--graph', action='store_true',
-                    help='replay the step from three hipGraphs (measured slower than the multi-stream eager step)')
+    ap.add_argument('--exec', dest='exec_mode', default='auto', choices=['auto', 'graph', 'eager'],
+                    help='graph: replay the step from three hipGraphs (no host launch cost; fastest on one GPU); eager: '
+                         'multi-stream eager step with bucketed all-reduce overlapped with backward; auto = graph on one '
+                         'GPU, eager on several')
+    ap.add_argument('--graph', action='store_true', help='same as --exec graph')
     ap.add_argument('--kernel-timing-steps', type=int, default=3, help='extra steps timed kernel by kernel (rank 0)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    args.graph = args.graph or args.exec_mode == 'graph' or (args.exec_mode == 'auto' and world == 1)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
@@ -295,6 +299,10 @@ def main():
         timer.enabled = True
         t1 = time.perf_counter()
         for i in range(args.kernel_timing_steps):
+            # park the GPU while the host enqueues the step: with the queue full, an event pair brackets kernel
+            # execution only (an eager step is host-paced; without this the pairs would also time the GPU waiting
+            # for the next launch packet and disagree with rocprofv3's per-kernel durations)
+            torch.cuda._sleep(int(2.0e8))
             step(args.warmup + args.steps + i)
         torch.cuda.synchronize()
         ms_instr = (time.perf_counter() - t1) / args.kernel_timing_steps * 1e3
