@@ -67,6 +67,41 @@ AUTOTUNE = os.environ.get('MSMC_AUTOTUNE', '1') != '0'
 _GATHER_CANDIDATES = tuple((int(v), 0) for v in os.environ.get('MSMC_GATHER_VARIANTS', '1,2,3').split(','))
 _WGRAD_CANDIDATES = ((2, 0), (2, -1), (2, 1), (1, 0))
 TUNED = {}                                    # (kind, shape signature) -> (variant, split_shift, {candidate: ms})
+TUNE_CACHE = os.environ.get('MSMC_TUNE_CACHE', os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                            'tuned_gfx950.json'))
+
+
+def load_tuned(path=None):
+    """Choices measured earlier on this GPU model (tools/tune_bench_shapes.py writes them): shapes found here skip
+    the timing launches; unseen shapes are still tuned on first use.  A missing or unreadable file is ignored."""
+    import json
+    try:
+        with open(path or TUNE_CACHE) as f:
+            for row in json.load(f)['choices']:
+                TUNED[tuple(_thaw(row['key']))] = (int(row['variant']), int(row['split_shift']),
+                                                   {tuple(_thaw(k)): v for k, v in row.get('ms', [])})
+    except Exception:
+        pass
+
+
+def save_tuned(path=None):
+    import json
+    rows = [dict(key=_freeze(k), variant=v[0], split_shift=v[1], ms=[[_freeze(c), t] for c, t in v[2].items()])
+            for k, v in sorted(TUNED.items(), key=lambda kv: repr(kv[0]))]
+    with open(path or TUNE_CACHE, 'w') as f:
+        json.dump(dict(device='gfx950', note='per-layer-shape kernel choices (msmc_conv_desc.variant / split_shift) '
+                       'timed on MI355X; regenerate with tools/tune_bench_shapes.py', choices=rows), f, indent=0)
+
+
+def _freeze(x):
+    return [_freeze(v) for v in x] if isinstance(x, (tuple, list)) else x
+
+
+def _thaw(x):
+    return tuple(_thaw(v) for v in x) if isinstance(x, list) else x
+
+
+load_tuned()
 
 
 def _signature(desc):

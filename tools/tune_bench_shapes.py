@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Runs ON the GPU box: time the kernel candidates of every convolution shape of the bench configuration (and of the
+GPU test-suite's layer cases) and write the choices to msmctts_amd/hip/tuned_gfx950.json (copied back via gpurun_out)."""
+import os, sys, random, shutil
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd'), os.path.join(ROOT, 'tests')]
+os.environ['MSMC_TUNE_CACHE'] = '/nonexistent'            # start from scratch
+import torch
+import bench
+from msmctts_amd.hip import conv
+from msmctts_amd.synthetic import make_batch
+
+
+class A(object):
+    codewords, heads, batch, frames, graph, dtype, no_autocast = 256, 4, 16, 400, False, 'bf16', False
+
+
+dev = torch.device('cuda:0')
+torch.cuda.set_device(0)
+for rep in range(2):                                      # two passes: keep the faster measurement of each candidate
+    saved = dict(conv.TUNED)
+    conv.TUNED.clear()
+    cfg, trainer = bench.build(A, dev, 0, 1)
+    batch = make_batch(A.batch, A.frames, 80, 300, seed=1234, rank=0, device='cpu')
+    lengths = batch['mel_length'].tolist()
+    batch = {k: v.to(dev) for k, v in batch.items()}
+    batch['mel_length_host'] = lengths
+    trainer.rng = random.Random(1234)
+    for i in range(2):
+        trainer.model.zero_grad()
+        trainer.optimizer.zero_grad()
+        trainer.train_step(batch, 10 + i)
+    torch.cuda.synchronize()
+    for k, v in saved.items():
+        if k in conv.TUNED:
+            times = {c: min(t, v[2].get(c, t)) for c, t in conv.TUNED[k][2].items()}
+            best = min(times, key=times.get)
+            conv.TUNED[k] = (best[0], best[1], times)
+        else:
+            conv.TUNED[k] = v
+    del trainer
+out = os.path.join(ROOT, 'gpurun_out', 'tuned_gfx950.json')
+conv.save_tuned(out)
+print('shapes tuned:', len(conv.TUNED))
