@@ -49,6 +49,7 @@ class KernelTimer(object):
     def __init__(self):
         self.records = {}
         self.enabled = False
+        self.count = lambda: 0
 
     def wrap(self, module, fn_name, label, work):
         inner = getattr(module, fn_name)
@@ -58,10 +59,12 @@ class KernelTimer(object):
             if not timer.enabled:
                 return inner(*args, **kw)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n0 = timer.count()
             s.record()
             out = inner(*args, **kw)
             e.record()
-            timer.records.setdefault(label(), []).append((s, e) + tuple(work(*args, **kw)))
+            # one call can be several kernels (a strided data gradient / transposed convolution launches one per phase)
+            timer.records.setdefault(label(), []).append((s, e) + tuple(work(*args, **kw)) + (max(1, timer.count() - n0),))
             return out
 
         setattr(module, fn_name, timed)
@@ -69,9 +72,9 @@ class KernelTimer(object):
     def summary(self):
         out = {}
         for label, recs in self.records.items():
-            ms = [s.elapsed_time(e) for s, e, _, _ in recs]
-            out[label] = dict(launches=len(ms), total_ms=sum(ms), flops=sum(r[2] for r in recs),
-                              bytes=sum(r[3] for r in recs))
+            ms = [r[0].elapsed_time(r[1]) for r in recs]
+            out[label] = dict(launches=sum(r[4] for r in recs), calls=len(ms), total_ms=sum(ms),
+                              flops=sum(r[2] for r in recs), bytes=sum(r[3] for r in recs))
         return out
 
 
@@ -222,6 +225,7 @@ def main():
         return 2.0 * n * x.shape[-1] * et.shape[1], n * vq_bytes_per_frame(x.shape[-1], et.shape[0])
 
     timer.wrap(hipvq, 'vq_search', lambda: 'vq_search_reg_kernel', vq_work)
+    timer.count = lambda: lib.get().msmc_conv_launch_count()
 
     # algorithmic work of one call: flops = 2 * output points * Cout * Cin * taps; bytes = every operand once
     def conv_work(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, **k):

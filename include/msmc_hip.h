@@ -127,6 +127,8 @@ void msmc_conv_set_gather_generation(int n);
 void msmc_conv_set_narrow(int on);
 /* Symbol of the kernel the calling thread's most recent msmc_conv_gather / msmc_conv_wgrad launched (profiling aid). */
 const char* msmc_conv_last_kernel(void);
+/* Number of kernels the calling thread's msmc_conv_gather / msmc_conv_wgrad calls have launched so far. */
+long msmc_conv_launch_count(void);
 
 /* out[q] = epilogue( sum_t sum_ci w[tap_w[t]][co][ci] * act(x[in(q, t)][ci]) + bias[co] ). */
 int msmc_conv_gather(const msmc_conv_desc* desc, msmc_stream stream);

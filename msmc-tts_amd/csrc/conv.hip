@@ -36,6 +36,8 @@ extern "C" void msmc_conv_set_narrow(int on) { msmc_conv_narrow_when_small = on;
 // bench.py attributes its per-launch HIP-event timings to the same symbols rocprofv3 reports)
 static thread_local const char* msmc_conv_last = "";
 extern "C" const char* msmc_conv_last_kernel(void) { return msmc_conv_last; }
+static thread_local long msmc_conv_launches = 0;          // kernels launched by this thread's gather / wgrad calls
+extern "C" long msmc_conv_launch_count(void) { return msmc_conv_launches; }
 template <typename T> struct EltName;
 template <> struct EltName<float> { static constexpr const char* v = "float"; };
 template <> struct EltName<unsigned short> { static constexpr const char* v = "unsigned short"; };
@@ -808,6 +810,7 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
 
 extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
     if (!d || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0) return MSMC_E_SHAPE;
+    ++msmc_conv_launches;
     if (d->dtype == 0) return cv_launch<float>(d, stream);
     if (d->dtype == 1) return cv_launch<unsigned short>(d, stream);
     return MSMC_E_SHAPE;
@@ -1544,6 +1547,7 @@ static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* 
 extern "C" int msmc_conv_wgrad(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream) {
     if (!d || !g || !dw || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0) return MSMC_E_SHAPE;
     if (d->ntaps <= 0 || d->ntaps > MSMC_CONV_MAX_TAPS) return MSMC_E_SHAPE;
+    ++msmc_conv_launches;
     if (d->dtype == 0) return wg_launch<float>(d, g, dw, db, stream);
     if (d->dtype == 1) {
         const int gen = d->variant > 0 ? d->variant : msmc_wgrad_generation;

@@ -80,6 +80,7 @@ _SIGNATURES.update({
     'msmc_conv_set_wgrad_generation': (None, [_i]),
     'msmc_conv_set_gather_generation': (None, [_i]),
     'msmc_conv_last_kernel': (ctypes.c_char_p, []),
+    'msmc_conv_launch_count': (ctypes.c_long, []),
     'msmc_conv_set_narrow': (None, [_i]),
     'msmc_conv_wgrad': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     'msmc_wn_prepare_multi': (_i, [_vp, _i, _i, _vp]),
