@@ -184,15 +184,15 @@ def main():
     ap.add_argument('--no-autocast', action='store_true',
                     help='bf16 only inside the HIP conv stacks; the transformer encoder/decoder stay fp32')
     ap.add_argument('--exec', dest='exec_mode', default='auto', choices=['auto', 'graph', 'eager'],
-                    help='graph: replay the step from three hipGraphs (no host launch cost; fastest on one GPU); eager: '
-                         'multi-stream eager step with bucketed all-reduce overlapped with backward; auto = graph on one '
-                         'GPU, eager on several')
+                    help='graph (= auto): replay the step from three hipGraphs, gradients all-reduced between the '
+                         'segments (no host launch cost: the eager step is paced by the host); eager: multi-stream eager '
+                         'step with bucketed all-reduce overlapped with backward')
     ap.add_argument('--graph', action='store_true', help='same as --exec graph')
     ap.add_argument('--kernel-timing-steps', type=int, default=3, help='extra steps timed kernel by kernel (rank 0)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    args.graph = args.graph or args.exec_mode == 'graph' or (args.exec_mode == 'auto' and world == 1)
+    args.graph = args.graph or args.exec_mode in ('graph', 'auto')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():

@@ -62,6 +62,7 @@ class GradReducer(object):
         self.group = group
         self.world = dist.get_world_size(group)
         self.buckets = []
+        self.hooks_enabled = True
         self._owner = {}
         self._inflight = []
         children = list(module.named_children()) or [('', module)]
@@ -87,6 +88,8 @@ class GradReducer(object):
             self._owner[id(p)] = b
 
     def _on_grad(self, p):
+        if not self.hooks_enabled:           # hipGraph mode: gradients are exchanged between the replayed segments
+            return
         b = self._owner.get(id(p))
         if b is None or p.grad is None:      # e.g. the token edge of a HIP conv: its gradient arrives by hand later
             return

@@ -201,6 +201,9 @@ class VQGANTrainer(BaseTrainer):
         phase = self._phase(iteration)
         if self.use_graphs and phase == 2:
             return self._train_step_graphed(batch)
+        reducer = getattr(self.model, 'grad_reducer', None)
+        if reducer is not None:
+            reducer.hooks_enabled = True         # eager step: bucketed all-reduce from the gradient hooks
         st = _StepState()
         st.phase, st.mel, st.mel_length = phase, batch['mel'], batch['mel_length']
         st.frame_window = st.target = None
@@ -219,6 +222,9 @@ class VQGANTrainer(BaseTrainer):
     # -- hipGraph replay of the GAN-phase step -----------------------------------------------------
     def _train_step_graphed(self, batch):
         g = self._graphs
+        reducer = getattr(self.model, 'grad_reducer', None)
+        if reducer is not None:
+            reducer.hooks_enabled = False        # no collectives inside capture; allreduce_child runs between segments
         if g is None:
             g = self._graphs = self._capture(batch)
         st = g['state']
@@ -291,15 +297,21 @@ class VQGANTrainer(BaseTrainer):
         _gc.collect()
         self.model.zero_grad(set_to_none=True)          # gradients get (static) graph-pool storage during capture
         ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga, stream=side):
+        # with a process group alive, RCCL's watchdog thread polls events while we capture: only this thread's calls
+        # may invalidate the capture
+        import torch.distributed as dist
+        mode = 'thread_local' if dist.is_available() and dist.is_initialized() else 'global'
+        with torch.cuda.graph(ga, stream=side, capture_error_mode=mode):
             self._build_windows(g, st)
             self._segment_a(st)
         self._sync_grads_static('discriminator')
-        with torch.cuda.graph(gb, pool=ga.pool(), stream=side):
+        torch.cuda.synchronize()
+        with torch.cuda.graph(gb, pool=ga.pool(), stream=side, capture_error_mode=mode):
             self._segment_b(st)
         self._sync_grads_static('autoencoder')
         keys = [k for k, v in st.losses.items() if torch.is_tensor(v)]
-        with torch.cuda.graph(gc, pool=ga.pool(), stream=side):
+        torch.cuda.synchronize()
+        with torch.cuda.graph(gc, pool=ga.pool(), stream=side, capture_error_mode=mode):
             self._segment_c(st)
             loss_vec = torch.stack([st.losses[k].detach().float().reshape(()) for k in keys])
         torch.cuda.synchronize()

@@ -149,6 +149,10 @@ def test_no_cpu_fallback():
 def test_graphed_step_matches_eager():
     """hipGraph replay of the GAN-phase step (three captured segments) against the eager step: same
     weights, batch and windows -> same losses and parameters (the small model has no dropout)."""
+    graphed_vs_eager()
+
+
+def graphed_vs_eager(arm_reducer=False):
     import random
     from msmctts_amd.synthetic import make_batch
     from msmctts_amd.trainers import build_trainer
@@ -160,6 +164,9 @@ def test_graphed_step_matches_eager():
         cfg, task = _parity.build_small(DEV)
         tr = build_trainer(cfg, task, num_gpus=0, rank=0)
         tr.model = task
+        if arm_reducer:       # gradient exchange between the graph segments / from the eager hooks
+            from msmctts_amd.distributed.distributed import apply_gradient_allreduce
+            apply_gradient_allreduce(task)
         tr.optimizer = build_optimizer(task, cfg.optimizer, capturable=True)
         tr.use_graphs = graphed
         tr.rng = random.Random(3)
@@ -194,7 +201,9 @@ def test_graphed_step_matches_eager():
 def test_rccl_gradient_reducer_single_rank_matches_reference():
     """The data-parallel path on the real backend: RCCL process group of one rank, bucketed reducer armed
     (autograd hooks + the HIP conv banks' hand-delivered gradients, collectives on RCCL's stream next to the
-    multi-stream backward).  Averaging over one rank is the identity, so the golden step must still match."""
+    multi-stream backward).  Averaging over one rank is the identity, so the golden step must still match; then
+    the hipGraph step (capture with the process group alive, flat all-reduce between the replayed segments)
+    against the eager step."""
     import subprocess, sys, os, socket
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -208,6 +217,8 @@ def test_rccl_gradient_reducer_single_rank_matches_reference():
         "dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d', world_size=1, rank=0)\n"
         "import _parity\n"
         "_parity.check_train_steps('cuda:0', arm_reducer=True)\n"
+        "import test_gpu_parity\n"
+        "test_gpu_parity.graphed_vs_eager(arm_reducer=True)\n"
         "dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()\n"
         "print('REDUCER-OK')\n" % (root, os.path.join(root, 'msmc-tts_amd'), os.path.join(root, 'tests'), port))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
