@@ -108,7 +108,9 @@ typedef struct msmc_conv_desc {
     int variant;            /* kernel choice, 0 = library heuristic.  msmc_conv_gather: 1 = first-generation dispatch
                                (pipelined / simple kernel), 2 = second generation with 128-byte channel chunks where
                                they fit, 3 = second generation, 64-byte chunks, 4 / 5 = as 2 / 3 with eight instead of
-                               four weight vectors in flight per work-item.  msmc_conv_wgrad (bf16): 1 = first,
+                               four weight vectors in flight per work-item, 6 / 7 = as 2 / 3 with the whole channel chunk in flight
+                               and the next chunk prefetched (small grids; MSMC_E_SHAPE when the chunk exceeds 16 vectors
+                               per work-item).  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation.  The host layer times the candidates once per layer shape.       */
     int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative)                */
     int dw_copies;          /* msmc_conv_wgrad: R > 1 = dw is [R][ntaps][Cout][Cin] and db [R][Cout]; workgroup i adds

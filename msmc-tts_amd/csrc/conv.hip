@@ -558,6 +558,81 @@ __global__ __launch_bounds__(256, 2) void conv_gather2_kernel(msmc_conv_desc d, 
             if (dst[u] >= 0) *(u32x4*)(wt + dst[u]) = vals[u];
     };
 
+    auto mma_taps = [&]() {
+        for (int t = 0; t < d.ntaps; ++t) {
+            const T* ap = xt + (size_t)(arow + (d.tap_dy[t] - G.dyMin) * IW + (d.tap_dx[t] - G.dxMin)) * XS;
+            const T* bp = wt + (size_t)(t * BN + i) * XS;
+#pragma unroll
+            for (int ks = 0; ks < CK / 16; ++ks) mma_chunk16<NT>(ap + ks * 16, bp + ks * 16, 32 * XS, g, acc);
+        }
+    };
+    if constexpr (SB == 16) {
+        // Small grids (about one workgroup per CU, nothing to overlap with): the WHOLE channel chunk -- halo tile and
+        // weight slices, up to 16 vectors per work-item -- is in flight at once and the loads of chunk c+1 are issued
+        // before the MFMAs of chunk c, so a chunk costs one global-load latency instead of one per 4-vector batch.
+        // One index space for the staging vectors: [0, nxv) input halo tile, [nxv, nv) weight slices.
+        const int nv = nxv + nwv;
+        u32x4 regs[16];
+        auto fetch = [&](int c0) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = u * 256 + tid;
+                regs[u] = zero4;
+                if (e >= nv) continue;
+                const T* src = nullptr;
+                int c;
+                if (e < nxv) {
+                    const int pi = e / CKV;
+                    const int off = in_off[pi];
+                    c = c0 + (e - pi * CKV) * VEC;
+                    if (off >= 0 && c < d.Cin) src = xb + off + c;
+                } else {
+                    const int e2 = e - nxv;
+                    const int row = e2 / CKV;
+                    const int t = row / BN, co = co0 + (row - t * BN);
+                    c = c0 + (e2 - row * CKV) * VEC;
+                    if (co < d.Cout && c < d.Cin) src = wg + ((size_t)tapw[t] * d.Cout + co) * d.Cin + c;
+                }
+                if (src) regs[u] = *(const u32x4*)src;            // launcher guarantees Cin % VEC == 0 here
+            }
+        };
+        auto commit = [&]() {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = u * 256 + tid;
+                if (e >= nv) continue;
+                if (e < nxv) {
+                    const int pi = e / CKV;
+                    u32x4 v = regs[u];
+                    if (slope != 1.f) {
+                        alignas(16) T tmp[VEC];
+                        *(u32x4*)tmp = v;
+#pragma unroll
+                        for (int q = 0; q < VEC; ++q) {
+                            float f = Elt<T>::ld(&tmp[q]);
+                            f = f > 0.f ? f : f * slope;
+                            Elt<T>::st(&tmp[q], f);
+                        }
+                        v = *(const u32x4*)tmp;
+                    }
+                    *(u32x4*)(xt + (size_t)pi * XS + (e - pi * CKV) * VEC) = v;
+                } else {
+                    const int e2 = e - nxv;
+                    const int row = e2 / CKV;
+                    *(u32x4*)(wt + (size_t)row * XS + (e2 - row * CKV) * VEC) = regs[u];
+                }
+            }
+        };
+        __syncthreads();                                          // offset tables ready
+        fetch(0);
+        for (int c0 = 0; c0 < d.Cin; c0 += CK) {
+            commit();
+            __syncthreads();
+            if (c0 + CK < d.Cin) fetch(c0 + CK);
+            mma_taps();
+            __syncthreads();
+        }
+    } else {
     for (int c0 = 0; c0 < d.Cin; c0 += CK) {
         __syncthreads();                      // tables ready (first pass) / previous chunk's fragments consumed
         {
@@ -582,12 +657,8 @@ __global__ __launch_bounds__(256, 2) void conv_gather2_kernel(msmc_conv_desc d, 
             store_w(wv, wd);
         }
         __syncthreads();
-        for (int t = 0; t < d.ntaps; ++t) {
-            const T* ap = xt + (size_t)(arow + (d.tap_dy[t] - G.dyMin) * IW + (d.tap_dx[t] - G.dxMin)) * XS;
-            const T* bp = wt + (size_t)(t * BN + i) * XS;
-#pragma unroll
-            for (int ks = 0; ks < CK / 16; ++ks) mma_chunk16<NT>(ap + ks * 16, bp + ks * 16, 32 * XS, g, acc);
-        }
+        mma_taps();
+    }
     }
 
     // ---- epilogue: accumulators -> fp32 LDS tile -> vectors of VEC consecutive output channels
@@ -705,8 +776,10 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
     // pipelined kernel unless generation 3 is forced (A/B): measured per layer on MI355X
     const int gen = d->variant > 0 ? d->variant : msmc_gather_generation;
     const bool sb8 = gen == 4 || gen == 5 || (d->variant == 0 && (long)d->ntaps * 32 * NT * (Elt<T>::CK / Elt<T>::VEC) > 1024);
-    const bool ck1 = gen == 3 || gen == 5;
+    const bool ck1 = gen == 3 || gen == 5 || gen == 7;
+    const bool want16 = gen == 6 || gen == 7;                  // whole chunk in flight + prefetch (small grids)
     bool shallow = d->Cin < 4 * Elt<T>::CK || (d->Cin % Elt<T>::VEC) != 0 || gen >= 3 || d->variant == 2;
+    if (want16 && (d->Cin % Elt<T>::VEC) != 0) return MSMC_E_SHAPE;
     if (!shallow && gen == 2) {
         // heuristic without a tuned variant: deep reductions go to the pipelined kernel only where it would use
         // 256-point (or wider) M tiles, i.e. where it amortises the weight staging over a large grid
@@ -733,11 +806,19 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
                    !ck1) ? 2 : 1;
         if (lds_of(nt, ckm) > 160 * 1024 && nt == 2) nt = 1;
         const size_t lds2 = lds_of(nt, ckm);
+        const long chunk_vectors = (npix + (long)d->ntaps * 32 * nt) * (Elt<T>::CK * ckm / Elt<T>::VEC);
+        const bool sb16 = want16 && chunk_vectors <= 16L * 256 && (d->Cin % Elt<T>::VEC) == 0;
+        if (want16 && !sb16) return MSMC_E_SHAPE;              // the tuner skips candidates that do not apply
         if (lds2 <= 160 * 1024) {
             dim3 grid((unsigned)(G2.tilesX * G2.tilesY * d->B), (unsigned)((d->Cout + 32 * nt - 1) / (32 * nt)));
 #define CV2_GO(NT_, CKM_)                                                                                          \
     do {                                                                                                           \
-        if (sb8) {                                                                                                 \
+        if (sb16) {                                                                                                \
+            rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, NT_, CKM_, 16>, (int)lds2);                   \
+            if (rc2) return rc2;                                                                                   \
+            MSMC_LAUNCH((conv_gather2_kernel<T, NT_, CKM_, 16>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d, \
+                        G2);                                                                                       \
+        } else if (sb8) {                                                                                                 \
             rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, NT_, CKM_, 8>, (int)lds2);                    \
             if (rc2) return rc2;                                                                                   \
             MSMC_LAUNCH((conv_gather2_kernel<T, NT_, CKM_, 8>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d,  \
@@ -754,7 +835,7 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
             else if (ckm == 2) CV2_GO(1, 2);
             else CV2_GO(1, 1);
 #undef CV2_GO
-            msmc_conv_last = msmc_kname2("conv_gather2_kernel", EltName<T>::v, nt, ckm, sb8 ? 8 : 4);
+            msmc_conv_last = msmc_kname2("conv_gather2_kernel", EltName<T>::v, nt, ckm, sb16 ? 16 : sb8 ? 8 : 4);
             return msmc_check_launch();
         }
     }

@@ -89,3 +89,23 @@ def test_conv_kernels_small_and_thin_shapes(case):
     thin and odd channel counts, ragged tiles, strided and reflect-padded 2-D layers, against PyTorch."""
     _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', batch_offset=1)
     _convcases.check_conv_case(case, torch.float32, 2e-4, 'cpu')
+
+
+@pytest.mark.parametrize('gen', [6, 7])
+def test_gather_whole_chunk_in_flight_variant(gen):
+    """variant 6 / 7 of the gather kernel (whole channel chunk in flight, next chunk prefetched) where it applies"""
+    from msmctts_amd.hip import lib
+    cases = [c for c in _convcases.SMALL if c[0] in ('gen k7 d3 C32', 'mpd 16->64 p3', 'gen k11 d5 C64')]
+    lib.get().msmc_conv_set_gather_generation(gen)
+    try:
+        ran = 0
+        for case in cases:
+            try:
+                _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=('fwd', 'dgrad'))
+                _convcases.check_conv_case(case, torch.float32, 2e-4, 'cpu', parts=('fwd', 'dgrad'))
+                ran += 1
+            except RuntimeError as e:                 # MSMC_E_SHAPE: chunk larger than 16 vectors per work-item
+                assert 'msmc_conv_gather' in str(e)
+        assert ran >= 2
+    finally:
+        lib.get().msmc_conv_set_gather_generation(2)
