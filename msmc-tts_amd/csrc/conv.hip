@@ -889,9 +889,247 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
     return msmc_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Direct (matrix-core-free) kernels for the layers an MFMA tile cannot fill: the first discriminator layers
+// (2 -> 4 .. 8 -> 16 channels), the score layers (C -> 1) and their data gradients (1 -> C).  They are a few MB of
+// memory traffic each; a 128 x 32 MFMA tile spends its time staging 64-byte channel chunks that are 87-97 % padding.
+//   small: one work-item per lattice point, all (<= 16) output channels in registers, weights as floats in LDS
+//   dot  : one wave per lattice point, lanes over 16-byte channel vectors, butterfly reduction      (Cout == 1)
+//   outer: one work-item per (lattice point, 16-byte vector of output channels)                      (Cin == 1)
+// Same descriptor semantics (lattice, taps, padding rule, input activation, epilogue) as conv_gather_kernel.
+// ------------------------------------------------------------------------------------------------
+struct DirPoint {
+    int b, qy, qx;
+    size_t out;                 // element offset of the output pixel's channel 0
+};
+MSMC_DEV DirPoint dir_point(const msmc_conv_desc& d, long p) {
+    DirPoint r;
+    const int per = d.QH * d.QW;
+    r.b = (int)(p / per);
+    const int rem = (int)(p - (long)r.b * per);
+    r.qy = rem / d.QW;
+    r.qx = rem - r.qy * d.QW;
+    r.out = (((size_t)r.b * d.Hout + (d.oy0 + r.qy * d.osy)) * d.Wout + (d.ox0 + r.qx * d.osx)) * d.Cout;
+    return r;
+}
+// element offset of input pixel (channel 0) for tap t of a point, or -1 when the tap reads zero padding
+MSMC_DEV long dir_in(const msmc_conv_desc& d, const DirPoint& pt, int t) {
+    int iy = pt.qy * d.isy + d.iy0 + d.tap_dy[t], ix = pt.qx * d.isx + d.ix0 + d.tap_dx[t];
+    if (d.pad_mode == 1) {
+        iy = reflect_index(iy, d.Hin);
+        ix = reflect_index(ix, d.Win);
+    } else if (iy < 0 || iy >= d.Hin || ix < 0 || ix >= d.Win) {
+        return -1;
+    }
+    return (((long)pt.b * d.Hin + iy) * d.Win + ix) * d.Cin;
+}
+template <typename T>
+MSMC_DEV float dir_epilogue(const msmc_conv_desc& d, float v, size_t o, int co) {
+    if (d.bias) v = v + d.bias[co];
+    if (d.mask_src) v = v * (Elt<T>::ld((const T*)d.mask_src + o) > 0.f ? 1.f : d.mask_slope);
+    if (d.res) v = v + Elt<T>::ld((const T*)d.res + o);
+    if (d.res2) v = Elt<T>::ld((const T*)d.res2 + o) + v;
+    if (d.out_div != 1.f) v = v / d.out_div;
+    if (d.out_slope != 1.f) v = v > 0.f ? v : v * d.out_slope;
+    return v;
+}
+MSMC_DEV float dir_act(float f, float slope) { return (slope == 1.f || f > 0.f) ? f : f * slope; }
+
+template <typename T, int CI, int CO>
+__global__ __launch_bounds__(256) void conv_direct_small_kernel(msmc_conv_desc d, long npoints) {
+    MSMC_DYN_LDS(smem);
+    float* wl = (float*)smem;                       // [ntaps][CI][CO], zero beyond the real channels
+    for (int e = threadIdx.x; e < d.ntaps * CI * CO; e += 256) {
+        const int co = e % CO, ci = (e / CO) % CI, t = e / (CO * CI);
+        float v = 0.f;
+        if (co < d.Cout && ci < d.Cin) v = Elt<T>::ld((const T*)d.w + ((size_t)d.tap_w[t] * d.Cout + co) * d.Cin + ci);
+        wl[e] = v;
+    }
+    __syncthreads();
+    const T* x = (const T*)d.x;
+    T* out = (T*)d.out;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npoints; p += (long)gridDim.x * 256) {
+        const DirPoint pt = dir_point(d, p);
+        float acc[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = 0.f;
+        for (int t = 0; t < d.ntaps; ++t) {
+            const long off = dir_in(d, pt, t);
+            if (off < 0) continue;
+            alignas(16) T xv[CI];
+            if (CI * sizeof(T) == 16 && d.Cin == CI) {
+                *(u32x4*)xv = *(const u32x4*)(x + off);
+            } else if (CI * sizeof(T) == 8 && d.Cin == CI) {
+                *(u32x2*)xv = *(const u32x2*)(x + off);
+            } else if (CI * sizeof(T) == 4 && d.Cin == CI) {
+                *(unsigned int*)xv = *(const unsigned int*)(x + off);
+            } else {
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) xv[ci] = ci < d.Cin ? x[off + ci] : (T)0;
+            }
+            const float* wt = wl + t * CI * CO;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) {
+                const float xf = dir_act(Elt<T>::ld(&xv[ci]), d.in_slope);
+#pragma unroll
+                for (int co = 0; co < CO; ++co) acc[co] = fmaf(wt[ci * CO + co], xf, acc[co]);
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < CO; ++co)
+            if (co < d.Cout) Elt<T>::st(out + pt.out + co, dir_epilogue<T>(d, acc[co], pt.out + co, co));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_direct_dot_kernel(msmc_conv_desc d, long npoints) {
+    MSMC_DYN_LDS(smem);
+    constexpr int VEC = Elt<T>::VEC;
+    T* wl = (T*)smem;                               // [ntaps][Cin]
+    const int nvec = d.Cin / VEC;
+    for (int e = threadIdx.x; e < d.ntaps * nvec; e += 256) {
+        const int t = e / nvec, v = e - t * nvec;
+        *(u32x4*)(wl + (size_t)t * d.Cin + v * VEC) = *(const u32x4*)((const T*)d.w + (size_t)d.tap_w[t] * d.Cin + v * VEC);
+    }
+    __syncthreads();
+    const T* x = (const T*)d.x;
+    T* out = (T*)d.out;
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    for (long p = wave; p < npoints; p += nwaves) {
+        const DirPoint pt = dir_point(d, p);
+        float acc = 0.f;
+        for (int t = 0; t < d.ntaps; ++t) {
+            const long off = dir_in(d, pt, t);
+            if (off < 0) continue;
+            for (int v = lane; v < nvec; v += 64) {
+                alignas(16) T xv[VEC], wv[VEC];
+                *(u32x4*)xv = *(const u32x4*)(x + off + v * VEC);
+                *(u32x4*)wv = *(const u32x4*)(wl + (size_t)t * d.Cin + v * VEC);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q)
+                    acc = fmaf(Elt<T>::ld(&wv[q]), dir_act(Elt<T>::ld(&xv[q]), d.in_slope), acc);
+            }
+        }
+        for (int m = 1; m < 64; m <<= 1) acc = acc + wave_xor(acc, m);
+        if (lane == 0) Elt<T>::st(out + pt.out, dir_epilogue<T>(d, acc, pt.out, 0));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_direct_outer_kernel(msmc_conv_desc d, long nitems) {
+    MSMC_DYN_LDS(smem);
+    constexpr int VEC = Elt<T>::VEC;
+    T* wl = (T*)smem;                               // [ntaps][Cout]   (Cin == 1)
+    const int nvec = d.Cout / VEC;
+    for (int e = threadIdx.x; e < d.ntaps * nvec; e += 256) {
+        const int t = e / nvec, v = e - t * nvec;
+        *(u32x4*)(wl + (size_t)t * d.Cout + v * VEC) = *(const u32x4*)((const T*)d.w + (size_t)d.tap_w[t] * d.Cout + v * VEC);
+    }
+    __syncthreads();
+    const T* x = (const T*)d.x;
+    T* out = (T*)d.out;
+    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < nitems; it += (long)gridDim.x * 256) {
+        const long p = it / nvec;
+        const int v = (int)(it - p * nvec);
+        const DirPoint pt = dir_point(d, p);
+        float acc[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
+        for (int t = 0; t < d.ntaps; ++t) {
+            const long off = dir_in(d, pt, t);
+            if (off < 0) continue;
+            const float xf = dir_act(Elt<T>::ld(x + off), d.in_slope);
+            alignas(16) T wv[VEC];
+            *(u32x4*)wv = *(const u32x4*)(wl + (size_t)t * d.Cout + v * VEC);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] = fmaf(Elt<T>::ld(&wv[q]), xf, acc[q]);
+        }
+        const size_t o = pt.out + (size_t)v * VEC;
+        alignas(16) T ov[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) Elt<T>::st(&ov[q], dir_epilogue<T>(d, acc[q], o + q, v * VEC + q));
+        *(u32x4*)(out + o) = *(const u32x4*)ov;
+    }
+}
+
+// returns 1 when a direct kernel was launched, 0 when none applies, < 0 on error
+template <typename T>
+static int cv_direct_launch(const msmc_conv_desc* d, msmc_stream stream) {
+    constexpr int VEC = Elt<T>::VEC;
+    const long npoints = (long)d->B * d->QH * d->QW;
+    auto blocks = [](long items) {
+        long b = (items + 255) / 256;
+        const long cap = 16L * MSMC_NUM_CU;
+        return (unsigned)(b < 1 ? 1 : b > cap ? cap : b);
+    };
+    int rc;
+    if (d->Cin <= 8 && d->Cout <= 16 && !(d->Cin == 1 && d->Cout % VEC == 0 && d->Cout >= 4 * VEC)) {
+        const int CI = d->Cin <= 1 ? 1 : d->Cin <= 2 ? 2 : d->Cin <= 4 ? 4 : 8;
+        const int CO = d->Cout <= 1 ? 1 : d->Cout <= 4 ? 4 : d->Cout <= 8 ? 8 : 16;
+        const size_t lds = (size_t)d->ntaps * CI * CO * sizeof(float);
+#define DIR_GO(CI_, CO_)                                                                                            \
+    do {                                                                                                            \
+        rc = msmc_allow_lds((const void*)conv_direct_small_kernel<T, CI_, CO_>, (int)lds);                          \
+        if (rc) return rc;                                                                                          \
+        MSMC_LAUNCH((conv_direct_small_kernel<T, CI_, CO_>), dim3(blocks(npoints)), dim3(256), lds,                 \
+                    (msmc_stream_t)stream, *d, npoints);                                                            \
+    } while (0)
+#define DIR_CO(CI_)                                                                                                 \
+    do {                                                                                                            \
+        if (CO == 1) DIR_GO(CI_, 1);                                                                                \
+        else if (CO == 4) DIR_GO(CI_, 4);                                                                           \
+        else if (CO == 8) DIR_GO(CI_, 8);                                                                           \
+        else DIR_GO(CI_, 16);                                                                                       \
+    } while (0)
+        if (CI == 1) DIR_CO(1);
+        else if (CI == 2) DIR_CO(2);
+        else if (CI == 4) DIR_CO(4);
+        else DIR_CO(8);
+#undef DIR_CO
+#undef DIR_GO
+        msmc_conv_last = msmc_kname2("conv_direct_small_kernel", EltName<T>::v, CI, CO, 0);
+        rc = msmc_check_launch();
+        return rc ? rc : 1;
+    }
+    if (d->Cout == 1 && d->Cin % VEC == 0 && d->Cin >= 8 * VEC) {
+        const size_t lds = (size_t)d->ntaps * d->Cin * sizeof(T);
+        if (lds > 160 * 1024) return 0;
+        rc = msmc_allow_lds((const void*)conv_direct_dot_kernel<T>, (int)lds);
+        if (rc) return rc;
+        long b = (npoints + 3) / 4;
+        if (b > 8L * MSMC_NUM_CU) b = 8L * MSMC_NUM_CU;
+        MSMC_LAUNCH((conv_direct_dot_kernel<T>), dim3((unsigned)(b < 1 ? 1 : b)), dim3(256), lds, (msmc_stream_t)stream, *d,
+                    npoints);
+        msmc_conv_last = msmc_kname("conv_direct_dot_kernel", EltName<T>::v, 0, -1);
+        rc = msmc_check_launch();
+        return rc ? rc : 1;
+    }
+    if (d->Cin == 1 && d->Cout % VEC == 0) {
+        const size_t lds = (size_t)d->ntaps * d->Cout * sizeof(T);
+        if (lds > 160 * 1024) return 0;
+        const long nitems = npoints * (d->Cout / VEC);
+        rc = msmc_allow_lds((const void*)conv_direct_outer_kernel<T>, (int)lds);
+        if (rc) return rc;
+        MSMC_LAUNCH((conv_direct_outer_kernel<T>), dim3(blocks(nitems)), dim3(256), lds, (msmc_stream_t)stream, *d, nitems);
+        msmc_conv_last = msmc_kname("conv_direct_outer_kernel", EltName<T>::v, 0, -1);
+        rc = msmc_check_launch();
+        return rc ? rc : 1;
+    }
+    return 0;
+}
+
 extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
     if (!d || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0) return MSMC_E_SHAPE;
     ++msmc_conv_launches;
+    // variant 8 = direct kernels (E_SHAPE when none applies); without a tuned variant they are the default for the
+    // layers they cover (generation 1 keeps the MFMA kernels everywhere: A/B tests)
+    if (d->variant == 8 || (d->variant == 0 && msmc_gather_generation >= 2)) {
+        int rc = d->dtype == 0 ? cv_direct_launch<float>(d, stream)
+                 : d->dtype == 1 ? cv_direct_launch<unsigned short>(d, stream) : MSMC_E_SHAPE;
+        if (rc != 0) return rc < 0 ? rc : 0;
+        if (d->variant == 8) return MSMC_E_SHAPE;
+    }
     if (d->dtype == 0) return cv_launch<float>(d, stream);
     if (d->dtype == 1) return cv_launch<unsigned short>(d, stream);
     return MSMC_E_SHAPE;
