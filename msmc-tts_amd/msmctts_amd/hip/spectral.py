@@ -164,6 +164,19 @@ def mrd_image(x, n_fft, hop, dft, fb):
     return _MrdImage.apply(mag, F)
 
 
+def stft_magnitude(x, n_fft, hop, dft, lo):
+    """x (B, L) -> (B, T', F) magnitude sqrt(clamp(re^2 + im^2, lo)) of the centred STFT (torch.stft defaults:
+    reflect padding n_fft // 2, window already folded into ``dft``)."""
+    B, L = x.shape
+    F = n_fft // 2 + 1
+    T = L // hop + 1
+    lo_, n_eff = dft[2], dft[3]
+    fr = _Frames.apply(x, T, n_eff, _pad4(n_eff), hop, n_fft // 2 - lo_)
+    spec = _ConstGemm.apply(fr, dft[0], dft[1])
+    mag = _SpecMag.apply(spec, F, _pad4(F), lo, 1)
+    return mag[:, 0, :, :F]
+
+
 def log_mel(y, n_fft, hop, dft, mel, num_mels):
     """y (B, L) -> log-mel [B, 1, T', pad4(num_mels)] per MelLoss.mel_spectrogram (manual reflect pad, no centring)."""
     B, L = y.shape

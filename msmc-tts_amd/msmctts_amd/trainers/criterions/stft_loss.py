@@ -74,20 +74,36 @@ class MelLoss(nn.Module):
 
 
 class STFTLoss(nn.Module):
+    """Spectral-convergence + log-magnitude terms of one resolution (reference stft_loss.py:117-150).  The
+    magnitude comes from the HIP spectral front-end (framing + windowed-DFT GEMM on the fp32 matrix cores +
+    magnitude kernel, hip/spectral.py) instead of ``torch.stft``."""
+
     def __init__(self, fft_size, hop_size, win_size, mel_scale=False, sample_rate=24000):
         super().__init__()
         assert not mel_scale, 'mel-scaled MR-STFT is not used by any shipped config'
         self.fft_size, self.hop_size, self.win_size = fft_size, hop_size, win_size
+        self._cache = {}
+
+    def _dft(self, device):
+        key = str(device)
+        if key not in self._cache:
+            from ...hip import spectral
+            win = torch.hann_window(self.win_size)
+            left = (self.fft_size - self.win_size) // 2
+            win = F.pad(win, (left, self.fft_size - self.win_size - left))     # torch.stft centres the window
+            self._cache[key] = spectral.dft_basis(self.fft_size, win, False, device)
+        return self._cache[key]
 
     def _mag(self, x):
-        win = torch.hann_window(self.win_size, dtype=x.dtype, device=x.device)
-        s = torch.stft(x, self.fft_size, self.hop_size, self.win_size, win, return_complex=True)
-        return torch.sqrt(torch.clamp(s.real ** 2 + s.imag ** 2, min=1e-7)).transpose(2, 1)
+        """x (B, L) -> (B, T', F) magnitudes of the centred (reflect-padded) STFT, clamp 1e-7 under the root."""
+        from ...hip import spectral
+        return spectral.stft_magnitude(x, self.fft_size, self.hop_size, self._dft(x.device), 1e-7)
 
     def forward(self, predicts, targets):
-        p, t = self._mag(predicts), self._mag(targets)
-        sc = torch.norm(t - p, p='fro') / torch.norm(t, p='fro')
-        mag = F.l1_loss(torch.log(torch.clamp(p, min=1e-5, max=10)), torch.log(torch.clamp(t, min=1e-5, max=10)))
+        with torch.autocast(device_type=predicts.device.type, enabled=False):
+            p, t = self._mag(predicts), self._mag(targets)
+            sc = torch.norm(t - p, p='fro') / torch.norm(t, p='fro')
+            mag = F.l1_loss(torch.log(torch.clamp(p, min=1e-5, max=10)), torch.log(torch.clamp(t, min=1e-5, max=10)))
         return sc, mag
 
 

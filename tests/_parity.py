@@ -176,3 +176,24 @@ def check_train_steps(device, arm_reducer=False):
                     close(sd[n], v, 1e-5, 1e-4, what=n)
                 else:
                     close(sd[n], v, 4.5e-4, what=n)
+
+
+def check_mr_stft(device):
+    """MultiResolutionSTFTLoss of the product against the reference values in frontends.npz."""
+    from msmctts_amd.trainers.criterions.stft_loss import MultiResolutionSTFTLoss
+    z = load_npz('frontends.npz')
+    wav, wav2 = t(z['wav']).to(device), t(z['wav2']).to(device).requires_grad_(True)
+    r = MultiResolutionSTFTLoss()(wav2, wav)
+    for k, ref in (('sc_loss', 'mrstft.sc'), ('mag_loss', 'mrstft.mag')):
+        got, want = float(r[k]), float(z[ref])
+        assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), (k, got, want)
+    (r['sc_loss'] + r['mag_loss']).backward()           # gradient flows through the HIP front-end
+    g = wav2.grad
+    assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    # same gradient as autograd through the oracle's torch.stft formulation
+    from oracle import audio
+    w2 = t(z['wav2']).clone().requires_grad_(True)
+    ro = audio.mr_stft_loss(w2, t(z['wav']))
+    (ro['sc_loss'] + ro['mag_loss']).backward()
+    scale = float(w2.grad.abs().max())
+    close(g.cpu(), w2.grad, 2e-3 * scale, 0.0, what='d(mr_stft)/d(wav) (scale %.2e)' % scale)

@@ -224,3 +224,8 @@ def test_rccl_gradient_reducer_single_rank_matches_reference():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and 'REDUCER-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_multi_resolution_stft_loss_matches_reference():
+    """SURVEY 8a L2 on the HIP spectral front-end (framing, windowed-DFT GEMM, magnitude) against the fixture."""
+    _parity.check_mr_stft(DEV)

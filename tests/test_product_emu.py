@@ -109,3 +109,7 @@ def test_gather_whole_chunk_in_flight_variant(gen):
         assert ran >= 2
     finally:
         lib.get().msmc_conv_set_gather_generation(2)
+
+
+def test_multi_resolution_stft_loss_matches_reference():
+    _parity.check_mr_stft('cpu')
