@@ -135,12 +135,23 @@ long msmc_conv_launch_count(void);
 
 /* out[q] = epilogue( sum_t sum_ci w[tap_w[t]][co][ci] * act(x[in(q, t)][ci]) + bias[co] ). */
 int msmc_conv_gather(const msmc_conv_desc* desc, msmc_stream stream);
+/* n (<= 16) INDEPENDENT convolutions, each with msmc_conv_gather semantics, issued in as few launches as their kernel
+ * choices allow: members that resolve to the same second-generation kernel instantiation share one grid (the three
+ * parallel ResBlocks of a generator stage; one layer of the five period / six resolution sub-discriminators).  Each
+ * alone is a grid of tens to a few hundred workgroups; together they fill the 256 CUs. */
+int msmc_conv_gather_group(const msmc_conv_desc* descs, int n, msmc_stream stream);
+/* 0: grouped entry points launch their members one by one (A/B tests); default 1. */
+void msmc_conv_set_grouping(int on);
 
 /* dw[tap_w[t]][co][ci] += sum_{b,q} g[b][out(q)][co] * act(x[b][in(q, t)][ci])   (fp32 atomics; caller zeroes dw).
  * Geometry fields as for the forward convolution it differentiates; desc->x = x, desc->out unused,
  * g has the forward output's shape [B][Hout][Wout][Cout] and dtype; desc->mask_slope is a leaky-ReLU
  * slope applied to g on load (1 = identity).  db (may be NULL): db[co] += sum_{b,q} g[b][out(q)][co]. */
 int msmc_conv_wgrad(const msmc_conv_desc* desc, const void* g, float* dw, float* db, msmc_stream stream);
+/* n (<= 16) independent weight gradients, msmc_conv_wgrad semantics each (db may be NULL, or db[i] NULL); bf16
+ * second-generation members share one grid per (at most six) members. */
+int msmc_conv_wgrad_group(const msmc_conv_desc* descs, const void* const* g, float* const* dw, float* const* db, int n,
+                          msmc_stream stream);
 
 /* Weight-norm (torch weight_norm, dim=0) for MANY convolutions in one launch.
  * Item i: v [A][Bc][T] fp32 contiguous (A = dim 0, the normalised axis; T = taps), g [A] fp32.

@@ -53,6 +53,8 @@ static const char* msmc_kname(const char* base, const char* elt, int a, int b) {
     else snprintf(buf, sizeof(buf), "%s<%d>", base, a);
     return buf;
 }
+#define MSMC_GROUP_LIMIT 16         // members one grouped call may carry (split into launches of <= MSMC_GROUP_MAX)
+extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream);
 static int msmc_gather_generation = 2;          // 1 = first-generation forward / data-gradient kernels (A/B tests)
 extern "C" void msmc_conv_set_gather_generation(int n) { msmc_gather_generation = n; }
 static int msmc_wgrad_generation = 2;           // 1 = first-generation bf16 weight-gradient kernel (A/B tests)
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void conv_gather_pipe_kernel(msmc_conv_desc d,
 //     instead of one 2-byte access per element.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NT, int CKM, int SB>
-__global__ __launch_bounds__(256, 2) void conv_gather2_kernel(msmc_conv_desc d, CvGeom G) {
+MSMC_DEV void cv2_body(const msmc_conv_desc& d, const CvGeom& G, const int block_x, const int block_y) {
     MSMC_DYN_LDS(smem);
     // CKM = 2: 128-byte channel chunks (half the load -> LDS -> MFMA round trips of a deep reduction);
     // SB: weight-slice vectors a work-item keeps in flight per batch (4 or 8)
@@ -434,12 +436,12 @@ __global__ __launch_bounds__(256, 2) void conv_gather2_kernel(msmc_conv_desc d, 
     T* wt = xt + (size_t)npix * XS;                             // [ntaps][BN][XS]
     float* ot = (float*)region;                                 // [128][OS] epilogue tile (aliases xt / wt)
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 31, g = lane >> 5;
-    int bt = blockIdx.x;
+    int bt = block_x;
     const int tx_ = bt % G.tilesX;
     bt /= G.tilesX;
     const int ty_ = bt % G.tilesY;
     const int b = bt / G.tilesY;
-    const int co0 = blockIdx.y * BN;
+    const int co0 = block_y * BN;
     const int qy0 = ty_ * G.TH, qx0 = tx_ * G.TW;
     const int iyBase = qy0 * d.isy + d.iy0 + G.dyMin, ixBase = qx0 * d.isx + d.ix0 + G.dxMin;
 
@@ -717,6 +719,36 @@ __global__ __launch_bounds__(256, 2) void conv_gather2_kernel(msmc_conv_desc d, 
     }
 }
 
+
+template <typename T, int NT, int CKM, int SB>
+__global__ __launch_bounds__(256, 2) void conv_gather2_kernel(msmc_conv_desc d, CvGeom G) {
+    cv2_body<T, NT, CKM, SB>(d, G, blockIdx.x, blockIdx.y);
+}
+
+// Grouped launch: up to MSMC_GROUP_MAX independent convolutions (same kernel instantiation, any geometry) share one
+// grid -- the three parallel ResBlocks of a generator stage, the same layer of the five period / six resolution
+// sub-discriminators.  Each of them alone is a small grid (tens to a few hundred workgroups) that leaves most of
+// the 256 CUs idle at its head and tail; hipGraph branches do not overlap on this stack, one grid does.
+#define MSMC_GROUP_MAX 6
+struct CvGroupArgs {
+    int n;
+    int first[MSMC_GROUP_MAX + 1];      // first flattened block of member k (first[n] = total)
+    int nx[MSMC_GROUP_MAX];             // blocks along x of member k (flattened id = x + nx * y)
+    msmc_conv_desc d[MSMC_GROUP_MAX];
+    CvGeom G[MSMC_GROUP_MAX];
+};
+MSMC_DEV int cv_group_member(const int* first, int n) {
+    int k = 0;
+    while (k + 1 < n && (int)blockIdx.x >= first[k + 1]) ++k;
+    return k;
+}
+template <typename T, int NT, int CKM, int SB>
+__global__ __launch_bounds__(256, 2) void conv_gather2_group_kernel(CvGroupArgs a) {
+    const int k = cv_group_member(a.first, a.n);
+    const int id = blockIdx.x - a.first[k];
+    cv2_body<T, NT, CKM, SB>(a.d[k], a.G[k], id % a.nx[k], id / a.nx[k]);
+}
+
 static int cv_geometry(const msmc_conv_desc* d, CvGeom* G, int elt_bytes, int XS, int BN, size_t* lds,
                        int bm = CV_BM) {
     if (d->ntaps <= 0 || d->ntaps > MSMC_CONV_MAX_TAPS) return MSMC_E_SHAPE;
@@ -761,9 +793,18 @@ static int cv_try_pipe(const msmc_conv_desc* d, msmc_stream stream, bool* done) 
     return msmc_check_launch();
 }
 
+// Kernel choice of the second-generation gather for one descriptor (shared by the single and the grouped launch).
+struct Cv2Plan {
+    int applies;            // 1: second generation; 0: first-generation dispatch
+    int nt, ckm, sb;
+    CvGeom G;
+    size_t lds;
+    unsigned gx, gy;
+};
 template <typename T>
-static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
+static int cv2_plan(const msmc_conv_desc* d, Cv2Plan* pl, int* narrow_nt) {
     constexpr int XS = Elt<T>::CK + Elt<T>::VEC;
+    pl->applies = 0;
     int NT = d->Cout > 32 ? 2 : 1;
     if (NT == 2 && msmc_conv_narrow_when_small) {
         // few output pixels: 32-channel N tiles double the workgroup count (two co-resident workgroups per CU
@@ -772,8 +813,9 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
         const long wide = mt * ((d->Cout + 63) / 64);
         if (wide < MSMC_NUM_CU || (wide < 2 * MSMC_NUM_CU && d->Cin >= 256)) NT = 1;
     }
+    *narrow_nt = NT;
     // second generation for shallow reductions (fewer than 4 channel chunks); deep ones keep the register-prefetching
-    // pipelined kernel unless generation 3 is forced (A/B): measured per layer on MI355X
+    // pipelined kernel unless a variant says otherwise: measured per layer on MI355X
     const int gen = d->variant > 0 ? d->variant : msmc_gather_generation;
     const bool sb8 = gen == 4 || gen == 5 || (d->variant == 0 && (long)d->ntaps * 32 * NT * (Elt<T>::CK / Elt<T>::VEC) > 1024);
     const bool ck1 = gen == 3 || gen == 5 || gen == 7;
@@ -787,58 +829,113 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
         const long ntile = (d->Cout + 32 * NT - 1) / (32 * NT);
         shallow = (points / (CV_BM * 2)) * ntile < 2 * MSMC_NUM_CU;
     }
-    if (gen >= 2 && shallow && (long)d->Hin * d->Win * d->Cin < (1L << 31) &&
-        (long)d->Hout * d->Wout < (1L << 31)) {
-        CvGeom G2;
-        size_t unused;
-        int rc2 = cv_geometry(d, &G2, sizeof(T), XS, 32, &unused);
-        if (rc2) return rc2;
-        const long npix = (long)G2.IH * G2.IW;
-        const size_t tables = (((size_t)(npix + 128 + 16) * sizeof(int)) + 15) & ~(size_t)15;
-        auto lds_of = [&](int nt, int ckm) {
-            const size_t xs = (size_t)Elt<T>::CK * ckm + Elt<T>::VEC;
-            const size_t stage = ((size_t)npix + (size_t)d->ntaps * 32 * nt) * xs * sizeof(T);
-            const size_t epi = (size_t)128 * (32 * nt + 4) * sizeof(float);
-            return tables + (stage > epi ? stage : epi);
-        };
-        int nt = NT;
-        int ckm = (d->Cin >= 2 * Elt<T>::CK && (d->Cin % Elt<T>::VEC) == 0 && lds_of(nt, 2) <= 64 * 1024 &&
-                   !ck1) ? 2 : 1;
-        if (lds_of(nt, ckm) > 160 * 1024 && nt == 2) nt = 1;
-        const size_t lds2 = lds_of(nt, ckm);
+    if (!(gen >= 2 && shallow && (long)d->Hin * d->Win * d->Cin < (1L << 31) && (long)d->Hout * d->Wout < (1L << 31)))
+        return 0;
+    size_t unused;
+    int rc = cv_geometry(d, &pl->G, sizeof(T), XS, 32, &unused);
+    if (rc) return rc;
+    const long npix = (long)pl->G.IH * pl->G.IW;
+    const size_t tables = (((size_t)(npix + 128 + 16) * sizeof(int)) + 15) & ~(size_t)15;
+    auto lds_of = [&](int nt, int ckm) {
+        const size_t xs = (size_t)Elt<T>::CK * ckm + Elt<T>::VEC;
+        const size_t stage = ((size_t)npix + (size_t)d->ntaps * 32 * nt) * xs * sizeof(T);
+        const size_t epi = (size_t)128 * (32 * nt + 4) * sizeof(float);
+        return tables + (stage > epi ? stage : epi);
+    };
+    int nt = NT;
+    int ckm = (d->Cin >= 2 * Elt<T>::CK && (d->Cin % Elt<T>::VEC) == 0 && lds_of(nt, 2) <= 64 * 1024 && !ck1) ? 2 : 1;
+    if (lds_of(nt, ckm) > 160 * 1024 && nt == 2) nt = 1;
+    const size_t lds2 = lds_of(nt, ckm);
+    const long chunk_vectors = (npix + (long)d->ntaps * 32 * nt) * (Elt<T>::CK * ckm / Elt<T>::VEC);
+    const bool sb16 = want16 && chunk_vectors <= 16L * 256 && (d->Cin % Elt<T>::VEC) == 0;
+    if (want16 && !sb16) return MSMC_E_SHAPE;                  // the tuner skips candidates that do not apply
+    if (lds2 > 160 * 1024) return 0;
+    pl->applies = 1;
+    pl->nt = nt;
+    pl->ckm = ckm;
+    pl->sb = sb16 ? 16 : sb8 ? 8 : 4;
+    pl->lds = lds2;
+    pl->gx = (unsigned)(pl->G.tilesX * pl->G.tilesY * d->B);
+    pl->gy = (unsigned)((d->Cout + 32 * nt - 1) / (32 * nt));
+    return 0;
+}
+
+// the same plan with the tile / chunk / batch parameters imposed (a grouped launch runs ONE instantiation: members
+// adopt the parameters of the member with the largest grid when they can)
+template <typename T>
+static int cv2_plan_forced(const msmc_conv_desc* d, Cv2Plan* pl, int nt, int ckm, int sb) {
+    constexpr int XS = Elt<T>::CK + Elt<T>::VEC;
+    pl->applies = 0;
+    if ((long)d->Hin * d->Win * d->Cin >= (1L << 31) || (long)d->Hout * d->Wout >= (1L << 31)) return 0;
+    if (ckm == 2 && (d->Cin < 2 * Elt<T>::CK || (d->Cin % Elt<T>::VEC) != 0)) return 0;
+    size_t unused;
+    int rc = cv_geometry(d, &pl->G, sizeof(T), XS, 32, &unused);
+    if (rc) return rc;
+    const long npix = (long)pl->G.IH * pl->G.IW;
+    const size_t tables = (((size_t)(npix + 128 + 16) * sizeof(int)) + 15) & ~(size_t)15;
+    const size_t xs = (size_t)Elt<T>::CK * ckm + Elt<T>::VEC;
+    const size_t stage = ((size_t)npix + (size_t)d->ntaps * 32 * nt) * xs * sizeof(T);
+    const size_t epi = (size_t)128 * (32 * nt + 4) * sizeof(float);
+    const size_t lds = tables + (stage > epi ? stage : epi);
+    if (lds > 160 * 1024) return 0;
+    if (sb == 16) {
         const long chunk_vectors = (npix + (long)d->ntaps * 32 * nt) * (Elt<T>::CK * ckm / Elt<T>::VEC);
-        const bool sb16 = want16 && chunk_vectors <= 16L * 256 && (d->Cin % Elt<T>::VEC) == 0;
-        if (want16 && !sb16) return MSMC_E_SHAPE;              // the tuner skips candidates that do not apply
-        if (lds2 <= 160 * 1024) {
-            dim3 grid((unsigned)(G2.tilesX * G2.tilesY * d->B), (unsigned)((d->Cout + 32 * nt - 1) / (32 * nt)));
-#define CV2_GO(NT_, CKM_)                                                                                          \
+        if (chunk_vectors > 16L * 256 || (d->Cin % Elt<T>::VEC) != 0) return 0;
+    }
+    pl->applies = 1;
+    pl->nt = nt;
+    pl->ckm = ckm;
+    pl->sb = sb;
+    pl->lds = lds;
+    pl->gx = (unsigned)(pl->G.tilesX * pl->G.tilesY * d->B);
+    pl->gy = (unsigned)((d->Cout + 32 * nt - 1) / (32 * nt));
+    return 0;
+}
+
+// launch one second-generation kernel instantiation: SINGLE (desc, geometry) or GROUP (CvGroupArgs)
+#define CV2_INST(T_, NT_, CKM_, SB_, GROUP_, ...)                                                                  \
     do {                                                                                                           \
-        if (sb16) {                                                                                                \
-            rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, NT_, CKM_, 16>, (int)lds2);                   \
-            if (rc2) return rc2;                                                                                   \
-            MSMC_LAUNCH((conv_gather2_kernel<T, NT_, CKM_, 16>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d, \
-                        G2);                                                                                       \
-        } else if (sb8) {                                                                                                 \
-            rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, NT_, CKM_, 8>, (int)lds2);                    \
-            if (rc2) return rc2;                                                                                   \
-            MSMC_LAUNCH((conv_gather2_kernel<T, NT_, CKM_, 8>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d,  \
-                        G2);                                                                                       \
+        if (GROUP_) {                                                                                              \
+            rc = msmc_allow_lds((const void*)conv_gather2_group_kernel<T_, NT_, CKM_, SB_>, (int)lds);             \
+            if (rc) return rc;                                                                                     \
+            MSMC_LAUNCH((conv_gather2_group_kernel<T_, NT_, CKM_, SB_>), grid, dim3(256), lds,                     \
+                        (msmc_stream_t)stream, *group);                                                            \
         } else {                                                                                                   \
-            rc2 = msmc_allow_lds((const void*)conv_gather2_kernel<T, NT_, CKM_, 4>, (int)lds2);                    \
-            if (rc2) return rc2;                                                                                   \
-            MSMC_LAUNCH((conv_gather2_kernel<T, NT_, CKM_, 4>), grid, dim3(256), lds2, (msmc_stream_t)stream, *d,  \
-                        G2);                                                                                       \
+            rc = msmc_allow_lds((const void*)conv_gather2_kernel<T_, NT_, CKM_, SB_>, (int)lds);                   \
+            if (rc) return rc;                                                                                     \
+            MSMC_LAUNCH((conv_gather2_kernel<T_, NT_, CKM_, SB_>), grid, dim3(256), lds, (msmc_stream_t)stream,    \
+                        *d, *G);                                                                                   \
         }                                                                                                          \
     } while (0)
-            if (nt == 2 && ckm == 2) CV2_GO(2, 2);
-            else if (nt == 2) CV2_GO(2, 1);
-            else if (ckm == 2) CV2_GO(1, 2);
-            else CV2_GO(1, 1);
-#undef CV2_GO
-            msmc_conv_last = msmc_kname2("conv_gather2_kernel", EltName<T>::v, nt, ckm, sb16 ? 16 : sb8 ? 8 : 4);
-            return msmc_check_launch();
-        }
-    }
+template <typename T>
+static int cv2_dispatch(int nt, int ckm, int sb, dim3 grid, size_t lds, msmc_stream stream, const msmc_conv_desc* d,
+                        const CvGeom* G, const CvGroupArgs* group) {
+    int rc;
+    const bool grp = group != nullptr;
+#define CV2_SB(NT_, CKM_)                                                                                          \
+    do {                                                                                                           \
+        if (sb == 16) CV2_INST(T, NT_, CKM_, 16, grp);                                                             \
+        else if (sb == 8) CV2_INST(T, NT_, CKM_, 8, grp);                                                          \
+        else CV2_INST(T, NT_, CKM_, 4, grp);                                                                       \
+    } while (0)
+    if (nt == 2 && ckm == 2) CV2_SB(2, 2);
+    else if (nt == 2) CV2_SB(2, 1);
+    else if (ckm == 2) CV2_SB(1, 2);
+    else CV2_SB(1, 1);
+#undef CV2_SB
+    msmc_conv_last = msmc_kname2(grp ? "conv_gather2_group_kernel" : "conv_gather2_kernel", EltName<T>::v, nt, ckm, sb);
+    return msmc_check_launch();
+}
+
+template <typename T>
+static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
+    constexpr int XS = Elt<T>::CK + Elt<T>::VEC;
+    Cv2Plan pl;
+    int NT;
+    int rc0 = cv2_plan<T>(d, &pl, &NT);
+    if (rc0) return rc0;
+    if (pl.applies)
+        return cv2_dispatch<T>(pl.nt, pl.ckm, pl.sb, dim3(pl.gx, pl.gy), pl.lds, stream, d, &pl.G, nullptr);
     // the pipelined kernel pays a slot-table prologue: worth it from ~4 channel chunks on (measured per layer)
     const bool deep = d->Cin >= 4 * Elt<T>::CK || msmc_conv_pipeline_enabled >= 2;
     if ((d->Cin % Elt<T>::VEC) == 0 && msmc_conv_pipeline_enabled && deep) {
@@ -1132,6 +1229,103 @@ extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
     }
     if (d->dtype == 0) return cv_launch<float>(d, stream);
     if (d->dtype == 1) return cv_launch<unsigned short>(d, stream);
+    return MSMC_E_SHAPE;
+}
+
+// which direct kernel would take this descriptor: 0 none, 1 small, 2 dot, 3 outer (mirrors cv_direct_launch)
+static int cv_direct_kind(const msmc_conv_desc* d) {
+    const int VEC = d->dtype == 0 ? 4 : 8;
+    if (d->Cin <= 8 && d->Cout <= 16 && !(d->Cin == 1 && d->Cout % VEC == 0 && d->Cout >= 4 * VEC)) return 1;
+    if (d->Cout == 1 && d->Cin % VEC == 0 && d->Cin >= 8 * VEC)
+        return (size_t)d->ntaps * d->Cin * (d->dtype == 0 ? 4 : 2) <= 160 * 1024 ? 2 : 0;
+    if (d->Cin == 1 && d->Cout % VEC == 0) return (size_t)d->ntaps * d->Cout * (d->dtype == 0 ? 4 : 2) <= 160 * 1024 ? 3 : 0;
+    return 0;
+}
+static bool cv_takes_direct(const msmc_conv_desc* d) {
+    return (d->variant == 8 || (d->variant == 0 && msmc_gather_generation >= 2)) && cv_direct_kind(d) != 0;
+}
+
+static int msmc_conv_grouping = 1;              // 0: grouped entry points launch their members one by one (A/B)
+extern "C" void msmc_conv_set_grouping(int on) { msmc_conv_grouping = on; }
+
+template <typename T>
+static int cv_group_launch(const msmc_conv_desc* descs, int n, msmc_stream stream) {
+    Cv2Plan plans[MSMC_GROUP_LIMIT];
+    bool pending[MSMC_GROUP_LIMIT];
+    for (int i = 0; i < n; ++i) {
+        pending[i] = false;
+        const msmc_conv_desc* d = &descs[i];
+        int nt_unused;
+        int rc = cv_takes_direct(d) ? 0 : cv2_plan<T>(d, &plans[i], &nt_unused);
+        if (rc) return rc;
+        if (cv_takes_direct(d) || !plans[i].applies) {          // direct / first-generation kernels: one launch each
+            rc = msmc_conv_gather(d, stream);
+            if (rc) return rc;
+        } else {
+            pending[i] = true;
+        }
+    }
+    for (;;) {
+        // leader = pending member with the largest grid; the others adopt its kernel parameters when they can
+        int i = -1;
+        for (int j = 0; j < n; ++j)
+            if (pending[j] && (i < 0 || plans[j].gx * plans[j].gy > plans[i].gx * plans[i].gy)) i = j;
+        if (i < 0) break;
+        CvGroupArgs a;
+        a.n = 0;
+        int blocks = 0;
+        size_t lds = 0;
+        for (int jj = 0; jj < n && a.n < MSMC_GROUP_MAX; ++jj) {
+            const int j = jj == 0 ? i : (jj <= i ? jj - 1 : jj);          // leader first, then the rest in order
+            if (!pending[j]) continue;
+            if (plans[j].nt != plans[i].nt || plans[j].ckm != plans[i].ckm || plans[j].sb != plans[i].sb) {
+                Cv2Plan alt;
+                int rc = cv2_plan_forced<T>(&descs[j], &alt, plans[i].nt, plans[i].ckm, plans[i].sb);
+                if (rc) return rc;
+                if (!alt.applies) continue;
+                plans[j] = alt;
+            }
+            a.first[a.n] = blocks;
+            a.nx[a.n] = (int)plans[j].gx;
+            a.d[a.n] = descs[j];
+            a.G[a.n] = plans[j].G;
+            blocks += (int)(plans[j].gx * plans[j].gy);
+            if (plans[j].lds > lds) lds = plans[j].lds;
+            pending[j] = false;
+            ++a.n;
+        }
+        a.first[a.n] = blocks;
+        ++msmc_conv_launches;
+        int rc;
+        if (a.n == 1)
+            rc = cv2_dispatch<T>(plans[i].nt, plans[i].ckm, plans[i].sb, dim3(plans[i].gx, plans[i].gy), plans[i].lds, stream,
+                                 &a.d[0], &a.G[0], nullptr);
+        else
+            rc = cv2_dispatch<T>(plans[i].nt, plans[i].ckm, plans[i].sb, dim3((unsigned)blocks), lds, stream, nullptr, nullptr,
+                                 &a);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// n independent convolutions (msmc_conv_gather semantics each) issued as few launches as their kernel choices allow
+extern "C" int msmc_conv_gather_group(const msmc_conv_desc* descs, int n, msmc_stream stream) {
+    if (!descs || n <= 0 || n > MSMC_GROUP_LIMIT) return MSMC_E_SHAPE;
+    bool same = true;
+    for (int i = 0; i < n; ++i) {
+        const msmc_conv_desc* d = &descs[i];
+        if (d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0) return MSMC_E_SHAPE;
+        same = same && d->dtype == descs[0].dtype;
+    }
+    if (!msmc_conv_grouping || !same || n == 1) {
+        for (int i = 0; i < n; ++i) {
+            int rc = msmc_conv_gather(&descs[i], stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    if (descs[0].dtype == 0) return cv_group_launch<float>(descs, n, stream);
+    if (descs[0].dtype == 1) return cv_group_launch<unsigned short>(descs, n, stream);
     return MSMC_E_SHAPE;
 }
 
@@ -1632,9 +1826,9 @@ MSMC_DEV void wg2_stage_g(unsigned short* gt, const int* gmeta, const msmc_conv_
 }
 
 template <int TPW>
-__global__ __launch_bounds__(256, 2) void conv_wgrad2_kernel(msmc_conv_desc d, const unsigned short* __restrict__ gptr,
-                                                            float* __restrict__ dw, float* __restrict__ db, CvGeom G,
-                                                            Wg2Params P) {
+MSMC_DEV void wg2_body(const msmc_conv_desc& d, const unsigned short* __restrict__ gptr, float* __restrict__ dw,
+                       float* __restrict__ db, const CvGeom& G, const Wg2Params& P, const int block_x, const int block_y,
+                       const int block_z) {
     MSMC_DYN_LDS(smem);
     const int npix = G.IH * G.IW, TM = P.TM, XSx = P.XSx, XSg = P.XSg;
     unsigned short* xt = (unsigned short*)smem;                  // [npix][XSx]
@@ -1643,8 +1837,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad2_kernel(msmc_conv_desc d, c
     int* gmeta = xmeta + npix;                                   // [TM]   (mty << 16) | mtx, -1 past the tile
     const int tid = threadIdx.x, w = wave_uniform(tid >> 6), lane = tid & 63, L = lane & 15, half = (lane >> 4) & 1;
     const int g = lane >> 5;
-    const int co0 = blockIdx.y * 64;
-    const int ciTile = blockIdx.z / P.ntg, tg = blockIdx.z - ciTile * P.ntg;
+    const int co0 = block_y * 64;
+    const int ciTile = block_z / P.ntg, tg = block_z - ciTile * P.ntg;
     const int ci0 = ciTile * 64;
     for (int pi = tid; pi < npix; pi += 256) {
         const int ry = pi / G.IW;
@@ -1695,16 +1889,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad2_kernel(msmc_conv_desc d, c
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     if (d.dw_copies > 1) {                              // privatised accumulators: copy (split index mod R)
-        const int copy = blockIdx.x % d.dw_copies;
+        const int copy = block_x % d.dw_copies;
         dw += (size_t)copy * d.ntaps * d.Cout * d.Cin;
         if (db) db += (size_t)copy * d.Cout;
     }
-    const bool do_bias = (db != nullptr) && (blockIdx.z == 0);
+    const bool do_bias = (db != nullptr) && (block_z == 0);
     float bsum[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) bsum[q] = 0.f;
     const int nks = TM >> 4;
-    const int t0 = blockIdx.x * P.tilesPerWg;
+    const int t0 = block_x * P.tilesPerWg;
     int t1 = t0 + P.tilesPerWg;
     if (t1 > P.totalTiles) t1 = P.totalTiles;
 
@@ -1788,6 +1982,34 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad2_kernel(msmc_conv_desc d, c
     }
 }
 
+template <int TPW>
+__global__ __launch_bounds__(256, 2) void conv_wgrad2_kernel(msmc_conv_desc d, const unsigned short* __restrict__ gptr,
+                                                            float* __restrict__ dw, float* __restrict__ db, CvGeom G,
+                                                            Wg2Params P) {
+    wg2_body<TPW>(d, gptr, dw, db, G, P, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// grouped weight gradients (see conv_gather2_group_kernel): members flattened over their (split, co tile, ci tile x taps)
+struct Wg2GroupArgs {
+    int n;
+    int first[MSMC_GROUP_MAX + 1];
+    int nx[MSMC_GROUP_MAX], ny[MSMC_GROUP_MAX];
+    const unsigned short* g[MSMC_GROUP_MAX];
+    float* dw[MSMC_GROUP_MAX];
+    float* db[MSMC_GROUP_MAX];
+    msmc_conv_desc d[MSMC_GROUP_MAX];
+    CvGeom G[MSMC_GROUP_MAX];
+    Wg2Params P[MSMC_GROUP_MAX];
+};
+template <int TPW>
+__global__ __launch_bounds__(256, 2) void conv_wgrad2_group_kernel(Wg2GroupArgs a) {
+    const int k = cv_group_member(a.first, a.n);
+    int id = blockIdx.x - a.first[k];
+    const int bx = id % a.nx[k];
+    id /= a.nx[k];
+    wg2_body<TPW>(a.d[k], a.g[k], a.dw[k], a.db[k], a.G[k], a.P[k], bx, id % a.ny[k], id / a.ny[k]);
+}
+
 static int wg2_vec_elems(int channels, const void* base) {
     int ve = 8;                                   // largest power of two dividing the pixel pitch and the base
     while (ve > 1 && ((channels % ve) != 0 || (((size_t)base) % (2 * ve)) != 0)) ve >>= 1;
@@ -1795,8 +2017,15 @@ static int wg2_vec_elems(int channels, const void* base) {
 }
 static int wg2_row_stride(int cp) { return cp == 32 ? 48 : cp + 8; }   // rows of a 4-row transpose read on disjoint banks
 
-static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream) {
+struct Wg2Plan {
     Wg2Params P;
+    CvGeom G;
+    size_t lds;
+    int tpw;
+    unsigned gx, gy, gz;
+};
+static int wg2_plan(const msmc_conv_desc* d, const void* g, Wg2Plan* pl) {
+    Wg2Params& P = pl->P;
     const int cx = d->Cin > 64 ? 64 : d->Cin, cg = d->Cout > 64 ? 64 : d->Cout;
     P.vex = wg2_vec_elems(d->Cin, d->x);
     P.veg = wg2_vec_elems(d->Cout, g);
@@ -1806,7 +2035,7 @@ static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* 
     while ((P.veg << P.shg) < cg) ++P.shg;
     P.XSx = wg2_row_stride((cx + 3) & ~3);
     P.XSg = wg2_row_stride((cg + 3) & ~3);
-    CvGeom G;
+    CvGeom& G = pl->G;
     size_t lds_unused, lds;
     int TM = WG_TM, rc;
     for (;;) {                                     // shrink the lattice tile until two workgroups fit a CU
@@ -1845,21 +2074,34 @@ static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* 
     if (nsplit < 1) nsplit = 1;
     P.tilesPerWg = (P.totalTiles + nsplit - 1) / nsplit;
     nsplit = (P.totalTiles + P.tilesPerWg - 1) / P.tilesPerWg;
-    dim3 grid((unsigned)nsplit, (unsigned)((d->Cout + 63) / 64), (unsigned)(((d->Cin + 63) / 64) * P.ntg));
+    pl->lds = lds;
+    pl->tpw = tpw <= 4 ? (tpw < 1 ? 1 : tpw) : 5;
+    pl->gx = (unsigned)nsplit;
+    pl->gy = (unsigned)((d->Cout + 63) / 64);
+    pl->gz = (unsigned)(((d->Cin + 63) / 64) * P.ntg);
+    return 0;
+}
+
+static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream) {
+    Wg2Plan pl;
+    int rc = wg2_plan(d, g, &pl);
+    if (rc) return rc;
+    const dim3 grid(pl.gx, pl.gy, pl.gz);
+    const size_t lds = pl.lds;
     const unsigned short* gp = (const unsigned short*)g;
 #define WG2_GO(TP)                                                                                           \
     do {                                                                                                     \
         rc = msmc_allow_lds((const void*)conv_wgrad2_kernel<TP>, (int)lds);                                  \
         if (rc) return rc;                                                                                   \
-        MSMC_LAUNCH((conv_wgrad2_kernel<TP>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, db, G, P); \
+        MSMC_LAUNCH((conv_wgrad2_kernel<TP>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, gp, dw, db, pl.G, pl.P); \
     } while (0)
-    if (tpw <= 1) WG2_GO(1);
-    else if (tpw <= 2) WG2_GO(2);
-    else if (tpw <= 3) WG2_GO(3);
-    else if (tpw <= 4) WG2_GO(4);
+    if (pl.tpw == 1) WG2_GO(1);
+    else if (pl.tpw == 2) WG2_GO(2);
+    else if (pl.tpw == 3) WG2_GO(3);
+    else if (pl.tpw == 4) WG2_GO(4);
     else WG2_GO(5);
 #undef WG2_GO
-    msmc_conv_last = msmc_kname("conv_wgrad2_kernel", nullptr, tpw <= 4 ? (tpw < 1 ? 1 : tpw) : 5, -1);
+    msmc_conv_last = msmc_kname("conv_wgrad2_kernel", nullptr, pl.tpw, -1);
     return msmc_check_launch();
 }
 
@@ -1873,6 +2115,74 @@ extern "C" int msmc_conv_wgrad(const msmc_conv_desc* d, const void* g, float* dw
         return gen == 1 ? wg_launch<unsigned short>(d, g, dw, db, stream) : wg2_launch(d, g, dw, db, stream);
     }
     return MSMC_E_SHAPE;
+}
+
+// n independent weight gradients (msmc_conv_wgrad semantics each): bf16 second-generation members share grids
+extern "C" int msmc_conv_wgrad_group(const msmc_conv_desc* descs, const void* const* g, float* const* dw, float* const* db,
+                                     int n, msmc_stream stream) {
+    if (!descs || !g || !dw || n <= 0 || n > MSMC_GROUP_LIMIT) return MSMC_E_SHAPE;
+    Wg2Plan plans[MSMC_GROUP_LIMIT];
+    bool pending[MSMC_GROUP_LIMIT];
+    for (int i = 0; i < n; ++i) {
+        const msmc_conv_desc* d = &descs[i];
+        pending[i] = false;
+        const int gen = d->variant > 0 ? d->variant : msmc_wgrad_generation;
+        if (!msmc_conv_grouping || d->dtype != 1 || gen == 1 || n == 1) {
+            int rc = msmc_conv_wgrad(d, g[i], dw[i], db ? db[i] : nullptr, stream);
+            if (rc) return rc;
+            continue;
+        }
+        if (!g[i] || !dw[i] || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0 || d->ntaps <= 0 ||
+            d->ntaps > MSMC_CONV_MAX_TAPS)
+            return MSMC_E_SHAPE;
+        int rc = wg2_plan(d, g[i], &plans[i]);
+        if (rc) return rc;
+        pending[i] = true;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!pending[i]) continue;
+        Wg2GroupArgs a;
+        a.n = 0;
+        int blocks = 0, tpw = 1;
+        size_t lds = 0;
+        for (int j = i; j < n && a.n < MSMC_GROUP_MAX; ++j) {
+            if (!pending[j]) continue;
+            const int k = a.n++;
+            a.first[k] = blocks;
+            a.nx[k] = (int)plans[j].gx;
+            a.ny[k] = (int)plans[j].gy;
+            a.g[k] = (const unsigned short*)g[j];
+            a.dw[k] = dw[j];
+            a.db[k] = db ? db[j] : nullptr;
+            a.d[k] = descs[j];
+            a.G[k] = plans[j].G;
+            a.P[k] = plans[j].P;
+            blocks += (int)(plans[j].gx * plans[j].gy * plans[j].gz);
+            if (plans[j].lds > lds) lds = plans[j].lds;
+            if (plans[j].tpw > tpw) tpw = plans[j].tpw;        // the widest member sets the accumulator budget
+            pending[j] = false;
+        }
+        a.first[a.n] = blocks;
+        ++msmc_conv_launches;
+        int rc;
+        const dim3 grid((unsigned)blocks);
+#define WG2G_GO(TP)                                                                                          \
+    do {                                                                                                     \
+        rc = msmc_allow_lds((const void*)conv_wgrad2_group_kernel<TP>, (int)lds);                            \
+        if (rc) return rc;                                                                                   \
+        MSMC_LAUNCH((conv_wgrad2_group_kernel<TP>), grid, dim3(256), lds, (msmc_stream_t)stream, a);          \
+    } while (0)
+        if (tpw == 1) WG2G_GO(1);
+        else if (tpw == 2) WG2G_GO(2);
+        else if (tpw == 3) WG2G_GO(3);
+        else if (tpw == 4) WG2G_GO(4);
+        else WG2G_GO(5);
+#undef WG2G_GO
+        msmc_conv_last = msmc_kname("conv_wgrad2_group_kernel", nullptr, tpw, -1);
+        rc = msmc_check_launch();
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // ================================================================================================

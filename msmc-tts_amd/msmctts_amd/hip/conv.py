@@ -228,8 +228,8 @@ def _opt_ptr(t, like):
     return t.data_ptr()
 
 
-def conv_forward(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, out_div=1.0, out_slope=1.0):
-    """x [B,Hin,Win,Cin] -> [B,Hout,Wout,Cout];  w [kh*kw, Cout, Cin]."""
+def _forward_desc(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, out_div=1.0, out_slope=1.0):
+    """descriptor (pointers filled in) and output tensor of one forward convolution; nothing is launched"""
     key = (x.dtype, x.shape[0], w.shape[1], w.shape[2], in_slope, out_div, out_slope)
     plan = geom.plans.get(key)
     if plan is None:
@@ -246,8 +246,45 @@ def conv_forward(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, out_d
     desc.x, desc.w, desc.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
     desc.bias = bias.data_ptr() if bias is not None else None
     desc.res, desc.res2, desc.mask_src = _opt_ptr(res, x), _opt_ptr(res2, x), None
+    return desc, out
+
+
+def conv_forward(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, out_div=1.0, out_slope=1.0):
+    """x [B,Hin,Win,Cin] -> [B,Hout,Wout,Cout];  w [kh*kw, Cout, Cin]."""
+    desc, out = _forward_desc(x, w, geom, bias, in_slope, res, res2, out_div, out_slope)
     _gather(desc, lib.stream(x), 'msmc_conv_gather')
     return out
+
+
+def _snapshot(desc, stream):
+    """by-value copy of a (tuned) descriptor: grouped calls may meet the same cached descriptor twice"""
+    if not getattr(desc, '_tuned', False):
+        fn = lib.get().msmc_conv_gather
+        _tune('gather', desc, lambda: fn(ctypes.byref(desc), stream), _GATHER_CANDIDATES)
+    return lib.ConvDesc.from_buffer_copy(desc)
+
+
+def _gather_group(snaps, stream, what):
+    """independent launches issued together (msmc_conv_gather_group)"""
+    if len(snaps) == 1:
+        lib.check(lib.get().msmc_conv_gather(ctypes.byref(snaps[0]), stream), what)
+        return
+    arr = (lib.ConvDesc * len(snaps))(*snaps)
+    lib.check(lib.get().msmc_conv_gather_group(arr, len(snaps), stream), what)
+
+
+def conv_forward_group(items):
+    """``items``: list of dicts with the arguments of ``conv_forward`` -- independent convolutions (the parallel
+    ResBlocks of a generator stage, one layer of several sub-discriminators) issued as one grouped launch where their
+    kernel choices coincide.  Returns the outputs in order."""
+    stream = lib.stream(items[0]['x'])
+    snaps, outs = [], []
+    for it in items:
+        desc, out = _forward_desc(**it)
+        snaps.append(_snapshot(desc, stream))
+        outs.append(out)
+    _gather_group(snaps, stream, 'msmc_conv_gather_group')
+    return outs
 
 
 def _phases(size, k, stride, dil, pad):
@@ -265,13 +302,8 @@ def _phases(size, k, stride, dil, pad):
     return out
 
 
-def conv_dgrad(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
-    """Data gradient of ``conv_forward``: g [B,Hout,Wout,Cout] -> gx [B,Hin(+2p),Win(+2p),Cin].
-
-    wb [kh*kw, Cin, Cout] (channel roles swapped).  For reflect-padded convolutions the gradient is
-    returned on the PADDED grid (Hin+2py, Win+2px); the caller folds the border back.
-    Epilogue: gx = gx * lrelu'(mask_src) + res.
-    """
+def _dgrad_descs(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
+    """per-phase descriptors (pointers filled in; None = phase no tap reaches, already written) and the output"""
     key = ('d', g.dtype, g.shape[0], wb.shape[1], wb.shape[2], mask_slope)
     plan = geom.plans.get(key)
     if plan is None:
@@ -291,15 +323,42 @@ def conv_dgrad(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
     gx = torch.empty(oshape, dtype=g.dtype, device=g.device)
     gp, wp, op = g.data_ptr(), wb.data_ptr(), gx.data_ptr()
     mp, rp = _opt_ptr(mask_src, g), _opt_ptr(res, g)
-    stream = lib.stream(g)
+    live = []
     for desc, ry, rx in descs:
         if desc is None:                      # phase that no kernel tap reaches: gradient is the epilogue of zero
             gx[:, ry::geom.sy, rx::geom.sx] = 0 if res is None else res[:, ry::geom.sy, rx::geom.sx]
             continue
         desc.x, desc.w, desc.out, desc.mask_src, desc.res = gp, wp, op, mp, rp
         desc.bias = desc.res2 = None
+        live.append(desc)
+    return live, gx
+
+
+def conv_dgrad(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
+    """Data gradient of ``conv_forward``: g [B,Hout,Wout,Cout] -> gx [B,Hin(+2p),Win(+2p),Cin].
+
+    wb [kh*kw, Cin, Cout] (channel roles swapped).  For reflect-padded convolutions the gradient is
+    returned on the PADDED grid (Hin+2py, Win+2px); the caller folds the border back.
+    Epilogue: gx = gx * lrelu'(mask_src) + res.
+    """
+    descs, gx = _dgrad_descs(g, wb, geom, mask_src, mask_slope, res)
+    stream = lib.stream(g)
+    for desc in descs:
         _gather(desc, stream, 'msmc_conv_gather(dgrad)')
     return gx
+
+
+def conv_dgrad_group(items):
+    """``items``: list of dicts with the arguments of ``conv_dgrad``; all phases of all members in one grouped call"""
+    stream = lib.stream(items[0]['g'])
+    snaps, outs = [], []
+    for it in items:
+        live, gx = _dgrad_descs(**it)
+        snaps.extend(_snapshot(d, stream) for d in live)
+        outs.append(gx)
+    for i in range(0, len(snaps), 16):                   # msmc_conv_gather_group carries at most 16 members
+        _gather_group(snaps[i:i + 16], stream, 'msmc_conv_gather_group(dgrad)')
+    return outs
 
 
 def conv_transpose1d_forward(x, w, k, stride, padding, bias=None, in_slope=1.0):
@@ -355,6 +414,36 @@ def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None, db=None, copies=1):
     desc.dw_copies = copies              # dw / db then hold ``copies`` privatised accumulators back to back
     _wgrad(desc, g.data_ptr(), dw, db, lib.stream(x), 'msmc_conv_wgrad')
     return dw
+
+
+def conv_wgrad_group(items):
+    """``items``: list of dicts with the arguments of ``conv_wgrad`` (``dw`` required): independent weight gradients
+    issued as grouped launches (msmc_conv_wgrad_group)."""
+    stream = lib.stream(items[0]['x'])
+    snaps, gs, dws, dbs = [], [], [], []
+    for it in items:
+        x, g, geom = it['x'], it['g'], it['geom']
+        in_slope, dw, db, copies = it.get('in_slope', 1.0), it['dw'], it.get('db'), it.get('copies', 1)
+        key = ('w', x.dtype, x.shape[0], x.shape[3], g.shape[3], in_slope)
+        desc = geom.plans.get(key)
+        if desc is None or not getattr(desc, '_tuned', False):
+            conv_wgrad(x, g, geom, it['n_slices'], in_slope=in_slope, dw=dw, db=db, copies=copies)   # builds + tunes
+            continue
+        _dev_ok(x)
+        _dev_ok(g)
+        desc.x = desc.w = desc.out = x.data_ptr()
+        desc.bias = desc.mask_src = desc.res = desc.res2 = None
+        desc.dw_copies = copies
+        snaps.append(lib.ConvDesc.from_buffer_copy(desc))
+        gs.append(g.data_ptr())
+        dws.append(dw.data_ptr())
+        dbs.append(db.data_ptr() if db is not None else None)
+    for i in range(0, len(snaps), 16):
+        n = len(snaps[i:i + 16])
+        arr = (lib.ConvDesc * n)(*snaps[i:i + 16])
+        vp = ctypes.c_void_p * n
+        lib.check(lib.get().msmc_conv_wgrad_group(arr, vp(*gs[i:i + 16]), vp(*dws[i:i + 16]), vp(*dbs[i:i + 16]), n, stream),
+                  'msmc_conv_wgrad_group')
 
 
 def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None, copies=1):

@@ -69,7 +69,7 @@ def fork_join(streams, thunks, inputs=()):
 
 def make_streams(device, n):
     """n side streams on a CUDA/HIP device; [] on the CPU (kernel-interpreter tests run sequentially)."""
-    if device.type != 'cuda' or n <= 1 or os.environ.get('MSMC_STREAMS', '1') == '0':
+    if device.type != 'cuda' or n <= 1 or os.environ.get('MSMC_STREAMS', '1') == '0' or GROUPED:
         return []
     return [torch.cuda.Stream(device=device) for _ in range(n)]
 
@@ -287,6 +287,100 @@ class _HipConv(torch.autograd.Function):
         # weight_token (the layer's weight_v) only ties the output to the parameters in the autograd graph;
         # parameter gradients are produced in kernel layout and delivered by ConvBank._finish_backward.
         return gx, (g if ctx.has_res else None), (g if ctx.has_res2 else None), None, None, None, None, None, None
+
+
+class _HipConvGroup(torch.autograd.Function):
+    """Several independent convolutions of one bank as grouped launches (K.conv_forward_group / conv_dgrad_group /
+    conv_wgrad_group): the parallel ResBlocks of a generator stage, one layer of all period / resolution
+    sub-discriminators.  ``specs[k] = (layer, in_slope, out_slope, out_div, has_res, has_res2)``; ``tensors`` is the
+    flattened list x_k, [res_k], [res2_k], weight_token_k."""
+
+    @staticmethod
+    def forward(ctx, bank, specs, *tensors):
+        items, pos, members = [], 0, []
+        for layer, in_slope, out_slope, out_div, has_res, has_res2 in specs:
+            x = tensors[pos]
+            res = tensors[pos + 1] if has_res else None
+            res2 = tensors[pos + 1 + has_res] if has_res2 else None
+            members.append((pos, x))
+            pos += 2 + has_res + has_res2
+            assert layer.kind == 'conv'
+            items.append(dict(x=x, w=layer.wf, geom=layer.geom(x.shape[1], x.shape[2]), bias=layer.module.bias,
+                              in_slope=in_slope, res=res, res2=res2, out_div=out_div, out_slope=out_slope))
+        outs = K.conv_forward_group(items)
+        ctx.bank, ctx.specs, ctx.ntensors = bank, specs, len(tensors)
+        ctx.xpos = [m[0] for m in members]
+        saved = [m[1] for m in members] + [o if sp[2] != 1.0 else None for o, sp in zip(outs, specs)]
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        n = len(ctx.specs)
+        saved = ctx.saved_tensors
+        xs, outs = saved[:n], saved[n:]
+        bank = ctx.bank
+        grads = [None] * ctx.ntensors
+        gl, d_items, d_members, w_items = [], [], [], []
+        for k, (layer, in_slope, out_slope, out_div, has_res, has_res2) in enumerate(ctx.specs):
+            g = gs[k].contiguous()
+            if out_slope != 1.0:                       # y = lrelu(z): dz = dy * (y > 0 ? 1 : slope)
+                g = K.lrelu_bwd(g, outs[k], out_slope)
+            if out_div != 1.0:
+                g = g / out_div
+            gl.append(g)
+            x = xs[k]
+            geom = layer.geom(x.shape[1], x.shape[2])
+            pos = ctx.xpos[k]
+            if ctx.needs_input_grad[2 + pos]:
+                mask = x if in_slope != 1.0 else None
+                if layer.reflect:
+                    d_items.append(dict(g=g, wb=layer.wb, geom=geom))
+                else:
+                    d_items.append(dict(g=g, wb=layer.wb, geom=geom, mask_src=mask, mask_slope=in_slope))
+                d_members.append(k)
+            if layer.weight.requires_grad:
+                w_items.append(dict(x=x, g=g, geom=geom, n_slices=layer.taps, in_slope=in_slope, dw=layer.dw, db=layer.db,
+                                    copies=layer.dw_copies))
+            if has_res:
+                grads[pos + 1] = g
+            if has_res2:
+                grads[pos + 1 + has_res] = g
+            if has_res or has_res2:
+                bank._hold.append(g)                  # shared gradient: see _HipConv.backward
+        if d_items:
+            for k, gx in zip(d_members, K.conv_dgrad_group(d_items)):
+                layer, in_slope = ctx.specs[k][0], ctx.specs[k][1]
+                if layer.reflect:
+                    x = xs[k]
+                    gx = K.reflect_fold(gx, x.shape[1], x.shape[2], layer.padding[0],
+                                        mask_src=x if in_slope != 1.0 else None, slope=in_slope)
+                grads[ctx.xpos[k]] = gx
+        if w_items:
+            K.conv_wgrad_group(w_items)
+        bank._queue_finish()
+        return (None, None) + tuple(grads)
+
+
+def hip_conv_group(bank, members):
+    """``members``: list of dicts(layer=, x=, res=None, res2=None, in_slope=1, out_slope=1, out_div=1) -- independent
+    convolutions issued together.  Returns the outputs in order."""
+    specs, tensors = [], []
+    for m in members:
+        res, res2 = m.get('res'), m.get('res2')
+        specs.append((m['layer'], float(m.get('in_slope', 1.0)), float(m.get('out_slope', 1.0)),
+                      float(m.get('out_div', 1.0)), int(res is not None), int(res2 is not None)))
+        tensors.append(m['x'])
+        if res is not None:
+            tensors.append(res)
+        if res2 is not None:
+            tensors.append(res2)
+        tensors.append(m['layer'].weight)
+    return list(_HipConvGroup.apply(bank, tuple(specs), *tensors))
+
+
+# grouped launches replace the fork/join streams (forked hipGraph branches do not overlap; one grid does)
+GROUPED = os.environ.get('MSMC_GROUPED', '1') != '0'
 
 
 def hip_conv(bank, layer, x, res=None, res2=None, in_slope=1.0, out_slope=1.0, out_div=1.0):

@@ -75,6 +75,8 @@ _SIGNATURES.update({
     'msmc_mse_const_multi_fwd': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp]),
     'msmc_mse_const_multi_bwd': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp]),
     'msmc_conv_gather': (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    'msmc_conv_gather_group': (_i, [ctypes.POINTER(ConvDesc), _i, _vp]),
+    'msmc_conv_set_grouping': (None, [_i]),
     'msmc_conv_set_pipeline': (None, [_i]),
     'msmc_conv_set_wgrad_split': (None, [_i]),
     'msmc_conv_set_wgrad_generation': (None, [_i]),
@@ -83,6 +85,8 @@ _SIGNATURES.update({
     'msmc_conv_launch_count': (ctypes.c_long, []),
     'msmc_conv_set_narrow': (None, [_i]),
     'msmc_conv_wgrad': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    'msmc_conv_wgrad_group': (_i, [ctypes.POINTER(ConvDesc), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                              _i, _vp]),
     'msmc_wn_prepare_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_wn_backward_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_colsum': (_i, [_vp, _vp, ctypes.c_long, _i, _i, _vp]),

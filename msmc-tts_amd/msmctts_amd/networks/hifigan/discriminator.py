@@ -9,7 +9,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ...hip.convnet import ConvBank, fork_join, hip_conv, make_streams
+from ...hip import convnet
+from ...hip.convnet import ConvBank, fork_join, hip_conv, hip_conv_group, make_streams
 from ...utils.audio import TorchSTFT
 from ..layers import WNConv2d
 from .common import get_padding
@@ -141,7 +142,44 @@ class Discriminator(nn.Module):
             y = y.unsqueeze(1)
         bank, (mrd, mpd) = self._hip()
         bank.prepare(self.hip_dtype)
+        if convnet.GROUPED:
+            return self._forward_grouped(bank, mrd, mpd, y)
         # the ten sub-discriminators are independent chains of small launches: one HIP stream each
         outs = fork_join(self._streams, self.mrd.thunks(bank, mrd, y, self.hip_dtype) +
                          self.mpd.thunks(bank, mpd, y, self.hip_dtype), inputs=(y,))
         return [o[0] for o in outs], [o[1] for o in outs]
+
+    def _forward_grouped(self, bank, mrd, mpd, y):
+        """The sub-discriminators advance layer by layer: layer i of all six resolution (all five period) stacks is ONE
+        grouped launch (hip_conv_group) -- each of them alone is a grid of tens to hundreds of workgroups."""
+        dtype = self.hip_dtype
+        assert self.mrd.domain == 'double', 'every shipped config uses the two-channel (mag, log-mag) image'
+        wav = y.squeeze(1)
+        xs = [stft.image_cl(wav).to(dtype) for stft in self.mrd.stfts]
+        r_fmaps = [[] for _ in xs]
+        last = len(mrd[0]) - 1
+        for i in range(last + 1):
+            xs = hip_conv_group(bank, [dict(layer=mrd[j][i], x=xs[j], out_slope=LRELU_SLOPE if i < last else 1.0)
+                                       for j in range(len(xs))])
+            if i < last:
+                for j, x in enumerate(xs):
+                    r_fmaps[j].append(x.permute(0, 3, 1, 2))    # aliased post-activation map, see module docstring
+        r_scores = [x.permute(0, 3, 1, 2) for x in xs]
+        ps = []
+        for d in self.mpd.discriminators:
+            b, c, t = y.shape
+            x = y
+            if t % d.period != 0:
+                x = F.pad(x, (0, d.period - (t % d.period)), 'reflect')
+                t = x.shape[2]
+            ps.append(x.reshape(b, t // d.period, d.period, 1).to(dtype))      # C == 1: NCHW and NHWC coincide
+        p_fmaps = [[] for _ in ps]
+        nl = len(mpd[0]) - 1
+        for i in range(nl):
+            ps = hip_conv_group(bank, [dict(layer=mpd[j][i], x=ps[j], in_slope=LRELU_SLOPE if i > 0 else 1.0)
+                                       for j in range(len(ps))])
+            for j, x in enumerate(ps):
+                p_fmaps[j].append(x.permute(0, 3, 1, 2))
+        ps = hip_conv_group(bank, [dict(layer=mpd[j][nl], x=ps[j], in_slope=LRELU_SLOPE) for j in range(len(ps))])
+        p_scores = [torch.flatten(x, 1, -1) for x in ps]
+        return r_scores + p_scores, r_fmaps + p_fmaps

@@ -9,7 +9,8 @@ weight norm is folded into one weight-preparation launch per forward.
 import torch
 import torch.nn as nn
 
-from ...hip.convnet import ConvBank, fork_join, hip_conv, make_streams
+from ...hip import convnet
+from ...hip.convnet import ConvBank, fork_join, hip_conv, hip_conv_group, make_streams
 from ..layers import WNConv1d, WNConvTranspose1d
 from .common import LRELU_SLOPE, ResBlock1
 
@@ -66,7 +67,20 @@ class Generator(nn.Module):
                     y = hip_conv(bank, c2s[m], t, res=y, in_slope=LRELU_SLOPE)
                 return y, hip_conv(bank, c1s[-1], y, in_slope=LRELU_SLOPE)
 
-            parts = fork_join(self._streams, [lambda j=j: block_body(j) for j in range(nk)], inputs=(x,))
+            if convnet.GROUPED:
+                # the nk parallel ResBlocks advance in lock step: one grouped launch per convolution position
+                ys = [x] * nk
+                nu = len(L['rb'][i * nk][0])
+                for m in range(nu - 1):
+                    ts = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][0][m], x=ys[j], in_slope=LRELU_SLOPE)
+                                               for j in range(nk)])
+                    ys = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][1][m], x=ts[j], res=ys[j],
+                                                    in_slope=LRELU_SLOPE) for j in range(nk)])
+                ts = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][0][nu - 1], x=ys[j], in_slope=LRELU_SLOPE)
+                                           for j in range(nk)])
+                parts = list(zip(ys, ts))
+            else:
+                parts = fork_join(self._streams, [lambda j=j: block_body(j) for j in range(nk)], inputs=(x,))
             xs = None
             for j, (y, t) in enumerate(parts):    # block outputs, running sum over blocks and the final mean
                 xs = hip_conv(bank, L['rb'][i * nk + j][1][-1], t, res=y, res2=xs, in_slope=LRELU_SLOPE,
