@@ -264,13 +264,46 @@ def _snapshot(desc, stream):
     return lib.ConvDesc.from_buffer_copy(desc)
 
 
-def _gather_group(snaps, stream, what):
-    """independent launches issued together (msmc_conv_gather_group)"""
+def _group_choice(kind, snaps, grouped_fn, single_fn):
+    """1: issue the members as one grouped call, 0: one by one.  Timed once per member-shape combination (grouping
+    fills the chip for small grids but imposes one kernel instantiation on all members)."""
     if len(snaps) == 1:
-        lib.check(lib.get().msmc_conv_gather(ctypes.byref(snaps[0]), stream), what)
-        return
+        return 0
+    if not AUTOTUNE or lib._host_pointers_ok or torch.cuda.is_current_stream_capturing():
+        return 1
+    sig = (kind,) + tuple(_signature(d) + (d.variant, d.split_shift) for d in snaps)
+    hit = TUNED.get(sig)
+    if hit is None:
+        times = {}
+        for name, fn in (('group', grouped_fn), ('single', single_fn)):
+            fn()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(3):
+                fn()
+            e.record()
+            e.synchronize()
+            times[(name, 0)] = s.elapsed_time(e) / 3.0
+        hit = TUNED[sig] = (1 if times[('group', 0)] <= times[('single', 0)] else 0, 0, times)
+    return hit[0]
+
+
+def _gather_group(snaps, stream, what):
+    """independent launches issued together (msmc_conv_gather_group) when that is the faster way for these shapes"""
+    L = lib.get()
+
+    def single():
+        for d in snaps:
+            lib.check(L.msmc_conv_gather(ctypes.byref(d), stream), what)
+
+    if len(snaps) == 1:
+        return single()
     arr = (lib.ConvDesc * len(snaps))(*snaps)
-    lib.check(lib.get().msmc_conv_gather_group(arr, len(snaps), stream), what)
+
+    def grouped():
+        lib.check(L.msmc_conv_gather_group(arr, len(snaps), stream), what)
+
+    (grouped if _group_choice('gather-group', snaps, grouped, single) else single)()
 
 
 def conv_forward_group(items):
@@ -438,12 +471,37 @@ def conv_wgrad_group(items):
         gs.append(g.data_ptr())
         dws.append(dw.data_ptr())
         dbs.append(db.data_ptr() if db is not None else None)
+    L = lib.get()
     for i in range(0, len(snaps), 16):
-        n = len(snaps[i:i + 16])
-        arr = (lib.ConvDesc * n)(*snaps[i:i + 16])
+        part = snaps[i:i + 16]
+        n = len(part)
+        arr = (lib.ConvDesc * n)(*part)
         vp = ctypes.c_void_p * n
-        lib.check(lib.get().msmc_conv_wgrad_group(arr, vp(*gs[i:i + 16]), vp(*dws[i:i + 16]), vp(*dbs[i:i + 16]), n, stream),
-                  'msmc_conv_wgrad_group')
+        ga, dwa, dba = vp(*gs[i:i + 16]), vp(*dws[i:i + 16]), vp(*dbs[i:i + 16])
+
+        def grouped():
+            lib.check(L.msmc_conv_wgrad_group(arr, ga, dwa, dba, n, stream), 'msmc_conv_wgrad_group')
+
+        def single():
+            for k in range(n):
+                lib.check(L.msmc_conv_wgrad(ctypes.byref(part[k]), ga[k], dwa[k], dba[k], stream), 'msmc_conv_wgrad')
+
+        if n == 1:
+            single()
+            continue
+        # the timing launches accumulate into the real dW / db: harmless only on scratch, so time on copies
+        if AUTOTUNE and not lib._host_pointers_ok and not torch.cuda.is_current_stream_capturing():
+            sig = ('wgrad-group',) + tuple(_signature(d) + (d.variant, d.split_shift) for d in part)
+            if sig not in TUNED:
+                keep = (dwa, dba)
+                scratch = [torch.zeros(max(1, d.dw_copies) * d.ntaps * d.Cout * d.Cin, dtype=torch.float32,
+                                       device=items[0]['x'].device) for d in part]
+                sb = [torch.zeros(max(1, d.dw_copies) * d.Cout, dtype=torch.float32, device=items[0]['x'].device)
+                      for d in part]
+                dwa, dba = vp(*[t.data_ptr() for t in scratch]), vp(*[t.data_ptr() for t in sb])
+                _group_choice('wgrad-group', part, grouped, single)
+                dwa, dba = keep
+        (grouped if _group_choice('wgrad-group', part, grouped, single) else single)()
 
 
 def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None, copies=1):

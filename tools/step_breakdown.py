@@ -59,6 +59,9 @@ wrap(hipconv, 'conv_wgrad', 'wgrad', lambda x, g, geom, n, *a, **k: (sh(x), sh(g
 wrap(hipconv, 'conv_transpose1d_forward', 'convT', lambda x, w, *a, **k: (sh(x), sh(w), ''))
 wrap(hipconv, 'conv_transpose1d_dgrad', 'convT dgrad', lambda g, w, *a, **k: (sh(g), sh(w), ''))
 wrap(hipconv, 'conv_transpose1d_wgrad', 'convT wgrad', lambda x, g, *a, **k: (sh(x), sh(g), ''))
+wrap(hipconv, 'conv_forward_group', 'fwd-group', lambda items: (sh(items[0]['x']), sh(items[0]['w']), 'n=%d' % len(items)))
+wrap(hipconv, 'conv_dgrad_group', 'dgrad-group', lambda items: (sh(items[0]['g']), sh(items[0]['wb']), 'n=%d' % len(items)))
+wrap(hipconv, 'conv_wgrad_group', 'wgrad-group', lambda items: (sh(items[0]['x']), sh(items[0]['g']), 'n=%d' % len(items)))
 wrap(hipconv, 'reflect_fold', 'reflect_fold', lambda g, *a, **k: (sh(g), '', ''))
 wrap(hipconv, 'lrelu_bwd', 'lrelu_bwd', lambda g, *a, **k: (sh(g), '', ''))
 wrap(hipconv, 'colsum', 'colsum', lambda g, *a, **k: (sh(g), '', ''))
