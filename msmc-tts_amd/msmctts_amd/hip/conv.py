@@ -77,11 +77,15 @@ def load_tuned(path=None):
     import json
     try:
         with open(path or TUNE_CACHE) as f:
-            for row in json.load(f)['choices']:
-                TUNED[tuple(_thaw(row['key']))] = (int(row['variant']), int(row['split_shift']),
-                                                   {tuple(_thaw(k)): v for k, v in row.get('ms', [])})
+            rows = json.load(f)['choices']
     except Exception:
-        pass
+        return
+    for row in rows:
+        try:
+            TUNED[tuple(_thaw(row['key']))] = (int(row['variant']), int(row['split_shift']),
+                                               {tuple(_thaw(k)): v for k, v in row.get('ms', [])})
+        except Exception:
+            continue
 
 
 def save_tuned(path=None):

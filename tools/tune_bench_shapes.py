@@ -35,7 +35,7 @@ for rep in range(2):                                      # two passes: keep the
         if k in conv.TUNED:
             times = {c: min(t, v[2].get(c, t)) for c, t in conv.TUNED[k][2].items()}
             best = min(times, key=times.get)
-            conv.TUNED[k] = (best[0], best[1], times)
+            conv.TUNED[k] = ((1 if best[0] == 'group' else 0) if isinstance(best[0], str) else best[0], best[1], times)
         else:
             conv.TUNED[k] = v
     del trainer
