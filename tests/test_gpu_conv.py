@@ -146,3 +146,54 @@ def test_autotune_picks_a_variant_and_every_variant_is_correct():
         conv._GATHER_CANDIDATES, conv._WGRAD_CANDIDATES = saved[0], saved[1]
         conv.TUNED.clear()
         conv.TUNED.update(saved[2])
+
+
+def test_grouped_launches_equal_single_launches():
+    """msmc_conv_gather_group / msmc_conv_wgrad_group against one launch per member: bit-identical outputs (forward,
+    strided data gradient with several phases) and equal weight / bias gradients"""
+    from msmctts_amd.hip import conv, lib
+    torch.manual_seed(0)
+    B, C, L = 4, 64, 700
+    x = torch.randn(B, 1, L, C, device=DEV).bfloat16()
+    items, refs = [], []
+    for k, dil in ((3, 1), (7, 3), (11, 1)):
+        geom = conv.Geometry(1, L, (1, k), (1, 1), (1, dil), (0, dil * (k - 1) // 2), False)
+        w = (torch.randn(k, C, C, device=DEV) / (C * k) ** 0.5).bfloat16()
+        b = torch.randn(C, device=DEV)
+        res = torch.randn(B, 1, L, C, device=DEV).bfloat16()
+        items.append(dict(x=x, w=w, geom=geom, bias=b, in_slope=0.1, res=res))
+        refs.append(conv.conv_forward(x, w, geom, bias=b, in_slope=0.1, res=res))
+    L0 = lib.get()
+    for grouping in (1, 0):
+        L0.msmc_conv_set_grouping(grouping)
+        try:
+            saved = dict(conv.TUNED)
+            conv.TUNED.update({k: (1, 0, v[2]) for k, v in conv.TUNED.items() if k[0].endswith('-group')})
+            outs = conv.conv_forward_group(items)
+        finally:
+            L0.msmc_conv_set_grouping(1)
+        for o, r in zip(outs, refs):
+            assert torch.equal(o, r)
+    gitems, grefs = [], []
+    for k, s_ in ((5, 3), (5, 1)):
+        H, W, Ci, Co = 300, 3, 16, 64
+        geom = conv.Geometry(H, W, (k, 1), (s_, 1), (1, 1), (2, 0), False)
+        g = torch.randn(B, geom.Hout, geom.Wout, Co, device=DEV).bfloat16()
+        wb = (torch.randn(k, Ci, Co, device=DEV) / (Co * k) ** 0.5).bfloat16()
+        xm = torch.randn(B, H, W, Ci, device=DEV).bfloat16()
+        gitems.append(dict(g=g, wb=wb, geom=geom, mask_src=xm, mask_slope=0.2))
+        grefs.append(conv.conv_dgrad(g, wb, geom, mask_src=xm, mask_slope=0.2))
+    for o, r in zip(conv.conv_dgrad_group(gitems), grefs):
+        assert torch.equal(o, r)
+    witems, wrefs = [], []
+    for k, dil in ((3, 1), (7, 3), (11, 1)):
+        geom = conv.Geometry(1, L, (1, k), (1, 1), (1, dil), (0, dil * (k - 1) // 2), False)
+        g = torch.randn(B, 1, L, C, device=DEV).bfloat16()
+        dw_ref, db_ref = torch.zeros(k, C, C, device=DEV), torch.zeros(C, device=DEV)
+        conv.conv_wgrad(x, g, geom, k, in_slope=0.1, dw=dw_ref, db=db_ref)
+        dw, db = torch.zeros(2, k, C, C, device=DEV), torch.zeros(2, C, device=DEV)
+        witems.append(dict(x=x, g=g, geom=geom, n_slices=k, in_slope=0.1, dw=dw.view(-1), db=db.view(-1), copies=2))
+        wrefs.append((dw_ref, db_ref, dw, db))
+    conv.conv_wgrad_group(witems)
+    for dw_ref, db_ref, dw, db in wrefs:
+        assert rel(dw.sum(0), dw_ref) < 1e-4 and rel(db.sum(0), db_ref) < 1e-4
