@@ -150,8 +150,9 @@ def test_autotune_picks_a_variant_and_every_variant_is_correct():
 
 
 def test_grouped_launches_equal_single_launches():
-    """msmc_conv_gather_group / msmc_conv_wgrad_group against one launch per member: bit-identical outputs (forward,
-    strided data gradient with several phases) and equal weight / bias gradients"""
+    """msmc_conv_gather_group / msmc_conv_wgrad_group against one launch per member (forward, strided data gradient with
+    several phases, weight / bias gradients).  Members of a group run the leader's kernel instantiation, whose fp32
+    accumulation order over (channel chunk, tap) can differ from a member's own tuned kernel: equal to bf16 rounding."""
     from msmctts_amd.hip import conv, lib
     torch.manual_seed(0)
     B, C, L = 4, 64, 700
@@ -174,7 +175,7 @@ def test_grouped_launches_equal_single_launches():
         finally:
             L0.msmc_conv_set_grouping(1)
         for o, r in zip(outs, refs):
-            assert torch.equal(o, r)
+            assert rel(o, r) < 1e-2
     gitems, grefs = [], []
     for k, s_ in ((5, 3), (5, 1)):
         H, W, Ci, Co = 300, 3, 16, 64
@@ -185,7 +186,7 @@ def test_grouped_launches_equal_single_launches():
         gitems.append(dict(g=g, wb=wb, geom=geom, mask_src=xm, mask_slope=0.2))
         grefs.append(conv.conv_dgrad(g, wb, geom, mask_src=xm, mask_slope=0.2))
     for o, r in zip(conv.conv_dgrad_group(gitems), grefs):
-        assert torch.equal(o, r)
+        assert rel(o, r) < 1e-2
     witems, wrefs = [], []
     for k, dil in ((3, 1), (7, 3), (11, 1)):
         geom = conv.Geometry(1, L, (1, k), (1, 1), (1, dil), (0, dil * (k - 1) // 2), False)
