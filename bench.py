@@ -241,7 +241,7 @@ def main():
         return (2.0 * pts * wb.shape[1] * wb.shape[2] * wb.shape[0],
                 (g.numel() + nx * (2 if mask_src is not None else 1) + wb.numel()) * esz(g))
 
-    def wgrad_work(x, g, geom, n_slices, *a, **k):
+    def wgrad_work(x, g, geom, n_slices, *a, **k):       # (also called with the keyword items of conv_wgrad_group)
         pts = x.shape[0] * geom.Hout * geom.Wout
         return (2.0 * pts * g.shape[3] * x.shape[3] * n_slices,
                 (x.numel() + g.numel()) * esz(x) + 8.0 * n_slices * g.shape[3] * x.shape[3])
@@ -263,10 +263,22 @@ def main():
     def last_kernel():
         return lib.get().msmc_conv_last_kernel().decode()
 
+    def group_work(one):
+        def work(items):
+            f = b = 0.0
+            for it in items:
+                df, db_ = one(**it)
+                f, b = f + df, b + db_
+            return f, b
+        return work
+
     for fn, work in (('conv_forward', conv_work), ('conv_dgrad', dgrad_work), ('conv_wgrad', wgrad_work),
                      ('conv_transpose1d_forward', convt_work), ('conv_transpose1d_dgrad', convt_dgrad_work),
                      ('conv_transpose1d_wgrad', convt_wgrad_work)):
         timer.wrap(hipconv, fn, last_kernel, work)
+    # grouped calls (several members per launch) are attributed to the symbol of their last launch
+    for fn, one in (('conv_forward_group', conv_work), ('conv_dgrad_group', dgrad_work), ('conv_wgrad_group', wgrad_work)):
+        timer.wrap(hipconv, fn, last_kernel, group_work(one))
 
     def step(i):
         if not trainer.use_graphs:
