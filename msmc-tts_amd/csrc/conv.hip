@@ -1033,7 +1033,7 @@ MSMC_DEV float dir_epilogue(const msmc_conv_desc& d, float v, size_t o, int co) 
 MSMC_DEV float dir_act(float f, float slope) { return (slope == 1.f || f > 0.f) ? f : f * slope; }
 
 template <typename T, int CI, int CO>
-__global__ __launch_bounds__(256) void conv_direct_small_kernel(msmc_conv_desc d, long npoints) {
+MSMC_DEV void dir_small_body(const msmc_conv_desc& d, const long npoints, const int block, const int nblocks) {
     MSMC_DYN_LDS(smem);
     float* wl = (float*)smem;                       // [ntaps][CI][CO], zero beyond the real channels
     for (int e = threadIdx.x; e < d.ntaps * CI * CO; e += 256) {
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(256) void conv_direct_small_kernel(msmc_conv_desc d
     __syncthreads();
     const T* x = (const T*)d.x;
     T* out = (T*)d.out;
-    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < npoints; p += (long)gridDim.x * 256) {
+    for (long p = (long)block * 256 + threadIdx.x; p < npoints; p += (long)nblocks * 256) {
         const DirPoint pt = dir_point(d, p);
         float acc[CO];
 #pragma unroll
@@ -1078,8 +1078,24 @@ __global__ __launch_bounds__(256) void conv_direct_small_kernel(msmc_conv_desc d
     }
 }
 
+struct DirGroupArgs {
+    int n;
+    int first[MSMC_GROUP_MAX + 1];
+    long items[MSMC_GROUP_MAX];         // lattice points (small, dot) or point x vector items (outer) of member k
+    msmc_conv_desc d[MSMC_GROUP_MAX];
+};
+template <typename T, int CI, int CO>
+__global__ __launch_bounds__(256) void conv_direct_small_kernel(msmc_conv_desc d, long npoints) {
+    dir_small_body<T, CI, CO>(d, npoints, blockIdx.x, gridDim.x);
+}
+template <typename T, int CI, int CO>
+__global__ __launch_bounds__(256) void conv_direct_small_group_kernel(DirGroupArgs a) {
+    const int k = cv_group_member(a.first, a.n);
+    dir_small_body<T, CI, CO>(a.d[k], a.items[k], blockIdx.x - a.first[k], a.first[k + 1] - a.first[k]);
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void conv_direct_dot_kernel(msmc_conv_desc d, long npoints) {
+MSMC_DEV void dir_dot_body(const msmc_conv_desc& d, const long npoints, const int block, const int nblocks) {
     MSMC_DYN_LDS(smem);
     constexpr int VEC = Elt<T>::VEC;
     T* wl = (T*)smem;                               // [ntaps][Cin]
@@ -1092,7 +1108,7 @@ __global__ __launch_bounds__(256) void conv_direct_dot_kernel(msmc_conv_desc d, 
     const T* x = (const T*)d.x;
     T* out = (T*)d.out;
     const int lane = threadIdx.x & 63;
-    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    const long wave = (long)block * 4 + (threadIdx.x >> 6), nwaves = (long)nblocks * 4;
     for (long p = wave; p < npoints; p += nwaves) {
         const DirPoint pt = dir_point(d, p);
         float acc = 0.f;
@@ -1114,7 +1130,17 @@ __global__ __launch_bounds__(256) void conv_direct_dot_kernel(msmc_conv_desc d, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void conv_direct_outer_kernel(msmc_conv_desc d, long nitems) {
+__global__ __launch_bounds__(256) void conv_direct_dot_kernel(msmc_conv_desc d, long npoints) {
+    dir_dot_body<T>(d, npoints, blockIdx.x, gridDim.x);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void conv_direct_dot_group_kernel(DirGroupArgs a) {
+    const int k = cv_group_member(a.first, a.n);
+    dir_dot_body<T>(a.d[k], a.items[k], blockIdx.x - a.first[k], a.first[k + 1] - a.first[k]);
+}
+
+template <typename T>
+MSMC_DEV void dir_outer_body(const msmc_conv_desc& d, const long nitems, const int block, const int nblocks) {
     MSMC_DYN_LDS(smem);
     constexpr int VEC = Elt<T>::VEC;
     T* wl = (T*)smem;                               // [ntaps][Cout]   (Cin == 1)
@@ -1126,7 +1152,7 @@ __global__ __launch_bounds__(256) void conv_direct_outer_kernel(msmc_conv_desc d
     __syncthreads();
     const T* x = (const T*)d.x;
     T* out = (T*)d.out;
-    for (long it = (long)blockIdx.x * 256 + threadIdx.x; it < nitems; it += (long)gridDim.x * 256) {
+    for (long it = (long)block * 256 + threadIdx.x; it < nitems; it += (long)nblocks * 256) {
         const long p = it / nvec;
         const int v = (int)(it - p * nvec);
         const DirPoint pt = dir_point(d, p);
@@ -1148,6 +1174,16 @@ __global__ __launch_bounds__(256) void conv_direct_outer_kernel(msmc_conv_desc d
         for (int q = 0; q < VEC; ++q) Elt<T>::st(&ov[q], dir_epilogue<T>(d, acc[q], o + q, v * VEC + q));
         *(u32x4*)(out + o) = *(const u32x4*)ov;
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_direct_outer_kernel(msmc_conv_desc d, long nitems) {
+    dir_outer_body<T>(d, nitems, blockIdx.x, gridDim.x);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void conv_direct_outer_group_kernel(DirGroupArgs a) {
+    const int k = cv_group_member(a.first, a.n);
+    dir_outer_body<T>(a.d[k], a.items[k], blockIdx.x - a.first[k], a.first[k + 1] - a.first[k]);
 }
 
 // returns 1 when a direct kernel was launched, 0 when none applies, < 0 on error
@@ -1245,25 +1281,132 @@ static bool cv_takes_direct(const msmc_conv_desc* d) {
     return (d->variant == 8 || (d->variant == 0 && msmc_gather_generation >= 2)) && cv_direct_kind(d) != 0;
 }
 
+struct DirKey {
+    int kind, ci, co;
+};
+static DirKey cv_direct_key(const msmc_conv_desc* d) {
+    DirKey k = {cv_direct_kind(d), 0, 0};
+    if (k.kind == 1) {
+        k.ci = d->Cin <= 1 ? 1 : d->Cin <= 2 ? 2 : d->Cin <= 4 ? 4 : 8;
+        k.co = d->Cout <= 1 ? 1 : d->Cout <= 4 ? 4 : d->Cout <= 8 ? 8 : 16;
+    }
+    return k;
+}
+
+// direct-kernel members with one key (same kernel instantiation) as one grid
+template <typename T>
+static int cv_direct_group_launch(const msmc_conv_desc* const* members, int m, DirKey key, msmc_stream stream) {
+    constexpr int VEC = Elt<T>::VEC;
+    DirGroupArgs a;
+    a.n = m;
+    int blocks = 0;
+    size_t lds = 0;
+    for (int k = 0; k < m; ++k) {
+        const msmc_conv_desc* d = members[k];
+        const long npoints = (long)d->B * d->QH * d->QW;
+        long items = npoints, nb;
+        size_t l;
+        if (key.kind == 1) {
+            nb = (npoints + 255) / 256;
+            if (nb > 8L * MSMC_NUM_CU) nb = 8L * MSMC_NUM_CU;
+            l = (size_t)d->ntaps * key.ci * key.co * sizeof(float);
+        } else if (key.kind == 2) {
+            nb = (npoints + 3) / 4;
+            if (nb > 4L * MSMC_NUM_CU) nb = 4L * MSMC_NUM_CU;
+            l = (size_t)d->ntaps * d->Cin * sizeof(T);
+        } else {
+            items = npoints * (d->Cout / VEC);
+            nb = (items + 255) / 256;
+            if (nb > 8L * MSMC_NUM_CU) nb = 8L * MSMC_NUM_CU;
+            l = (size_t)d->ntaps * d->Cout * sizeof(T);
+        }
+        if (nb < 1) nb = 1;
+        a.first[k] = blocks;
+        a.items[k] = items;
+        a.d[k] = *d;
+        blocks += (int)nb;
+        if (l > lds) lds = l;
+    }
+    a.first[m] = blocks;
+    int rc;
+    const dim3 grid((unsigned)blocks);
+    if (key.kind == 1) {
+#define DIRG_GO(CI_, CO_)                                                                                           \
+    do {                                                                                                            \
+        rc = msmc_allow_lds((const void*)conv_direct_small_group_kernel<T, CI_, CO_>, (int)lds);                    \
+        if (rc) return rc;                                                                                          \
+        MSMC_LAUNCH((conv_direct_small_group_kernel<T, CI_, CO_>), grid, dim3(256), lds, (msmc_stream_t)stream, a); \
+    } while (0)
+#define DIRG_CO(CI_)                                                                                                \
+    do {                                                                                                            \
+        if (key.co == 1) DIRG_GO(CI_, 1);                                                                           \
+        else if (key.co == 4) DIRG_GO(CI_, 4);                                                                      \
+        else if (key.co == 8) DIRG_GO(CI_, 8);                                                                      \
+        else DIRG_GO(CI_, 16);                                                                                      \
+    } while (0)
+        if (key.ci == 1) DIRG_CO(1);
+        else if (key.ci == 2) DIRG_CO(2);
+        else if (key.ci == 4) DIRG_CO(4);
+        else DIRG_CO(8);
+#undef DIRG_CO
+#undef DIRG_GO
+        msmc_conv_last = msmc_kname2("conv_direct_small_group_kernel", EltName<T>::v, key.ci, key.co, 0);
+    } else if (key.kind == 2) {
+        rc = msmc_allow_lds((const void*)conv_direct_dot_group_kernel<T>, (int)lds);
+        if (rc) return rc;
+        MSMC_LAUNCH((conv_direct_dot_group_kernel<T>), grid, dim3(256), lds, (msmc_stream_t)stream, a);
+        msmc_conv_last = msmc_kname("conv_direct_dot_group_kernel", EltName<T>::v, 0, -1);
+    } else {
+        rc = msmc_allow_lds((const void*)conv_direct_outer_group_kernel<T>, (int)lds);
+        if (rc) return rc;
+        MSMC_LAUNCH((conv_direct_outer_group_kernel<T>), grid, dim3(256), lds, (msmc_stream_t)stream, a);
+        msmc_conv_last = msmc_kname("conv_direct_outer_group_kernel", EltName<T>::v, 0, -1);
+    }
+    return msmc_check_launch();
+}
+
 static int msmc_conv_grouping = 1;              // 0: grouped entry points launch their members one by one (A/B)
 extern "C" void msmc_conv_set_grouping(int on) { msmc_conv_grouping = on; }
 
 template <typename T>
 static int cv_group_launch(const msmc_conv_desc* descs, int n, msmc_stream stream) {
     Cv2Plan plans[MSMC_GROUP_LIMIT];
-    bool pending[MSMC_GROUP_LIMIT];
+    bool pending[MSMC_GROUP_LIMIT], direct[MSMC_GROUP_LIMIT];
     for (int i = 0; i < n; ++i) {
-        pending[i] = false;
+        pending[i] = direct[i] = false;
         const msmc_conv_desc* d = &descs[i];
         int nt_unused;
         int rc = cv_takes_direct(d) ? 0 : cv2_plan<T>(d, &plans[i], &nt_unused);
         if (rc) return rc;
-        if (cv_takes_direct(d) || !plans[i].applies) {          // direct / first-generation kernels: one launch each
+        if (cv_takes_direct(d)) {
+            direct[i] = true;
+        } else if (!plans[i].applies) {                         // first-generation kernels: one launch each
             rc = msmc_conv_gather(d, stream);
             if (rc) return rc;
         } else {
             pending[i] = true;
         }
+    }
+    for (int i = 0; i < n; ++i) {                               // direct kernels: one grid per kernel instantiation
+        if (!direct[i]) continue;
+        const DirKey key = cv_direct_key(&descs[i]);
+        const msmc_conv_desc* members[MSMC_GROUP_MAX];
+        int m = 0;
+        for (int j = i; j < n && m < MSMC_GROUP_MAX; ++j) {
+            if (!direct[j]) continue;
+            const DirKey kj = cv_direct_key(&descs[j]);
+            if (kj.kind != key.kind || kj.ci != key.ci || kj.co != key.co) continue;
+            members[m++] = &descs[j];
+            direct[j] = false;
+        }
+        int rc;
+        if (m == 1) {
+            rc = msmc_conv_gather(members[0], stream);
+        } else {
+            ++msmc_conv_launches;
+            rc = cv_direct_group_launch<T>(members, m, key, stream);
+        }
+        if (rc) return rc;
     }
     for (;;) {
         // leader = pending member with the largest grid; the others adopt its kernel parameters when they can
