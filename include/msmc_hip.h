@@ -193,6 +193,13 @@ int msmc_reflect_fold(const void* gp, const void* mask_src, void* gx, int B, int
 /* gx = g * (y > 0 ? 1 : slope): backward of a leaky ReLU from its OUTPUT y (sign-preserving), n elements. */
 int msmc_lrelu_bwd(const void* g, const void* y, void* gx, long n, float slope, int dtype, msmc_stream stream);
 
+/* Multi-tensor forms of the two helpers above: n (<= 6) tensors per launch (the same layer of all resolution
+ * sub-discriminators), 16-byte channel vectors where every member allows. */
+int msmc_reflect_fold_multi(const void* const* gp, const void* const* mask_src, void* const* gx, const int* B, const int* H,
+                            const int* W, const int* C, int n, int p, float slope, int dtype, msmc_stream stream);
+int msmc_lrelu_bwd_multi(const void* const* g, const void* const* y, void* const* gx, const long* nelem, int n, float slope,
+                         int dtype, msmc_stream stream);
+
 /* Column sums: out[c] = sum_rows g[row][c] (bias gradients); g dtype as above, out fp32 (overwritten). */
 int msmc_colsum(const void* g, float* out, long rows, int C, int dtype, msmc_stream stream);
 

@@ -2495,9 +2495,121 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const T* __restrict__
     }
 }
 
+// multi-tensor, vectorised versions of the two element-wise backward helpers (one launch for the same layer of all
+// resolution sub-discriminators; V consecutive channels per work-item)
+struct FoldMultiArgs {
+    int n, p;
+    float slope;
+    int first[MSMC_GROUP_MAX + 1];
+    const void* gp[MSMC_GROUP_MAX];
+    const void* mask[MSMC_GROUP_MAX];
+    void* gx[MSMC_GROUP_MAX];
+    int H[MSMC_GROUP_MAX], W[MSMC_GROUP_MAX], C[MSMC_GROUP_MAX];
+    long items[MSMC_GROUP_MAX];         // B * H * W * (C / V)
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void reflect_fold_multi_kernel(FoldMultiArgs a) {
+    const int k = cv_group_member(a.first, a.n);
+    const int nb = a.first[k + 1] - a.first[k], p = a.p;
+    const int H = a.H[k], W = a.W[k], C = a.C[k], CV = C / V, Hp = H + 2 * p, Wp = W + 2 * p;
+    const T* gp = (const T*)a.gp[k];
+    const T* mask = (const T*)a.mask[k];
+    T* gx = (T*)a.gx[k];
+    for (long e = (long)(blockIdx.x - a.first[k]) * 256 + threadIdx.x; e < a.items[k]; e += (long)nb * 256) {
+        const int c = (int)(e % CV) * V;
+        long r = e / CV;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = y + p;
+        if (y >= 1 && y <= p) ys[ny++] = p - y;
+        if (y <= H - 2 && y >= H - 1 - p) ys[ny++] = 2 * (H - 1) - y + p;
+        xs[nx++] = x + p;
+        if (x >= 1 && x <= p) xs[nx++] = p - x;
+        if (x <= W - 2 && x >= W - 1 - p) xs[nx++] = 2 * (W - 1) - x + p;
+        float sacc[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) sacc[q] = 0.f;
+        for (int i = 0; i < ny; ++i)
+            for (int j = 0; j < nx; ++j) {
+                const T* src = gp + (((size_t)b * Hp + ys[i]) * Wp + xs[j]) * C + c;
+                alignas(16) T v[V];
+                if (V * sizeof(T) == 16) *(u32x4*)v = *(const u32x4*)src;
+                else v[0] = src[0];
+#pragma unroll
+                for (int q = 0; q < V; ++q) sacc[q] = sacc[q] + Elt<T>::ld(&v[q]);
+            }
+        const size_t o = (((size_t)b * H + y) * W + x) * C + c;
+        alignas(16) T mv[V], ov[V];
+        if (mask) {
+            if (V * sizeof(T) == 16) *(u32x4*)mv = *(const u32x4*)(mask + o);
+            else mv[0] = mask[o];
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            float sv = sacc[q];
+            if (mask) sv = sv * (Elt<T>::ld(&mv[q]) > 0.f ? 1.f : a.slope);
+            Elt<T>::st(&ov[q], sv);
+        }
+        if (V * sizeof(T) == 16) *(u32x4*)(gx + o) = *(const u32x4*)ov;
+        else gx[o] = ov[0];
+    }
+}
+
+struct LreluMultiArgs {
+    int n;
+    float slope;
+    int first[MSMC_GROUP_MAX + 1];
+    const void* g[MSMC_GROUP_MAX];
+    const void* y[MSMC_GROUP_MAX];
+    void* gx[MSMC_GROUP_MAX];
+    long items[MSMC_GROUP_MAX];         // elements / V
+};
+template <typename T, int V>
+__global__ __launch_bounds__(256) void lrelu_bwd_multi_kernel(LreluMultiArgs a) {
+    const int k = cv_group_member(a.first, a.n);
+    const int nb = a.first[k + 1] - a.first[k];
+    const T* g = (const T*)a.g[k];
+    const T* y = (const T*)a.y[k];
+    T* gx = (T*)a.gx[k];
+    for (long e = (long)(blockIdx.x - a.first[k]) * 256 + threadIdx.x; e < a.items[k]; e += (long)nb * 256) {
+        alignas(16) T gv[V], yv[V], ov[V];
+        if (V * sizeof(T) == 16) {
+            *(u32x4*)gv = *(const u32x4*)(g + e * V);
+            *(u32x4*)yv = *(const u32x4*)(y + e * V);
+        } else {
+            gv[0] = g[e];
+            yv[0] = y[e];
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const float gf = Elt<T>::ld(&gv[q]);
+            Elt<T>::st(&ov[q], Elt<T>::ld(&yv[q]) > 0.f ? gf : gf * a.slope);
+        }
+        if (V * sizeof(T) == 16) *(u32x4*)(gx + e * V) = *(const u32x4*)ov;
+        else gx[e] = ov[0];
+    }
+}
+
 __global__ void zero_kernel(float* p, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.f;
+}
+
+template <typename T>
+static int fold_multi_launch(FoldMultiArgs& a, bool vec, int blocks, msmc_stream stream) {
+    if (vec) MSMC_LAUNCH((reflect_fold_multi_kernel<T, Elt<T>::VEC>), dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
+    else MSMC_LAUNCH((reflect_fold_multi_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
+    return msmc_check_launch();
+}
+
+template <typename T>
+static int lrelu_multi_launch(LreluMultiArgs& a, bool vec, int blocks, msmc_stream stream) {
+    if (vec) MSMC_LAUNCH((lrelu_bwd_multi_kernel<T, Elt<T>::VEC>), dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
+    else MSMC_LAUNCH((lrelu_bwd_multi_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
+    return msmc_check_launch();
 }
 
 extern "C" {
@@ -2543,6 +2655,65 @@ int msmc_lrelu_bwd(const void* g, const void* y, void* gx, long n, float slope, 
                     (const unsigned short*)g, (const unsigned short*)y, (unsigned short*)gx, n, slope);
     else return MSMC_E_SHAPE;
     return msmc_check_launch();
+}
+
+int msmc_reflect_fold_multi(const void* const* gp, const void* const* mask_src, void* const* gx, const int* B, const int* H,
+                            const int* W, const int* C, int n, int p, float slope, int dtype, msmc_stream stream) {
+    if (!gp || !gx || !B || !H || !W || !C || n <= 0 || n > MSMC_GROUP_MAX || p < 0 || dtype < 0 || dtype > 1)
+        return MSMC_E_SHAPE;
+    const int VEC = dtype == 0 ? 4 : 8;
+    bool vec = true;
+    for (int k = 0; k < n; ++k) {
+        if (!gp[k] || !gx[k] || B[k] <= 0 || C[k] <= 0 || H[k] <= p || W[k] <= p) return MSMC_E_SHAPE;
+        vec = vec && (C[k] % VEC) == 0;
+    }
+    FoldMultiArgs a;
+    a.n = n;
+    a.p = p;
+    a.slope = slope;
+    int blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        a.gp[k] = gp[k];
+        a.mask[k] = mask_src ? mask_src[k] : nullptr;
+        a.gx[k] = gx[k];
+        a.H[k] = H[k];
+        a.W[k] = W[k];
+        a.C[k] = C[k];
+        a.items[k] = (long)B[k] * H[k] * W[k] * (C[k] / (vec ? VEC : 1));
+        long nb = (a.items[k] + 255) / 256;
+        if (nb > 4L * MSMC_NUM_CU) nb = 4L * MSMC_NUM_CU;
+        a.first[k] = blocks;
+        blocks += (int)(nb < 1 ? 1 : nb);
+    }
+    a.first[n] = blocks;
+    return dtype == 0 ? fold_multi_launch<float>(a, vec, blocks, stream) : fold_multi_launch<unsigned short>(a, vec, blocks, stream);
+}
+
+int msmc_lrelu_bwd_multi(const void* const* g, const void* const* y, void* const* gx, const long* nelem, int n, float slope,
+                         int dtype, msmc_stream stream) {
+    if (!g || !y || !gx || !nelem || n <= 0 || n > MSMC_GROUP_MAX || dtype < 0 || dtype > 1) return MSMC_E_SHAPE;
+    const int VEC = dtype == 0 ? 4 : 8;
+    bool vec = true;
+    for (int k = 0; k < n; ++k) {
+        if (!g[k] || !y[k] || !gx[k] || nelem[k] <= 0) return MSMC_E_SHAPE;
+        vec = vec && (nelem[k] % VEC) == 0;
+    }
+    LreluMultiArgs a;
+    a.n = n;
+    a.slope = slope;
+    int blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        a.g[k] = g[k];
+        a.y[k] = y[k];
+        a.gx[k] = gx[k];
+        a.items[k] = nelem[k] / (vec ? VEC : 1);
+        long nb = (a.items[k] + 255) / 256;
+        if (nb > 4L * MSMC_NUM_CU) nb = 4L * MSMC_NUM_CU;
+        a.first[k] = blocks;
+        blocks += (int)(nb < 1 ? 1 : nb);
+    }
+    a.first[n] = blocks;
+    return dtype == 0 ? lrelu_multi_launch<float>(a, vec, blocks, stream) : lrelu_multi_launch<unsigned short>(a, vec, blocks, stream);
 }
 
 int msmc_colsum(const void* g, float* out, long rows, int C, int dtype, msmc_stream stream) {

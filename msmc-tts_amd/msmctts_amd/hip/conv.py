@@ -555,3 +555,49 @@ def lrelu_bwd(g, y, slope):
     lib.check(lib.get().msmc_lrelu_bwd(lib.ptr(g), lib.ptr(y), lib.ptr(gx), g.numel(), float(slope), _DT[g.dtype],
                                        lib.stream(g)), 'msmc_lrelu_bwd')
     return gx
+
+
+def lrelu_bwd_group(pairs, slope):
+    """[(g, y), ...] -> [g * (y > 0 ? 1 : slope), ...] in launches of up to six tensors (msmc_lrelu_bwd_multi)."""
+    outs = []
+    L = lib.get()
+    for i in range(0, len(pairs), 6):
+        part = pairs[i:i + 6]
+        n = len(part)
+        gxs = []
+        for g, y in part:
+            assert g.shape == y.shape and g.dtype == y.dtype == part[0][0].dtype and g.is_contiguous() and y.is_contiguous()
+            _dev_ok(g)
+            _dev_ok(y)
+            gxs.append(torch.empty_like(g))
+        vp = ctypes.c_void_p * n
+        lib.check(L.msmc_lrelu_bwd_multi(vp(*[g.data_ptr() for g, _ in part]), vp(*[y.data_ptr() for _, y in part]),
+                                         vp(*[t.data_ptr() for t in gxs]), (ctypes.c_long * n)(*[g.numel() for g, _ in part]),
+                                         n, float(slope), _DT[part[0][0].dtype], lib.stream(part[0][0])),
+                  'msmc_lrelu_bwd_multi')
+        outs.extend(gxs)
+    return outs
+
+
+def reflect_fold_group(items, p=1, slope=1.0):
+    """[(gp, H, W, mask_src or None), ...] -> folded gradients, up to six tensors per launch (msmc_reflect_fold_multi)."""
+    outs = []
+    L = lib.get()
+    for i in range(0, len(items), 6):
+        part = items[i:i + 6]
+        n = len(part)
+        gxs, masks = [], []
+        for gp, H, W, mask in part:
+            assert gp.shape[1:3] == (H + 2 * p, W + 2 * p) and gp.is_contiguous() and gp.dtype == part[0][0].dtype
+            _dev_ok(gp)
+            if mask is not None:
+                _dev_ok(mask)
+            gxs.append(torch.empty((gp.shape[0], H, W, gp.shape[3]), dtype=gp.dtype, device=gp.device))
+            masks.append(mask.data_ptr() if mask is not None else None)
+        vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+        lib.check(L.msmc_reflect_fold_multi(vp(*[t[0].data_ptr() for t in part]), vp(*masks), vp(*[t.data_ptr() for t in gxs]),
+                                            ip(*[t[0].shape[0] for t in part]), ip(*[t[1] for t in part]),
+                                            ip(*[t[2] for t in part]), ip(*[t[0].shape[3] for t in part]), n, p, float(slope),
+                                            _DT[part[0][0].dtype], lib.stream(part[0][0])), 'msmc_reflect_fold_multi')
+        outs.extend(gxs)
+    return outs

@@ -322,10 +322,14 @@ class _HipConvGroup(torch.autograd.Function):
         bank = ctx.bank
         grads = [None] * ctx.ntensors
         gl, d_items, d_members, w_items = [], [], [], []
+        gs = [g.contiguous() for g in gs]
+        # y = lrelu(z): dz = dy * (y > 0 ? 1 : slope) -- one multi-tensor launch per slope value
+        for slope in sorted(set(sp[2] for sp in ctx.specs if sp[2] != 1.0)):
+            ks = [k for k, sp in enumerate(ctx.specs) if sp[2] == slope]
+            for k, gm in zip(ks, K.lrelu_bwd_group([(gs[k], outs[k]) for k in ks], slope)):
+                gs[k] = gm
         for k, (layer, in_slope, out_slope, out_div, has_res, has_res2) in enumerate(ctx.specs):
-            g = gs[k].contiguous()
-            if out_slope != 1.0:                       # y = lrelu(z): dz = dy * (y > 0 ? 1 : slope)
-                g = K.lrelu_bwd(g, outs[k], out_slope)
+            g = gs[k]
             if out_div != 1.0:
                 g = g / out_div
             gl.append(g)
@@ -349,13 +353,18 @@ class _HipConvGroup(torch.autograd.Function):
             if has_res or has_res2:
                 bank._hold.append(g)                  # shared gradient: see _HipConv.backward
         if d_items:
+            folds = {}
             for k, gx in zip(d_members, K.conv_dgrad_group(d_items)):
                 layer, in_slope = ctx.specs[k][0], ctx.specs[k][1]
-                if layer.reflect:
+                if layer.reflect:           # gradient on the padded grid: fold the border back (multi-tensor launch)
                     x = xs[k]
-                    gx = K.reflect_fold(gx, x.shape[1], x.shape[2], layer.padding[0],
-                                        mask_src=x if in_slope != 1.0 else None, slope=in_slope)
-                grads[ctx.xpos[k]] = gx
+                    folds.setdefault((layer.padding[0], in_slope), []).append(
+                        (k, (gx, x.shape[1], x.shape[2], x if in_slope != 1.0 else None)))
+                else:
+                    grads[ctx.xpos[k]] = gx
+            for (pad, in_slope), members in folds.items():
+                for (k, _), gx in zip(members, K.reflect_fold_group([m[1] for m in members], pad, in_slope)):
+                    grads[ctx.xpos[k]] = gx
         if w_items:
             K.conv_wgrad_group(w_items)
         bank._queue_finish()

@@ -113,3 +113,21 @@ def test_gather_whole_chunk_in_flight_variant(gen):
 
 def test_multi_resolution_stft_loss_matches_reference():
     _parity.check_mr_stft('cpu')
+
+
+def test_multi_tensor_fold_and_lrelu_equal_single_tensor_kernels():
+    from msmctts_amd.hip import conv
+    torch.manual_seed(0)
+    for dt in (torch.bfloat16, torch.float32):
+        for C in (8, 6):                                   # vector path / scalar path
+            items, refs = [], []
+            for (H, W) in ((9, 13), (5, 21), (12, 4)):
+                gp = torch.randn(2, H + 2, W + 2, C).to(dt)
+                m = torch.randn(2, H, W, C).to(dt)
+                items.append((gp, H, W, m))
+                refs.append(conv.reflect_fold(gp, H, W, 1, mask_src=m, slope=0.2))
+            for o, r in zip(conv.reflect_fold_group(items, 1, 0.2), refs):
+                assert torch.equal(o, r)
+            pairs = [(torch.randn(3, 7, 5, C).to(dt), torch.randn(3, 7, 5, C).to(dt)) for _ in range(4)]
+            for (g, y), o in zip(pairs, conv.lrelu_bwd_group(pairs, 0.2)):
+                assert torch.equal(o, conv.lrelu_bwd(g, y, 0.2))
