@@ -360,10 +360,11 @@ def main():
     if kernels:
         label = max(kernels, key=lambda k: kernels[k]['ms_per_step'])
         k = kernels[label]
-        traffic = None
+        traffic = mfma_util = None
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
             traffic = pmc['kernels'][label]['hbm_bytes_per_launch']
+            mfma_util = pmc['kernels'][label].get('mfma_util_percent')
         except Exception:
             pass
         if k['bound'] == 'mfma':
@@ -372,7 +373,7 @@ def main():
         else:
             roof = dict(bound='hbm', achieved=k['gbps'], peak=HBM_PEAK_GBS, unit='GB/s', frac=k['frac_hbm'],
                         traffic=traffic)
-        roof.update(kernel=label, launches=k['launches'], avg_us=k['avg_us'], ms_per_step=k['ms_per_step'],
+        roof.update(mfma_util_percent_pmc=mfma_util, kernel=label, launches=k['launches'], avg_us=k['avg_us'], ms_per_step=k['ms_per_step'],
                     bytes_per_launch=k['bytes_per_launch'], flops_per_launch=k['flops_per_launch'])
         roof['note'] = ('dominant hand-written kernel by summed HIP-event time over %d instrumented single-stream steps; achieved = '
                         'algorithmic flops (or bytes) of its launches / their summed durations; bound = the roofline '

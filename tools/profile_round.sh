@@ -13,7 +13,8 @@ cp $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kerne
 SHORT="--steps 2 --warmup 2 --no-microbench --cpu-steps 0 --kernel-timing-steps 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python $REPO/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- python $REPO/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_write.log
-python $REPO/tools/pmc_summary.py $OUT/${TAG}_pmc_traffic.json FETCH=/tmp/prof_fetch WRITE=/tmp/prof_write > $OUT/${TAG}_pmc_summary.txt 2>&1
+rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d /tmp/prof_mfma -- python $REPO/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_mfma.log
+python $REPO/tools/pmc_summary.py $OUT/${TAG}_pmc_traffic.json FETCH=/tmp/prof_fetch WRITE=/tmp/prof_write MFMA=/tmp/prof_mfma > $OUT/${TAG}_pmc_summary.txt 2>&1
 cd $REPO
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.log
 tail -c 1500 $OUT/${TAG}_bench.json
