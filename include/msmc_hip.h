@@ -111,7 +111,8 @@ typedef struct msmc_conv_desc {
                                four weight vectors in flight per work-item, 6 / 7 = as 2 / 3 with the whole channel chunk in flight
                                and the next chunk prefetched (small grids; MSMC_E_SHAPE when the chunk exceeds 16 vectors
                                per work-item), 8 = direct (matrix-core-free) kernels for <= 8 -> <= 16 channel layers,
-                               C -> 1 and 1 -> C layers (MSMC_E_SHAPE otherwise).  msmc_conv_wgrad (bf16): 1 = first,
+                               C -> 1 and 1 -> C layers (MSMC_E_SHAPE otherwise), 9 = 32-point tiles with the channel
+                               chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation.  The host layer times the candidates once per layer shape.       */
     int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative)                */
     int dw_copies;          /* msmc_conv_wgrad: R > 1 = dw is [R][ntaps][Cout][Cin] and db [R][Cout]; workgroup i adds

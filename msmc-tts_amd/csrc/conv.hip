@@ -1252,6 +1252,9 @@ static int cv_direct_launch(const msmc_conv_desc* d, msmc_stream stream) {
     return 0;
 }
 
+template <typename T>
+static int cv_ks_launch(const msmc_conv_desc* d, msmc_stream stream);
+
 extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
     if (!d || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0) return MSMC_E_SHAPE;
     ++msmc_conv_launches;
@@ -1263,9 +1266,221 @@ extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
         if (rc != 0) return rc < 0 ? rc : 0;
         if (d->variant == 8) return MSMC_E_SHAPE;
     }
+    if (d->variant == 9) {                      // wave-split deep reduction (E_SHAPE when it does not apply)
+        int rc = d->dtype == 0 ? cv_ks_launch<float>(d, stream)
+                 : d->dtype == 1 ? cv_ks_launch<unsigned short>(d, stream) : MSMC_E_SHAPE;
+        return rc < 0 ? rc : rc == 1 ? 0 : MSMC_E_SHAPE;
+    }
     if (d->dtype == 0) return cv_launch<float>(d, stream);
     if (d->dtype == 1) return cv_launch<unsigned short>(d, stream);
     return MSMC_E_SHAPE;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deep reductions on small grids (FFT-block convolutions at T/4, conv_pre, the deep MPD / MRD layers): the 128-point
+// kernels leave most CUs idle and walk 16-38 dependent channel-chunk round trips.  Here a workgroup owns 32 lattice
+// points x BN channels and its four waves split the channel chunks (wave w takes chunks w, w+4, ...), each staging
+// into its own LDS region with wave-level hand-offs only; the four partial tiles meet in LDS before the epilogue.
+// Four times the workgroups, a quarter of the chain.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NT, int CKM>
+__global__ __launch_bounds__(256) void conv_gather_ks_kernel(msmc_conv_desc d, CvGeom G, int region_bytes) {
+    MSMC_DYN_LDS(smem);
+    constexpr int VEC = Elt<T>::VEC, CK = Elt<T>::CK * CKM, CKV = CK / VEC, XS = CK + VEC, BN = 32 * NT, OS = BN + 4;
+    constexpr int BNV = BN / VEC, SB = 8;
+    const int npix = G.IH * G.IW, IW = G.IW;
+    int* in_off = (int*)smem;                                   // [npix]
+    int* out_off = in_off + npix;                               // [32]
+    int* tapw = out_off + 32;                                   // [16]
+    char* regions = smem + (((size_t)(npix + 32 + 16) * sizeof(int) + 15) & ~(size_t)15);
+    const int tid = threadIdx.x, w = wave_uniform(tid >> 6), lane = tid & 63, i = lane & 31, g = lane >> 5;
+    T* xt = (T*)(regions + (size_t)w * region_bytes);           // this wave's [npix][XS]
+    T* wt = xt + (size_t)npix * XS;                             //             [ntaps][BN][XS]
+    int bt = blockIdx.x;
+    const int tx_ = bt % G.tilesX;
+    bt /= G.tilesX;
+    const int ty_ = bt % G.tilesY;
+    const int b = bt / G.tilesY;
+    const int co0 = blockIdx.y * BN;
+    const int qy0 = ty_ * G.TH, qx0 = tx_ * G.TW;
+    const int iyBase = qy0 * d.isy + d.iy0 + G.dyMin, ixBase = qx0 * d.isx + d.ix0 + G.dxMin;
+    for (int pi = tid; pi < npix; pi += 256) {
+        const int ry = pi / IW, rx = pi - ry * IW;
+        int iy = iyBase + ry, ix = ixBase + rx;
+        bool inside = true;
+        if (d.pad_mode == 1) {
+            iy = reflect_index(iy, d.Hin);
+            ix = reflect_index(ix, d.Win);
+        } else {
+            inside = (iy >= 0) && (iy < d.Hin) && (ix >= 0) && (ix < d.Win);
+        }
+        in_off[pi] = inside ? (iy * d.Win + ix) * d.Cin : -1;
+    }
+    if (tid < 32) {
+        const int mty = tid / G.TW, mtx = tid - mty * G.TW;
+        const int qy = qy0 + mty, qx = qx0 + mtx;
+        const bool valid = mty < G.TH && qy < d.QH && qx < d.QW;
+        out_off[tid] = valid ? (d.oy0 + qy * d.osy) * d.Wout + (d.ox0 + qx * d.osx) : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < MSMC_CONV_MAX_TAPS; ++t)
+        if (tid == 64 + t) tapw[t] = t < d.ntaps ? d.tap_w[t] : 0;
+    int arow;
+    {
+        const int mty = i / G.TW, mtx = i - mty * G.TW;
+        arow = (mty < G.TH) ? (mty * d.isy) * IW + mtx * d.isx : 0;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const T* xb = (const T*)d.x + (size_t)b * d.Hin * d.Win * d.Cin;
+    const T* wg = (const T*)d.w;
+    const float slope = d.in_slope;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const int nxv = npix * CKV, nwv = d.ntaps * BN * CKV;
+    __syncthreads();                                            // offset tables ready
+
+    for (int c0 = w * CK; c0 < d.Cin; c0 += 4 * CK) {
+        for (int e0 = lane; e0 < nxv; e0 += 64 * SB) {
+            u32x4 vals[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int e = e0 + 64 * u;
+                vals[u] = zero4;
+                if (e < nxv) {
+                    const int pi = e / CKV;
+                    const int off = in_off[pi], c = c0 + (e - pi * CKV) * VEC;
+                    if (off >= 0 && c < d.Cin) vals[u] = *(const u32x4*)(xb + off + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int e = e0 + 64 * u;
+                if (e >= nxv) continue;
+                const int pi = e / CKV;
+                if (slope != 1.f) {
+                    alignas(16) T tmp[VEC];
+                    *(u32x4*)tmp = vals[u];
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        float f = Elt<T>::ld(&tmp[q]);
+                        f = f > 0.f ? f : f * slope;
+                        Elt<T>::st(&tmp[q], f);
+                    }
+                    vals[u] = *(const u32x4*)tmp;
+                }
+                *(u32x4*)(xt + (size_t)pi * XS + (e - pi * CKV) * VEC) = vals[u];
+            }
+        }
+        for (int e0 = lane; e0 < nwv; e0 += 64 * SB) {
+            u32x4 vals[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int e = e0 + 64 * u;
+                vals[u] = zero4;
+                if (e < nwv) {
+                    const int row = e / CKV;
+                    const int t = row / BN, co = co0 + (row - t * BN), c = c0 + (e - row * CKV) * VEC;
+                    if (co < d.Cout && c < d.Cin) vals[u] = *(const u32x4*)(wg + ((size_t)tapw[t] * d.Cout + co) * d.Cin + c);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int e = e0 + 64 * u;
+                if (e >= nwv) continue;
+                const int row = e / CKV;
+                *(u32x4*)(wt + (size_t)row * XS + (e - row * CKV) * VEC) = vals[u];
+            }
+        }
+        wave_sync();                                            // this wave's tiles are complete
+        for (int t = 0; t < d.ntaps; ++t) {
+            const T* ap = xt + (size_t)(arow + (d.tap_dy[t] - G.dyMin) * IW + (d.tap_dx[t] - G.dxMin)) * XS;
+            const T* bp = wt + (size_t)(t * BN + i) * XS;
+#pragma unroll
+            for (int ks = 0; ks < CK / 16; ++ks) mma_chunk16<NT>(ap + ks * 16, bp + ks * 16, 32 * XS, g, acc);
+        }
+        wave_sync();                                            // fragments consumed before the next chunk lands
+    }
+    // ---- the four partial tiles meet in LDS (each wave parks its own in its own region), then the usual epilogue
+    float* pt = (float*)(regions + (size_t)w * region_bytes);   // [32][OS]
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pt[((r & 3) + 8 * (r >> 2) + 4 * g) * OS + n * 32 + i] = acc[n][r];
+    __syncthreads();
+    const T* mask = (const T*)d.mask_src;
+    const T* res = (const T*)d.res;
+    const T* res2 = (const T*)d.res2;
+    T* out = (T*)d.out;
+    const size_t img = (size_t)b * d.Hout * d.Wout;
+    const int fstride = region_bytes / (int)sizeof(float);
+    const float* p0 = (const float*)regions;
+    for (int e = tid; e < 32 * BNV; e += 256) {
+        const int m = e / BNV, vcol = (e - m * BNV) * VEC;
+        const int po = out_off[m], co = co0 + vcol;
+        if (po < 0 || co >= d.Cout) continue;
+        const size_t o = (img + po) * d.Cout + co;
+        alignas(16) T mk[VEC], r1[VEC], r2[VEC], ov[VEC];
+        if (mask) *(u32x4*)mk = *(const u32x4*)(mask + o);
+        if (res) *(u32x4*)r1 = *(const u32x4*)(res + o);
+        if (res2) *(u32x4*)r2 = *(const u32x4*)(res2 + o);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const int idx = m * OS + vcol + q;
+            float x = ((p0[idx] + p0[fstride + idx]) + p0[2 * fstride + idx]) + p0[3 * fstride + idx];
+            if (d.bias) x = x + d.bias[co + q];
+            if (mask) x = x * (Elt<T>::ld(&mk[q]) > 0.f ? 1.f : d.mask_slope);
+            if (res) x = x + Elt<T>::ld(&r1[q]);
+            if (res2) x = Elt<T>::ld(&r2[q]) + x;
+            if (d.out_div != 1.f) x = x / d.out_div;
+            if (d.out_slope != 1.f) x = x > 0.f ? x : x * d.out_slope;
+            Elt<T>::st(&ov[q], x);
+        }
+        *(u32x4*)(out + o) = *(const u32x4*)ov;
+    }
+}
+
+// returns 1 when launched, 0 when the kernel does not apply
+template <typename T>
+static int cv_ks_launch(const msmc_conv_desc* d, msmc_stream stream) {
+    constexpr int VEC = Elt<T>::VEC;
+    if ((d->Cin % VEC) != 0 || (d->Cout % VEC) != 0 || d->Cin < 8 * Elt<T>::CK) return 0;
+    if ((long)d->Hin * d->Win * d->Cin >= (1L << 31) || (long)d->Hout * d->Wout >= (1L << 31)) return 0;
+    CvGeom G;
+    size_t unused;
+    int rc = cv_geometry(d, &G, sizeof(T), 0, 0, &unused, 32);
+    if (rc) return rc;
+    const long npix = (long)G.IH * G.IW;
+    const int nt = d->Cout > 32 ? 2 : 1;
+    const size_t tables = (((size_t)(npix + 32 + 16) * sizeof(int)) + 15) & ~(size_t)15;
+    auto region = [&](int ckm) {
+        const size_t xs = (size_t)Elt<T>::CK * ckm + VEC;
+        size_t r = ((size_t)npix + (size_t)d->ntaps * 32 * nt) * xs * sizeof(T);
+        const size_t part = (size_t)32 * (32 * nt + 4) * sizeof(float);
+        if (r < part) r = part;
+        return (r + 15) & ~(size_t)15;
+    };
+    int ckm = (tables + 4 * region(2) <= 150 * 1024) ? 2 : 1;
+    const size_t reg = region(ckm), lds = tables + 4 * reg;
+    if (lds > 160 * 1024) return 0;
+    dim3 grid((unsigned)(G.tilesX * G.tilesY * d->B), (unsigned)((d->Cout + 32 * nt - 1) / (32 * nt)));
+#define KS_GO(NT_, CKM_)                                                                                            \
+    do {                                                                                                            \
+        rc = msmc_allow_lds((const void*)conv_gather_ks_kernel<T, NT_, CKM_>, (int)lds);                            \
+        if (rc) return rc;                                                                                          \
+        MSMC_LAUNCH((conv_gather_ks_kernel<T, NT_, CKM_>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, G,      \
+                    (int)reg);                                                                                      \
+    } while (0)
+    if (nt == 2 && ckm == 2) KS_GO(2, 2);
+    else if (nt == 2) KS_GO(2, 1);
+    else if (ckm == 2) KS_GO(1, 2);
+    else KS_GO(1, 1);
+#undef KS_GO
+    msmc_conv_last = msmc_kname("conv_gather_ks_kernel", EltName<T>::v, nt, ckm);
+    rc = msmc_check_launch();
+    return rc ? rc : 1;
 }
 
 // which direct kernel would take this descriptor: 0 none, 1 small, 2 dot, 3 outer (mirrors cv_direct_launch)
@@ -1376,9 +1591,12 @@ static int cv_group_launch(const msmc_conv_desc* descs, int n, msmc_stream strea
         pending[i] = direct[i] = false;
         const msmc_conv_desc* d = &descs[i];
         int nt_unused;
-        int rc = cv_takes_direct(d) ? 0 : cv2_plan<T>(d, &plans[i], &nt_unused);
+        int rc = (cv_takes_direct(d) || d->variant == 9) ? 0 : cv2_plan<T>(d, &plans[i], &nt_unused);
         if (rc) return rc;
-        if (cv_takes_direct(d)) {
+        if (d->variant == 9) {
+            rc = msmc_conv_gather(d, stream);
+            if (rc) return rc;
+        } else if (cv_takes_direct(d)) {
             direct[i] = true;
         } else if (!plans[i].applies) {                         // first-generation kernels: one launch each
             rc = msmc_conv_gather(d, stream);

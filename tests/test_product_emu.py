@@ -131,3 +131,34 @@ def test_multi_tensor_fold_and_lrelu_equal_single_tensor_kernels():
             pairs = [(torch.randn(3, 7, 5, C).to(dt), torch.randn(3, 7, 5, C).to(dt)) for _ in range(4)]
             for (g, y), o in zip(pairs, conv.lrelu_bwd_group(pairs, 0.2)):
                 assert torch.equal(o, conv.lrelu_bwd(g, y, 0.2))
+
+
+def test_gather_wave_split_deep_reduction_variant():
+    """variant 9 (32-point tiles, channel chunks split over the four waves) on deep layers, bf16 and fp32"""
+    from msmctts_amd.hip import conv
+    cases = [('ks fft k3 1024->64', 2, 1024, 64, 1, 50, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.0),
+             ('ks k5x1 s3 512->40', 1, 512, 40, 20, 3, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
+             ('ks 3x3 reflect 256->32', 1, 256, 32, 7, 9, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0)]
+    saved = conv._GATHER_CANDIDATES
+    # force the variant through the descriptor: the interpreter skips tuning, so patch the descriptor builder
+    real = conv._build_desc
+    used = []
+
+    def forced(*a, **k):
+        d = real(*a, **k)
+        vec = 4 if d.dtype == 0 else 8
+        if d.Cin >= 32 * vec and d.Cin % vec == 0 and d.Cout % vec == 0:      # where the kernel applies
+            d.variant = 9
+            used.append((d.Cin, d.Cout))
+        return d
+    conv._build_desc = forced
+    try:
+        for case in cases:
+            for g in list(conv._PLANS):
+                del conv._PLANS[g]
+            _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=('fwd', 'dgrad'))
+            _convcases.check_conv_case(case, torch.float32, 2e-4, 'cpu', parts=('fwd', 'dgrad'))
+    finally:
+        conv._build_desc = real
+        conv._GATHER_CANDIDATES = saved
+    assert len(used) >= 6
