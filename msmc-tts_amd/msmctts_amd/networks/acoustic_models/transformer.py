@@ -40,6 +40,10 @@ def get_non_pad_mask(seq):
     return seq.ne(0).unsqueeze(-1)
 
 
+# fused scaled_dot_product_attention for the FFT blocks (stock PyTorch-ROCm operator); MSMC_SDPA=0 keeps the bmm chain
+USE_SDPA = os.environ.get('MSMC_SDPA', '1') != '0'
+
+
 class ScaledDotProductAttention(nn.Module):
     def __init__(self, temperature, attn_dropout=0.1, name=None):
         super().__init__()
@@ -48,6 +52,15 @@ class ScaledDotProductAttention(nn.Module):
             self.dropout = nn.Dropout(attn_dropout)
 
     def forward(self, q, k, v, mask=None, acts=None):
+        if USE_SDPA and mask is not None:
+            # PyTorch-ROCm's fused attention: same math (softmax(QK^T / sqrt(d) + key-padding mask) V, dropout on the
+            # probabilities) in one or two kernels instead of six; the probabilities themselves are not materialised
+            # (no caller of the training path reads them)
+            p = self.dropout.p if (hasattr(self, 'dropout') and self.training) else 0.0
+            out = F.scaled_dot_product_attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0),
+                                                 attn_mask=(~mask).unsqueeze(0), dropout_p=p,
+                                                 scale=1.0 / self.temperature)
+            return out.squeeze(0), None
         attn = torch.bmm(q, k.transpose(1, 2)) / self.temperature
         if mask is not None:
             attn = attn.masked_fill(mask, -math.inf)
