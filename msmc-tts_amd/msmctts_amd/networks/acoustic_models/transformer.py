@@ -85,6 +85,17 @@ class MultiHeadAttention(nn.Module):
     def forward(self, x, mask=None, acts=None):
         bs, T, _ = x.shape
         H, dk, dv = self.n_head, self.d_k, self.d_v
+        if USE_SDPA and mask is not None:
+            # heads as a strided view of the fused QKV projection and the key-padding mask broadcast over heads: no
+            # permute / repeat copies around the fused attention operator
+            qkv = self.linear(x).view(bs, T, H, 2 * dk + dv).transpose(1, 2)             # [bs, H, T, 2dk+dv]
+            att = self.attention
+            p = att.dropout.p if (hasattr(att, 'dropout') and att.training) else 0.0
+            out = F.scaled_dot_product_attention(qkv[..., :dk], qkv[..., dk:2 * dk], qkv[..., 2 * dk:],
+                                                 attn_mask=(~mask).unsqueeze(1), dropout_p=p, scale=1.0 / att.temperature)
+            out = out.transpose(1, 2).reshape(bs, T, H * dv)
+            out = self.dropout(self.fc(out)) + x
+            return self.layer_norm(out), None
         qkv = self.linear(x).view(bs, T, H, 2 * dk + dv).permute(2, 0, 1, 3).reshape(H * bs, T, 2 * dk + dv)
         q, k, v = qkv[..., :dk], qkv[..., dk:2 * dk], qkv[..., 2 * dk:]
         out, attn = self.attention(q, k, v, mask=None if mask is None else mask.repeat(H, 1, 1))
