@@ -117,10 +117,12 @@ def _signature(desc):
 def _tune(kind, desc, launch, candidates):
     """Time ``launch()`` under every candidate (variant, split_shift); leave the fastest in the descriptor."""
     desc._tuned = True
-    if not AUTOTUNE or lib._host_pointers_ok or torch.cuda.is_current_stream_capturing():
+    if lib._host_pointers_ok:
         return
     sig = (kind,) + _signature(desc)
     hit = TUNED.get(sig)
+    if hit is None and (not AUTOTUNE or torch.cuda.is_current_stream_capturing()):
+        return                      # no timing launches now: library heuristic for this shape
     if hit is None:
         times = {}
         for variant, shift in candidates:
@@ -150,7 +152,10 @@ def _wgrad(desc, g_ptr, dw, db, stream, what):
     fn = lib.get().msmc_conv_wgrad
     dbp = db.data_ptr() if db is not None else None
     if not getattr(desc, '_tuned', False):
-        if AUTOTUNE and not lib._host_pointers_ok and not torch.cuda.is_current_stream_capturing():
+        cached = TUNED.get(('wgrad',) + _signature(desc)) if not lib._host_pointers_ok else None
+        if cached is not None:
+            desc.variant, desc.split_shift, desc._tuned = cached[0], cached[1], True
+        elif AUTOTUNE and not lib._host_pointers_ok and not torch.cuda.is_current_stream_capturing():
             R = max(1, desc.dw_copies)                       # candidates accumulate into scratch, not into dW
             sdw = torch.zeros(R * desc.ntaps * desc.Cout * desc.Cin, dtype=torch.float32, device=dw.device)
             sdb = torch.zeros(R * desc.Cout, dtype=torch.float32, device=dw.device) if db is not None else None
@@ -273,10 +278,12 @@ def _group_choice(kind, snaps, grouped_fn, single_fn):
     fills the chip for small grids but imposes one kernel instantiation on all members)."""
     if len(snaps) == 1:
         return 0
-    if not AUTOTUNE or lib._host_pointers_ok or torch.cuda.is_current_stream_capturing():
+    if lib._host_pointers_ok:
         return 1
     sig = (kind,) + tuple(_signature(d) + (d.variant, d.split_shift) for d in snaps)
     hit = TUNED.get(sig)
+    if hit is None and (not AUTOTUNE or torch.cuda.is_current_stream_capturing()):
+        return 1
     if hit is None:
         times = {}
         for name, fn in (('group', grouped_fn), ('single', single_fn)):
