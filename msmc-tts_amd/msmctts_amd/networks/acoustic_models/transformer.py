@@ -91,8 +91,11 @@ class MultiHeadAttention(nn.Module):
             qkv = self.linear(x).view(bs, T, H, 2 * dk + dv).transpose(1, 2)             # [bs, H, T, 2dk+dv]
             att = self.attention
             p = att.dropout.p if (hasattr(att, 'dropout') and att.training) else 0.0
+            # a key-padding mask arrives expanded over the query axis (stride 0): invert the [bs, 1, T_k] original
+            # (6 400 elements), not the [bs, T_q, T_k] expansion (2.5 M), and let the operator broadcast it
+            keep = ~(mask[:, :1, :] if mask.stride(1) == 0 else mask)
             out = F.scaled_dot_product_attention(qkv[..., :dk], qkv[..., dk:2 * dk], qkv[..., 2 * dk:],
-                                                 attn_mask=(~mask).unsqueeze(1), dropout_p=p, scale=1.0 / att.temperature)
+                                                 attn_mask=keep.unsqueeze(1), dropout_p=p, scale=1.0 / att.temperature)
             out = out.transpose(1, 2).reshape(bs, T, H * dv)
             out = self.dropout(self.fc(out)) + x
             return self.layer_norm(out), None
