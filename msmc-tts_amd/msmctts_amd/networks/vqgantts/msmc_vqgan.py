@@ -46,6 +46,23 @@ class MultiStageEncoder(nn.Module):
         return outputs
 
 
+def _pointwise(module, x):
+    """``module`` (a kernel-size-1 ``nn.Conv1d``, kept for its checkpoint keys) applied to channels-last x (B, T, C):
+    a 1x1 convolution IS a linear layer on the last axis -- no transposes, no NCHW convolution kernel."""
+    return F.linear(x, module.weight.squeeze(-1), module.bias)
+
+
+def _pointwise_stack(seq, x):
+    """nn.Sequential of 1x1 Conv1d / Tanh (reference pre-processor, msmc_vqgan.py:115-136) on channels-last x;
+    falls back to the channels-first modules for anything else (the optional BatchNorm1d)."""
+    mods = list(seq)
+    if all(isinstance(m, nn.Tanh) or (isinstance(m, nn.Conv1d) and m.kernel_size == (1,)) for m in mods):
+        for m in mods:
+            x = torch.tanh(x) if isinstance(m, nn.Tanh) else _pointwise(m, x)
+        return x
+    return seq(x.transpose(1, 2)).transpose(1, 2)
+
+
 class PriorPredictor(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size=5, dilation_rate=1, n_layers=4):
         super().__init__()
@@ -55,9 +72,8 @@ class PriorPredictor(nn.Module):
     def forward(self, x, x_lengths):
         x = x.transpose(1, 2)
         x_mask = (~get_mask_from_lengths(x_lengths.to(x.device), x.shape[2])).unsqueeze(1).to(x.dtype)
-        h = self.enc(x, x_mask)
-        o = self.proj(h) * x_mask
-        return h.transpose(1, 2), o.transpose(1, 2)
+        h = self.enc(x, x_mask).transpose(1, 2)
+        return h, _pointwise(self.proj, h) * x_mask.transpose(1, 2)
 
 
 class MultiStageQuantizer(nn.Module):
@@ -103,7 +119,7 @@ class MultiStageQuantizer(nn.Module):
                 q_in = pred_q
             elif from_encoder:
                 pre_in = emb if residual is None else torch.cat((emb, residual), dim=-1)
-                q_in = self.preprocessor[i](pre_in.transpose(1, 2)).transpose(1, 2)
+                q_in = _pointwise_stack(self.preprocessor[i], pre_in)
             else:
                 q_in = emb
             quant, dff, ind = self.quantizer[i](q_in, length, update=self.update_codebook)
