@@ -37,7 +37,7 @@ class Quantize(nn.Module):
         embed, cs, ea = self._packed()
         embed_t, enorm = hipvq.vq_prepare(embed)
         quant, diff, ind = hipvq.vq_search(input, embed_t, enorm)
-        if self.training and update:
+        if self.training and update and input.numel() > 0:          # (an empty batch has no statistics to add)
             x3 = input.detach().reshape(input.shape[0], -1, input.shape[-1])
             self._ws = hipvq.vq_ema_update(x3, ind.reshape(x3.shape[0], x3.shape[1], -1), input_length, embed, cs, ea,
                                            self.decay, self.eps, self._ws)
@@ -80,7 +80,7 @@ class MultiHeadQuantize(nn.Module):
         embed, cs, ea = self._packed()
         embed_t, enorm = hipvq.vq_prepare(embed)
         quant, diff, ind = hipvq.vq_search(input, embed_t, enorm)
-        if self.training and update:
+        if self.training and update and input.numel() > 0:          # (an empty batch has no statistics to add)
             x3 = input.detach().reshape(input.shape[0], -1, input.shape[-1])
             self._ws = hipvq.vq_ema_update(x3, ind.reshape(x3.shape[0], x3.shape[1], -1), input_length, embed, cs, ea,
                                            self.decay, self.eps, self._ws)

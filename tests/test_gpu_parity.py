@@ -229,3 +229,7 @@ def test_rccl_gradient_reducer_single_rank_matches_reference():
 def test_multi_resolution_stft_loss_matches_reference():
     """SURVEY 8a L2 on the HIP spectral front-end (framing, windowed-DFT GEMM, magnitude) against the fixture."""
     _parity.check_mr_stft(DEV)
+
+
+def test_vq_edge_cases_empty_single_frame_zero_length_ragged():
+    _parity.check_vq_edge_cases(DEV)

@@ -162,3 +162,7 @@ def test_gather_wave_split_deep_reduction_variant():
         conv._build_desc = real
         conv._GATHER_CANDIDATES = saved
     assert len(used) >= 6
+
+
+def test_vq_edge_cases_empty_single_frame_zero_length_ragged():
+    _parity.check_vq_edge_cases('cpu')
