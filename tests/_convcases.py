@@ -51,6 +51,10 @@ SMALL = [
     ('mrd 4->8 s2', 2, 4, 8, 9, 37, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
     ('mrd 8->16 s1', 1, 8, 16, 11, 21, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
     ('mrd 64->72 s2', 1, 64, 72, 13, 18, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
+    # inputs smaller than the receptive field / the reflection border
+    ('tiny L3 k11 d5', 1, 32, 32, 1, 3, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
+    ('tiny 2x2 reflect 4->8', 1, 4, 8, 2, 2, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
+    ('tiny 3x2 reflect 64->64 s2', 2, 64, 64, 3, 2, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
 ]
 
 
