@@ -28,6 +28,7 @@ for p in (ROOT, os.path.join(ROOT, 'msmc-tts_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import msmctts_amd  # noqa: E402,F401  (first: sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before any HIP call, see its docstring)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -121,26 +122,41 @@ def say(msg):
 T_START = time.perf_counter()
 
 
-def cpu_baseline(cfg, state_dict, batch, windows, steps, threads, sample):
-    """Oracle train step on host cores: same weights, the first ``sample`` utterances of the same batch,
-    same windows (a bounded sample of the workload; throughput is per mel-frame of the sample)."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(cfg, state_dict, batch, windows, steps, warmups, threads, sample):
+    """Oracle train step on host cores: same weights, the first ``sample`` utterances of the same batch
+    (default: all of it), same windows; ``warmups`` untimed + ``steps`` timed steps, median, for the GAN phase and the
+    warm-up phase (no vocoder / discriminator).  Returns {phase: (seconds per step, mel frames per step)}."""
     from oracle.step import OracleTrainer
     torch.set_num_threads(threads)
     task = cfg.task.to_dict()
-    tcfg = {k: v for k, v in cfg.trainer.to_dict().items() if k != '_name'}
-    tr = OracleTrainer({k: v.detach().float().cpu() for k, v in state_dict.items()}, task, tcfg)
     cb = {k: v.detach().cpu()[:sample] for k, v in batch.items() if torch.is_tensor(v)}
     T = int(cb['mel_length'].max())
     cb['mel'], cb['wav'] = cb['mel'][:, :T], cb['wav'][:, :T * 300]
     windows = (windows[0][:sample], windows[1][:sample])
-    times = []
-    for i in range(steps + 1):
-        t0 = time.perf_counter()
-        tr.train_step(cb, 10 + i, windows=windows)
-        times.append(time.perf_counter() - t0)
-        say('cpu oracle step %d: %.2f s' % (i, times[-1]))
-    timed = sorted(times[1:])
-    return timed[len(timed) // 2], float(cb['mel_length'].sum())
+    out = {}
+    for phase, wsteps in (('gan', 0), ('warmup', 10 ** 9)):
+        tcfg = {k: v for k, v in cfg.trainer.to_dict().items() if k != '_name'}
+        tcfg['warmup_steps'] = wsteps
+        tr = OracleTrainer({k: v.detach().float().cpu() for k, v in state_dict.items()}, task, tcfg)
+        times = []
+        for i in range(warmups + steps):
+            t0 = time.perf_counter()
+            tr.train_step(cb, 10 + i, windows=windows)
+            times.append(time.perf_counter() - t0)
+            say('cpu oracle %s step %d: %.2f s' % (phase, i, times[-1]))
+        timed = sorted(times[warmups:])
+        out[phase] = (timed[len(timed) // 2], float(cb['mel_length'].sum()))
+    return out
 
 
 def vq_microbench(device, H, K, D=256, N=1 << 20, iters=20, variant=1):
@@ -177,8 +193,11 @@ def main():
     ap.add_argument('--heads', type=int, default=4)
     ap.add_argument('--codewords', type=int, default=256)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
-    ap.add_argument('--cpu-steps', type=int, default=2, help='timed oracle steps for cpu_baseline (0 = skip)')
-    ap.add_argument('--cpu-batch', type=int, default=4, help='utterances of the batch in the cpu_baseline sample')
+    ap.add_argument('--cpu-steps', type=int, default=5, help='timed oracle steps per phase for cpu_baseline (0 = skip)')
+    ap.add_argument('--cpu-warmup', type=int, default=2, help='untimed oracle steps per phase')
+    ap.add_argument('--cpu-batch', type=int, default=0, help='utterances of the batch in the cpu_baseline sample (0 = all)')
+    ap.add_argument('--warmup-phase-steps', type=int, default=10,
+                    help='extra eager steps of the warm-up phase (no vocoder / discriminator) timed after the headline')
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = min(available cores, 32)')
     ap.add_argument('--no-microbench', action='store_true')
     ap.add_argument('--no-autocast', action='store_true',
@@ -325,6 +344,20 @@ def main():
         timer.enabled = False
         convnet.STREAMS_ENABLED = True
         trainer.use_graphs = graphs_were
+    # warm-up phase (iteration < warmup_steps: autoencoder + frame decoder only), SURVEY.md 8d asks for it separately
+    warm_ms = None
+    if rank == 0 and world == 1 and args.warmup_phase_steps > 0:
+        keep = trainer.warmup_steps
+        trainer.warmup_steps = 10 ** 9
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.warmup_phase_steps):
+            step(i)
+        torch.cuda.synchronize()
+        warm_ms = (time.perf_counter() - t1) / args.warmup_phase_steps * 1e3
+        trainer.warmup_steps = keep
     if world > 1:
         dist.barrier()
     if world > 1:
@@ -397,7 +430,18 @@ def main():
         'kernels': kernels,
         'ms_per_step_instrumented': ms_instr,
         'losses': {k: float(v) for k, v in log['loss'].items()},
+        'warmup_phase': None if warm_ms is None else dict(
+            ms_per_step=warm_ms, value=frames_per_step / (warm_ms * 1e-3), unit='mel-frames/s',
+            note='iteration < warmup_steps (no vocoder, no discriminator), eager, %d steps' % args.warmup_phase_steps),
+        'runtime': {'DEBUG_CLR_GRAPH_PACKET_CAPTURE': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'),
+                    'note': 'hipGraph memset nodes are mis-ordered on the AQL packet-capture path of ROCm 7.2 '
+                            '(tools/repro_graph_memset.py); the package disables that path before the first HIP call'},
     }
+    bad = [k for k, v in out['losses'].items() if v != v or v in (float('inf'), float('-inf'))]
+    if bad:
+        sys.stderr.write('bench.py: non-finite losses after the timed steps: %s -- the step does not train; '
+                         'no result line\n' % bad)
+        sys.exit(3)
     if not args.no_microbench:
         out['vq_microbench'] = [vq_microbench(device, args.heads, args.codewords), vq_microbench(device, 4, 64),
                                 vq_microbench(device, 8, 512),
@@ -413,14 +457,19 @@ def main():
             fw.append((s, s + 40))
         sw = [(s * 300, e * 300) for s, e in fw]
         threads = args.cpu_threads or min(cores, 32)
-        sec, sample_frames = cpu_baseline(cfg, state0, batch, (fw, sw), args.cpu_steps, threads, args.cpu_batch)
+        nsample = args.cpu_batch or args.batch
+        res = cpu_baseline(cfg, state0, batch, (fw, sw), args.cpu_steps, args.cpu_warmup, threads, nsample)
+        sec, sample_frames = res['gan']
+        wsec, _ = res['warmup']
         out['cpu_baseline'] = dict(value=sample_frames / sec, unit='mel-frames/s', cores=threads, kind='port',
-                                   sample='oracle (plain PyTorch fp32) GAN-phase train step on the first %d utterances '
+                                   sample='oracle (plain PyTorch fp32) GAN-phase train step on %s utterances '
                                           '(%d mel frames) of the same batch with the same weights; median of %d timed '
-                                          'steps after 1 warm-up; %d of %d visible cores; torch %s'
-                                          % (args.cpu_batch, sample_frames, args.cpu_steps, threads, cores,
+                                          'steps after %d warm-ups; %d of %d visible cores; %s; torch %s'
+                                          % ('all %d' % nsample if nsample == args.batch else 'the first %d' % nsample,
+                                             sample_frames, args.cpu_steps, args.cpu_warmup, threads, cores, cpu_model(),
                                              torch.__version__),
-                                   s_per_step=sec)
+                                   s_per_step=sec, cpu_model=cpu_model(),
+                                   warmup_phase=dict(value=sample_frames / wsec, unit='mel-frames/s', s_per_step=wsec))
         out['speedup_vs_cpu'] = value / out['cpu_baseline']['value']
     print(json.dumps(out))
     if world > 1:

@@ -184,6 +184,8 @@ typedef struct msmc_wn_item {
 
 int msmc_wn_prepare_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream);
 int msmc_wn_backward_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream);
+/* accumulate != 0: gv / gg / gb += instead of = (a second backward before the gradients were reset: torch .grad semantics) */
+int msmc_wn_backward_multi_acc(const msmc_wn_item* items, int nitems, int total_blocks, int accumulate, msmc_stream stream);
 
 /* Backward of ReflectionPad2d(p) fused with the leaky-ReLU' mask, channels-last:
  *   gx[b][y][x][c] = (sum of gp over the padded positions that reflect onto (y, x)) * (mask_src > 0 ? 1 : slope)

@@ -2599,7 +2599,8 @@ __global__ __launch_bounds__(256) void wn_prepare_kernel(const msmc_wn_item* __r
     }
 }
 
-__global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __restrict__ items, int nitems) {
+__global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __restrict__ items, int nitems,
+                                                         int accumulate) {
     __shared__ float red[256];
     const msmc_wn_item it = items[wn_find(items, nitems, blockIdx.x)];
     const int a = blockIdx.x - it.block0;
@@ -2623,7 +2624,7 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     if (it.g) {
         dot = block_sum(dot, red);
         const float inv = it.inv_norm[a], gval = it.g[a];
-        if (threadIdx.x == 0) it.gg[a] = dot * inv;
+        if (threadIdx.x == 0) it.gg[a] = accumulate ? it.gg[a] + dot * inv : dot * inv;
         k1 = gval * inv;
         k2 = dot * inv * inv;
     }
@@ -2631,7 +2632,8 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     for (int e = threadIdx.x; e < n; e += 256) {
         const int b = e / it.T, t = e - b * it.T;
         const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
-        gv[e] = k1 * (dw[o] - v[e] * k2);
+        const float gnew = k1 * (dw[o] - v[e] * k2);
+        gv[e] = accumulate ? gv[e] + gnew : gnew;
         dw[o] = 0.f;                                  // each accumulator element has exactly this one reader
     }
     if (it.db && threadIdx.x == 0)
@@ -2642,7 +2644,7 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
                 sum = sum + it.db[c + r * it.db_copy_stride];
                 it.db[c + r * it.db_copy_stride] = 0.f;
             }
-            it.gb[c] = sum;
+            it.gb[c] = accumulate ? it.gb[c] + sum : sum;
         }
 }
 
@@ -2838,10 +2840,14 @@ int msmc_wn_prepare_multi(const msmc_wn_item* items, int nitems, int total_block
     return msmc_check_launch();
 }
 
-int msmc_wn_backward_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream) {
+int msmc_wn_backward_multi_acc(const msmc_wn_item* items, int nitems, int total_blocks, int accumulate, msmc_stream stream) {
     if (!items || nitems <= 0 || total_blocks <= 0) return MSMC_E_SHAPE;
-    MSMC_LAUNCH(wn_backward_kernel, dim3(total_blocks), dim3(256), 0, (msmc_stream_t)stream, items, nitems);
+    MSMC_LAUNCH(wn_backward_kernel, dim3(total_blocks), dim3(256), 0, (msmc_stream_t)stream, items, nitems, accumulate);
     return msmc_check_launch();
+}
+
+int msmc_wn_backward_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream) {
+    return msmc_wn_backward_multi_acc(items, nitems, total_blocks, 0, stream);
 }
 
 int msmc_reflect_fold(const void* gp, const void* mask_src, void* gx, int B, int H, int W, int C, int p, float slope,

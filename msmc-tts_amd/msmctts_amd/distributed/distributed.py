@@ -65,6 +65,7 @@ class GradReducer(object):
         self.hooks_enabled = True
         self._owner = {}
         self._inflight = []
+        self._flat = {}                      # per child: persistent flat exchange buffer of the graph-mode path
         children = list(module.named_children()) or [('', module)]
         for _, child in children:
             params = [p for p in child.parameters() if p.requires_grad]
@@ -108,24 +109,37 @@ class GradReducer(object):
         b.ready = []
         b.pending = set(id(p) for p in b.params)
 
-    def allreduce_child(self, child):
-        """Synchronous exchange of every existing gradient of one child (used between hipGraph replays, where
-        the hooks do not fire): one flat all-reduce, averaged, written back in place."""
-        ps = [p for p in child.parameters() if p.requires_grad and p.grad is not None]
-        if not ps:
-            return
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    def allreduce_child(self, child, grads=None):
+        """Synchronous exchange of one child's gradients (used between hipGraph replays, where the hooks do not fire):
+        one flat all-reduce, averaged, written back in place.  ``grads``: the static gradient tensors the graphs write
+        (the trainer records them at capture, so that a loop resetting ``p.grad`` cannot make this a silent no-op);
+        without it, every existing ``p.grad`` of the child."""
+        if grads is None:
+            grads = [p.grad for p in child.parameters() if p.requires_grad and p.grad is not None]
+        if not grads:
+            raise RuntimeError('gradient exchange found no gradients: ranks would silently diverge')
+        flat = self._flat.get(id(child))
+        total = sum(g.numel() for g in grads)
+        if flat is None or flat.numel() != total or flat.device != grads[0].device:
+            flat = self._flat[id(child)] = torch.empty(total, dtype=torch.float32, device=grads[0].device)
+        views = self._views(flat, grads)
+        torch._foreach_copy_(views, grads)
         dist.all_reduce(flat, group=self.group)
         flat.div_(self.world)
-        off = 0
-        for p in ps:
-            n = p.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p.grad))
-            off += n
+        torch._foreach_copy_(grads, views)
         for b in self.buckets:                      # drop hook state recorded while capturing
             b.ready = []
             b.pending = set(id(q) for q in b.params)
         self._inflight = []
+
+    @staticmethod
+    def _views(flat, grads):
+        out, off = [], 0
+        for g in grads:
+            n = g.numel()
+            out.append(flat[off:off + n].view_as(g))
+            off += n
+        return out
 
     def finish(self):
         """Flush partial buckets, wait for the collectives, write back grad / world_size."""

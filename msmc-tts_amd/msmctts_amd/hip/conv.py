@@ -18,6 +18,9 @@ from . import lib
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
+# diagnostic switches (tools/nan_bisect.py): "0" makes one grouped entry point issue its members one by one
+_G = {k: os.environ.get('MSMC_G_' + k, '1') != '0' for k in ('FWD', 'DGRAD', 'WGRAD', 'LRELU', 'FOLD')}
+
 
 class Geometry(object):
     """Forward geometry of conv(kernel (kh,kw), stride, dilation, padding) on an (Hin, Win) image."""
@@ -321,6 +324,8 @@ def conv_forward_group(items):
     """``items``: list of dicts with the arguments of ``conv_forward`` -- independent convolutions (the parallel
     ResBlocks of a generator stage, one layer of several sub-discriminators) issued as one grouped launch where their
     kernel choices coincide.  Returns the outputs in order."""
+    if not _G['FWD']:
+        return [conv_forward(**it) for it in items]
     stream = lib.stream(items[0]['x'])
     snaps, outs = [], []
     for it in items:
@@ -394,6 +399,8 @@ def conv_dgrad(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
 
 def conv_dgrad_group(items):
     """``items``: list of dicts with the arguments of ``conv_dgrad``; all phases of all members in one grouped call"""
+    if not _G['DGRAD']:
+        return [conv_dgrad(**it) for it in items]
     stream = lib.stream(items[0]['g'])
     snaps, outs = [], []
     for it in items:
@@ -463,6 +470,11 @@ def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None, db=None, copies=1):
 def conv_wgrad_group(items):
     """``items``: list of dicts with the arguments of ``conv_wgrad`` (``dw`` required): independent weight gradients
     issued as grouped launches (msmc_conv_wgrad_group)."""
+    if not _G['WGRAD']:
+        for it in items:
+            conv_wgrad(it['x'], it['g'], it['geom'], it['n_slices'], in_slope=it.get('in_slope', 1.0), dw=it['dw'],
+                       db=it.get('db'), copies=it.get('copies', 1))
+        return
     stream = lib.stream(items[0]['x'])
     snaps, gs, dws, dbs = [], [], [], []
     for it in items:
@@ -566,6 +578,8 @@ def lrelu_bwd(g, y, slope):
 
 def lrelu_bwd_group(pairs, slope):
     """[(g, y), ...] -> [g * (y > 0 ? 1 : slope), ...] in launches of up to six tensors (msmc_lrelu_bwd_multi)."""
+    if not _G['LRELU']:
+        return [lrelu_bwd(g, y, slope) for g, y in pairs]
     outs = []
     L = lib.get()
     for i in range(0, len(pairs), 6):
@@ -588,6 +602,8 @@ def lrelu_bwd_group(pairs, slope):
 
 def reflect_fold_group(items, p=1, slope=1.0):
     """[(gp, H, W, mask_src or None), ...] -> folded gradients, up to six tensors per launch (msmc_reflect_fold_multi)."""
+    if not _G['FOLD']:
+        return [reflect_fold(gp, H, W, p, mask_src=mask, slope=slope) for gp, H, W, mask in items]
     outs = []
     L = lib.get()
     for i in range(0, len(items), 6):

@@ -115,6 +115,7 @@ class ConvBank(object):
             l.index = i
         self._sig = None
         self._queued = False
+        self._touched = set()           # layers whose weight gradient was accumulated in the running backward pass
         self._hold = []                 # gradients shared by several consumers, pinned until the backward ends
         self.streams = []               # side streams whose backward launches write this bank's accumulators
 
@@ -199,25 +200,42 @@ class ConvBank(object):
             self._queued = True
             Variable._execution_engine.queue_callback(self._finish_backward)
 
+    @staticmethod
+    def _grad_pairs(l):
+        m = l.module
+        return (((m.bias, l.gb_view), (m.weight, l.gv_view)) if l.plain else
+                ((m.bias, l.gb_view), (m.weight_g, l.gg_view), (m.weight_v, l.gv_view)))
+
     def _finish_backward(self):
         self._queued = False
         del self._hold[:]
+        touched, self._touched = self._touched, set()
+        if not touched:                 # a pass that only propagated through this network (frozen D in the G step)
+            return
         if self.streams:                # weight-gradient launches ran on the side streams of their forward
             cur = torch.cuda.current_stream()
             for st in self.streams:
                 cur.wait_stream(st)
-        lib.check(lib.get().msmc_wn_backward_multi(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
-                                                   lib.stream(self.w1)), 'msmc_wn_backward_multi')
         with torch.no_grad():
+            # torch .grad semantics: a gradient that is still live (no zero_grad since the last backward) is added to.
+            # The live gradients ARE the bank's output buffers, so the kernel accumulates in place; buffers of
+            # parameters whose gradient was reset are cleared first.
+            live = lambda p, gview: p.grad is not None and p.grad.data_ptr() == gview.data_ptr()
+            accumulate = any(live(p, gv) for l in self.layers for p, gv in self._grad_pairs(l))
+            if accumulate:
+                for l in self.layers:
+                    for p, gview in self._grad_pairs(l):
+                        if not live(p, gview):
+                            gview.zero_()
+            lib.check(lib.get().msmc_wn_backward_multi_acc(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
+                                                           1 if accumulate else 0, lib.stream(self.w1)),
+                      'msmc_wn_backward_multi_acc')
             for l in self.layers:
-                m = l.module
-                if not l.weight.requires_grad:
+                if l.index not in touched or not l.weight.requires_grad:
                     continue
                 # gradients ARE the bank's output buffers (no copies): they stay valid until the next backward
                 # of this network, i.e. past the optimizer step that consumes them
-                pairs = (((m.bias, l.gb_view), (m.weight, l.gv_view)) if l.plain else
-                         ((m.bias, l.gb_view), (m.weight_g, l.gg_view), (m.weight_v, l.gv_view)))
-                for p, gview in pairs:
+                for p, gview in self._grad_pairs(l):
                     if p.grad is None:
                         p.grad = gview
                     elif p.grad.data_ptr() != gview.data_ptr():
@@ -276,6 +294,7 @@ class _HipConv(torch.autograd.Function):
                 K.conv_transpose1d_wgrad(x, g, layer.kernel[1], layer.stride[1], layer.padding[1],
                                          in_slope=ctx.in_slope, dw=layer.dw, copies=layer.dw_copies)
                 layer.db.add_(K.colsum(g.reshape(-1, g.shape[-1])))
+            bank._touched.add(layer.index)
             bank._queue_finish()
         if ctx.has_res or ctx.has_res2:
             # g goes to several consumers that may replay on different streams.  The autograd engine accumulates
@@ -309,6 +328,7 @@ class _HipConvGroup(torch.autograd.Function):
                               in_slope=in_slope, res=res, res2=res2, out_div=out_div, out_slope=out_slope))
         outs = K.conv_forward_group(items)
         ctx.bank, ctx.specs, ctx.ntensors = bank, specs, len(tensors)
+        ctx.need_w = [sp[0].weight.requires_grad for sp in specs]     # as of the forward (a frozen pass stays frozen)
         ctx.xpos = [m[0] for m in members]
         saved = [m[1] for m in members] + [o if sp[2] != 1.0 else None for o, sp in zip(outs, specs)]
         ctx.save_for_backward(*saved)
@@ -343,9 +363,10 @@ class _HipConvGroup(torch.autograd.Function):
                 else:
                     d_items.append(dict(g=g, wb=layer.wb, geom=geom, mask_src=mask, mask_slope=in_slope))
                 d_members.append(k)
-            if layer.weight.requires_grad:
+            if ctx.need_w[k]:
                 w_items.append(dict(x=x, g=g, geom=geom, n_slices=layer.taps, in_slope=in_slope, dw=layer.dw, db=layer.db,
                                     copies=layer.dw_copies))
+                bank._touched.add(layer.index)
             if has_res:
                 grads[pos + 1] = g
             if has_res2:

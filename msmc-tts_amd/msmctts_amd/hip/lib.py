@@ -89,6 +89,7 @@ _SIGNATURES.update({
                               _i, _vp]),
     'msmc_wn_prepare_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_wn_backward_multi': (_i, [_vp, _i, _i, _vp]),
+    'msmc_wn_backward_multi_acc': (_i, [_vp, _i, _i, _i, _vp]),
     'msmc_reflect_fold_multi': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i),
                                 ctypes.POINTER(_i), _i, _i, _f, _i, _vp]),
     'msmc_lrelu_bwd_multi': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_long), _i, _f, _i, _vp]),

@@ -38,6 +38,10 @@ class BaseTrainer(object):
     def train_step(self, batch, iteration):
         raise NotImplementedError
 
+    def replays(self, iteration):
+        """True when ``train_step(iteration)`` replays captured hipGraphs (trainers with a graph mode override)."""
+        return False
+
     def _sync_grads(self):
         reducer = getattr(self.model, 'grad_reducer', None)
         if reducer is not None:
@@ -46,8 +50,9 @@ class BaseTrainer(object):
     # -- loop ------------------------------------------------------------------------------
     def train(self, data_loader, logger=None):
         """Run until ``config.training_steps``; ``data_loader`` is re-iterated as epochs."""
+        graphs = getattr(self, 'use_graphs', False)
         if self.optimizer is None:
-            self.optimizer = build_optimizer(self.model, self.config.optimizer)
+            self.optimizer = build_optimizer(self.model, self.config.optimizer, capturable=graphs)
         scheduler = build_lr_scheduler(self.config.lr_scheduler) if 'lr_scheduler' in self.config else None
         iteration = self.attempt_load_checkpoint()
         self.model.train()
@@ -56,8 +61,9 @@ class BaseTrainer(object):
                 if scheduler is not None:
                     scheduler.step(self.optimizer, iteration)
                 batch = to_model(batch)
-                self.model.zero_grad()
-                self.optimizer.zero_grad()
+                if not (graphs and self.replays(iteration)):    # replayed steps own static gradient buffers
+                    self.model.zero_grad()
+                    self.optimizer.zero_grad()
                 log = self.train_step(batch, iteration)
                 if logger is not None:
                     logger(iteration, log)

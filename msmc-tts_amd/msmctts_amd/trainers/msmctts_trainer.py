@@ -197,6 +197,9 @@ class VQGANTrainer(BaseTrainer):
             return 0
         return 2 if iteration > self.warmup_steps else 1
 
+    def replays(self, iteration):
+        return bool(self.use_graphs) and self._phase(iteration) == 2
+
     def train_step(self, batch, iteration):
         phase = self._phase(iteration)
         if self.use_graphs and phase == 2:
@@ -239,17 +242,46 @@ class VQGANTrainer(BaseTrainer):
             st.mel_length.copy_(batch['mel_length'], non_blocking=True)
             g['wav'].copy_(batch['wav'].reshape(g['wav'].shape), non_blocking=True)
         g['a'].replay()
-        self._sync_grads_static('discriminator')
+        self._sync_grads_static('discriminator', g)
         g['b'].replay()
-        self._sync_grads_static('autoencoder')
+        self._sync_grads_static('autoencoder', g)
         g['c'].replay()
         vec = g['loss_vec'].clone()                  # the graph's outputs are static buffers: hand out a snapshot
         return {'loss': {k: vec[i] for i, k in enumerate(g['loss_keys'])}}
 
-    def _sync_grads_static(self, child):
+    def _sync_grads_static(self, child, g=None):
+        """Gradient exchange between two replayed segments.  The gradients are the STATIC tensors the graphs write
+        (recorded at capture): a training loop that sets ``p.grad = None`` between steps cannot hide them."""
         reducer = getattr(self.model, 'grad_reducer', None)
         if reducer is not None:
-            reducer.allreduce_child(getattr(self.model, child))
+            grads = g['grads'][child] if g is not None and 'grads' in g else None
+            reducer.allreduce_child(getattr(self.model, child), grads=grads)
+
+    # -- the eager warm-up inside _capture really trains (parameters, VQ codebooks, optimizer moments move): undo it,
+    #    so that a graphed run performs exactly the optimizer steps an eager run performs
+    def _snapshot_state(self):
+        """by NAME: modules may re-register their buffers during the first forward (the quantiser packs its per-head
+        codebooks into one tensor), so tensor identities taken before the warm-up can go stale"""
+        opt = []
+        for o in self.optimizer.optimizers.values():
+            for st in o.state.values():
+                opt.extend(v for v in st.values() if torch.is_tensor(v))
+        return {'model': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+                'opt': [(t, t.detach().clone()) for t in opt]}
+
+    def _restore_state(self, snap):
+        with torch.no_grad():
+            live = self.model.state_dict()                 # aliases the registered parameters / buffers
+            for k, saved in snap['model'].items():
+                live[k].copy_(saved)
+            for t, saved in snap['opt']:
+                t.copy_(saved)
+            known = set(id(t) for t, _ in snap['opt'])
+            for o in self.optimizer.optimizers.values():
+                for st in o.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v) and id(v) not in known:       # moments / step created by the warm-up
+                            v.zero_()
 
     def _build_windows(self, g, st):
         """Frame / sample index tensors from the per-utterance window starts (device arithmetic only)."""
@@ -264,6 +296,10 @@ class VQGANTrainer(BaseTrainer):
         """Warm up eagerly on a side stream, then record segments A, B, C into three graphs sharing one pool."""
         dev = batch['mel'].device
         B = batch['mel'].shape[0]
+        from ..hip import graphs as hipgraphs
+        if not hipgraphs.memset_nodes_ordered(dev):
+            raise RuntimeError(hipgraphs.HINT)
+        snap = self._snapshot_state()
         st = _StepState()
         st.phase = 2
         st.mel, st.mel_length = batch['mel'].clone(), batch['mel_length'].clone()
@@ -274,9 +310,7 @@ class VQGANTrainer(BaseTrainer):
         def run_eager():
             self._build_windows(g, st)
             self._segment_a(st)
-            self._sync_grads_static('discriminator')
-            self._segment_b(st)
-            self._sync_grads_static('autoencoder')
+            self._segment_b(st)                      # (no gradient exchange: the warm-up's updates are rolled back)
             self._segment_c(st)
 
         side = torch.cuda.Stream()
@@ -304,18 +338,21 @@ class VQGANTrainer(BaseTrainer):
         with torch.cuda.graph(ga, stream=side, capture_error_mode=mode):
             self._build_windows(g, st)
             self._segment_a(st)
-        self._sync_grads_static('discriminator')
         torch.cuda.synchronize()
         with torch.cuda.graph(gb, pool=ga.pool(), stream=side, capture_error_mode=mode):
             self._segment_b(st)
-        self._sync_grads_static('autoencoder')
         keys = [k for k, v in st.losses.items() if torch.is_tensor(v)]
         torch.cuda.synchronize()
         with torch.cuda.graph(gc, pool=ga.pool(), stream=side, capture_error_mode=mode):
             self._segment_c(st)
             loss_vec = torch.stack([st.losses[k].detach().float().reshape(()) for k in keys])
         torch.cuda.synchronize()
-        g.update(a=ga, b=gb, c=gc, loss_vec=loss_vec, loss_keys=keys)
+        # the static gradient tensors each segment writes, per child, in parameter order (identical on every rank)
+        grads = {name: [p.grad for p in getattr(self.model, name).parameters() if p.requires_grad and p.grad is not None]
+                 for name in ('discriminator', 'autoencoder') if hasattr(self.model, name)}
+        g.update(a=ga, b=gb, c=gc, loss_vec=loss_vec, loss_keys=keys, grads=grads)
+        self._restore_state(snap)
+        torch.cuda.synchronize()
         return g
 
 

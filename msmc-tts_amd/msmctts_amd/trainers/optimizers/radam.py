@@ -1,7 +1,8 @@
 """Rectified Adam (selectable as ``optimizer._name: RAdam``; reference trainers/optimizers/radam.py:8-85).
 
 Written from the RAdam paper's update rule (Liu et al. 2020, Algorithm 2) in the variant the
-reference uses: variance rectification when rho_t > 4 (SGD-with-momentum step otherwise) and
+reference uses: variance rectification when rho_t >= 5 (reference radam.py:63,73 -- 'more conservative' than the
+paper's rho_t > 4; SGD-with-momentum step otherwise) and
 weight decay applied as an L2 term to the parameter before the update.
 """
 import math
@@ -38,7 +39,7 @@ class RAdam(Optimizer):
                 w = p.float()
                 if group['weight_decay'] != 0:
                     w.add_(w, alpha=-group['weight_decay'] * group['lr'])
-                if rho_t > 4:
+                if rho_t >= 5:
                     rect = math.sqrt((1 - b2t) * (rho_t - 4) / (rho_inf - 4) * (rho_t - 2) / rho_t * rho_inf / (rho_inf - 2))
                     w.addcdiv_(st['exp_avg'], st['exp_avg_sq'].sqrt().add_(group['eps']),
                                value=-group['lr'] * rect / (1 - b1 ** t))

@@ -11,6 +11,9 @@ for p in (ROOT, os.path.join(ROOT, 'msmc-tts_amd'), os.path.dirname(os.path.absp
         sys.path.insert(0, p)
 
 
+import msmctts_amd  # noqa: E402,F401  -- before the first HIP call: sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (see its docstring)
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
