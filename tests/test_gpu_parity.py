@@ -171,17 +171,10 @@ def graphed_vs_eager(arm_reducer=False):
         tr.use_graphs = graphed
         tr.rng = random.Random(3)
         if graphed:
-            log = tr.train_step(batch, 6)                      # 2 eager warm-up steps (window start 0) + capture + replay
+            log = tr.train_step(batch, 6)        # capture (its eager warm-up is rolled back) + first replay
             log = {'loss': {k: float(v) for k, v in log['loss'].items()}}
             log2 = tr.train_step(batch, 7)
         else:
-            zero = lambda ml: ([(0, 8)] * 3, [(0, 2400)] * 3)
-            rs = tr.random_select
-            tr.random_select = zero
-            for it in (6, 6):
-                task.zero_grad()
-                tr.train_step(batch, it)
-            tr.random_select = rs
             task.zero_grad()
             log = tr.train_step(batch, 6)
             task.zero_grad()
