@@ -111,7 +111,10 @@ typedef struct msmc_conv_desc {
                                four weight vectors in flight per work-item, 6 / 7 = as 2 / 3 with the whole channel chunk in flight
                                and the next chunk prefetched (small grids; MSMC_E_SHAPE when the chunk exceeds 16 vectors
                                per work-item), 8 = direct (matrix-core-free) kernels for <= 8 -> <= 16 channel layers,
-                               C -> 1 and 1 -> C layers (MSMC_E_SHAPE otherwise), 9 = 32-point tiles with the channel
+                               C -> 1 and 1 -> C layers (MSMC_E_SHAPE otherwise), 16..23 = third generation (bf16: 64-row wave
+                               tiles, LDS-DMA weight stream, one barrier per chunk; 16 + (256- instead of 128-point tiles) +
+                               2*(64- instead of 32-column wave tiles) + 4*(128- instead of 64-byte chunks); MSMC_E_SHAPE
+                               where a configuration does not apply), 9 = 32-point tiles with the channel
                                chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation.  The host layer times the candidates once per layer shape.       */
     int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative)                */

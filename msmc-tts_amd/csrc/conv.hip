@@ -774,6 +774,8 @@ static int cv_geometry(const msmc_conv_desc* d, CvGeom* G, int elt_bytes, int XS
     return 0;
 }
 
+#include "gather3.inc"
+
 template <typename T, int NT, int MT>
 static int cv_try_pipe(const msmc_conv_desc* d, msmc_stream stream, bool* done) {
     constexpr int XS = Elt<T>::CK + Elt<T>::VEC, CKV = Elt<T>::CK / Elt<T>::VEC;
@@ -1266,6 +1268,10 @@ extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
         if (rc != 0) return rc < 0 ? rc : 0;
         if (d->variant == 8) return MSMC_E_SHAPE;
     }
+    if (cv3_is_variant(d->variant)) {           // third generation (bf16): E_SHAPE when the configuration does not apply
+        const int rc = cv3_launch(d, stream);
+        return rc < 0 ? rc : rc == 1 ? 0 : MSMC_E_SHAPE;
+    }
     if (d->variant == 9) {                      // wave-split deep reduction (E_SHAPE when it does not apply)
         int rc = d->dtype == 0 ? cv_ks_launch<float>(d, stream)
                  : d->dtype == 1 ? cv_ks_launch<unsigned short>(d, stream) : MSMC_E_SHAPE;
@@ -1587,9 +1593,45 @@ template <typename T>
 static int cv_group_launch(const msmc_conv_desc* descs, int n, msmc_stream stream) {
     Cv2Plan plans[MSMC_GROUP_LIMIT];
     bool pending[MSMC_GROUP_LIMIT], direct[MSMC_GROUP_LIMIT];
+    // third-generation members: one grid per configuration (tile shape, chunk, halo registers)
+    Cv3Plan p3[MSMC_GROUP_LIMIT];
+    bool gen3[MSMC_GROUP_LIMIT];
+    for (int i = 0; i < n; ++i) {
+        gen3[i] = false;
+        if (!cv3_is_variant(descs[i].variant)) continue;
+        int rc = cv3_plan(&descs[i], descs[i].variant, &p3[i]);
+        if (rc) return rc;
+        if (!p3[i].applies) return MSMC_E_SHAPE;
+        gen3[i] = true;
+    }
+    for (int i = 0; i < n; ++i) {
+        if (!gen3[i]) continue;
+        CvGroupArgs a;
+        a.n = 0;
+        int blocks = 0;
+        size_t lds = 0;
+        for (int j = i; j < n && a.n < MSMC_GROUP_MAX; ++j) {
+            if (!gen3[j] || p3[j].wm != p3[i].wm || p3[j].ntw != p3[i].ntw || p3[j].ckm != p3[i].ckm || p3[j].xv != p3[i].xv)
+                continue;
+            a.first[a.n] = blocks;
+            a.nx[a.n] = (int)p3[j].gx;
+            a.d[a.n] = descs[j];
+            a.G[a.n] = p3[j].G;
+            blocks += (int)(p3[j].gx * p3[j].gy);
+            if (p3[j].lds > lds) lds = p3[j].lds;
+            gen3[j] = false;
+            ++a.n;
+        }
+        a.first[a.n] = blocks;
+        ++msmc_conv_launches;
+        int rc = a.n == 1 ? cv3_dispatch(p3[i], dim3(p3[i].gx, p3[i].gy), p3[i].lds, stream, &a.d[0], &a.G[0], nullptr)
+                          : cv3_dispatch(p3[i], dim3((unsigned)blocks), lds, stream, nullptr, nullptr, &a);
+        if (rc) return rc;
+    }
     for (int i = 0; i < n; ++i) {
         pending[i] = direct[i] = false;
         const msmc_conv_desc* d = &descs[i];
+        if (cv3_is_variant(d->variant)) continue;
         int nt_unused;
         int rc = (cv_takes_direct(d) || d->variant == 9) ? 0 : cv2_plan<T>(d, &plans[i], &nt_unused);
         if (rc) return rc;

@@ -78,6 +78,40 @@ MSMC_DEV u16x4 lds_read_tr16(const unsigned short* p) {
     return __builtin_bit_cast(u16x4, v);
 }
 
+// ---- LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane from a per-lane global address straight into LDS at
+// wave-uniform base + 16 * lane (the image is lane-linear: swizzle the SOURCE, never the destination); no registers.
+// lds_dma_wait() retires every outstanding piece of the calling wave; a barrier must follow before other waves read.
+MSMC_DEV void lds_dma16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+MSMC_DEV void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// The machine scheduler must not move instructions across this point (software pipelines written in source order:
+// hipcc otherwise sinks prefetching LDS reads down to their first use and waits with lgkmcnt(0)).
+MSMC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+// ---- hand-counted LDS reads: hipcc waits with lgkmcnt(0) at the first use of an LDS read issued before a loop
+// back edge, which exposes one LDS round trip per iteration of a software-pipelined fragment loop.  These reads are
+// invisible to the compiler's wait insertion; the CALLER retires them with lds_wait<N>() (= at most N younger LDS
+// operations of this wave still outstanding; LDS operations return in order) before the first use, and must drain
+// (lds_wait<0>) before the destination registers die.  cdna_hip_programming.md 5.7, form (iii).
+MSMC_DEV u16x8 lds_read128_async(const void* p) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((__attribute__((address_space(3))) const char*)p));
+    return __builtin_bit_cast(u16x8, v);
+}
+MSMC_DEV int lds_read32_async(const void* p) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"((__attribute__((address_space(3))) const char*)p));
+    return v;
+}
+template <int N>
+MSMC_DEV void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---- bf16 <-> f32 (round to nearest even), bit-level so host and device agree ---------------
 MSMC_DEV unsigned short f32_to_bf16_bits(float f) {
     unsigned int u = __float_as_uint(f);

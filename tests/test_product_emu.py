@@ -166,3 +166,41 @@ def test_gather_wave_split_deep_reduction_variant():
 
 def test_vq_edge_cases_empty_single_frame_zero_length_ragged():
     _parity.check_vq_edge_cases('cpu')
+
+
+@pytest.mark.parametrize('variant', [16, 17, 18, 19, 20, 21, 22, 23])
+def test_gather_third_generation_variants(variant):
+    """variants 16..23 (gather3.inc: 64-row wave tiles, LDS-DMA weight stream with source-side swizzle, one barrier per
+    channel chunk): every tile shape / chunk width where it applies, forward and data gradient, ragged tiles,
+    dilation, stride, reflection, Cout not a multiple of the tile"""
+    from msmctts_amd.hip import conv
+    cases = [('g3 k3 64->64', 2, 64, 64, 1, 150, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
+             ('g3 k11 d5 128->32', 1, 128, 32, 1, 70, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
+             ('g3 k5x1 s3 64->96', 1, 64, 96, 40, 3, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
+             ('g3 3x3 reflect s2 64->72', 1, 64, 72, 13, 18, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
+             ('g3 k1 256->136', 1, 256, 136, 1, 37, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+             ('g3 k3 128->128', 1, 128, 128, 1, 45, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1)]
+    real = conv._build_desc
+    used = []
+
+    def forced(*a, **k):
+        d = real(*a, **k)
+        if d.dtype == 1:
+            d.variant = variant
+            used.append((d.Cin, d.Cout))
+        return d
+    conv._build_desc = forced
+    ran = 0
+    try:
+        for case in cases:
+            for part in ('fwd', 'dgrad'):
+                conv._PLANS.clear()
+                try:
+                    _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=(part,))
+                    ran += 1
+                except RuntimeError as e:             # MSMC_E_SHAPE: this configuration does not apply to the layer
+                    assert 'msmc_conv_gather' in str(e), e
+    finally:
+        conv._build_desc = real
+        conv._PLANS.clear()
+    assert ran >= 2, (variant, ran)
