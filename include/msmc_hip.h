@@ -116,7 +116,7 @@ typedef struct msmc_conv_desc {
                                2*(64- instead of 32-column wave tiles) + 4*(128- instead of 64-byte chunks); MSMC_E_SHAPE
                                where a configuration does not apply), 9 = 32-point tiles with the channel
                                chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
-                               2 = second generation.  The host layer times the candidates once per layer shape.       */
+                               2 = second generation (fp32 atomics), 3 = third (split partials + fixed-order reduce).  The host layer times the candidates once per layer shape.       */
     int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative)                */
     int dw_copies;          /* msmc_conv_wgrad: R > 1 = dw is [R][ntaps][Cout][Cin] and db [R][Cout]; workgroup i adds
                                into copy i % R (same-address atomics retire serially; R copies shorten the chain R
@@ -156,6 +156,16 @@ int msmc_conv_wgrad(const msmc_conv_desc* desc, const void* g, float* dw, float*
  * second-generation members share one grid per (at most six) members. */
 int msmc_conv_wgrad_group(const msmc_conv_desc* descs, const void* const* g, float* const* dw, float* const* db, int n,
                           msmc_stream stream);
+/* Third generation (desc->variant == 3, bf16): NO atomics.  The pixel reduction is split only as far as it takes to fill
+ * the chip; every split stores its partial dW (and db) into its own region of a caller-provided workspace with plain
+ * stores, and a second launch adds the regions to dw / db in split order (bit-reproducible).  With a single split the
+ * kernel accumulates straight into dw and needs no workspace.  msmc_conv_wgrad_workspace: bytes this descriptor needs
+ * (0 for other variants / dtypes); a group needs the sum over its members.  MSMC_E_WORKSPACE when it is too small. */
+size_t msmc_conv_wgrad_workspace(const msmc_conv_desc* desc, const void* g);
+int msmc_conv_wgrad_ws(const msmc_conv_desc* desc, const void* g, float* dw, float* db, void* workspace,
+                       size_t workspace_bytes, msmc_stream stream);
+int msmc_conv_wgrad_group_ws(const msmc_conv_desc* descs, const void* const* g, float* const* dw, float* const* db, int n,
+                             void* workspace, size_t workspace_bytes, msmc_stream stream);
 
 /* Weight-norm (torch weight_norm, dim=0) for MANY convolutions in one launch.
  * Item i: v [A][Bc][T] fp32 contiguous (A = dim 0, the normalised axis; T = taps), g [A] fp32.

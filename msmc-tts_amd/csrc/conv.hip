@@ -2126,6 +2126,9 @@ static int wg_launch(const msmc_conv_desc* d, const void* g, float* dw, float* d
 //   * tile coordinates come from LDS tables built once per workgroup.
 // ------------------------------------------------------------------------------------------------
 struct Wg2Params {
+    float* ws;               // third generation: per-split partial results [nsplit][ws_stride] (dW then db), NULL = none
+    long ws_stride;          // floats per split region
+    int direct;              // 1: this launch owns every dW element exactly once -> plain (non-atomic) accumulation
     int TM, tilesPerWg, totalTiles;
     int XSx, XSg;            // LDS row strides (elements)
     int vex, veg;            // elements per staging vector (1, 2, 4, 8)
@@ -2291,7 +2294,11 @@ MSMC_DEV void wg2_body(const msmc_conv_desc& d, const unsigned short* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    if (d.dw_copies > 1) {                              // privatised accumulators: copy (split index mod R)
+    const bool partial = P.ws != nullptr;               // plain stores into this split's workspace region
+    if (partial) {
+        dw = P.ws + (size_t)block_x * P.ws_stride;
+        if (db) db = dw + (size_t)d.ntaps * d.Cout * d.Cin;
+    } else if (d.dw_copies > 1 && !P.direct) {          // privatised accumulators: copy (split index mod R)
         const int copy = block_x % d.dw_copies;
         dw += (size_t)copy * d.ntaps * d.Cout * d.Cin;
         if (db) db += (size_t)copy * d.Cout;
@@ -2367,8 +2374,12 @@ MSMC_DEV void wg2_body(const msmc_conv_desc& d, const unsigned short* __restrict
                 if (q < ve) red[w * 64 + lane * ve + q] = bsum[q];
         }
         __syncthreads();
-        if (tid < nv * ve && co0 + tid < d.Cout)
-            atomicAdd(db + co0 + tid, ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid]);
+        if (tid < nv * ve && co0 + tid < d.Cout) {
+            const float bs = ((red[tid] + red[64 + tid]) + red[128 + tid]) + red[192 + tid];
+            if (partial) db[co0 + tid] = bs;
+            else if (P.direct) db[co0 + tid] = db[co0 + tid] + bs;
+            else atomicAdd(db + co0 + tid, bs);
+        }
     }
     // D fragment: row (co) = 32*cb + (r&3) + 8*(r>>2) + 4*g, col (ci) = 32*ib + (lane & 31)
 #pragma unroll
@@ -2380,8 +2391,103 @@ MSMC_DEV void wg2_body(const msmc_conv_desc& d, const unsigned short* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + 32 * cb + (r & 3) + 8 * (r >> 2) + 4 * g;
-            if (co < d.Cout) atomicAdd(dst + (size_t)co * d.Cin + ci, acc[j][r]);
+            if (co >= d.Cout) continue;
+            float* q = dst + (size_t)co * d.Cin + ci;
+            if (partial) *q = acc[j][r];
+            else if (P.direct) *q = *q + acc[j][r];
+            else atomicAdd(q, acc[j][r]);
         }
+    }
+}
+
+// second stage of the third-generation weight gradient: the splits' partial results are summed in split order
+// (bit-reproducible).  Small dW with many splits (thin layers over long signals) would leave this stage with a dozen
+// workgroups, so it runs in two levels there: groups of consecutive splits are summed into `groups` intermediate
+// regions (stored), then the groups are added to dW / db.  A member is one such pass: nsplit source regions of
+// `stride` floats -> either an intermediate region (dst_ws) or the final dw | db pair.
+struct WgReduceArgs {
+    int n;
+    int first[MSMC_GROUP_MAX + 1];          // first block of member k
+    int eblocks[MSMC_GROUP_MAX];            // blocks per group of member k (1024 floats each)
+    const float* src[MSMC_GROUP_MAX];
+    long stride[MSMC_GROUP_MAX];
+    long n_dw[MSMC_GROUP_MAX];
+    int nsplit[MSMC_GROUP_MAX], per_group[MSMC_GROUP_MAX], n_db[MSMC_GROUP_MAX];
+    float* dst_ws[MSMC_GROUP_MAX];          // not NULL: intermediate level, group gi stores its sums at dst_ws + gi * stride
+    float* dw[MSMC_GROUP_MAX];              // final level (one group): dw[e] += sum, db[e - n_dw] += sum
+    float* db[MSMC_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WgReduceArgs a) {
+    const int k = cv_group_member(a.first, a.n);
+    const int id = blockIdx.x - a.first[k];
+    const int gi = id / a.eblocks[k], eb = id - gi * a.eblocks[k];
+    const long stride = a.stride[k], n_dw = a.n_dw[k], total = n_dw + a.n_db[k];
+    const int s0 = gi * a.per_group[k];
+    int S = a.nsplit[k] - s0;
+    if (S > a.per_group[k]) S = a.per_group[k];
+    const float* ws = a.src[k] + (size_t)s0 * stride;
+    const long e0 = ((long)eb * 256 + threadIdx.x) * 4;
+    if (e0 >= total || S <= 0) return;
+    float* mid = a.dst_ws[k] ? a.dst_ws[k] + (size_t)gi * stride : nullptr;
+    // (regions are padded to a multiple of four floats: an intermediate level may run past `total` inside them)
+    if ((n_dw & 3) == 0 && (mid ? e0 + 4 <= stride : e0 + 4 <= n_dw)) {
+        f32x4 sum = *(const f32x4*)(ws + e0);
+        for (int s_ = 1; s_ < S; ++s_) {
+            const f32x4 v = *(const f32x4*)(ws + (size_t)s_ * stride + e0);
+            sum = sum + v;
+        }
+        if (mid) { *(f32x4*)(mid + e0) = sum; return; }
+        f32x4* q = (f32x4*)(a.dw[k] + e0);
+        *q = *q + sum;
+        return;
+    }
+    for (long e = e0; e < e0 + 4 && e < total; ++e) {
+        float sum = ws[e];
+        for (int s_ = 1; s_ < S; ++s_) sum = sum + ws[(size_t)s_ * stride + e];
+        if (mid) mid[e] = sum;
+        else if (e < n_dw) a.dw[k][e] = a.dw[k][e] + sum;
+        else if (a.db[k]) a.db[k][e - n_dw] = a.db[k][e - n_dw] + sum;
+    }
+}
+
+// plan of the second stage for one weight gradient: groups == 1 -> one level
+struct Wg3Reduce {
+    int groups, per_group;      // intermediate regions and splits per region (the last one may hold fewer)
+};
+static Wg3Reduce wg3_reduce_plan(long total, int nsplit) {
+    Wg3Reduce r = {1, nsplit};
+    const long echunks = (total + 1023) / 1024;
+    if (nsplit >= 32 && echunks < 2 * MSMC_NUM_CU) {
+        int groups = (int)((2 * MSMC_NUM_CU + echunks - 1) / echunks);
+        if (groups > nsplit / 8) groups = nsplit / 8;
+        if (groups > 32) groups = 32;
+        if (groups > 1) {
+            r.per_group = (nsplit + groups - 1) / groups;
+            r.groups = (nsplit + r.per_group - 1) / r.per_group;
+        }
+    }
+    return r;
+}
+// append the pass of one weight gradient at `level` (0: split groups -> intermediate regions, only when the plan has
+// several groups; 1: -> dw | db) to a launch; `mid` = the intermediate regions (groups * stride floats)
+static void wg3_reduce_add(WgReduceArgs& a, int* blocks, const float* ws, long stride, long n_dw, int n_db, int nsplit,
+                           float* mid, float* dw, float* db, int level) {
+    const long total = n_dw + n_db;
+    const Wg3Reduce r = wg3_reduce_plan(total, nsplit);
+    if (level == 0 && r.groups == 1) return;
+    const int k = a.n++;
+    a.first[k] = *blocks;
+    a.eblocks[k] = (int)((total + 1023) / 1024);
+    a.stride[k] = stride; a.n_dw[k] = n_dw; a.n_db[k] = n_db;
+    if (level == 0) {
+        a.src[k] = ws; a.nsplit[k] = nsplit; a.per_group[k] = r.per_group;
+        a.dst_ws[k] = mid; a.dw[k] = nullptr; a.db[k] = nullptr;
+        *blocks += a.eblocks[k] * r.groups;
+    } else {
+        a.src[k] = r.groups == 1 ? ws : mid;
+        a.nsplit[k] = a.per_group[k] = r.groups == 1 ? nsplit : r.groups;
+        a.dst_ws[k] = nullptr; a.dw[k] = dw; a.db[k] = db;
+        *blocks += a.eblocks[k];
     }
 }
 
@@ -2426,9 +2532,15 @@ struct Wg2Plan {
     size_t lds;
     int tpw;
     unsigned gx, gy, gz;
+    size_t ws_floats;            // third generation: workspace this launch needs (0: direct accumulation, one split)
 };
-static int wg2_plan(const msmc_conv_desc* d, const void* g, Wg2Plan* pl) {
+#define WG3_WS_CAP_FLOATS (12L * 1024 * 1024)       // 48 MiB of partial results per launch at most
+static int wg2_plan(const msmc_conv_desc* d, const void* g, Wg2Plan* pl, bool gen3 = false) {
     Wg2Params& P = pl->P;
+    P.ws = nullptr;
+    P.ws_stride = 0;
+    P.direct = 0;
+    pl->ws_floats = 0;
     const int cx = d->Cin > 64 ? 64 : d->Cin, cg = d->Cout > 64 ? 64 : d->Cout;
     P.vex = wg2_vec_elems(d->Cin, d->x);
     P.veg = wg2_vec_elems(d->Cout, g);
@@ -2471,12 +2583,29 @@ static int wg2_plan(const msmc_conv_desc* d, const void* g, Wg2Plan* pl) {
     if (d->split_shift > 0) nsplit <<= d->split_shift;
     else if (d->split_shift < 0) nsplit >>= -d->split_shift;
     const int cap = (4 * MSMC_NUM_CU + cols - 1) / cols;
+    const long n_dw = (long)d->ntaps * d->Cout * d->Cin;
+    const long stride = ((n_dw + d->Cout + 3) / 4) * 4;
+    if (gen3) {
+        // third generation: no atomics.  A split costs one plain store of its partial dW and one read in the second
+        // stage, so the pixel reduction is split only as far as it takes to fill the chip (~3 workgroups per CU), and
+        // never beyond the workspace cap; one split accumulates straight into dW.
+        nsplit = (3 * MSMC_NUM_CU + cols - 1) / cols;
+        if (d->split_shift > 0) nsplit <<= d->split_shift;
+        else if (d->split_shift < 0) nsplit >>= -d->split_shift;
+        const long fit = WG3_WS_CAP_FLOATS / stride;            // (the intermediate regions of a two-level second stage
+        if (nsplit > fit) nsplit = (int)(fit > 1 ? fit : 1);    //  are at most an eighth on top)
+    }
     if (msmc_wgrad_split_override > 0) nsplit = msmc_wgrad_split_override;
-    else if (nsplit > cap) nsplit = cap;
+    else if (!gen3 && nsplit > cap) nsplit = cap;
     if (nsplit > P.totalTiles) nsplit = P.totalTiles;
     if (nsplit < 1) nsplit = 1;
     P.tilesPerWg = (P.totalTiles + nsplit - 1) / nsplit;
     nsplit = (P.totalTiles + P.tilesPerWg - 1) / P.tilesPerWg;
+    if (gen3) {
+        P.direct = nsplit == 1;
+        P.ws_stride = stride;
+        pl->ws_floats = nsplit > 1 ? (size_t)(nsplit + wg3_reduce_plan(n_dw + d->Cout, nsplit).groups) * stride : 0;
+    }
     pl->lds = lds;
     pl->tpw = tpw <= 4 ? (tpw < 1 ? 1 : tpw) : 5;
     pl->gx = (unsigned)nsplit;
@@ -2485,10 +2614,22 @@ static int wg2_plan(const msmc_conv_desc* d, const void* g, Wg2Plan* pl) {
     return 0;
 }
 
-static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream) {
+static int wg3_reduce_launch(WgReduceArgs& a, int blocks, msmc_stream stream) {
+    MSMC_LAUNCH(conv_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
+    ++msmc_conv_launches;
+    return msmc_check_launch();
+}
+
+static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream,
+                      float* ws = nullptr, size_t ws_floats = 0) {
     Wg2Plan pl;
-    int rc = wg2_plan(d, g, &pl);
+    const bool gen3 = d->variant == 3;
+    int rc = wg2_plan(d, g, &pl, gen3);
     if (rc) return rc;
+    if (gen3 && pl.ws_floats) {
+        if (!ws || ws_floats < pl.ws_floats) return MSMC_E_WORKSPACE;
+        pl.P.ws = ws;
+    }
     const dim3 grid(pl.gx, pl.gy, pl.gz);
     const size_t lds = pl.lds;
     const unsigned short* gp = (const unsigned short*)g;
@@ -2505,47 +2646,90 @@ static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* 
     else WG2_GO(5);
 #undef WG2_GO
     msmc_conv_last = msmc_kname("conv_wgrad2_kernel", nullptr, pl.tpw, -1);
-    return msmc_check_launch();
+    rc = msmc_check_launch();
+    if (rc || !pl.P.ws) return rc;
+    const long n_dw = (long)d->ntaps * d->Cout * d->Cin;
+    float* mid = ws + (size_t)pl.gx * pl.P.ws_stride;
+    for (int level = 0; level < 2; ++level) {
+        WgReduceArgs a;
+        a.n = 0;
+        int blocks = 0;
+        wg3_reduce_add(a, &blocks, ws, pl.P.ws_stride, n_dw, db ? d->Cout : 0, (int)pl.gx, mid, dw, db, level);
+        if (!a.n) continue;
+        a.first[a.n] = blocks;
+        rc = wg3_reduce_launch(a, blocks, stream);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
-extern "C" int msmc_conv_wgrad(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream) {
+extern "C" int msmc_conv_wgrad_ws(const msmc_conv_desc* d, const void* g, float* dw, float* db, void* workspace,
+                                  size_t workspace_bytes, msmc_stream stream) {
     if (!d || !g || !dw || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0) return MSMC_E_SHAPE;
     if (d->ntaps <= 0 || d->ntaps > MSMC_CONV_MAX_TAPS) return MSMC_E_SHAPE;
     ++msmc_conv_launches;
-    if (d->dtype == 0) return wg_launch<float>(d, g, dw, db, stream);
+    if (d->dtype == 0) return d->variant == 3 ? MSMC_E_SHAPE : wg_launch<float>(d, g, dw, db, stream);
     if (d->dtype == 1) {
         const int gen = d->variant > 0 ? d->variant : msmc_wgrad_generation;
-        return gen == 1 ? wg_launch<unsigned short>(d, g, dw, db, stream) : wg2_launch(d, g, dw, db, stream);
+        if (gen == 1) return wg_launch<unsigned short>(d, g, dw, db, stream);
+        msmc_conv_desc e = *d;
+        e.variant = gen;                                      // (the generation switch selects the third one too)
+        return wg2_launch(&e, g, dw, db, stream, (float*)workspace, workspace_bytes / sizeof(float));
     }
     return MSMC_E_SHAPE;
 }
+extern "C" int msmc_conv_wgrad(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream) {
+    return msmc_conv_wgrad_ws(d, g, dw, db, nullptr, 0, stream);
+}
+extern "C" size_t msmc_conv_wgrad_workspace(const msmc_conv_desc* d, const void* g) {
+    if (!d || d->dtype != 1 || (d->variant > 0 ? d->variant : msmc_wgrad_generation) != 3) return 0;
+    Wg2Plan pl;
+    if (wg2_plan(d, g, &pl, true)) return 0;
+    return pl.ws_floats * sizeof(float);
+}
 
-// n independent weight gradients (msmc_conv_wgrad semantics each): bf16 second-generation members share grids
-extern "C" int msmc_conv_wgrad_group(const msmc_conv_desc* descs, const void* const* g, float* const* dw, float* const* db,
-                                     int n, msmc_stream stream) {
+// n independent weight gradients (msmc_conv_wgrad semantics each): bf16 second- / third-generation members share grids.
+// Third-generation members (variant 3) take consecutive regions of the workspace; one grouped second-stage launch
+// folds the partial results of all of them.
+extern "C" int msmc_conv_wgrad_group_ws(const msmc_conv_desc* descs, const void* const* g, float* const* dw,
+                                        float* const* db, int n, void* workspace, size_t workspace_bytes,
+                                        msmc_stream stream) {
     if (!descs || !g || !dw || n <= 0 || n > MSMC_GROUP_LIMIT) return MSMC_E_SHAPE;
     Wg2Plan plans[MSMC_GROUP_LIMIT];
     bool pending[MSMC_GROUP_LIMIT];
+    float* wsp = (float*)workspace;
+    size_t ws_left = workspace_bytes / sizeof(float);
     for (int i = 0; i < n; ++i) {
         const msmc_conv_desc* d = &descs[i];
         pending[i] = false;
         const int gen = d->variant > 0 ? d->variant : msmc_wgrad_generation;
         if (!msmc_conv_grouping || d->dtype != 1 || gen == 1 || n == 1) {
-            int rc = msmc_conv_wgrad(d, g[i], dw[i], db ? db[i] : nullptr, stream);
+            size_t need = msmc_conv_wgrad_workspace(d, g[i]) / sizeof(float);
+            if (need > ws_left) return MSMC_E_WORKSPACE;
+            int rc = msmc_conv_wgrad_ws(d, g[i], dw[i], db ? db[i] : nullptr, wsp, need * sizeof(float), stream);
             if (rc) return rc;
+            wsp += need;
+            ws_left -= need;
             continue;
         }
         if (!g[i] || !dw[i] || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0 || d->ntaps <= 0 ||
             d->ntaps > MSMC_CONV_MAX_TAPS)
             return MSMC_E_SHAPE;
-        int rc = wg2_plan(d, g[i], &plans[i]);
+        int rc = wg2_plan(d, g[i], &plans[i], gen == 3);
         if (rc) return rc;
+        if (plans[i].ws_floats) {
+            if (plans[i].ws_floats > ws_left) return MSMC_E_WORKSPACE;
+            plans[i].P.ws = wsp;
+            wsp += plans[i].ws_floats;
+            ws_left -= plans[i].ws_floats;
+        }
         pending[i] = true;
     }
     for (int i = 0; i < n; ++i) {
         if (!pending[i]) continue;
         Wg2GroupArgs a;
         a.n = 0;
+        int members[MSMC_GROUP_MAX], nmembers = 0;            // third-generation members of this launch
         int blocks = 0, tpw = 1;
         size_t lds = 0;
         for (int j = i; j < n && a.n < MSMC_GROUP_MAX; ++j) {
@@ -2563,6 +2747,7 @@ extern "C" int msmc_conv_wgrad_group(const msmc_conv_desc* descs, const void* co
             blocks += (int)(plans[j].gx * plans[j].gy * plans[j].gz);
             if (plans[j].lds > lds) lds = plans[j].lds;
             if (plans[j].tpw > tpw) tpw = plans[j].tpw;        // the widest member sets the accumulator budget
+            if (plans[j].P.ws) members[nmembers++] = j;
             pending[j] = false;
         }
         a.first[a.n] = blocks;
@@ -2584,8 +2769,29 @@ extern "C" int msmc_conv_wgrad_group(const msmc_conv_desc* descs, const void* co
         msmc_conv_last = msmc_kname("conv_wgrad2_group_kernel", nullptr, tpw, -1);
         rc = msmc_check_launch();
         if (rc) return rc;
+        for (int level = 0; level < 2 && nmembers; ++level) {
+            WgReduceArgs r;
+            r.n = 0;
+            int rblocks = 0;
+            for (int q = 0; q < nmembers; ++q) {
+                const int j = members[q];
+                const msmc_conv_desc& dj = descs[j];
+                float* wsj = plans[j].P.ws;
+                wg3_reduce_add(r, &rblocks, wsj, plans[j].P.ws_stride, (long)dj.ntaps * dj.Cout * dj.Cin,
+                               (db && db[j]) ? dj.Cout : 0, (int)plans[j].gx, wsj + (size_t)plans[j].gx * plans[j].P.ws_stride,
+                               dw[j], db ? db[j] : nullptr, level);
+            }
+            if (!r.n) continue;
+            r.first[r.n] = rblocks;
+            rc = wg3_reduce_launch(r, rblocks, stream);
+            if (rc) return rc;
+        }
     }
     return 0;
+}
+extern "C" int msmc_conv_wgrad_group(const msmc_conv_desc* descs, const void* const* g, float* const* dw, float* const* db,
+                                     int n, msmc_stream stream) {
+    return msmc_conv_wgrad_group_ws(descs, g, dw, db, n, nullptr, 0, stream);
 }
 
 // ================================================================================================

@@ -68,7 +68,7 @@ _PLANS = {}
 # that differ by 2x between layers of equal arithmetic.  Off inside hipGraph capture and on the interpreter.
 AUTOTUNE = os.environ.get('MSMC_AUTOTUNE', '1') != '0'
 _GATHER_CANDIDATES = tuple((int(v), 0) for v in os.environ.get('MSMC_GATHER_VARIANTS', '1,2,3,4,5,8,9,16,17,18,19,20,21,22,23').split(','))
-_WGRAD_CANDIDATES = ((2, 0), (2, -1), (2, 1), (1, 0))
+_WGRAD_CANDIDATES = ((3, 0), (3, -1), (3, -2), (3, 1), (2, 0), (2, -1), (2, 1), (1, 0))
 TUNED = {}                                    # (kind, shape signature) -> (variant, split_shift, {candidate: ms})
 TUNE_CACHE = os.environ.get('MSMC_TUNE_CACHE', os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                                             'tuned_gfx950.json'))
@@ -151,8 +151,28 @@ def _gather(desc, stream, what):
     lib.check(fn(ctypes.byref(desc), stream), what)
 
 
+_WORKSPACES = {}            # (device, stream) -> fp32 scratch of the third-generation weight gradient (split partials)
+
+
+def _workspace(device, stream, nbytes):
+    """stream-private scratch, grown geometrically; launches on one stream are ordered, so one buffer serves them all"""
+    if nbytes <= 0:
+        return None, 0
+    key = (device.index, stream.value)
+    t = _WORKSPACES.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        grow = max(nbytes, 2 * (t.numel() * 4 if t is not None else 0), 8 << 20)
+        t = _WORKSPACES[key] = torch.empty((grow + 3) // 4, dtype=torch.float32, device=device)
+    return t.data_ptr(), t.numel() * 4
+
+
 def _wgrad(desc, g_ptr, dw, db, stream, what):
-    fn = lib.get().msmc_conv_wgrad
+    L = lib.get()
+
+    def fn(dref, gp, dwp, dbp, st):
+        need = L.msmc_conv_wgrad_workspace(dref, gp)
+        wsp, wsb = _workspace(dw.device, st, need) if need else (None, 0)
+        return L.msmc_conv_wgrad_ws(dref, gp, dwp, dbp, wsp, wsb, st)
     dbp = db.data_ptr() if db is not None else None
     if not getattr(desc, '_tuned', False):
         cached = TUNED.get(('wgrad',) + _signature(desc)) if not lib._host_pointers_ok else None
@@ -502,12 +522,16 @@ def conv_wgrad_group(items):
         vp = ctypes.c_void_p * n
         ga, dwa, dba = vp(*gs[i:i + 16]), vp(*dws[i:i + 16]), vp(*dbs[i:i + 16])
 
+        need = sum(L.msmc_conv_wgrad_workspace(ctypes.byref(part[k]), ga[k]) for k in range(n))
+        wsp, wsb = _workspace(items[0]['x'].device, stream, need) if need else (None, 0)
+
         def grouped():
-            lib.check(L.msmc_conv_wgrad_group(arr, ga, dwa, dba, n, stream), 'msmc_conv_wgrad_group')
+            lib.check(L.msmc_conv_wgrad_group_ws(arr, ga, dwa, dba, n, wsp, wsb, stream), 'msmc_conv_wgrad_group_ws')
 
         def single():
             for k in range(n):
-                lib.check(L.msmc_conv_wgrad(ctypes.byref(part[k]), ga[k], dwa[k], dba[k], stream), 'msmc_conv_wgrad')
+                lib.check(L.msmc_conv_wgrad_ws(ctypes.byref(part[k]), ga[k], dwa[k], dba[k], wsp, wsb, stream),
+                          'msmc_conv_wgrad_ws')
 
         if n == 1:
             single()

@@ -87,6 +87,10 @@ _SIGNATURES.update({
     'msmc_conv_wgrad': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     'msmc_conv_wgrad_group': (_i, [ctypes.POINTER(ConvDesc), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                               _i, _vp]),
+    'msmc_conv_wgrad_workspace': (_sz, [ctypes.POINTER(ConvDesc), _vp]),
+    'msmc_conv_wgrad_ws': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _sz, _vp]),
+    'msmc_conv_wgrad_group_ws': (_i, [ctypes.POINTER(ConvDesc), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                 _i, _vp, _sz, _vp]),
     'msmc_wn_prepare_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_wn_backward_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_wn_backward_multi_acc': (_i, [_vp, _i, _i, _i, _vp]),

@@ -25,16 +25,34 @@ def test_conv_small_and_thin_shapes(case):
     check_conv_case(case, torch.float32, 2e-4, DEV)
 
 
-@pytest.mark.parametrize('gen', [1, 2])
+@pytest.mark.parametrize('gen', [1, 2, 3])
 def test_wgrad_generations_agree(gen):
-    """A/B switch of the bf16 weight-gradient kernels: both generations against PyTorch on a mid-size layer"""
-    from msmctts_amd.hip import lib
-    lib.get().msmc_conv_set_wgrad_generation(gen)
+    """every generation of the bf16 weight-gradient kernels (1: first, 2: fp32 atomics, 3: split partials + fixed-order
+    second stage), forced through the descriptor, against PyTorch on mid-size layers; generation 3 is bit-reproducible"""
+    from msmctts_amd.hip import conv
+    saved = (conv._WGRAD_CANDIDATES, dict(conv.TUNED))
+    conv._WGRAD_CANDIDATES = ((gen, 0),)
     try:
-        for case in (CONVS[2], CONVS[8], CONVS[14]):
-            check_conv_case(case, torch.bfloat16, 2e-2, DEV, parts=('wgrad',))
+        for case in (CONVS[2], CONVS[8], CONVS[9], CONVS[14]):
+            conv.TUNED.clear()
+            conv._PLANS.clear()
+            fresh = (case[0] + ' gen%d' % gen,) + tuple(case[1:])
+            check_conv_case(fresh, torch.bfloat16, 2e-2, DEV, parts=('wgrad',))
+        if gen == 3:
+            name, B, Cin, Cout, H, W, k, s, dil, pad, reflect, slope = CONVS[3]
+            geom = conv.Geometry(H, W, k, s, dil, pad, reflect)
+            x = torch.randn(B, H, W, Cin, device=DEV).bfloat16()
+            g = torch.randn(B, geom.Hout, geom.Wout, Cout, device=DEV).bfloat16()
+            outs = []
+            for _ in range(3):
+                dw, db = torch.zeros(k[0] * k[1], Cout, Cin, device=DEV), torch.zeros(Cout, device=DEV)
+                conv.conv_wgrad(x, g, geom, k[0] * k[1], in_slope=slope, dw=dw, db=db)
+                outs.append((dw, db))
+            assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
     finally:
-        lib.get().msmc_conv_set_wgrad_generation(2)
+        conv._WGRAD_CANDIDATES = saved[0]
+        conv.TUNED.clear()
+        conv.TUNED.update(saved[1])
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])

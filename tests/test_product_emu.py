@@ -204,3 +204,43 @@ def test_gather_third_generation_variants(variant):
         conv._build_desc = real
         conv._PLANS.clear()
     assert ran >= 2, (variant, ran)
+
+
+def test_wgrad_third_generation_split_partials():
+    """generation 3 of the bf16 weight gradient (no atomics: per-split partial results in a workspace, second stage in
+    split order), single and grouped launches, forced splits included, against PyTorch on the interpreter"""
+    from msmctts_amd.hip import conv, lib
+    L = lib.get()
+    L.msmc_conv_set_wgrad_generation(3)
+    try:
+        for split in (0, 3):
+            L.msmc_conv_set_wgrad_split(split)
+            for case in [c for c in _convcases.SMALL if c[0] in ('gen k11 d5 C64', 'gen k3 C96->40', 'mpd 16->64 p3',
+                                                                   'mrd 64->72 s2', 'mrd 4->8 s2', 'tiny L3 k11 d5')]:
+                conv._PLANS.clear()
+                _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=('wgrad',))
+        # many splits of a small dW: the second stage runs in two levels (split groups -> intermediate regions -> dW)
+        L.msmc_conv_set_wgrad_split(47)
+        conv._PLANS.clear()
+        _convcases.check_conv_case(('thin long C32 k3', 1, 32, 32, 1, 6000, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
+                                   torch.bfloat16, 2e-2, 'cpu', parts=('wgrad',))
+        # grouped: three members, two splits each
+        L.msmc_conv_set_wgrad_split(2)
+        torch.manual_seed(0)
+        B, C, Lx = 2, 64, 90
+        x = torch.randn(B, 1, Lx, C).bfloat16()
+        items, refs = [], []
+        for k, dil in ((3, 1), (7, 3), (11, 1)):
+            geom = conv.Geometry(1, Lx, (1, k), (1, 1), (1, dil), (0, dil * (k - 1) // 2), False)
+            g = torch.randn(B, 1, Lx, C).bfloat16()
+            dw_ref, db_ref = torch.zeros(k, C, C), torch.zeros(C)
+            conv.conv_wgrad(x, g, geom, k, in_slope=0.1, dw=dw_ref, db=db_ref)
+            dw, db = torch.zeros(k, C, C), torch.zeros(C)
+            items.append(dict(x=x, g=g, geom=geom, n_slices=k, in_slope=0.1, dw=dw.view(-1), db=db, copies=1))
+            refs.append((dw_ref, db_ref, dw, db))
+        conv.conv_wgrad_group(items)
+        for dw_ref, db_ref, dw, db in refs:
+            assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    finally:
+        L.msmc_conv_set_wgrad_generation(2)
+        L.msmc_conv_set_wgrad_split(0)
