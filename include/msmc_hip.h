@@ -277,6 +277,36 @@ int msmc_l1_multi_bwd(const msmc_tensor_table* t, const float* gout, msmc_stream
 int msmc_mse_const_multi_fwd(const msmc_tensor_table* t, float target, float* out, msmc_stream stream);
 int msmc_mse_const_multi_bwd(const msmc_tensor_table* t, float target, const float* gout, msmc_stream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * E1/V3  fused element-wise / row-normalisation kernels of the FFT blocks and the quantiser glue (csrc/norm.hip).
+ * Replace the stock-kernel chains behind
+ *   layer_norm(dropout(h) + residual) [* non_pad_mask]   reference acoustic_models/transformer.py:262-266, 318-323, 352-356
+ *   tanh(a) * sigmoid(b) (+ dropout)                     reference vqgantts/modules.py:172-179, 241
+ *   Tanh of the 1x1 stacks                               reference vqgantts/msmc_vqgan.py:115-136
+ * Rows [N][C] fp32 (dtype 0) / bf16 (dtype 1); statistics and parameter gradients fp32.  Dropout masks are functions of
+ * (seed[0] on the device, salt, element index): nothing is stored, both passes regenerate them; seed may be NULL when
+ * p_drop == 0.  C <= 1024.
+ * ------------------------------------------------------------------------------------------- */
+/* v = drop(x) + res (res may be NULL); y = LayerNorm(v) * gamma + beta, rows with keep_row[n] == 0 zeroed (keep_row may be
+ * NULL); v, mean [N], rstd [N] are kept for the backward pass. */
+int msmc_add_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, const unsigned char* keep_row,
+                    void* y, void* v, float* mean, float* rstd, long N, int C, float eps, float p_drop,
+                    const long long* seed, long long salt, int dtype, msmc_stream stream);
+size_t msmc_add_ln_bwd_workspace(long N, int C);
+/* gx = d/dx, gres = d/dres (may be NULL), dgamma / dbeta fp32 [C] (accumulate != 0: +=), fixed reduction order. */
+int msmc_add_ln_bwd(const void* g, const void* v, const float* mean, const float* rstd, const float* gamma,
+                    const unsigned char* keep_row, void* gx, void* gres, float* dgamma, float* dbeta, void* workspace,
+                    size_t workspace_bytes, long N, int C, float p_drop, const long long* seed, long long salt, int accumulate,
+                    int dtype, msmc_stream stream);
+/* x [N][2C] -> y [N][C] = drop(tanh(x[:, :C]) * sigmoid(x[:, C:])); backward recomputes from x. */
+int msmc_gate_fwd(const void* x, void* y, long N, int C, float p_drop, const long long* seed, long long salt, int dtype,
+                  msmc_stream stream);
+int msmc_gate_bwd(const void* x, const void* g, void* gx, long N, int C, float p_drop, const long long* seed, long long salt,
+                  int dtype, msmc_stream stream);
+/* y = tanh(x); gx = g * (1 - y*y) over n elements. */
+int msmc_tanh_fwd(const void* x, void* y, long n, int dtype, msmc_stream stream);
+int msmc_tanh_bwd(const void* y, const void* g, void* gx, long n, int dtype, msmc_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

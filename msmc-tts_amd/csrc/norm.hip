@@ -1,0 +1,324 @@
+// norm.hip -- fused element-wise / row-normalisation kernels of the FFT blocks and the quantiser glue.
+//
+// Replaces, in one launch each, the chains of stock kernels behind
+//   MultiHeadAttention.forward / PositionwiseFeedForward.forward tails
+//       layer_norm(dropout(h) + residual) [* non_pad_mask]        reference acoustic_models/transformer.py:262-266,318-323,352-356
+//   the WaveNet gate  tanh(a) * sigmoid(b)                        reference vqgantts/modules.py:172-179
+//   the Tanh between the 1x1 stacks of the quantiser              reference vqgantts/msmc_vqgan.py:115-136
+// Activations are row-major [N][C] in fp32 (dtype 0) or bf16 (dtype 1); statistics and parameter gradients are fp32.
+// Dropout masks are not stored: both passes derive them from a counter-based hash of (seed word on the device, call
+// salt, element index), so a hipGraph replay draws fresh masks when the seed word is advanced inside the graph.
+#include <msmc_rt.hpp>
+#include <msmc_hip.h>
+
+MSMC_DEV float nm_ld(const float* p, long i) { return p[i]; }
+MSMC_DEV float nm_ld(const unsigned short* p, long i) { return bf16_bits_to_f32(p[i]); }
+MSMC_DEV void nm_st(float* p, long i, float v) { p[i] = v; }
+MSMC_DEV void nm_st(unsigned short* p, long i, float v) { p[i] = f32_to_bf16_bits(v); }
+
+// keep-probability test: 32-bit mix of (key, element index) against the drop threshold
+MSMC_DEV bool nm_keep(unsigned long long key, unsigned long long idx, unsigned int thresh) {
+    unsigned long long z = key + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (unsigned int)(z >> 32) >= thresh;
+}
+MSMC_DEV unsigned long long nm_key(const long long* seed, long long salt) {
+    const unsigned long long s = seed ? (unsigned long long)seed[0] : 0ull;
+    return s * 0xD1342543DE82EF95ull + (unsigned long long)salt * 0x2545F4914F6CDD1Dull + 0x632BE59BD9B4E019ull;
+}
+MSMC_DEV float nm_wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = v + wave_xor(v, m);
+    return v;
+}
+
+#define NM_MAXE 16          // elements per lane: C <= 1024
+
+// one wave per row: v = drop(x) + res; y = (v - mean) * rstd * gamma + beta, zeroed where keep_row == 0
+template <typename T>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const unsigned char* __restrict__ keep_row, T* __restrict__ y,
+                                                         T* __restrict__ v_out, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out, long N, int C, float eps,
+                                                         float p_drop, const long long* seed, long long salt) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const int ne = (C + 63) / 64;
+    const unsigned long long key = nm_key(seed, salt);
+    const unsigned int thresh = p_drop > 0.f ? (unsigned int)(p_drop * 4294967296.0) : 0u;
+    const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    float v[NM_MAXE];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NM_MAXE; ++j) {
+        v[j] = 0.f;
+        const int c = lane + 64 * j;
+        if (j < ne && c < C) {
+            const long i = row * C + c;
+            float a = nm_ld(x, i);
+            if (thresh) a = nm_keep(key, (unsigned long long)i, thresh) ? a * scale : 0.f;
+            if (res) a = a + nm_ld(res, i);
+            v[j] = a;
+            sum = sum + a;
+        }
+    }
+    const float mean = nm_wave_sum(sum) / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NM_MAXE; ++j) {
+        const int c = lane + 64 * j;
+        if (j < ne && c < C) sq = fmaf(v[j] - mean, v[j] - mean, sq);
+    }
+    const float rstd = 1.f / sqrtf(nm_wave_sum(sq) / C + eps);
+    const bool live = !keep_row || keep_row[row] != 0;
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int j = 0; j < NM_MAXE; ++j) {
+        const int c = lane + 64 * j;
+        if (j < ne && c < C) {
+            const long i = row * C + c;
+            nm_st(v_out, i, v[j]);
+            nm_st(y, i, live ? (v[j] - mean) * rstd * gamma[c] + beta[c] : 0.f);
+        }
+    }
+}
+
+// backward: gy = g * live; dxhat = gy * gamma; dv = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat));
+// gres = dv; gx = dv * dropmask * scale.  Parameter-gradient partials per workgroup: part[block][0][c] = sum gy*xhat,
+// part[block][1][c] = sum gy (reduced in a fixed order by add_ln_param_kernel).
+template <typename T>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ g, const T* __restrict__ v_in,
+                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                         const float* __restrict__ gamma,
+                                                         const unsigned char* __restrict__ keep_row, T* __restrict__ gx,
+                                                         T* __restrict__ gres, float* __restrict__ part, long N, int C,
+                                                         float p_drop, const long long* seed, long long salt, int rows_per_block) {
+    MSMC_DYN_LDS(smem);
+    float* acc = (float*)smem;                     // [4 waves][2][C]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ne = (C + 63) / 64;
+    const unsigned long long key = nm_key(seed, salt);
+    const unsigned int thresh = p_drop > 0.f ? (unsigned int)(p_drop * 4294967296.0) : 0u;
+    const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    float dg[NM_MAXE], dbt[NM_MAXE], gm[NM_MAXE];
+#pragma unroll
+    for (int j = 0; j < NM_MAXE; ++j) {
+        dg[j] = dbt[j] = 0.f;
+        const int c = lane + 64 * j;
+        gm[j] = (j < ne && c < C) ? gamma[c] : 0.f;
+    }
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    for (long row = r0 + w; row < r0 + rows_per_block && row < N; row += 4) {
+        const bool live = !keep_row || keep_row[row] != 0;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        float dx[NM_MAXE], xh[NM_MAXE];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NM_MAXE; ++j) {
+            dx[j] = xh[j] = 0.f;
+            const int c = lane + 64 * j;
+            if (j < ne && c < C) {
+                const long i = row * C + c;
+                const float gy = live ? nm_ld(g, i) : 0.f;
+                xh[j] = (nm_ld(v_in, i) - mean) * rstd;
+                dx[j] = gy * gm[j];
+                s1 = s1 + dx[j];
+                s2 = fmaf(dx[j], xh[j], s2);
+                dg[j] = fmaf(gy, xh[j], dg[j]);
+                dbt[j] = dbt[j] + gy;
+            }
+        }
+        const float m1 = nm_wave_sum(s1) / C, m2 = nm_wave_sum(s2) / C;
+#pragma unroll
+        for (int j = 0; j < NM_MAXE; ++j) {
+            const int c = lane + 64 * j;
+            if (j < ne && c < C) {
+                const long i = row * C + c;
+                const float dv = rstd * (dx[j] - m1 - xh[j] * m2);
+                if (gres) nm_st(gres, i, dv);
+                float d = dv;
+                if (thresh) d = nm_keep(key, (unsigned long long)i, thresh) ? dv * scale : 0.f;
+                nm_st(gx, i, d);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NM_MAXE; ++j) {
+        const int c = lane + 64 * j;
+        if (j < ne && c < C) {
+            acc[(w * 2 + 0) * C + c] = dg[j];
+            acc[(w * 2 + 1) * C + c] = dbt[j];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += 256) {
+        const int k = e / C, c = e - k * C;
+        part[((size_t)blockIdx.x * 2 + k) * C + c] =
+            ((acc[(0 * 2 + k) * C + c] + acc[(1 * 2 + k) * C + c]) + acc[(2 * 2 + k) * C + c]) + acc[(3 * 2 + k) * C + c];
+    }
+}
+
+// dgamma[c] (+)= sum_b part[b][0][c], dbeta[c] (+)= sum_b part[b][1][c], in block order
+__global__ __launch_bounds__(256) void add_ln_param_kernel(const float* __restrict__ part, int nblocks, int C,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int accumulate) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 2 * C) return;
+    const int k = e / C, c = e - k * C;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s = s + part[((size_t)b * 2 + k) * C + c];
+    float* dst = k == 0 ? dgamma : dbeta;
+    dst[c] = accumulate ? dst[c] + s : s;
+}
+
+// ---- gate / tanh ---------------------------------------------------------------------------------------------
+// x [N][2C] -> y [N][C] = tanh(x[:, :C]) * sigmoid(x[:, C:])   (optionally dropped out);  backward from x
+template <typename T>
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long N, int C, float p_drop,
+                                                       const long long* seed, long long salt) {
+    const long total = N * C;
+    const unsigned long long key = nm_key(seed, salt);
+    const unsigned int thresh = p_drop > 0.f ? (unsigned int)(p_drop * 4294967296.0) : 0u;
+    const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / C;
+        const int c = (int)(i - n * C);
+        const float a = nm_ld(x, n * 2 * C + c), b = nm_ld(x, n * 2 * C + C + c);
+        float v = tanhf(a) * (1.f / (1.f + expf(-b)));
+        if (thresh) v = nm_keep(key, (unsigned long long)i, thresh) ? v * scale : 0.f;
+        nm_st(y, i, v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ x, const T* __restrict__ g, T* __restrict__ gx, long N,
+                                                       int C, float p_drop, const long long* seed, long long salt) {
+    const long total = N * C;
+    const unsigned long long key = nm_key(seed, salt);
+    const unsigned int thresh = p_drop > 0.f ? (unsigned int)(p_drop * 4294967296.0) : 0u;
+    const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / C;
+        const int c = (int)(i - n * C);
+        const float a = nm_ld(x, n * 2 * C + c), b = nm_ld(x, n * 2 * C + C + c);
+        float gv = nm_ld(g, i);
+        if (thresh) gv = nm_keep(key, (unsigned long long)i, thresh) ? gv * scale : 0.f;
+        const float t = tanhf(a), s = 1.f / (1.f + expf(-b));
+        nm_st(gx, n * 2 * C + c, gv * s * (1.f - t * t));
+        nm_st(gx, n * 2 * C + C + c, gv * t * s * (1.f - s));
+    }
+}
+// y = tanh(x);  gx = g * (1 - y*y)   (n elements)
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) nm_st(y, i, tanhf(nm_ld(x, i)));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const T* __restrict__ y, const T* __restrict__ g, T* __restrict__ gx, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float t = nm_ld(y, i);
+        nm_st(gx, i, nm_ld(g, i) * (1.f - t * t));
+    }
+}
+
+static int nm_grid(long n) {
+    long b = (n + 255) / 256;
+    const long cap = 8L * MSMC_NUM_CU;
+    return (int)(b < 1 ? 1 : b > cap ? cap : b);
+}
+
+extern "C" {
+
+int msmc_add_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, const unsigned char* keep_row,
+                    void* y, void* v, float* mean, float* rstd, long N, int C, float eps, float p_drop,
+                    const long long* seed, long long salt, int dtype, msmc_stream stream) {
+    if (!x || !gamma || !beta || !y || !v || !mean || !rstd || N < 0 || C <= 0 || C > 64 * NM_MAXE || p_drop < 0.f || p_drop >= 1.f)
+        return MSMC_E_SHAPE;
+    if (N == 0) return 0;
+    const dim3 grid((unsigned)((N + 3) / 4));
+    if (dtype == 0)
+        MSMC_LAUNCH(add_ln_fwd_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, (const float*)x, (const float*)res, gamma,
+                    beta, keep_row, (float*)y, (float*)v, mean, rstd, N, C, eps, p_drop, seed, salt);
+    else if (dtype == 1)
+        MSMC_LAUNCH(add_ln_fwd_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)x,
+                    (const unsigned short*)res, gamma, beta, keep_row, (unsigned short*)y, (unsigned short*)v, mean, rstd, N, C,
+                    eps, p_drop, seed, salt);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+
+size_t msmc_add_ln_bwd_workspace(long N, int C) {
+    const long rows = 64;
+    return (size_t)((N + rows - 1) / rows) * 2 * C * sizeof(float);
+}
+
+int msmc_add_ln_bwd(const void* g, const void* v, const float* mean, const float* rstd, const float* gamma,
+                    const unsigned char* keep_row, void* gx, void* gres, float* dgamma, float* dbeta, void* workspace,
+                    size_t workspace_bytes, long N, int C, float p_drop, const long long* seed, long long salt, int accumulate,
+                    int dtype, msmc_stream stream) {
+    if (!g || !v || !mean || !rstd || !gamma || !gx || !dgamma || !dbeta || N < 0 || C <= 0 || C > 64 * NM_MAXE) return MSMC_E_SHAPE;
+    const int rows = 64;
+    const int nblocks = (int)((N + rows - 1) / rows);
+    if (workspace_bytes < msmc_add_ln_bwd_workspace(N, C) || (nblocks && !workspace)) return MSMC_E_WORKSPACE;
+    const size_t lds = (size_t)4 * 2 * C * sizeof(float);
+    if (nblocks) {
+        if (dtype == 0)
+            MSMC_LAUNCH(add_ln_bwd_kernel<float>, dim3((unsigned)nblocks), dim3(256), lds, (msmc_stream_t)stream, (const float*)g,
+                        (const float*)v, mean, rstd, gamma, keep_row, (float*)gx, (float*)gres, (float*)workspace, N, C, p_drop,
+                        seed, salt, rows);
+        else if (dtype == 1)
+            MSMC_LAUNCH(add_ln_bwd_kernel<unsigned short>, dim3((unsigned)nblocks), dim3(256), lds, (msmc_stream_t)stream,
+                        (const unsigned short*)g, (const unsigned short*)v, mean, rstd, gamma, keep_row, (unsigned short*)gx,
+                        (unsigned short*)gres, (float*)workspace, N, C, p_drop, seed, salt, rows);
+        else return MSMC_E_SHAPE;
+        int rc = msmc_check_launch();
+        if (rc) return rc;
+    }
+    MSMC_LAUNCH(add_ln_param_kernel, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, (msmc_stream_t)stream,
+                (const float*)workspace, nblocks, C, dgamma, dbeta, accumulate);
+    return msmc_check_launch();
+}
+
+int msmc_gate_fwd(const void* x, void* y, long N, int C, float p_drop, const long long* seed, long long salt, int dtype,
+                  msmc_stream stream) {
+    if (!x || !y || N < 0 || C <= 0 || p_drop < 0.f || p_drop >= 1.f) return MSMC_E_SHAPE;
+    if (N == 0) return 0;
+    const dim3 grid((unsigned)nm_grid(N * C));
+    if (dtype == 0) MSMC_LAUNCH(gate_fwd_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, (const float*)x, (float*)y, N, C, p_drop, seed, salt);
+    else if (dtype == 1) MSMC_LAUNCH(gate_fwd_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)x, (unsigned short*)y, N, C, p_drop, seed, salt);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+int msmc_gate_bwd(const void* x, const void* g, void* gx, long N, int C, float p_drop, const long long* seed, long long salt,
+                  int dtype, msmc_stream stream) {
+    if (!x || !g || !gx || N < 0 || C <= 0) return MSMC_E_SHAPE;
+    if (N == 0) return 0;
+    const dim3 grid((unsigned)nm_grid(N * C));
+    if (dtype == 0) MSMC_LAUNCH(gate_bwd_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, (const float*)x, (const float*)g, (float*)gx, N, C, p_drop, seed, salt);
+    else if (dtype == 1) MSMC_LAUNCH(gate_bwd_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)x, (const unsigned short*)g, (unsigned short*)gx, N, C, p_drop, seed, salt);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+int msmc_tanh_fwd(const void* x, void* y, long n, int dtype, msmc_stream stream) {
+    if (!x || !y || n < 0) return MSMC_E_SHAPE;
+    if (n == 0) return 0;
+    const dim3 grid((unsigned)nm_grid(n));
+    if (dtype == 0) MSMC_LAUNCH(tanh_fwd_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, (const float*)x, (float*)y, n);
+    else if (dtype == 1) MSMC_LAUNCH(tanh_fwd_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)x, (unsigned short*)y, n);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+int msmc_tanh_bwd(const void* y, const void* g, void* gx, long n, int dtype, msmc_stream stream) {
+    if (!y || !g || !gx || n < 0) return MSMC_E_SHAPE;
+    if (n == 0) return 0;
+    const dim3 grid((unsigned)nm_grid(n));
+    if (dtype == 0) MSMC_LAUNCH(tanh_bwd_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, (const float*)y, (const float*)g, (float*)gx, n);
+    else if (dtype == 1) MSMC_LAUNCH(tanh_bwd_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)y, (const unsigned short*)g, (unsigned short*)gx, n);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+
+}  // extern "C"

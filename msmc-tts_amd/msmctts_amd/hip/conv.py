@@ -186,7 +186,11 @@ def _wgrad(desc, g_ptr, dw, db, stream, what):
             _tune('wgrad', desc, lambda: fn(ctypes.byref(desc), g_ptr, sdw.data_ptr(), sdbp, stream), _WGRAD_CANDIDATES)
         else:
             desc._tuned = True
-    lib.check(fn(ctypes.byref(desc), g_ptr, dw.data_ptr(), dbp, stream), what)
+    rc = fn(ctypes.byref(desc), g_ptr, dw.data_ptr(), dbp, stream)
+    if rc != 0:
+        raise RuntimeError('%s failed with code %d (dtype %d variant %d split_shift %d copies %d, x %dx%dx%dx%d -> %dx%dx%d, '
+                           '%d taps)' % (what, rc, desc.dtype, desc.variant, desc.split_shift, desc.dw_copies, desc.B, desc.Hin,
+                                         desc.Win, desc.Cin, desc.Hout, desc.Wout, desc.Cout, desc.ntaps))
 
 
 
@@ -205,11 +209,13 @@ def _ptr(t):
 
 
 def _fill(desc_unused, x, w, out, B, Hin, Win, Cin, Hout, Wout, Cout, lattice, taps, pad_mode, bias=None, mask_src=None,
-          res=None, res2=None, in_slope=1.0, mask_slope=1.0, out_div=1.0, out_slope=1.0):
+          res=None, res2=None, in_slope=1.0, mask_slope=1.0, out_div=1.0, out_slope=1.0, kind='gather'):
     """Descriptor for one launch.  The geometry part is built once per distinct (shape, lattice, taps, flags) and
     cached -- per call only the seven pointers change (the step issues ~2000 convolution launches, so the
     host cost of a launch matters as much as its GPU time)."""
-    key = (x.dtype, B, Hin, Win, Cin, Hout, Wout, Cout, lattice, tuple(taps), pad_mode, in_slope, mask_slope, out_div,
+    # ``kind``: a weight gradient and a data gradient of one transposed convolution share every geometry field, but
+    # their descriptors carry DIFFERENT kernel choices (desc.variant means another thing to msmc_conv_wgrad)
+    key = (kind, x.dtype, B, Hin, Win, Cin, Hout, Wout, Cout, lattice, tuple(taps), pad_mode, in_slope, mask_slope, out_div,
            out_slope)
     desc = _PLANS.get(key)
     if desc is None:
@@ -564,7 +570,7 @@ def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None, copi
     lattice = (1, Lin, 0, 1, 0, 1, 1, stride, 0, -padding)
     # kernel roles: "x" = g (fine, channels Cout), "g" = x (coarse, channels Cin) -> dw[k][Cin][Cout]
     d = _fill(None, g, g, g, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, in_slope=1.0,
-              mask_slope=in_slope)
+              mask_slope=in_slope, kind='wgrad')
     lib.ptr(dw, torch.float32)
     d.dw_copies = copies
     _wgrad(d, lib.ptr(x), dw, None, lib.stream(x), 'msmc_conv_wgrad(convT)')

@@ -98,6 +98,15 @@ _SIGNATURES.update({
                                 ctypes.POINTER(_i), _i, _i, _f, _i, _vp]),
     'msmc_lrelu_bwd_multi': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_long), _i, _f, _i, _vp]),
     'msmc_colsum': (_i, [_vp, _vp, ctypes.c_long, _i, _i, _vp]),
+    'msmc_add_ln_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _i, _f, _f, _vp, ctypes.c_longlong,
+                        _i, _vp]),
+    'msmc_add_ln_bwd_workspace': (_sz, [ctypes.c_long, _i]),
+    'msmc_add_ln_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, ctypes.c_long, _i, _f, _vp,
+                        ctypes.c_longlong, _i, _i, _vp]),
+    'msmc_gate_fwd': (_i, [_vp, _vp, ctypes.c_long, _i, _f, _vp, ctypes.c_longlong, _i, _vp]),
+    'msmc_gate_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _i, _f, _vp, ctypes.c_longlong, _i, _vp]),
+    'msmc_tanh_fwd': (_i, [_vp, _vp, ctypes.c_long, _i, _vp]),
+    'msmc_tanh_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _i, _vp]),
     'msmc_lrelu_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _f, _i, _vp]),
     'msmc_reflect_fold': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
 })

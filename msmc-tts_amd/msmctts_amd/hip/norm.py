@@ -1,0 +1,140 @@
+"""Fused element-wise / row-normalisation ops over csrc/norm.hip: the tails of the FFT-block sub-layers
+(``layer_norm(dropout(h) + residual) * non_pad_mask``, reference acoustic_models/transformer.py:262-266, 318-323,
+352-356), the WaveNet gate (vqgantts/modules.py:172-179) and the Tanh of the quantiser's 1x1 stacks
+(vqgantts/msmc_vqgan.py:115-136) -- one launch per pass each instead of a chain of stock kernels.
+
+Dropout masks are never stored: both passes derive them from (a seed word on the device, a per-call salt, the element
+index).  ``advance_seed(device)`` bumps the seed word with one tiny kernel -- inside a captured hipGraph too, so every
+replay draws fresh masks.
+"""
+import itertools
+
+import torch
+
+from . import lib
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+_SEEDS = {}
+_SALT = itertools.count(1)
+
+
+def seed_word(device):
+    key = (device.type, device.index)
+    t = _SEEDS.get(key)
+    if t is None:
+        t = _SEEDS[key] = torch.zeros(1, dtype=torch.int64, device=device)
+        t.fill_(int(torch.initial_seed() & 0x7fffffff))
+    return t
+
+
+def advance_seed(device):
+    """once per training step, before the first dropout of the step (captured into the graph in graph mode)"""
+    seed_word(device).add_(1)
+
+
+def new_salt():
+    """a process-unique call-site id: two dropouts of one step never share a mask"""
+    return next(_SALT)
+
+
+def _rows(x):
+    C = x.shape[-1]
+    return x.numel() // C, C
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, gamma, beta, keep_row, p_drop, salt, eps):
+        assert x.dtype in _DT and x.is_contiguous() and (res is None or (res.dtype == x.dtype and res.is_contiguous()))
+        N, C = _rows(x)
+        y, v = torch.empty_like(x), torch.empty_like(x)
+        mean = torch.empty(N, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(N, dtype=torch.float32, device=x.device)
+        seed = seed_word(x.device) if p_drop > 0 else None
+        lib.check(lib.get().msmc_add_ln_fwd(lib.ptr(x), lib.ptr(res), lib.ptr(gamma, torch.float32), lib.ptr(beta, torch.float32),
+                                            lib.ptr(keep_row, torch.uint8), lib.ptr(y), lib.ptr(v), lib.ptr(mean), lib.ptr(rstd),
+                                            N, C, float(eps), float(p_drop), lib.ptr(seed), salt, _DT[x.dtype], lib.stream(x)),
+                  'msmc_add_ln_fwd')
+        ctx.save_for_backward(v, mean, rstd, gamma, keep_row)
+        ctx.p_drop, ctx.salt, ctx.has_res = float(p_drop), salt, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        v, mean, rstd, gamma, keep_row = ctx.saved_tensors
+        g = g.contiguous()
+        N, C = _rows(v)
+        L = lib.get()
+        gx = torch.empty_like(v)
+        gres = torch.empty_like(v) if ctx.has_res else None
+        dgamma = torch.empty(C, dtype=torch.float32, device=v.device)
+        dbeta = torch.empty(C, dtype=torch.float32, device=v.device)
+        nbytes = int(L.msmc_add_ln_bwd_workspace(N, C))
+        ws = torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.float32, device=v.device)
+        seed = seed_word(v.device) if ctx.p_drop > 0 else None
+        lib.check(L.msmc_add_ln_bwd(lib.ptr(g), lib.ptr(v), lib.ptr(mean), lib.ptr(rstd), lib.ptr(gamma, torch.float32),
+                                    lib.ptr(keep_row, torch.uint8), lib.ptr(gx), lib.ptr(gres), lib.ptr(dgamma), lib.ptr(dbeta),
+                                    lib.ptr(ws), ws.numel() * 4, N, C, ctx.p_drop, lib.ptr(seed), ctx.salt, 0, _DT[v.dtype],
+                                    lib.stream(v)), 'msmc_add_ln_bwd')
+        return gx, gres, dgamma, dbeta, None, None, None, None
+
+
+def add_layer_norm(x, res, gamma, beta, keep_row=None, p_drop=0.0, salt=0, eps=1e-5):
+    """LayerNorm(dropout(x) + res) * gamma + beta over the last axis, rows with ``keep_row == 0`` zeroed.
+    x / res: same dtype (fp32 or bf16), contiguous; gamma / beta fp32; keep_row uint8 [rows] or None."""
+    return _AddLayerNorm.apply(x, res, gamma, beta, keep_row, p_drop, salt, eps)
+
+
+class _Gate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p_drop, salt):
+        assert x.dtype in _DT and x.is_contiguous() and x.shape[-1] % 2 == 0
+        C = x.shape[-1] // 2
+        N = x.numel() // (2 * C)
+        y = torch.empty(x.shape[:-1] + (C,), dtype=x.dtype, device=x.device)
+        seed = seed_word(x.device) if p_drop > 0 else None
+        lib.check(lib.get().msmc_gate_fwd(lib.ptr(x), lib.ptr(y), N, C, float(p_drop), lib.ptr(seed), salt, _DT[x.dtype],
+                                          lib.stream(x)), 'msmc_gate_fwd')
+        ctx.save_for_backward(x)
+        ctx.p_drop, ctx.salt = float(p_drop), salt
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        C = x.shape[-1] // 2
+        N = x.numel() // (2 * C)
+        gx = torch.empty_like(x)
+        g = g.contiguous()                       # (bound to a name: a temporary would be freed before the launch reads it)
+        seed = seed_word(x.device) if ctx.p_drop > 0 else None
+        lib.check(lib.get().msmc_gate_bwd(lib.ptr(x), lib.ptr(g), lib.ptr(gx), N, C, ctx.p_drop, lib.ptr(seed),
+                                          ctx.salt, _DT[x.dtype], lib.stream(x)), 'msmc_gate_bwd')
+        return gx, None, None
+
+
+def gate(x, p_drop=0.0, salt=0):
+    """x [..., 2C] -> dropout(tanh(x[..., :C]) * sigmoid(x[..., C:]))"""
+    return _Gate.apply(x, p_drop, salt)
+
+
+class _Tanh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        assert x.dtype in _DT and x.is_contiguous()
+        y = torch.empty_like(x)
+        lib.check(lib.get().msmc_tanh_fwd(lib.ptr(x), lib.ptr(y), x.numel(), _DT[x.dtype], lib.stream(x)), 'msmc_tanh_fwd')
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        gx = torch.empty_like(y)
+        g = g.contiguous()
+        lib.check(lib.get().msmc_tanh_bwd(lib.ptr(y), lib.ptr(g), lib.ptr(gx), y.numel(), _DT[y.dtype],
+                                          lib.stream(y)), 'msmc_tanh_bwd')
+        return gx
+
+
+def tanh(x):
+    return _Tanh.apply(x)

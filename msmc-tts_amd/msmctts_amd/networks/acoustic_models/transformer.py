@@ -1,11 +1,14 @@
 """Feed-forward Transformer (FFT) blocks used by the multi-stage encoder and the frame decoder
 (drop-in for reference msmctts/networks/acoustic_models/transformer.py:71-424).
 
-SURVEY.md 8a/E1: this stack stays on stock PyTorch-ROCm operators in round 1 (hipBLASLt GEMMs,
-MIOpen k=3 convolutions, fused SDPA-free softmax) -- north_star's kernel list does not name
-attention; a fused MFMA version is the first "next" row.  Module / parameter names
-and numerics follow the reference: fused QKV projection, post-LayerNorm, key-padding mask with
--inf, conv feed-forward, output zeroed on padding after both sub-layers.
+Module / parameter names and numerics follow the reference: fused QKV projection, post-LayerNorm, key-padding mask
+with -inf, conv feed-forward, output zeroed on padding after both sub-layers.  On the GPU a block is eight launches
+forward: the fused-QKV and output projections are 1-tap convolutions on the gfx950 implicit-GEMM
+kernels (bias fused, activations stay in the compute dtype: no cast kernels), the position-wise convolutions run on
+the same kernels, and ``layer_norm(dropout(h) + residual) * non_pad_mask`` is one fused kernel per sub-layer
+(csrc/norm.hip, masks regenerated in the backward pass).  The (T <= 2400, d_k = 64) softmax-attention core is PyTorch-ROCm's fused
+``scaled_dot_product_attention`` on strided views of the QKV projection.  ``MSMC_FFT_HIP=0`` / ``use_hip = False``
+keeps the stock operator chain (stand-alone use, A/B runs).
 """
 import math
 import os
@@ -15,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...hip import norm as hipnorm
 from ...hip.convnet import ConvBank, ConvLayer, hip_conv
 
 
@@ -81,6 +85,29 @@ class MultiHeadAttention(nn.Module):
         self.fc = nn.Linear(n_head * d_v, d_model)
         nn.init.xavier_normal_(self.fc.weight)
         self.dropout = nn.Dropout(dropout)
+        self._salt = hipnorm.new_salt()
+
+    def hip_layers(self):
+        """the two projections as 1-tap convolutions of the block stack's ConvBank (a Linear weight (out, in) is the
+        (out, in, 1) weight of a kernel-size-1 convolution)"""
+        return [ConvLayer(m, 'conv', (1, 1), plain=True) for m in (self.linear, self.fc)]
+
+    def forward_hip(self, x, keep_row, key_keep, hip):
+        """x [B, T, C] in the compute dtype; key_keep [B, 1, 1, T] bool (True = attend); returns the masked sub-layer
+        output layer_norm(dropout(fc(attention)) + x) * non_pad_mask"""
+        bank, (l_qkv, l_fc) = hip
+        bs, T, _ = x.shape
+        H, dk, dv = self.n_head, self.d_k, self.d_v
+        qkv = hip_conv(bank, l_qkv, x.unsqueeze(1)).view(bs, T, H, 2 * dk + dv).transpose(1, 2)       # [bs, H, T, 2dk+dv]
+        att = self.attention
+        p = att.dropout.p if (hasattr(att, 'dropout') and att.training) else 0.0
+        out = F.scaled_dot_product_attention(qkv[..., :dk], qkv[..., dk:2 * dk], qkv[..., 2 * dk:], attn_mask=key_keep,
+                                             dropout_p=p, scale=1.0 / att.temperature)
+        out = out.transpose(1, 2).reshape(bs, 1, T, H * dv)
+        h = hip_conv(bank, l_fc, out).squeeze(1)
+        pd = self.dropout.p if self.training else 0.0
+        return hipnorm.add_layer_norm(h, x, self.layer_norm.weight, self.layer_norm.bias, keep_row=keep_row, p_drop=pd,
+                                      salt=self._salt, eps=self.layer_norm.eps)
 
     def forward(self, x, mask=None, acts=None):
         bs, T, _ = x.shape
@@ -115,10 +142,21 @@ class PositionwiseFeedForward(nn.Module):
         self.w_2 = nn.Conv1d(d_hid, d_in, kernel_size=fft_conv1d_kernel, padding=fft_conv1d_padding)
         self.layer_norm = nn.LayerNorm(d_in)
         self.dropout = nn.Dropout(dropout)
+        self._salt = hipnorm.new_salt()
 
     def hip_layers(self):
         k, p = self.w_1.kernel_size[0], self.w_1.padding[0]
         return [ConvLayer(m, 'conv', (1, k), (1, 1), (1, 1), (0, p), plain=True) for m in (self.w_1, self.w_2)]
+
+    def forward_hip(self, x, keep_row, hip):
+        """x [B, T, C] (already masked) in the compute dtype -> layer_norm(dropout(w_2(relu(w_1 x))) + x) * non_pad_mask"""
+        bank, (l1, l2) = hip
+        # [B, T, C] IS the channels-last layout of a 1-D convolution: no transposes; the ReLU between the two
+        # convolutions is the second one's input activation (leaky slope 0)
+        h = hip_conv(bank, l2, hip_conv(bank, l1, x.unsqueeze(1)), in_slope=0.0).squeeze(1)
+        pd = self.dropout.p if self.training else 0.0
+        return hipnorm.add_layer_norm(h, x, self.layer_norm.weight, self.layer_norm.bias, keep_row=keep_row, p_drop=pd,
+                                      salt=self._salt, eps=self.layer_norm.eps)
 
     def forward(self, x, acts=None, hip=None):
         if hip is None:         # stock operators (stand-alone use of the block)
@@ -139,6 +177,9 @@ class FFTBlock(nn.Module):
         self.slf_attn = MultiHeadAttention(n_head, d_model, d_k, d_v, dropout, name + '.slf_attn', attn_dropout)
         self.pos_ffn = PositionwiseFeedForward(d_model, d_inner, fft_conv1d_kernel, fft_conv1d_padding, dropout,
                                                name + '.pos_ffn')
+
+    def forward_hip(self, x, keep_row, key_keep, hip_attn, hip_ffn):
+        return self.pos_ffn.forward_hip(self.slf_attn.forward_hip(x, keep_row, key_keep, hip_attn), keep_row, hip_ffn)
 
     def forward(self, input, non_pad_mask=None, slf_attn_mask=None, acts=None, hip=None):
         keep = non_pad_mask.to(input.dtype)
@@ -165,19 +206,28 @@ class FFTBlocks(nn.Module):
 
     def _hip(self):
         if self._bank is None:
-            self._layers = [blk.pos_ffn.hip_layers() for blk in self.layer_stack]
-            self._bank = ConvBank([l for pair in self._layers for l in pair])
+            self._layers = [(blk.slf_attn.hip_layers(), blk.pos_ffn.hip_layers()) for blk in self.layer_stack]
+            self._bank = ConvBank([l for attn, ffn in self._layers for l in attn + ffn])
         return self._bank, self._layers
 
     def forward(self, seq, pos, return_attns=False, acts=None):
-        mask = get_attn_key_pad_mask(pos, pos)
         keep = get_non_pad_mask(pos)
         out = seq + self.position(pos)
-        hips = [None] * len(self.layer_stack)
-        if self.use_hip:
+        if self.use_hip and (out.is_cuda or _interpreter_bound()):
             bank, layers = self._hip()
-            bank.prepare(self.hip_dtype)          # one launch: kernel-layout weights of the 2 x n_layers convolutions
-            hips = [(bank, pair, self.hip_dtype) for pair in layers]
-        for layer, hip in zip(self.layer_stack, hips):
-            out, _ = layer(out, non_pad_mask=keep, slf_attn_mask=mask, hip=hip)
+            bank.prepare(self.hip_dtype)          # one launch: kernel-layout weights of the 4 x n_layers GEMMs / convolutions
+            keep_row = pos.ne(0).to(torch.uint8).reshape(-1)
+            key_keep = pos.ne(0).view(pos.shape[0], 1, 1, pos.shape[1])       # broadcast over heads and queries
+            out = out.to(self.hip_dtype)
+            for layer, (attn, ffn) in zip(self.layer_stack, layers):
+                out = layer.forward_hip(out, keep_row, key_keep, (bank, attn), (bank, ffn))
+            return out, keep
+        mask = get_attn_key_pad_mask(pos, pos)
+        for layer in self.layer_stack:
+            out, _ = layer(out, non_pad_mask=keep, slf_attn_mask=mask, hip=None)
         return out, keep
+
+
+def _interpreter_bound():
+    from ...hip import lib
+    return lib._host_pointers_ok

@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...hip import norm as hipnorm
 from ...utils.utils import get_mask_from_lengths
 from ..acoustic_models.transformer import FFTBlocks
 from ..hifigan.generator import Generator as HifiGANGenerator
@@ -192,6 +193,8 @@ class MSMCVQGAN(nn.Module):
         return x
 
     def forward(self, mel, mel_length, warmup=False, window=None):
+        if self.training:
+            hipnorm.advance_seed(mel.device)        # fresh dropout masks for the fused kernels of this step
         enc = self.encoder(self.in_linear(mel), mel_length)
         qs = self.quantizer(enc)
         feats, lens = zip(*enc)
