@@ -162,17 +162,27 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ g
     }
 }
 
-// dgamma[c] (+)= sum_b part[b][0][c], dbeta[c] (+)= sum_b part[b][1][c], in block order
+// dgamma[c] (+)= sum_b part[b][0][c], dbeta[c] (+)= sum_b part[b][1][c].  A workgroup owns 32 columns of one of the two
+// vectors; its 8 slices each sum a contiguous range of blocks in order, then the slices are added in order (deterministic).
 __global__ __launch_bounds__(256) void add_ln_param_kernel(const float* __restrict__ part, int nblocks, int C,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            int accumulate) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= 2 * C) return;
-    const int k = e / C, c = e - k * C;
+    __shared__ float red[8][32];
+    const int groups = (C + 31) / 32;
+    const int k = blockIdx.x / groups, c = (blockIdx.x - k * groups) * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+    const int per = (nblocks + 7) / 8, b0 = sl * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s = s + part[((size_t)b * 2 + k) * C + c];
-    float* dst = k == 0 ? dgamma : dbeta;
-    dst[c] = accumulate ? dst[c] + s : s;
+    if (c < C)
+        for (int b = b0; b < b1; ++b) s = s + part[((size_t)b * 2 + k) * C + c];
+    red[sl][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        float t = red[0][threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t = t + red[q][threadIdx.x];
+        float* dst = k == 0 ? dgamma : dbeta;
+        dst[c] = accumulate ? dst[c] + t : t;
+    }
 }
 
 // ---- gate / tanh ---------------------------------------------------------------------------------------------
@@ -250,8 +260,9 @@ int msmc_add_ln_fwd(const void* x, const void* res, const float* gamma, const fl
     return msmc_check_launch();
 }
 
+#define NM_BWD_ROWS 16          // rows per workgroup of the backward pass (4 per wave)
 size_t msmc_add_ln_bwd_workspace(long N, int C) {
-    const long rows = 64;
+    const long rows = NM_BWD_ROWS;
     return (size_t)((N + rows - 1) / rows) * 2 * C * sizeof(float);
 }
 
@@ -260,7 +271,7 @@ int msmc_add_ln_bwd(const void* g, const void* v, const float* mean, const float
                     size_t workspace_bytes, long N, int C, float p_drop, const long long* seed, long long salt, int accumulate,
                     int dtype, msmc_stream stream) {
     if (!g || !v || !mean || !rstd || !gamma || !gx || !dgamma || !dbeta || N < 0 || C <= 0 || C > 64 * NM_MAXE) return MSMC_E_SHAPE;
-    const int rows = 64;
+    const int rows = NM_BWD_ROWS;
     const int nblocks = (int)((N + rows - 1) / rows);
     if (workspace_bytes < msmc_add_ln_bwd_workspace(N, C) || (nblocks && !workspace)) return MSMC_E_WORKSPACE;
     const size_t lds = (size_t)4 * 2 * C * sizeof(float);
@@ -277,7 +288,7 @@ int msmc_add_ln_bwd(const void* g, const void* v, const float* mean, const float
         int rc = msmc_check_launch();
         if (rc) return rc;
     }
-    MSMC_LAUNCH(add_ln_param_kernel, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, (msmc_stream_t)stream,
+    MSMC_LAUNCH(add_ln_param_kernel, dim3((unsigned)(2 * ((C + 31) / 32))), dim3(256), 0, (msmc_stream_t)stream,
                 (const float*)workspace, nblocks, C, dgamma, dbeta, accumulate);
     return msmc_check_launch();
 }
