@@ -307,6 +307,29 @@ int msmc_gate_bwd(const void* x, const void* g, void* gx, long N, int C, float p
 int msmc_tanh_fwd(const void* x, void* y, long n, int dtype, msmc_stream stream);
 int msmc_tanh_bwd(const void* y, const void* g, void* gx, long n, int dtype, msmc_stream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * O1  gradient-norm clipping + AdamW for all tensors of one child in three launches (csrc/optim.hip).
+ * Replaces clip_grad_norm_ + the per-child AdamW step of
+ *   reference msmctts/trainers/optimizers/__init__.py:53-78, msmctts/trainers/msmctts_trainer.py:205-206.
+ * ``table`` is a DEVICE array sorted by first_chunk; tensor i owns workgroups [first_chunk, first_chunk + ceil(n / chunk)).
+ * lr [1], step [1] (incremented by the call, as float), norm_coef [2] (out: total gradient norm, clip coefficient) and
+ * partial [nblocks] live on the device.  max_norm <= 0: no clipping (coefficient 1).  write_grads != 0: the clipped
+ * gradients are written back (clip_grad_norm_'s in-place semantics).  torch.optim.AdamW arithmetic, fp32.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct msmc_opt_tensor {
+    float* p;               /* parameter */
+    float* g;               /* gradient */
+    float* m;               /* exp_avg */
+    float* v;               /* exp_avg_sq */
+    long n;                 /* elements */
+    int first_chunk;
+    int pad_;
+} msmc_opt_tensor;
+int msmc_opt_chunk(void);   /* elements per workgroup */
+int msmc_opt_clip_adamw(const msmc_opt_tensor* table, int ntensors, int nblocks, float max_norm, float* partial,
+                        float* norm_coef, const float* lr, float* step, float beta1, float beta2, float eps,
+                        float weight_decay, int write_grads, msmc_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

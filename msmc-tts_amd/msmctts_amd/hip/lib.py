@@ -52,6 +52,11 @@ class WnItem(ctypes.Structure):
                 ('dw_copy_stride', ctypes.c_long), ('db_copy_stride', ctypes.c_long)]
 
 
+class OptTensor(ctypes.Structure):
+    """msmc_opt_tensor of include/msmc_hip.h."""
+    _fields_ = [('p', _vp), ('g', _vp), ('m', _vp), ('v', _vp), ('n', ctypes.c_long), ('first_chunk', _i), ('pad_', _i)]
+
+
 MAX_TENSORS = 64
 
 
@@ -107,6 +112,8 @@ _SIGNATURES.update({
     'msmc_gate_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _i, _f, _vp, ctypes.c_longlong, _i, _vp]),
     'msmc_tanh_fwd': (_i, [_vp, _vp, ctypes.c_long, _i, _vp]),
     'msmc_tanh_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _i, _vp]),
+    'msmc_opt_chunk': (_i, []),
+    'msmc_opt_clip_adamw': (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _vp]),
     'msmc_lrelu_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _f, _i, _vp]),
     'msmc_reflect_fold': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
 })

@@ -188,6 +188,9 @@ class VQGANTrainer(BaseTrainer):
         st.g_loss.backward()
 
     def _segment_c(self, st):
+        if hasattr(self.optimizer, 'clip_and_step'):           # clip + AdamW of all tensors in three launches
+            self.grad_norm = self.optimizer.clip_and_step('autoencoder', self.grad_clip_thresh)
+            return
         self.grad_norm = nn.utils.clip_grad_norm_(self.model.autoencoder.parameters(), self.grad_clip_thresh)
         self.optimizer.step(['autoencoder'])
 
@@ -339,10 +342,13 @@ class VQGANTrainer(BaseTrainer):
             self._build_windows(g, st)
             self._segment_a(st)
         torch.cuda.synchronize()
+        prepare = getattr(self.optimizer, 'prepare', lambda names=None: None)
+        prepare(['discriminator'])              # (tensor tables over the static gradients segment A just allocated)
         with torch.cuda.graph(gb, pool=ga.pool(), stream=side, capture_error_mode=mode):
             self._segment_b(st)
         keys = [k for k, v in st.losses.items() if torch.is_tensor(v)]
         torch.cuda.synchronize()
+        prepare(['autoencoder'])
         with torch.cuda.graph(gc, pool=ga.pool(), stream=side, capture_error_mode=mode):
             self._segment_c(st)
             loss_vec = torch.stack([st.losses[k].detach().float().reshape(()) for k in keys])

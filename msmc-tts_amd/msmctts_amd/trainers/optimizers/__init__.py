@@ -1,15 +1,21 @@
 """Per-child optimizer bundle (drop-in for reference msmctts/trainers/optimizers/__init__.py:8-78).
 
 One optimizer per top-level child of the task (``autoencoder``, ``discriminator``), configured by
-``optimizer.<child>`` or ``optimizer._default``; ``zero_grad``/``step`` take child names.  On the GPU
-AdamW runs as PyTorch's fused multi-tensor kernel (one launch per child instead of one per tensor).
+``optimizer.<child>`` or ``optimizer._default``; ``zero_grad``/``step`` take child names.  On the GPU AdamW (and Adam
+without weight decay, which is the same update) is ``HipAdamW``: gradient-norm clipping + update of every tensor of a
+child in three launches (csrc/optim.hip), learning rate / step count on the device (hipGraph-replayable).
+``MSMC_HIP_ADAMW=0`` keeps ``torch.optim``'s fused kernels (A/B runs).
 """
+import os
 import re
 
 import torch
 from torch.optim import Adam, AdamW
 
+from .hip_adamw import HipAdamW
 from .radam import RAdam
+
+HIP_ADAMW = os.environ.get('MSMC_HIP_ADAMW', '1') != '0'
 
 
 def get_optimizer(parameters, config, capturable=False):
@@ -20,6 +26,9 @@ def get_optimizer(parameters, config, capturable=False):
         return RAdam(parameters, *args)
     cls = {'Adam': Adam, 'AdamW': AdamW}[name]
     fused = any(p.is_cuda for p in parameters)
+    from ...hip import lib
+    if HIP_ADAMW and (fused or lib._host_pointers_ok) and (name == 'AdamW' or config.weight_decay == 0):
+        return HipAdamW(parameters, *args)
     if fused and capturable:         # hipGraph replay: step counters and lr live on the device
         dev = next(p.device for p in parameters if p.is_cuda)
         return cls(parameters, torch.tensor(float(config.learning_rate), device=dev), tuple(config.betas), config.eps,
@@ -71,3 +80,21 @@ class Optimizer(object):
     def step(self, names=None):
         for k in self._names(names):
             self.optimizers[k].step()
+
+    def prepare(self, names=None):
+        """optimizers that keep device-side tables of their tensors build them now (called outside hipGraph capture)"""
+        for k in self._names(names):
+            if hasattr(self.optimizers[k], 'prepare'):
+                self.optimizers[k].prepare()
+
+    def clip_and_step(self, name, max_norm):
+        """clip the global gradient norm of child ``name`` to ``max_norm`` and step it; returns the pre-clip norm
+        (reference: clip_grad_norm_ then optimizer.step, msmctts_trainer.py:205-207)"""
+        opt = self.optimizers[name]
+        if isinstance(opt, HipAdamW):
+            opt.step(max_norm=max_norm)
+            return opt.grad_norm
+        params = [p for g in opt.param_groups for p in g['params']]
+        norm = torch.nn.utils.clip_grad_norm_(params, max_norm)
+        opt.step()
+        return norm

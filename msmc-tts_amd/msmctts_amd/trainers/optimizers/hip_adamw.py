@@ -1,0 +1,122 @@
+"""AdamW (+ gradient-norm clipping) over csrc/optim.hip: three launches per step for all tensors of a child
+(reference trainers/optimizers/__init__.py:53-78 builds ``torch.optim.AdamW`` per child; msmctts_trainer.py:205-206 clips
+the autoencoder first).  Same arithmetic and the same ``state_dict`` layout as ``torch.optim.AdamW`` (per-parameter
+``step`` / ``exp_avg`` / ``exp_avg_sq``), so checkpoints move both ways.  Learning rate, step count and clip
+coefficient live on the device: the step replays from a hipGraph unchanged.
+"""
+import ctypes
+
+import torch
+from torch.optim.optimizer import Optimizer
+
+from ...hip import lib
+
+
+class HipAdamW(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        params = list(params)
+        dev = next((p.device for p in params if torch.is_tensor(p)), torch.device('cpu'))
+        lr_t = lr if torch.is_tensor(lr) else torch.tensor(float(lr), dtype=torch.float32, device=dev)
+        super().__init__(params, dict(lr=lr_t, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self._built = None          # (signature of gradient pointers, tables) per group
+        self.grad_norm = None
+
+    # -- flat state ---------------------------------------------------------------------------
+    def _ensure_state(self, group):
+        ps = [p for p in group['params'] if p.requires_grad]
+        if 'flat' in group and group['flat']['n'] == sum(p.numel() for p in ps):
+            return ps
+        dev = ps[0].device
+        n = sum(p.numel() for p in ps)
+        flat = dict(n=n, m=torch.zeros(n, dtype=torch.float32, device=dev), v=torch.zeros(n, dtype=torch.float32, device=dev),
+                    step=torch.zeros(1, dtype=torch.float32, device=dev),
+                    norm_coef=torch.zeros(2, dtype=torch.float32, device=dev))
+        off = 0
+        for p in ps:
+            assert p.dtype == torch.float32 and p.is_contiguous(), 'HipAdamW updates contiguous fp32 parameters'
+            k = p.numel()
+            old = self.state.get(p)
+            st = {'step': flat['step'].view(()), 'exp_avg': flat['m'][off:off + k].view_as(p),
+                  'exp_avg_sq': flat['v'][off:off + k].view_as(p)}
+            if old:                                   # state loaded from a checkpoint: adopt its values
+                st['exp_avg'].copy_(old['exp_avg'])
+                st['exp_avg_sq'].copy_(old['exp_avg_sq'])
+                flat['step'].fill_(float(old['step']))
+            self.state[p] = st
+            off += k
+        group['flat'] = flat
+        return ps
+
+    def _table(self, group, ps):
+        live = [p for p in ps if p.grad is not None]
+        sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in live)
+        cached = group.get('table')
+        if cached is not None and cached[0] == sig:
+            return cached[1:5]
+        chunk = lib.get().msmc_opt_chunk()
+        items = (lib.OptTensor * max(1, len(live)))()
+        blocks = 0
+        for it, p in zip(items, live):
+            g = p.grad
+            assert g.dtype == torch.float32 and g.is_contiguous(), 'HipAdamW takes contiguous fp32 gradients'
+            st = self.state[p]
+            it.p, it.g, it.m, it.v = p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr()
+            it.n, it.first_chunk = p.numel(), blocks
+            blocks += (p.numel() + chunk - 1) // chunk
+        dev = ps[0].device
+        if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('HipAdamW: the tensor table must exist before hipGraph capture (gradient storage changed): '
+                               'call optimizer.prepare() between the backward pass and the captured step')
+        table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
+        partial = torch.empty(max(1, blocks), dtype=torch.float32, device=dev)
+        group['table'] = (sig, table, partial, len(live), blocks)
+        return table, partial, len(live), blocks
+
+    def prepare(self):
+        """build the flat state and the tensor table for the gradients that exist now (before capturing a step)"""
+        for group in self.param_groups:
+            self._table(group, self._ensure_state(group))
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm=0.0):
+        """one AdamW step of every group; ``max_norm > 0`` clips the global gradient norm of the group first (in place,
+        like clip_grad_norm_) -- ``self.grad_norm`` then holds the pre-clip norm (device tensor)"""
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            ps = self._ensure_state(group)
+            table, partial, nt, blocks = self._table(group, ps)
+            if nt == 0:
+                continue
+            flat = group['flat']
+            lr = group['lr']
+            if not torch.is_tensor(lr):
+                lr = group['lr'] = torch.tensor(float(lr), dtype=torch.float32, device=ps[0].device)
+            b1, b2 = group['betas']
+            lib.check(lib.get().msmc_opt_clip_adamw(lib.ptr(table), nt, blocks, float(max_norm or 0.0), lib.ptr(partial),
+                                                    lib.ptr(flat['norm_coef']), lib.ptr(lr.reshape(1)), lib.ptr(flat['step']),
+                                                    float(b1), float(b2), float(group['eps']), float(group['weight_decay']), 1,
+                                                    lib.stream(partial)), 'msmc_opt_clip_adamw')
+            self.grad_norm = flat['norm_coef'][0]
+        return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:           # re-home the loaded moments in the flat buffers at the next step
+            group.pop('flat', None)
+            group.pop('table', None)
+            if not torch.is_tensor(group['lr']):
+                dev = group['params'][0].device
+                group['lr'] = torch.tensor(float(group['lr']), dtype=torch.float32, device=dev)
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for g in sd['param_groups']:
+            g.pop('flat', None)
+            g.pop('table', None)
+            if torch.is_tensor(g['lr']):
+                g['lr'] = float(g['lr'])
+        for st in sd['state'].values():           # torch.optim.AdamW layout: a 0-dim fp32 ``step`` per parameter
+            st['step'] = st['step'].detach().clone().reshape(())
+            st['exp_avg'] = st['exp_avg'].detach().clone()
+            st['exp_avg_sq'] = st['exp_avg_sq'].detach().clone()
+        return sd

@@ -131,7 +131,16 @@ def test_fp32_step_matches_oracle(name):
         snaps[key] = {n: p.grad.detach().float().cpu().clone() for n, p in task.named_parameters()
                       if n.startswith(key + '.') and p.grad is not None}
         return real_step(names)
+    real_clip_step = tr.optimizer.clip_and_step
+
+    def clip_spy(name, max_norm):               # the fused clip + AdamW: gradients are clipped in place, as clip_grad_norm_ does
+        out = real_clip_step(name, max_norm)
+        torch.cuda.synchronize()
+        snaps[name] = {n: p.grad.detach().float().cpu().clone() for n, p in task.named_parameters()
+                       if n.startswith(name + '.') and p.grad is not None}
+        return out
     tr.optimizer.step = spy
+    tr.optimizer.clip_and_step = clip_spy
     task.zero_grad()
     log = tr.train_step(batch, 10)
     keep = {}

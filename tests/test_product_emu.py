@@ -301,3 +301,41 @@ def test_fused_add_layernorm_gate_tanh_match_torch(dtype, tol):
     norm.advance_seed(xg.device)
     y2 = norm.gate(xg.detach(), p_drop=p, salt=salt)
     assert not torch.equal(y2 != 0, y != 0)
+
+
+def test_hip_adamw_matches_torch_adamw_with_clipping():
+    """csrc/optim.hip (grad-norm clip + AdamW of all tensors in three launches) against clip_grad_norm_ + torch.optim.AdamW
+    over several steps, odd sizes and unaligned views; state_dict round trip both ways"""
+    from msmctts_amd.trainers.optimizers.hip_adamw import HipAdamW
+    torch.manual_seed(0)
+    shapes = [(7,), (33, 5), (4096,), (5000,), (3, 3, 3)]
+    base = torch.randn(20000)
+    mine = [torch.nn.Parameter(torch.randn(*s)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    a = HipAdamW(mine, lr=2e-3, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01)
+    b = torch.optim.AdamW(ref, lr=2e-3, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01)
+    for step in range(4):
+        for p, q in zip(mine, ref):
+            g = torch.randn_like(p) * (3.0 if step % 2 == 0 else 0.01)
+            p.grad = g.clone() if step != 2 else base[1:1 + g.numel()].view_as(g).clone()
+            q.grad = p.grad.clone()
+        norm = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        b.step()
+        a.step(max_norm=1.0)
+        assert abs(float(a.grad_norm) - float(norm)) <= 1e-5 * max(1.0, float(norm))
+        for p, q in zip(mine, ref):
+            assert (p - q).abs().max() <= 2e-6, step
+            assert (p.grad - q.grad).abs().max() <= 1e-6 * max(1.0, float(q.grad.abs().max()))       # clipped in place
+    sd = a.state_dict()
+    assert set(sd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'} and float(sd['state'][0]['step']) == 4.0
+    b2 = torch.optim.AdamW([torch.nn.Parameter(p.detach().clone()) for p in mine], lr=2e-3, betas=(0.8, 0.99), weight_decay=0.01)
+    b2.load_state_dict(sd)                                  # our checkpoint into torch's optimizer
+    a2 = HipAdamW([torch.nn.Parameter(p.detach().clone()) for p in mine], lr=2e-3, betas=(0.8, 0.99), weight_decay=0.01)
+    a2.load_state_dict(b.state_dict())                      # torch's checkpoint into ours
+    for opt in (a2, b2):
+        for p in opt.param_groups[0]['params']:
+            p.grad = torch.ones_like(p) * 0.1
+    a2.step()
+    b2.step()
+    for p, q in zip(a2.param_groups[0]['params'], b2.param_groups[0]['params']):
+        assert (p - q).abs().max() <= 2e-6
