@@ -3,11 +3,14 @@
 Same classes, constructor kwargs (the YAML surface), ``state_dict`` keys and output dictionary.
 The quantiser calls the gfx950 VQ kernels; the vocoder is ``HifiGANGenerator``.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ...hip import norm as hipnorm
+from ...hip.convnet import ConvBank, ConvLayer, hip_conv
 from ...utils.utils import get_mask_from_lengths
 from ..acoustic_models.transformer import FFTBlocks
 from ..hifigan.generator import Generator as HifiGANGenerator
@@ -69,12 +72,44 @@ class PriorPredictor(nn.Module):
         super().__init__()
         self.enc = ResStack(in_channels, kernel_size, dilation_rate, n_layers)
         self.proj = nn.Conv1d(in_channels, out_channels, 1)
+        self._salts = [hipnorm.new_salt() for _ in range(n_layers)]
 
     def forward(self, x, x_lengths):
         x = x.transpose(1, 2)
         x_mask = (~get_mask_from_lengths(x_lengths.to(x.device), x.shape[2])).unsqueeze(1).to(x.dtype)
         h = self.enc(x, x_mask).transpose(1, 2)
         return h, _pointwise(self.proj, h) * x_mask.transpose(1, 2)
+
+    def hip_layers(self):
+        """[(in_layer_i, res_skip_i) ...] + [proj] as layers of the quantiser's ConvBank (channels-last [B,1,T,C])"""
+        pairs = [(a.hip_layer(), b.hip_layer()) for a, b in zip(self.enc.in_layers, self.enc.res_skip_layers)]
+        return pairs, ConvLayer(self.proj, 'conv', (1, 1), plain=True)
+
+    def forward_hip(self, x, x_lengths, hip):
+        """x [B, T, C] in the compute dtype -> (hidden, projection): the WaveNet stack of vqgantts/modules.py:229-251 with
+        its convolutions on the implicit-GEMM kernels and tanh * sigmoid (+ dropout) as one kernel per layer"""
+        bank, (pairs, l_proj) = hip
+        C = self.enc.hidden_channels
+        keep = (~get_mask_from_lengths(x_lengths.to(x.device), x.shape[1])).unsqueeze(-1).to(x.dtype)       # [B, T, 1]
+        x4 = x.unsqueeze(1)
+        out = None
+        pd = self.enc.drop.p if self.training else 0.0
+        for i, (l_in, l_rs) in enumerate(pairs):
+            acts = hipnorm.gate(hip_conv(bank, l_in, x4), p_drop=pd, salt=self._salts[i])
+            rs = hip_conv(bank, l_rs, acts)
+            if i < len(pairs) - 1:
+                x4 = (x4 + rs[..., :C]) * keep.unsqueeze(1)
+                skip = rs[..., C:]
+            else:
+                skip = rs
+            out = skip if out is None else out + skip
+        h = (out * keep.unsqueeze(1)).contiguous()
+        return h.squeeze(1), hip_conv(bank, l_proj, h).squeeze(1) * keep
+
+
+def _interpreter_bound():
+    from ...hip import lib
+    return lib._host_pointers_ok
 
 
 class MultiStageQuantizer(nn.Module):
@@ -102,6 +137,28 @@ class MultiStageQuantizer(nn.Module):
             if upsampling != 'repeat':
                 k = u * 2 if u % 2 == 0 else u * 2 + 1
                 self.transposed_conv.append(nn.ConvTranspose1d(n_model_size, n_model_size, k, u, padding=(k - u) // 2))
+        self.hip_dtype = torch.float32        # compute dtype of the HIP GEMMs (trainer: bfloat16 in bf16 runs)
+        self.use_hip = os.environ.get('MSMC_QUANT_HIP', '1') != '0' and not norm
+        self._bank = None
+
+    # -- the 1x1 channel GEMMs, the prior predictor's WaveNet stack and their Tanh / gate on the gfx950 kernels ---------
+    def _hip(self):
+        if self._bank is None:
+            k1 = lambda m: ConvLayer(m, 'conv', (1, 1), plain=True)
+            self._stages = []
+            for pre, post, pred in zip(self.preprocessor, self.postprocessor, self.predictor):
+                self._stages.append(((k1(pre[0]), k1(pre[2])), (k1(post[0]), k1(post[2])), pred.hip_layers()))
+            flat = []
+            for pre, post, (pairs, proj) in self._stages:
+                flat += list(pre) + list(post) + [l for pr in pairs for l in pr] + [proj]
+            self._bank = ConvBank(flat)
+        return self._bank, self._stages
+
+    @staticmethod
+    def _stack_hip(bank, pair, x):
+        """conv1x1 -> Tanh -> conv1x1 on channels-last x [B, T, C] (pre- / post-processor, msmc_vqgan.py:115-136)"""
+        h = hipnorm.tanh(hip_conv(bank, pair[0], x.unsqueeze(1)))
+        return hip_conv(bank, pair[1], h).squeeze(1)
 
     def forward(self, encoder_states, from_encoder=True):
         states = list(encoder_states)
@@ -109,23 +166,35 @@ class MultiStageQuantizer(nn.Module):
             states = states[::-1]                   # coarse -> fine
         residual = None
         quants, diffs, inds, preds = [], [], [], []
+        dev = next(self.parameters()).device
+        hip = None
+        if self.use_hip and (dev.type == 'cuda' or _interpreter_bound()):
+            bank, stages = self._hip()
+            bank.prepare(self.hip_dtype)              # one launch: kernel-layout weights of every GEMM of the quantiser
+            hip, dt = (bank, stages), self.hip_dtype
         for i, (emb, length) in enumerate(states):
             if residual is None:
                 pred_q = None
             else:
                 residual = residual[:, :(emb.shape[1] if emb is not None else int(length.max()))]
-                hid, pred_q = self.predictor[i](residual, length)
+                if hip is None:
+                    hid, pred_q = self.predictor[i](residual, length)
+                else:
+                    hid, pred_q = self.predictor[i].forward_hip(residual.to(dt).contiguous(), length, (bank, stages[i][2]))
                 residual = residual + F.dropout(hid, p=self.dropout, training=self.training)
             if emb is None:
                 q_in = pred_q
             elif from_encoder:
                 pre_in = emb if residual is None else torch.cat((emb, residual), dim=-1)
-                q_in = _pointwise_stack(self.preprocessor[i], pre_in)
+                q_in = (_pointwise_stack(self.preprocessor[i], pre_in) if hip is None else
+                        self._stack_hip(bank, stages[i][0], pre_in.to(dt).contiguous()))
             else:
                 q_in = emb
             quant, dff, ind = self.quantizer[i](q_in, length, update=self.update_codebook)
             post_in = quant if residual is None else torch.cat((residual, quant), dim=-1)
-            post = F.dropout(self.postprocessor[i](post_in), p=self.dropout, training=self.training)
+            post = (self.postprocessor[i](post_in) if hip is None else
+                    self._stack_hip(bank, stages[i][1], post_in.to(dt).contiguous()))
+            post = F.dropout(post, p=self.dropout, training=self.training)
             residual = post if residual is None else residual + post
             quants.append(quant)
             diffs.append(dff)
@@ -186,6 +255,26 @@ class MSMCVQGAN(nn.Module):
             self.frame_decoder = FFTBlocks(d_model=n_model_size, name='frame_decoder', **frame_decoder_config)
         if pred_mel:
             self.mel_predictor = nn.Linear(n_model_size, in_dim)
+        self.hip_dtype = torch.float32
+        self.use_hip = os.environ.get('MSMC_QUANT_HIP', '1') != '0'
+        self._bank = None
+
+    def _hip_ready(self, dev):
+        """(build and) refresh the kernel-layout weights of in_linear / mel_predictor: one launch per forward"""
+        if not (self.use_hip and (dev.type == 'cuda' or _interpreter_bound())):
+            return False
+        if self._bank is None:
+            mods = [self.in_linear] + ([self.mel_predictor] if hasattr(self, 'mel_predictor') else [])
+            self._layers = {id(m): ConvLayer(m, 'conv', (1, 1), plain=True) for m in mods}
+            self._bank = ConvBank([self._layers[id(m)] for m in mods])
+        self._bank.prepare(self.hip_dtype)
+        return True
+
+    def _linear(self, module, x, hip):
+        """in_linear / mel_predictor as 1-tap implicit GEMMs (bias fused, compute dtype in and out)"""
+        if not hip:
+            return module(x)
+        return hip_conv(self._bank, self._layers[id(module)], x.to(self.hip_dtype).contiguous().unsqueeze(1)).squeeze(1)
 
     def _decode_frames(self, x, lengths):
         if hasattr(self, 'frame_decoder'):
@@ -195,7 +284,8 @@ class MSMCVQGAN(nn.Module):
     def forward(self, mel, mel_length, warmup=False, window=None):
         if self.training:
             hipnorm.advance_seed(mel.device)        # fresh dropout masks for the fused kernels of this step
-        enc = self.encoder(self.in_linear(mel), mel_length)
+        hip = self._hip_ready(mel.device)
+        enc = self.encoder(self._linear(self.in_linear, mel, hip), mel_length)
         qs = self.quantizer(enc)
         feats, lens = zip(*enc)
         out = {'encoder_outputs': feats[::-1], 'encoder_lengths': lens[::-1],
@@ -203,7 +293,7 @@ class MSMCVQGAN(nn.Module):
                'decoder_diffs': qs['predictor_diffs']}
         dec_in = self._decode_frames(qs['residual_output'], mel_length)
         if hasattr(self, 'mel_predictor'):
-            out['mel_outputs'] = self.mel_predictor(dec_in)
+            out['mel_outputs'] = self._linear(self.mel_predictor, dec_in, hip)
         if not warmup:
             if torch.is_tensor(window):            # (B, n_frames) frame indices on the device: graph-replayable
                 dec_in = torch.gather(dec_in, 1, window.unsqueeze(-1).expand(-1, -1, dec_in.shape[-1]))
