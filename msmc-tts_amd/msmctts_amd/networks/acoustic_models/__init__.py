@@ -1,0 +1,1 @@
+from .multi_stage_predictor import MultiStagePredictor  # noqa: F401

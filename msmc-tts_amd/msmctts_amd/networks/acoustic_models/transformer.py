@@ -231,3 +231,61 @@ class FFTBlocks(nn.Module):
 def _interpreter_bound():
     from ...hip import lib
     return lib._host_pointers_ok
+
+
+class DurationPredictor(nn.Module):
+    """conv-ReLU-LN-dropout x2 + linear on the phoneme axis (reference transformer.py:481-534); a few hundred phonemes
+    per batch: stock operators."""
+
+    def __init__(self, input_size, filter_size, kernel, dropout, fused_layernorm=False):
+        super().__init__()
+        self.input_size, self.filter_size, self.kernel, self.dropout = input_size, filter_size, kernel, dropout
+        self.conv1d_1 = nn.Conv1d(input_size, filter_size, kernel_size=kernel, padding=1)
+        self.relu_1 = nn.ReLU()
+        self.layer_norm_1 = nn.LayerNorm(filter_size)
+        self.dropout_1 = nn.Dropout(dropout)
+        self.conv1d_2 = nn.Conv1d(filter_size, filter_size, kernel_size=kernel, padding=1)
+        self.relu_2 = nn.ReLU()
+        self.layer_norm_2 = nn.LayerNorm(filter_size)
+        self.dropout_2 = nn.Dropout(dropout)
+        self.linear_layer = nn.Linear(filter_size, 1, bias=True)
+
+    def forward(self, input, input_mask):
+        out = input * input_mask.to(input.dtype)
+        out = self.dropout_1(self.layer_norm_1(self.relu_1(self.conv1d_1(out.transpose(1, 2)).transpose(1, 2))))
+        out = self.dropout_2(self.layer_norm_2(self.relu_2(self.conv1d_2(out.transpose(1, 2)).transpose(1, 2))))
+        out = self.linear_layer(out) * input_mask.to(out.dtype)
+        return out.squeeze(-1)
+
+
+class LengthRegulator(nn.Module):
+    """Phoneme -> frame expansion by (target or predicted) durations (reference transformer.py:427-478)."""
+
+    def __init__(self, input_size, duration_predictor_filter_size, duration_predictor_kernel_size, dropout,
+                 fused_layernorm=False):
+        super().__init__()
+        self.duration_predictor = DurationPredictor(input_size, duration_predictor_filter_size,
+                                                    duration_predictor_kernel_size, dropout, fused_layernorm)
+
+    def forward(self, input, input_mask, target=None, alpha=1.0):
+        duration = self.duration_predictor(input, input_mask)
+        if self.training:
+            output, pos = self.get_output(input, target, alpha)
+            return output, pos, duration
+        duration = torch.clamp_min(duration, 0) if target is None else target
+        output, pos = self.get_output(input, duration, alpha)
+        return output, pos, torch.round(duration).long()
+
+    def get_output(self, input, duration, alpha):
+        """one gather for the whole batch: frame t of utterance b copies phoneme searchsorted(cumsum(repeats_b), t);
+        zero-padded to the longest utterance, positions 1..len (0 on padding) like the reference's pad_sequence"""
+        repeats = torch.round(duration.float() * alpha).long().clamp_min(0)
+        ends = repeats.cumsum(1)                                              # [B, P]
+        total = ends[:, -1]
+        width = int(total.max())
+        t = torch.arange(width, device=input.device).unsqueeze(0).expand(input.shape[0], -1)
+        src = torch.searchsorted(ends, t.contiguous(), right=True).clamp_max(input.shape[1] - 1)
+        valid = t < total.unsqueeze(1)
+        output = torch.gather(input, 1, src.unsqueeze(-1).expand(-1, -1, input.shape[2])) * valid.unsqueeze(-1).to(input.dtype)
+        pos = (t + 1) * valid.long()
+        return output, pos

@@ -46,6 +46,19 @@ class Quantize(nn.Module):
     def embed_code(self, embed_id):
         return F.embedding(embed_id, self.embed.transpose(0, 1))
 
+    def compute_triple_loss(self, prd_quant, trg_quant, reduction='mean', margin=1e-6, adaptive_margin=False):
+        """hinge of (squared distance to the target codeword) against the squared distance to every codeword (reference
+        modules.py:86-116, the 'masked version'): [B, T] per-frame loss.  Predictor training only (a few thousand
+        frames per step): stock operators on the expanded distance matrix, like the reference."""
+        B, T, D = prd_quant.shape
+        flat = prd_quant.reshape(-1, self.dim)
+        dist = (flat.pow(2).sum(1, keepdim=True) - 2 * flat @ self.embed + self.embed.pow(2).sum(0, keepdim=True)).reshape(B, T, -1)
+        pos = F.mse_loss(prd_quant, self.embed_code(trg_quant), reduction='none').sum(-1)
+        triple = pos.unsqueeze(-1) - dist
+        mask = triple != 0
+        triple = mask * (torch.clamp(triple + margin, min=0) / self.dim)
+        return triple.mean(-1) if reduction == 'mean' else triple.sum(-1) if reduction == 'sum' else triple
+
 
 class MultiHeadQuantize(nn.Module):
     """H independent codebooks over contiguous feature chunks (reference modules.py:119-169)."""
@@ -85,6 +98,17 @@ class MultiHeadQuantize(nn.Module):
             self._ws = hipvq.vq_ema_update(x3, ind.reshape(x3.shape[0], x3.shape[1], -1), input_length, embed, cs, ea,
                                            self.decay, self.eps, self._ws)
         return quant, diff, ind
+
+
+    def compute_triple_loss(self, prd_quant, trg_quant, reduction='mean', margin=1e-6, adaptive_margin=False):
+        """mean over heads of the per-head triple loss (reference modules.py:152-168); trg_quant [B, T, H] indices"""
+        prds = torch.chunk(prd_quant, self.n_head, dim=-1)
+        trgs = torch.chunk(trg_quant, self.n_head, dim=-1)
+        losses = []
+        for q, p, t in zip(self.quantizers, prds, trgs):
+            assert t.shape[-1] == 1
+            losses.append(q.compute_triple_loss(p, t.squeeze(-1), reduction, margin, adaptive_margin))
+        return sum(losses) / len(losses)
 
 
 class ResStack(nn.Module):

@@ -230,8 +230,12 @@ class MultiStageQuantizer(nn.Module):
                     B, T, D = p.shape
                     loss = F.cross_entropy(p.view(-1, D), st['target_indices'].detach().view(-1),
                                            reduction='none').view(B, T)
+                elif method in ('triple', 'triple_mean'):
+                    loss = self.quantizer[i].compute_triple_loss(p, st['target_indices'])
+                elif method == 'triple_sum':
+                    loss = self.quantizer[i].compute_triple_loss(p, st['target_indices'], reduction='sum')
                 else:
-                    raise NotImplementedError('%s loss belongs to predictor training (SURVEY.md 8f)' % method)
+                    raise NotImplementedError('embedding loss %r' % method)
                 lengths = st['target_lengths']
                 loss = loss.masked_fill(get_mask_from_lengths(lengths.to(loss.device), loss.shape[1]), 0)
                 loss = loss.sum() / lengths.sum()

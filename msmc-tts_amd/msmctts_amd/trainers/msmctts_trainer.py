@@ -364,3 +364,68 @@ class VQGANTrainer(BaseTrainer):
 
 class _StepState(object):
     pass
+
+
+class DurationLoss(nn.Module):
+    """masked MSE between predicted and target phoneme durations (reference msmctts_trainer.py:12-36)"""
+
+    def __init__(self, lambda_dur=1):
+        super().__init__()
+        self.lambda_dur = lambda_dur
+
+    def forward(self, outputs, targets):
+        dur_target = targets['dur'].float()
+        lengths = targets['text_length']
+        loss = F.mse_loss(outputs['duration'], dur_target, reduction='none')
+        loss = loss.masked_fill(get_mask_from_lengths(lengths.to(loss.device), loss.shape[1]), 0).sum() / lengths.sum()
+        return {'total_loss': self.lambda_dur * loss, 'dur_loss': loss}
+
+
+class PredictorTrainer(BaseTrainer):
+    """Predictor training against a frozen autoencoder (reference msmctts_trainer.py:222-295, BASELINE config #4): the
+    autoencoder's ``analysis`` (eval mode, no gradient) turns the mel batch into per-stage quantised targets, the predictor
+    maps text to those stages, and the loss is the per-stage embedding losses (``training_methods``, e.g. 'mse' +
+    'triple_sum') plus the duration loss; gradient-norm clipping, one optimizer step on the ``predictor`` child."""
+
+    def __init__(self, config, model, num_gpus=1, rank=0, grad_clip_thresh=1.0, eval_inteval_iters=1000,
+                 training_methods=['mse'], loss_weights=[1.0], lambda_dur=1.0):
+        super().__init__(config, model, num_gpus, rank)
+        self.training_methods, self.loss_weights = list(training_methods), loss_weights
+        self.grad_clip_thresh, self.eval_inteval_iters = grad_clip_thresh, eval_inteval_iters
+        self.dur_loss = DurationLoss(lambda_dur)
+
+    def build_autoencoder(self):
+        """the frozen autoencoder named by ``task.autoencoder._checkpoint`` / ``_config`` (reference :288-295)"""
+        from ..tasks import load_model
+        acfg = self.config.task.autoencoder
+        self.autoencoder = load_model('autoencoder', acfg._checkpoint, acfg._config if hasattr(acfg, '_config') else None)
+        self.autoencoder = self.autoencoder.to(next(self.model.parameters()).device)
+
+    def train_step(self, batch, iteration):
+        batch = dict(batch)
+        if not hasattr(self, 'autoencoder'):
+            self.build_autoencoder()
+        self.autoencoder.eval()
+        with torch.no_grad():
+            qs = self.autoencoder.analysis(batch.pop('mel'), batch.pop('mel_length').int())
+        batch['feat'] = [f.float() for f in qs['quantizer_outputs']]
+        batch['feat_length'] = qs['quantizer_lengths']
+        output = self.model.predictor(**batch)
+        losses = {'total_loss': 0}
+        emb = self.autoencoder.compute_embedding_loss(output['feat'], output['feat_length'], qs,
+                                                      methods=self.training_methods, loss_weights=self.loss_weights)
+        losses['total_loss'] = losses['total_loss'] + emb.pop('total_loss')
+        losses.update(emb)
+        dur = self.dur_loss(output, batch)
+        losses['total_loss'] = losses['total_loss'] + dur.pop('total_loss')
+        losses.update(dur)
+        self.optimizer.zero_grad(['predictor'])
+        losses['total_loss'].backward()
+        self._sync_grads()
+        if self.grad_clip_thresh is not None and hasattr(self.optimizer, 'clip_and_step'):
+            losses['grad_norm'] = self.optimizer.clip_and_step('predictor', self.grad_clip_thresh)
+        else:
+            if self.grad_clip_thresh is not None:
+                losses['grad_norm'] = nn.utils.clip_grad_norm_(self.model.predictor.parameters(), self.grad_clip_thresh)
+            self.optimizer.step(['predictor'])
+        return {'loss': {k: (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()}}

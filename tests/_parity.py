@@ -10,7 +10,7 @@ import random
 import numpy as np
 import torch
 
-from _util import SMALL_TRAINER, fmap_digest, json_field, load_npz, small_task_cfg, t
+from _util import PREDICTOR_TRAINER, SMALL_TRAINER, fmap_digest, json_field, load_npz, small_predictor_cfg, small_task_cfg, t
 
 TOL = 1e-3
 
@@ -184,6 +184,72 @@ def check_train_steps(device, arm_reducer=False):
                     close(sd[n], v, 1e-5, 1e-4, what=n)
                 else:
                     close(sd[n], v, 4.5e-4, what=n)
+
+
+def check_predictor_step(device):
+    """BASELINE config #4: one PredictorTrainer.train_step of the product against the reference's own step
+    (tests/golden/small_predictor.npz): forward predictions, durations, every loss, every clipped gradient norm, and the
+    spot-checked post-step parameters."""
+    from msmctts_amd.tasks import build_task
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    from msmctts_amd.utils.config import Config
+    z = load_npz('small_predictor.npz')
+    cfg = Config({'id': 'small_predictor', 'task': {'_name': 'MSMCTTS', '_mode': 'train_predictor', 'predictor': small_predictor_cfg()},
+                  'trainer': dict(PREDICTOR_TRAINER, _name='PredictorTrainer'),
+                  'optimizer': {'_default': dict(_name='Adam', learning_rate=2e-4, betas=[0.9, 0.98], eps=1e-9, weight_decay=0)},
+                  'dataset': dict(samplerate=24000, feature=['mel', 'wav'], frameshift=[300, 1])})
+    task = build_task(cfg, mode='train')
+    task.load_state_dict({k[len('state.'):]: t(v) for k, v in z.items() if k.startswith('state.')})
+    task = task.to(device).train()
+    _, atask = build_small(device)
+    batch = {k[len('batch.'):]: t(v).to(device) for k, v in z.items() if k.startswith('batch.')}
+    # forward alone (teacher-forced stage features), like the fixture
+    atask.autoencoder.eval()
+    with torch.no_grad():
+        qs = atask.autoencoder.analysis(batch['mel'], batch['mel_length'].int())
+        fo = task.predictor(text=batch['text'], text_length=batch['text_length'], dur=batch['dur'],
+                            feat=[f.float() for f in qs['quantizer_outputs']], feat_length=qs['quantizer_lengths'])
+    for i in range(2):
+        assert np.array_equal(qs['quantizer_indices'][i].cpu().numpy(), z['ae.quantizer_indices.%d' % i])
+        close(qs['quantizer_outputs'][i], z['ae.quantizer_outputs.%d' % i], 1e-5, what='analysis %d' % i)
+        close(fo['feat'][i], z['fwd.feat.%d' % i], what='feat %d' % i)
+        assert np.array_equal(fo['feat_length'][i].cpu().numpy(), z['fwd.feat_length.%d' % i])
+    close(fo['duration'], z['fwd.duration'], what='duration')
+    # one training step
+    tr = build_trainer(cfg, task, num_gpus=0, rank=0)
+    tr.autoencoder = atask.autoencoder
+    tr.optimizer = build_optimizer(task, cfg.optimizer)
+    snaps = {}
+    real_step = tr.optimizer.step
+
+    def spy(names=None):
+        snaps['predictor'] = {n: p.grad.detach().clone() for n, p in task.named_parameters() if p.grad is not None}
+        return real_step(names)
+    tr.optimizer.step = spy
+    if hasattr(tr.optimizer, 'clip_and_step'):
+        real_clip_step = tr.optimizer.clip_and_step
+
+        def clip_spy(name, max_norm):
+            out = real_clip_step(name, max_norm)
+            snaps[name] = {n: p.grad.detach().clone() for n, p in task.named_parameters() if p.grad is not None}
+            return out
+        tr.optimizer.clip_and_step = clip_spy
+    log = tr.train_step({k: v.clone() for k, v in batch.items()}, 0)
+    want = {k[len('loss.'):]: float(v) for k, v in z.items() if k.startswith('loss.')}
+    assert set(want) == set(log['loss']), (sorted(want), sorted(log['loss']))
+    for k, v in want.items():
+        got = float(log['loss'][k])
+        assert abs(got - v) <= TOL * max(1.0, abs(v)), (k, got, v)
+    names = json_field(z['grad_names'])
+    assert set(names) == set(snaps['predictor']), set(names) ^ set(snaps['predictor'])
+    for n, w in zip(names, z['grad_l2']):
+        g = snaps['predictor'][n].double().norm().item()
+        assert abs(g - w) <= 2e-3 * max(w, 1e-3) + 1e-6, (n, g, w)
+    sd = task.state_dict()
+    for k, v in z.items():
+        if k.startswith('post.'):
+            close(sd[k[len('post.'):]], v, 1e-5, what=k)
 
 
 def check_mr_stft(device):

@@ -47,6 +47,21 @@ def small_task_cfg():
     }
 
 
+def small_predictor_cfg():
+    """The predictor of tests/golden/make_golden_predictor.py::PRED_TASK (data, not code); every nn.Dropout was zeroed when
+    the fixture was generated, hence attn_dropout=0."""
+    fft = dict(n_layers=1, n_head=2, d_k=8, d_v=8, d_model=32, d_inner=64, fft_conv1d_kernel=3, fft_conv1d_padding=1,
+               dropout=0.0, attn_dropout=0.0, fused_layernorm=False)
+    return {'_name': 'MultiStagePredictor', 'n_symbols': [20, 5, 2], 'n_model_size': 32, 'n_pred_size': 32,
+            'n_pred_scale': [4, 1],
+            'encoder_config': dict(max_seq_len=32, name='phoneme_side', **fft),
+            'adaptor_config': dict(input_size=32, duration_predictor_filter_size=16, duration_predictor_kernel_size=3,
+                                   dropout=0.0, fused_layernorm=False),
+            'decoder_config': dict(max_seq_len=64, name='mel_side', **fft)}
+
+
+PREDICTOR_TRAINER = dict(grad_clip_thresh=10.0, training_methods=['mse', 'triple_sum'],
+                         loss_weights=[[1.0, 1.0], [1.0, 1.0]], lambda_dur=1.0)
 SMALL_TRAINER = dict(grad_clip_thresh=1.0, warmup_steps=5, sample_lengths=2400, lambda_vq=1, lambda_pr=0.1,
                      lambda_frame=450, lambda_fm=2, lambda_stft=45)
 

@@ -34,6 +34,11 @@ def test_train_steps_match_reference():
     _parity.check_train_steps(DEV)
 
 
+def test_predictor_step_matches_reference():
+    """BASELINE config #4 (predictor training against the frozen autoencoder)"""
+    _parity.check_predictor_step(DEV)
+
+
 @pytest.mark.parametrize('H,K,D,N', [(1, 64, 256, 777), (4, 64, 256, 6400), (4, 256, 256, 1600), (8, 512, 256, 530),
                                      (4, 16, 32, 51), (2, 48, 24, 1), (4, 64, 256, 16), (4, 64, 256, 17)])
 def test_vq_search_bit_exact_vs_c_oracle(H, K, D, N):

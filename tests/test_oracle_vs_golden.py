@@ -184,6 +184,35 @@ def test_train_step_matches_reference(tag, iteration):
                 close(tr.P[n], v, 4.5e-4)       # one AdamW step moves a parameter by <= lr*(1+eps) = 2e-4
 
 
+def test_predictor_step():
+    """config #4: the oracle's predictor step against the reference's (tests/golden/small_predictor.npz)"""
+    from oracle import predictor as op
+    from _util import PREDICTOR_TRAINER, small_predictor_cfg
+    z = load_npz('small_predictor.npz')
+    P = {k[len('state.'):]: t(v).clone() for k, v in z.items() if k.startswith('state.')}
+    for k, v in P.items():
+        if not k.endswith('position.weight'):
+            v.requires_grad_(True)
+    P_ae = prepare_params(_small())
+    batch = {k[len('batch.'):]: t(v) for k, v in z.items() if k.startswith('batch.')}
+    losses, grads, out = op.predictor_step(P, small_predictor_cfg(), P_ae, small_task_cfg()['autoencoder'], batch,
+                                           PREDICTOR_TRAINER['training_methods'], PREDICTOR_TRAINER['loss_weights'],
+                                           PREDICTOR_TRAINER['lambda_dur'], PREDICTOR_TRAINER['grad_clip_thresh'])
+    for i in range(2):
+        close(out['feat'][i], z['fwd.feat.%d' % i], 1e-5)
+        assert np.array_equal(out['feat_length'][i].numpy(), z['fwd.feat_length.%d' % i])
+    close(out['duration'], z['fwd.duration'], 1e-5)
+    want = {k[len('loss.'):]: float(v) for k, v in z.items() if k.startswith('loss.')}
+    assert set(want) == set(losses)
+    for k, v in want.items():
+        assert abs(float(losses[k]) - v) <= 1e-4 * max(1.0, abs(v)), (k, float(losses[k]), v)
+    names = json_field(z['grad_names'])
+    assert set(names) == set(grads), set(names) ^ set(grads)
+    for n, w in zip(names, z['grad_l2']):
+        g = grads[n].double().norm().item()
+        assert abs(g - w) <= 1e-3 * max(w, 1e-3) + 1e-6, (n, g, w)
+
+
 def test_lr_schedule_matches_reference():
     with open(os.path.join(GOLDEN, 'schedule.json')) as f:
         s = json.load(f)

@@ -35,6 +35,10 @@ def test_train_steps_match_reference():
     _parity.check_train_steps('cpu')
 
 
+def test_predictor_step_matches_reference():
+    _parity.check_predictor_step('cpu')
+
+
 @pytest.mark.parametrize('H,K,D,N', [
     (4, 256, 256, 200),    # codebook of one head per LDS pass: 4 restaged groups per tile
     (1, 64, 256, 100),     # single head, d=256: falls back to 2-wave workgroups
