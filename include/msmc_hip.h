@@ -66,6 +66,16 @@ int msmc_vq_ema_update(const float* x, const int64_t* ind, const int64_t* length
                        float* cluster_size, float* embed_avg, void* workspace, size_t workspace_bytes,
                        int B, int T, int D, int H, int K, float decay, float eps, msmc_stream stream);
 
+/* The two halves of msmc_vq_ema_update, for data-parallel codebook synchronisation (an option the reference does not
+ * have: its ranks EMA-update from their local batch, distributed.py:154-204 never touches buffers): _stats writes
+ * stats = [H][K][d] per-codeword sums followed by [H][K] counts of THIS rank's valid frames; the host sums `stats` over
+ * ranks (one all-reduce) and _apply performs the buffer update from the summed statistics.  _stats + _apply on one rank
+ * is bit-identical to msmc_vq_ema_update.  stats: H*K*(D/H + 1) floats. */
+int msmc_vq_ema_stats(const float* x, const int64_t* ind, const int64_t* length, float* stats, void* workspace,
+                      size_t workspace_bytes, int B, int T, int D, int H, int K, msmc_stream stream);
+int msmc_vq_ema_apply(const float* stats, float* embed, float* cluster_size, float* embed_avg, int D, int H, int K,
+                      float decay, float eps, msmc_stream stream);
+
 /* Backward of (quant, diff) wrt x:  gx = g_quant + g_diff * 2*(x - quant)/H   (straight-through +
  * the un-reduced commitment term, modules.py:59-60).  g_diff may be NULL (treated as zero). */
 int msmc_vq_backward(const float* g_quant, const float* g_diff, const float* x, const float* quant,

@@ -553,6 +553,21 @@ __global__ __launch_bounds__(256) void vq_ema_kernel(const float* __restrict__ p
 }
 
 // ------------------------------------------------------------------------------------------------
+// EMA statistics alone (data-parallel codebook synchronisation): fixed-order reduction over tiles into
+// stats = [H][K][d] sums followed by [H][K] counts -- the layout vq_ema_kernel reads with ntiles = 1
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_stats_reduce_kernel(const float* __restrict__ part, const float* __restrict__ pcnt,
+                                                             float* __restrict__ stats, int ntiles, long nsum, long ncnt) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nsum + ncnt; e += (long)gridDim.x * blockDim.x) {
+        const float* src = e < nsum ? part + e : pcnt + (e - nsum);
+        const long stride = e < nsum ? nsum : ncnt;
+        float s = 0.f;
+        for (int t = 0; t < ntiles; ++t) s = s + src[(size_t)t * stride];
+        stats[e] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vq_backward_kernel(const float* __restrict__ gq, const float* __restrict__ gd,
@@ -688,6 +703,42 @@ int msmc_vq_ema_update(const float* x, const int64_t* ind, const int64_t* length
     const size_t lds2 = (size_t)(K + 256) * sizeof(float);
     MSMC_LAUNCH(vq_ema_kernel, dim3(H), dim3(256), lds2, (msmc_stream_t)stream, (const float*)part, (const float*)pcnt,
                 embed, cluster_size, embed_avg, ntiles, H, d, K, decay, omd, eps, keps);
+    return msmc_check_launch();
+}
+
+int msmc_vq_ema_stats(const float* x, const int64_t* ind, const int64_t* length, float* stats, void* workspace,
+                      size_t workspace_bytes, int B, int T, int D, int H, int K, msmc_stream stream) {
+    const int N = B * T;
+    if (N <= 0 || H <= 0 || D % H || K <= 0) return MSMC_E_SHAPE;
+    const int d = D / H;
+    if (d > 512) return MSMC_E_SHAPE;
+    if (workspace_bytes < msmc_vq_ema_workspace(N, D, H, K)) return MSMC_E_WORKSPACE;
+    const int TN = vq_stats_tile(N);
+    const int ntiles = (N + TN - 1) / TN;
+    float* part = (float*)workspace;
+    float* pcnt = part + (size_t)ntiles * H * K * d;
+    const size_t lds1 = (size_t)(2 * TN + 2 * K + 1) * sizeof(int);
+    MSMC_LAUNCH(vq_stats_kernel, dim3(ntiles, H), dim3(256), lds1, (msmc_stream_t)stream, x, ind, length, part, pcnt, N,
+                T, D, H, K, TN);
+    int rc = msmc_check_launch();
+    if (rc) return rc;
+    const long nsum = (long)H * K * d, ncnt = (long)H * K;
+    long blocks = (nsum + ncnt + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    MSMC_LAUNCH(vq_stats_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, (const float*)part,
+                (const float*)pcnt, stats, ntiles, nsum, ncnt);
+    return msmc_check_launch();
+}
+
+int msmc_vq_ema_apply(const float* stats, float* embed, float* cluster_size, float* embed_avg, int D, int H, int K,
+                      float decay, float eps, msmc_stream stream) {
+    if (H <= 0 || D % H || K <= 0) return MSMC_E_SHAPE;
+    const int d = D / H;
+    const float omd = (float)(1.0 - (double)decay);
+    const float keps = (float)((double)K * (double)eps);
+    const size_t lds2 = (size_t)(K + 256) * sizeof(float);
+    MSMC_LAUNCH(vq_ema_kernel, dim3(H), dim3(256), lds2, (msmc_stream_t)stream, stats, stats + (size_t)H * K * d, embed,
+                cluster_size, embed_avg, 1, H, d, K, decay, omd, eps, keps);
     return msmc_check_launch();
 }
 

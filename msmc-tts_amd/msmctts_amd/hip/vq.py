@@ -78,3 +78,60 @@ def vq_ema_update(x, ind, length, embed, cluster_size, embed_avg, decay, eps, wo
                                    workspace.numel() * workspace.element_size(), B, T, D, H, K, float(decay),
                                    float(eps), lib.stream(xc)), 'msmc_vq_ema_update')
     return workspace
+
+
+# -- data-parallel codebook synchronisation (opt-in; the reference's ranks EMA-update from their local batch) ----------
+class CodebookSync(object):
+    """Pending EMA statistics of one quantiser stage: this rank's [H][K][d] sums + [H][K] counts in a persistent buffer
+    (static across hipGraph replays), applied to the packed buffers after the cross-rank sum."""
+
+    def __init__(self, embed, cluster_size, embed_avg, decay, eps):
+        H, d, K = embed.shape
+        self.embed, self.cluster_size, self.embed_avg, self.decay, self.eps = embed, cluster_size, embed_avg, decay, eps
+        self.stats = torch.zeros(H * K * (d + 1), dtype=torch.float32, device=embed.device)
+        self.workspace = None
+
+    def matches(self, embed):
+        return self.embed.data_ptr() == embed.data_ptr() and self.embed.shape == embed.shape
+
+    def collect(self, x, ind, length):
+        B, T, D = x.shape
+        H, d, K = self.embed.shape
+        L = lib.get()
+        need = int(L.msmc_vq_ema_workspace(B * T, D, H, K))
+        if self.workspace is None or self.workspace.numel() * 4 < need:
+            self.workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
+        xc = x.detach().contiguous().float()
+        indc = ind.contiguous()
+        length = length.to(device=x.device, dtype=torch.int64).contiguous()
+        lib.check(L.msmc_vq_ema_stats(lib.ptr(xc), lib.ptr(indc, torch.int64), lib.ptr(length), lib.ptr(self.stats),
+                                      lib.ptr(self.workspace), self.workspace.numel() * 4, B, T, D, H, K, lib.stream(xc)),
+                  'msmc_vq_ema_stats')
+
+    def apply(self):
+        H, d, K = self.embed.shape
+        lib.check(lib.get().msmc_vq_ema_apply(lib.ptr(self.stats), lib.ptr(self.embed, torch.float32),
+                                              lib.ptr(self.cluster_size, torch.float32), lib.ptr(self.embed_avg, torch.float32),
+                                              H * d, H, K, float(self.decay), float(self.eps), lib.stream(self.stats)),
+                  'msmc_vq_ema_apply')
+
+
+PENDING = []          # CodebookSync objects whose statistics were collected by a forward and not yet applied
+
+
+def flush_codebook_sync(pending=None, group=None, local=False):
+    """ONE all-reduce (sum) over the statistics of every pending stage, then the per-stage buffer updates: afterwards
+    every rank holds the codebooks a single process would have computed from the global batch.  ``local``: no exchange
+    (the trainer's capture warm-up, which is rolled back)."""
+    import torch.distributed as dist
+    items = PENDING if pending is None else pending
+    if not items:
+        return
+    if not local and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        flat = torch.cat([it.stats for it in items])
+        dist.all_reduce(flat, group=group)
+        torch._foreach_copy_([it.stats for it in items], list(flat.split([it.stats.numel() for it in items])))
+    for it in items:
+        it.apply()
+    if pending is None:
+        del PENDING[:]

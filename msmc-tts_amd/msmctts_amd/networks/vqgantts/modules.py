@@ -16,6 +16,21 @@ from ...hip import vq as hipvq
 from ..layers import WNConv1d
 
 
+def _ema(q, x3, ind, length, embed, cs, ea):
+    """EMA codebook update of one stage: fused (reference semantics: this rank's frames only) or, with
+    ``q.sync_stats`` (VQGANTrainer sync_codebook_stats=True), statistics now and the update after the cross-rank sum
+    (hip/vq.py flush_codebook_sync, called by the trainer between forward and backward)."""
+    if not getattr(q, 'sync_stats', False):
+        q._ws = hipvq.vq_ema_update(x3, ind, length, embed, cs, ea, q.decay, q.eps, q._ws)
+        return
+    cb = getattr(q, '_sync', None)
+    if cb is None or not cb.matches(embed):
+        cb = q._sync = hipvq.CodebookSync(embed, cs, ea, q.decay, q.eps)
+    cb.collect(x3, ind, length)
+    if not any(c is cb for c in hipvq.PENDING):
+        hipvq.PENDING.append(cb)
+
+
 class Quantize(nn.Module):
     """Single-codebook EMA quantiser (reference modules.py:10-116)."""
 
@@ -39,8 +54,7 @@ class Quantize(nn.Module):
         quant, diff, ind = hipvq.vq_search(input, embed_t, enorm)
         if self.training and update and input.numel() > 0:          # (an empty batch has no statistics to add)
             x3 = input.detach().reshape(input.shape[0], -1, input.shape[-1])
-            self._ws = hipvq.vq_ema_update(x3, ind.reshape(x3.shape[0], x3.shape[1], -1), input_length, embed, cs, ea,
-                                           self.decay, self.eps, self._ws)
+            _ema(self, x3, ind.reshape(x3.shape[0], x3.shape[1], -1), input_length, embed, cs, ea)
         return quant, diff, ind.squeeze(-1)
 
     def embed_code(self, embed_id):
@@ -95,8 +109,7 @@ class MultiHeadQuantize(nn.Module):
         quant, diff, ind = hipvq.vq_search(input, embed_t, enorm)
         if self.training and update and input.numel() > 0:          # (an empty batch has no statistics to add)
             x3 = input.detach().reshape(input.shape[0], -1, input.shape[-1])
-            self._ws = hipvq.vq_ema_update(x3, ind.reshape(x3.shape[0], x3.shape[1], -1), input_length, embed, cs, ea,
-                                           self.decay, self.eps, self._ws)
+            _ema(self, x3, ind.reshape(x3.shape[0], x3.shape[1], -1), input_length, embed, cs, ea)
         return quant, diff, ind
 
 

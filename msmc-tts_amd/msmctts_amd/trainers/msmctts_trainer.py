@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..hip import losses as hiploss
+from ..hip import vq as hipvq
 from ..utils.utils import get_mask_from_lengths
 from .base_trainer import BaseTrainer
 from .criterions.stft_loss import MelLoss, MultiResolutionSTFTLoss
@@ -67,8 +68,16 @@ def _frozen(module):
 class VQGANTrainer(BaseTrainer):
     def __init__(self, config, model, num_gpus=1, rank=0, warmup_steps=0, lambda_frame=1.0,
                  eval_inteval_iters=1000, grad_clip_thresh=1.0, sample_lengths=24000, lambda_vq=1, lambda_pr=1,
-                 lambda_fm=2, lambda_stft=45, stft_loss_func='mel_loss', stft_loss_config=None):
+                 lambda_fm=2, lambda_stft=45, stft_loss_func='mel_loss', stft_loss_config=None,
+                 sync_codebook_stats=False):
         super().__init__(config, model, num_gpus, rank)
+        # Not in the reference (its ranks EMA-update their VQ codebooks from the local batch and rank 0's copy is the
+        # one checkpointed): sum the EMA statistics over ranks -- one small all-reduce per step -- so that every rank
+        # holds the codebooks of the global batch.
+        self.sync_codebook_stats = bool(sync_codebook_stats)
+        for m in self.model.modules():
+            if hasattr(m, 'decay') and hasattr(m, 'n_embed'):
+                m.sync_stats = self.sync_codebook_stats
         self.lambda_frame, self.warmup_steps = lambda_frame, warmup_steps
         self.frameshift = self.config.dataset.frameshift[self.config.dataset.feature.index('mel')]
         self.frame_lengths = -1 if sample_lengths == -1 else sample_lengths // self.frameshift
@@ -218,6 +227,7 @@ class VQGANTrainer(BaseTrainer):
             st.frame_window = frame_windows
             st.target = torch.stack([batch['wav'][i, s:e] for i, (s, e) in enumerate(sample_windows)], dim=0).squeeze(-1)
         self._segment_a(st)
+        self._sync_codebooks()
         if phase == 2:
             self._sync_grads()
         self._segment_b(st)
@@ -245,12 +255,19 @@ class VQGANTrainer(BaseTrainer):
             st.mel_length.copy_(batch['mel_length'], non_blocking=True)
             g['wav'].copy_(batch['wav'].reshape(g['wav'].shape), non_blocking=True)
         g['a'].replay()
+        self._sync_codebooks(g['codebooks'])
         self._sync_grads_static('discriminator', g)
         g['b'].replay()
         self._sync_grads_static('autoencoder', g)
         g['c'].replay()
         vec = g['loss_vec'].clone()                  # the graph's outputs are static buffers: hand out a snapshot
         return {'loss': {k: vec[i] for i, k in enumerate(g['loss_keys'])}}
+
+    def _sync_codebooks(self, pending=None):
+        """sync_codebook_stats: cross-rank sum of the EMA statistics the forward collected, then the codebook updates
+        (``pending``: the stages recorded at capture -- a replayed forward refills their static buffers)"""
+        if self.sync_codebook_stats:
+            hipvq.flush_codebook_sync(pending)
 
     def _sync_grads_static(self, child, g=None):
         """Gradient exchange between two replayed segments.  The gradients are the STATIC tensors the graphs write
@@ -313,6 +330,7 @@ class VQGANTrainer(BaseTrainer):
         def run_eager():
             self._build_windows(g, st)
             self._segment_a(st)
+            hipvq.flush_codebook_sync(local=True)
             self._segment_b(st)                      # (no gradient exchange: the warm-up's updates are rolled back)
             self._segment_c(st)
 
@@ -341,6 +359,8 @@ class VQGANTrainer(BaseTrainer):
         with torch.cuda.graph(ga, stream=side, capture_error_mode=mode):
             self._build_windows(g, st)
             self._segment_a(st)
+        g['codebooks'] = list(hipvq.PENDING)    # (sync_codebook_stats: the stages whose statistics segment A refills)
+        del hipvq.PENDING[:]
         torch.cuda.synchronize()
         prepare = getattr(self.optimizer, 'prepare', lambda names=None: None)
         prepare(['discriminator'])              # (tensor tables over the static gradients segment A just allocated)

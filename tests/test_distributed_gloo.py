@@ -47,7 +47,8 @@ def _toy_worker(rank, world, port, out):
     g = torch.Generator().manual_seed(7)
     x = torch.randn(8, 6, generator=g)
     y = torch.randn(8, 3, generator=g)
-    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    n = 8 // world
+    xs, ys = x[rank * n:(rank + 1) * n], y[rank * n:(rank + 1) * n]
     # step 1: only child a participates (like the D-frozen G step)
     loss = ((m.a(xs) - ys) ** 2).mean()
     loss.backward()
@@ -60,18 +61,35 @@ def _toy_worker(rank, world, port, out):
     loss.backward()
     m.grad_reducer.finish()
     gb = [p.grad.clone() for p in m.parameters()]
-    out[rank] = dict(state={k: v.clone() for k, v in m.state_dict().items()}, ga=ga, b_none=b_none, gb=gb,
-                     nbuckets=len(m.grad_reducer.buckets))
+    # step 3: the hipGraph-mode exchange -- hooks off, static gradient tensors recorded once, a loop that resets
+    # p.grad must not turn the exchange into a no-op (zero_grad vs the reducer in graph mode)
+    red = m.grad_reducer
+    red.hooks_enabled = False
+    m.zero_grad()
+    (m.b(m.a(xs)) ** 2).mean().backward()
+    static = [p.grad for p in m.b.parameters()]
+    for p in m.b.parameters():
+        p.grad = None                                # what ``optimizer.zero_grad(set_to_none=True)`` does
+    red.allreduce_child(m.b, grads=static)
+    gs = [g.clone() for g in static]
+    try:
+        red.allreduce_child(m.b)                     # nothing to exchange: must raise, not silently diverge
+        raised = False
+    except RuntimeError:
+        raised = True
+    out[rank] = dict(state={k: v.clone() for k, v in m.state_dict().items()}, ga=ga, b_none=b_none, gb=gb, gs=gs,
+                     raised=raised, nbuckets=len(m.grad_reducer.buckets))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_equals_full_batch():
+@pytest.mark.parametrize('world', [2, 4])
+def test_bucketed_allreduce_equals_full_batch(world):
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_toy_worker, args=(2, port, out), nprocs=2, join=True)
-    r0, r1 = out[0], out[1]
+    mp.spawn(_toy_worker, args=(world, port, out), nprocs=world, join=True)
+    r0, r1 = out[0], out[world - 1]
     assert r0['nbuckets'] >= 3
     for k in r0['state']:
         assert torch.equal(r0['state'][k], r1['state'][k]), k
@@ -91,9 +109,73 @@ def test_bucketed_allreduce_equals_full_batch():
     for a, b, c in zip(r0['gb'], r1['gb'], [p.grad for p in ref.parameters()]):
         assert torch.equal(a, b)
         assert torch.allclose(a, c, atol=1e-6)
+    for a, b, c in zip(r0['gs'], r1['gs'], [p.grad for p in ref.b.parameters()]):        # graph-mode exchange
+        assert torch.equal(a, b)
+        assert torch.allclose(a, c, atol=1e-6)
+    assert r0['raised'] and r1['raised']
 
 
-def _trainer_worker(rank, world, port, out):
+def _codebook_worker(rank, world, port, out):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd')]
+    from msmctts_amd.distributed.distributed import init_distributed
+    from msmctts_amd.hip import lib, vq as hipvq
+    from msmctts_amd.networks.vqgantts.modules import MultiHeadQuantize
+    torch.set_num_threads(1)
+    lib.use_library_for_tests(os.path.join(ROOT, 'tests', 'emu', 'libmsmc_emu.so'))
+    init_distributed(rank, world, 'g', 'gloo', 'tcp://127.0.0.1:%d' % port)
+    torch.manual_seed(3)
+    q = MultiHeadQuantize(32, 16, 4).train()
+    q.sync_stats = True
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 37, 32, generator=g)
+    ln = torch.tensor([37, 20, 5, 31])
+    n = 4 // world
+    for _ in range(2):
+        q(x[rank * n:(rank + 1) * n], ln[rank * n:(rank + 1) * n], update=True)
+        assert len(hipvq.PENDING) == 1
+        hipvq.flush_codebook_sync()
+        assert not hipvq.PENDING
+    out[rank] = {k: v.clone() for k, v in q.state_dict().items()}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_codebook_statistics_sync_equals_single_process_global_batch():
+    """sync_codebook_stats: two ranks x half the batch == one process x the whole batch (the fused update)"""
+    import subprocess
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'tests', 'emu')])
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_codebook_worker, args=(2, port, out), nprocs=2, join=True)
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd')]
+    from msmctts_amd.hip import lib
+    from msmctts_amd.networks.vqgantts.modules import MultiHeadQuantize
+    lib.use_library_for_tests(os.path.join(ROOT, 'tests', 'emu', 'libmsmc_emu.so'))
+    torch.manual_seed(3)
+    q = MultiHeadQuantize(32, 16, 4).train()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 37, 32, generator=g)
+    ln = torch.tensor([37, 20, 5, 31])
+    for _ in range(2):
+        q(x, ln, update=True)
+    want = q.state_dict()
+    for k in want:
+        assert torch.equal(out[0][k], out[1][k]), k
+        assert torch.allclose(out[0][k], want[k], rtol=1e-5, atol=1e-6), k
+    # and on one process the two-launch path is the fused update, bit for bit
+    torch.manual_seed(3)
+    q2 = MultiHeadQuantize(32, 16, 4).train()
+    q2.sync_stats = True
+    from msmctts_amd.hip import vq as hipvq
+    for _ in range(2):
+        q2(x, ln, update=True)
+        hipvq.flush_codebook_sync()
+    for k, v in q2.state_dict().items():
+        assert torch.equal(v, want[k]), k
+
+
+def _trainer_worker(rank, world, port, out, sync_codebooks=False):
     sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd'), os.path.join(ROOT, 'tests')]
     import random
     import _parity
@@ -110,7 +192,10 @@ def _trainer_worker(rank, world, port, out):
         with torch.no_grad():
             for p in task.parameters():
                 p.add_(0.01)                                          # must be overwritten by the broadcast
+    if sync_codebooks:
+        cfg.trainer.sync_codebook_stats = True
     tr = build_trainer(cfg, task, num_gpus=world, rank=rank)
+    assert tr.sync_codebook_stats == sync_codebooks
     tr.optimizer = build_optimizer(tr.model, cfg.optimizer)
     tr.rng = random.Random(5 + rank)
     batch = make_batch(3, 24, 80, 300, seed=11, rank=rank)
@@ -142,3 +227,16 @@ def test_vqgan_trainer_two_ranks_stay_in_sync():
     assert n_param > 300 and n_buf_diff > 0
     assert out[0]['logs'][0]['frame_loss'] != out[1]['logs'][0]['frame_loss']     # different shards
     assert all(torch.isfinite(torch.tensor(list(l.values()))).all() for l in out[0]['logs'])
+
+
+def test_vqgan_trainer_sync_codebook_stats_keeps_codebooks_identical():
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_trainer_worker, args=(2, port, out, True), nprocs=2, join=True)
+    s0, s1 = out[0]['state'], out[1]['state']
+    n = 0
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+        n += k.endswith(('.embed', '.cluster_size', '.embed_avg'))
+    assert n >= 6
