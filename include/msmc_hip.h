@@ -70,10 +70,10 @@ int msmc_vq_ema_update(const float* x, const int64_t* ind, const int64_t* length
  * have: its ranks EMA-update from their local batch, distributed.py:154-204 never touches buffers): _stats writes
  * stats = [H][K][d] per-codeword sums followed by [H][K] counts of THIS rank's valid frames; the host sums `stats` over
  * ranks (one all-reduce) and _apply performs the buffer update from the summed statistics.  _stats + _apply on one rank
- * is bit-identical to msmc_vq_ema_update.  stats: H*K*(D/H + 1) floats. */
+ * is bit-identical to msmc_vq_ema_update.  stats: H*K*(D/H + 2) floats (sums, counts, H*K of scratch for _apply). */
 int msmc_vq_ema_stats(const float* x, const int64_t* ind, const int64_t* length, float* stats, void* workspace,
                       size_t workspace_bytes, int B, int T, int D, int H, int K, msmc_stream stream);
-int msmc_vq_ema_apply(const float* stats, float* embed, float* cluster_size, float* embed_avg, int D, int H, int K,
+int msmc_vq_ema_apply(float* stats, float* embed, float* cluster_size, float* embed_avg, int D, int H, int K,
                       float decay, float eps, msmc_stream stream);
 
 /* Backward of (quant, diff) wrt x:  gx = g_quant + g_diff * 2*(x - quant)/H   (straight-through +
@@ -200,12 +200,18 @@ typedef struct msmc_wn_item {
     float* db;              /* backward: [nbias] bias-gradient accumulator (consumed and zeroed), may be NULL */
     float* gb;              /* backward: [nbias] bias gradient out */
     int copies;             /* backward: dw / db hold this many privatised copies (0 or 1 = one), summed here */
-    int pad_;
+    int tblock0;            /* msmc_wn_prepare_multi_tiled: first tile-block of this item (see there) */
     long dw_copy_stride;    /* elements between copies of dw */
     long db_copy_stride;    /* elements between copies of db */
 } msmc_wn_item;
 
 int msmc_wn_prepare_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream);
+/* Same result in two launches: the row pass writes layout 1 and inv_norm, then a tiled pass writes layout 2 -- the
+ * transpose of the parameter's own order -- through LDS with 64 consecutive elements per store instead of one 2-byte store
+ * per cache line.  Item i owns tile-blocks [tblock0, tblock0 + ceil(A/64) * ceil(Bc/16)) of total_tile_blocks (items
+ * without dst2 own none); T <= MSMC_CONV_MAX_TAPS. */
+int msmc_wn_prepare_multi_tiled(const msmc_wn_item* items, int nitems, int total_blocks, int total_tile_blocks,
+                                msmc_stream stream);
 int msmc_wn_backward_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream);
 /* accumulate != 0: gv / gg / gb += instead of = (a second backward before the gradients were reset: torch .grad semantics) */
 int msmc_wn_backward_multi_acc(const msmc_wn_item* items, int nitems, int total_blocks, int accumulate, msmc_stream stream);

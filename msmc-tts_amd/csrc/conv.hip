@@ -677,45 +677,74 @@ MSMC_DEV void cv2_body(const msmc_conv_desc& d, const CvGeom& G, const int block
     T* out = (T*)d.out;
     const bool ovec = (d.Cout % VEC) == 0;
     const size_t img = (size_t)b * d.Hout * d.Wout;
+    if (ovec) {
+        // EB output vectors per work-item at a time: every mask / residual load of the batch is in flight before the first
+        // use (one global-load latency per batch instead of one per vector)
+        constexpr int EB = 4;
+        const float mslope = d.mask_slope, odiv = d.out_div, oslope = d.out_slope;
+        for (int e0 = tid; e0 < 128 * BNV; e0 += 256 * EB) {
+            u32x4 mk[EB], r1[EB], r2[EB];
+            size_t oo[EB];
+            int mm[EB], vc[EB];
+            bool ok[EB];
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                const int e = e0 + 256 * u;
+                const int m = e / BNV;
+                vc[u] = (e - m * BNV) * VEC;
+                mm[u] = m;
+                const int po = e < 128 * BNV ? out_off[m] : -1, co = co0 + vc[u];
+                ok[u] = po >= 0 && co < d.Cout;
+                oo[u] = ok[u] ? (img + po) * d.Cout + co : 0;
+                if (ok[u]) {
+                    if (mask) mk[u] = *(const u32x4*)(mask + oo[u]);
+                    if (res) r1[u] = *(const u32x4*)(res + oo[u]);
+                    if (res2) r2[u] = *(const u32x4*)(res2 + oo[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EB; ++u) {
+                if (!ok[u]) continue;
+                const int co = co0 + vc[u];
+                alignas(16) T mkv[VEC], r1v[VEC], r2v[VEC], ov[VEC];
+                if (mask) *(u32x4*)mkv = mk[u];
+                if (res) *(u32x4*)r1v = r1[u];
+                if (res2) *(u32x4*)r2v = r2[u];
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    float x = ot[mm[u] * OS + vc[u] + q] + (d.bias ? d.bias[co + q] : 0.f);
+                    if (mask) x = x * (Elt<T>::ld(&mkv[q]) > 0.f ? 1.f : mslope);
+                    if (res) x = x + Elt<T>::ld(&r1v[q]);
+                    if (res2) x = Elt<T>::ld(&r2v[q]) + x;
+                    if (odiv != 1.f) x = x / odiv;
+                    if (oslope != 1.f) x = x > 0.f ? x : x * oslope;
+                    Elt<T>::st(&ov[q], x);
+                }
+                *(u32x4*)(out + oo[u]) = *(const u32x4*)ov;
+            }
+        }
+        return;
+    }
     for (int e = tid; e < 128 * BNV; e += 256) {
         const int m = e / BNV, vcol = (e - m * BNV) * VEC;
         const int po = out_off[m], co = co0 + vcol;
         if (po < 0 || co >= d.Cout) continue;
         const size_t o = (img + po) * d.Cout + co;
-        float v[VEC];
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) v[q] = ot[m * OS + vcol + q] + ((d.bias && co + q < d.Cout) ? d.bias[co + q] : 0.f);
-        alignas(16) T mk[VEC], r1[VEC], r2[VEC], ov[VEC];
-        if (ovec) {
-            if (mask) *(u32x4*)mk = *(const u32x4*)(mask + o);
-            if (res) *(u32x4*)r1 = *(const u32x4*)(res + o);
-            if (res2) *(u32x4*)r2 = *(const u32x4*)(res2 + o);
-        } else {
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) {
-                const bool in = co + q < d.Cout;
-                if (mask) mk[q] = in ? mask[o + q] : (T)0;
-                if (res) r1[q] = in ? res[o + q] : (T)0;
-                if (res2) r2[q] = in ? res2[o + q] : (T)0;
-            }
-        }
+        alignas(16) T ov[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            float x = v[q];
-            if (mask) x = x * (Elt<T>::ld(&mk[q]) > 0.f ? 1.f : d.mask_slope);
-            if (res) x = x + Elt<T>::ld(&r1[q]);
-            if (res2) x = Elt<T>::ld(&r2[q]) + x;
+            const bool in = co + q < d.Cout;
+            float x = ot[m * OS + vcol + q] + ((d.bias && in) ? d.bias[co + q] : 0.f);
+            if (mask) x = x * (Elt<T>::ld(in ? mask + o + q : mask) > 0.f ? 1.f : d.mask_slope);
+            if (res && in) x = x + Elt<T>::ld(res + o + q);
+            if (res2 && in) x = Elt<T>::ld(res2 + o + q) + x;
             if (d.out_div != 1.f) x = x / d.out_div;
             if (d.out_slope != 1.f) x = x > 0.f ? x : x * d.out_slope;
             Elt<T>::st(&ov[q], x);
         }
-        if (ovec) {
-            *(u32x4*)(out + o) = *(const u32x4*)ov;
-        } else {
 #pragma unroll
-            for (int q = 0; q < VEC; ++q)
-                if (co + q < d.Cout) out[o + q] = ov[q];
-        }
+        for (int q = 0; q < VEC; ++q)
+            if (co + q < d.Cout) out[o + q] = ov[q];
     }
 }
 
@@ -2824,7 +2853,7 @@ MSMC_DEV void wn_store(void* dst, int dtype, long off, float v) {
     else ((unsigned short*)dst)[off] = f32_to_bf16_bits(v);
 }
 
-__global__ __launch_bounds__(256) void wn_prepare_kernel(const msmc_wn_item* __restrict__ items, int nitems) {
+__global__ __launch_bounds__(256) void wn_prepare_kernel(const msmc_wn_item* __restrict__ items, int nitems, int skip2) {
     __shared__ float red[256];
     const msmc_wn_item it = items[wn_find(items, nitems, blockIdx.x)];
     const int a = blockIdx.x - it.block0;
@@ -2843,7 +2872,48 @@ __global__ __launch_bounds__(256) void wn_prepare_kernel(const msmc_wn_item* __r
         const int b = e / it.T, t = e - b * it.T;
         const float wv = v[e] * scale;
         wn_store(it.dst1, it.dtype, t * it.s1[0] + a * it.s1[1] + b * it.s1[2], wv);
-        if (it.dst2) wn_store(it.dst2, it.dtype, t * it.s2[0] + a * it.s2[1] + b * it.s2[2], wv);
+        if (it.dst2 && !skip2) wn_store(it.dst2, it.dtype, t * it.s2[0] + a * it.s2[1] + b * it.s2[2], wv);
+    }
+}
+
+// Layout 2 is the transpose of the parameter's own order (the normalised axis a runs fastest): written row by row from
+// wn_prepare_kernel it is one 2-byte store per cache line.  Here a workgroup owns a tile of 64 rows (a) x 16 columns (b),
+// all taps: the parameter is read in its own order (contiguous 16*T floats per row) into LDS and written out with a
+// fastest -- 64 consecutive elements per store.  Runs after wn_prepare_kernel (inv_norm); item i owns tile-blocks
+// [tblock0, tblock0 + ceil(A/64) * ceil(Bc/16)).
+#define WN_TA 64
+#define WN_TB 16
+MSMC_DEV int wn_find_tile(const msmc_wn_item* items, int n, int blk) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (items[mid].tblock0 <= blk) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void wn_transpose_kernel(const msmc_wn_item* __restrict__ items, int nitems) {
+    MSMC_DYN_LDS(smem);
+    float* tile = (float*)smem;                         // [WN_TA][WN_TB * T + 1]
+    float* scl = tile + WN_TA * (WN_TB * MSMC_CONV_MAX_TAPS + 1);
+    const msmc_wn_item it = items[wn_find_tile(items, nitems, blockIdx.x)];
+    const int tb = blockIdx.x - it.tblock0;
+    const int nbt = (it.Bc + WN_TB - 1) / WN_TB;
+    const int a0 = (tb / nbt) * WN_TA, b0 = (tb - (tb / nbt) * nbt) * WN_TB;
+    const int T = it.T, span = WN_TB * T, pitch = span + 1;
+    const int nb = it.Bc - b0 < WN_TB ? it.Bc - b0 : WN_TB, na = it.A - a0 < WN_TA ? it.A - a0 : WN_TA;
+    for (int e = threadIdx.x; e < WN_TA * span; e += 256) {
+        const int r = e / span, c = e - r * span;
+        if (r < na && c < nb * T) tile[r * pitch + c] = it.v[((size_t)(a0 + r) * it.Bc + b0) * T + c];
+    }
+    if (threadIdx.x < WN_TA)
+        scl[threadIdx.x] = (it.g && (int)threadIdx.x < na) ? it.g[a0 + threadIdx.x] * it.inv_norm[a0 + threadIdx.x] : 1.f;
+    __syncthreads();
+    for (int e = threadIdx.x; e < WN_TA * span; e += 256) {
+        const int r = e % WN_TA, c = e / WN_TA;          // c = b * T + t
+        const int b = c / T, t = c - b * T;
+        if (r < na && b < nb)
+            wn_store(it.dst2, it.dtype, t * it.s2[0] + (a0 + r) * it.s2[1] + (b0 + b) * it.s2[2], tile[r * pitch + c] * scl[r]);
     }
 }
 
@@ -3084,7 +3154,20 @@ extern "C" {
 
 int msmc_wn_prepare_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream) {
     if (!items || nitems <= 0 || total_blocks <= 0) return MSMC_E_SHAPE;
-    MSMC_LAUNCH(wn_prepare_kernel, dim3(total_blocks), dim3(256), 0, (msmc_stream_t)stream, items, nitems);
+    MSMC_LAUNCH(wn_prepare_kernel, dim3(total_blocks), dim3(256), 0, (msmc_stream_t)stream, items, nitems, 0);
+    return msmc_check_launch();
+}
+
+int msmc_wn_prepare_multi_tiled(const msmc_wn_item* items, int nitems, int total_blocks, int total_tile_blocks,
+                                msmc_stream stream) {
+    if (!items || nitems <= 0 || total_blocks <= 0 || total_tile_blocks < 0) return MSMC_E_SHAPE;
+    MSMC_LAUNCH(wn_prepare_kernel, dim3(total_blocks), dim3(256), 0, (msmc_stream_t)stream, items, nitems, 1);
+    int rc = msmc_check_launch();
+    if (rc || total_tile_blocks == 0) return rc;
+    const size_t lds = (size_t)(WN_TA * (WN_TB * MSMC_CONV_MAX_TAPS + 1) + WN_TA) * sizeof(float);
+    rc = msmc_allow_lds((const void*)wn_transpose_kernel, (int)lds);
+    if (rc) return rc;
+    MSMC_LAUNCH(wn_transpose_kernel, dim3(total_tile_blocks), dim3(256), lds, (msmc_stream_t)stream, items, nitems);
     return msmc_check_launch();
 }
 

@@ -36,53 +36,107 @@ MSMC_DEV float nm_wave_sum(float v) {
 
 #define NM_MAXE 16          // elements per lane: C <= 1024
 
-// one wave per row: v = drop(x) + res; y = (v - mean) * rstd * gamma + beta, zeroed where keep_row == 0
-template <typename T>
+// V consecutive elements of a row as one vector access (V = 4: 16 bytes of fp32, 8 bytes of bf16; V = 1: scalar)
+template <int V> MSMC_DEV void nm_ldv(const float* p, long i, float (&o)[V]) {
+    if constexpr (V == 4) {
+        const f32x4 t = *(const f32x4*)(p + i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = t[q];
+    } else {
+        o[0] = p[i];
+    }
+}
+template <int V> MSMC_DEV void nm_ldv(const unsigned short* p, long i, float (&o)[V]) {
+    if constexpr (V == 4) {
+        const u32x2 t = *(const u32x2*)(p + i);
+        o[0] = __uint_as_float(t[0] << 16);
+        o[1] = __uint_as_float(t[0] & 0xffff0000u);
+        o[2] = __uint_as_float(t[1] << 16);
+        o[3] = __uint_as_float(t[1] & 0xffff0000u);
+    } else {
+        o[0] = bf16_bits_to_f32(p[i]);
+    }
+}
+template <int V> MSMC_DEV void nm_stv(float* p, long i, const float (&v)[V]) {
+    if constexpr (V == 4) {
+        f32x4 t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = v[q];
+        *(f32x4*)(p + i) = t;
+    } else {
+        p[i] = v[0];
+    }
+}
+template <int V> MSMC_DEV void nm_stv(unsigned short* p, long i, const float (&v)[V]) {
+    if constexpr (V == 4) {
+        u32x2 t;
+        t[0] = (unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16);
+        t[1] = (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16);
+        *(u32x2*)(p + i) = t;
+    } else {
+        p[i] = f32_to_bf16_bits(v[0]);
+    }
+}
+
+// one wave per row: v = drop(x) + res; y = (v - mean) * rstd * gamma + beta, zeroed where keep_row == 0.
+// A lane owns the V-element groups (lane + 64 jj) * V .. + V of its row (V = 4 when C % 4 == 0: vector accesses).
+template <typename T, int V>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const unsigned char* __restrict__ keep_row, T* __restrict__ y,
                                                          T* __restrict__ v_out, float* __restrict__ mean_out,
                                                          float* __restrict__ rstd_out, long N, int C, float eps,
                                                          float p_drop, const long long* seed, long long salt) {
+    constexpr int NG = NM_MAXE / V;
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= N) return;
-    const int ne = (C + 63) / 64;
     const unsigned long long key = nm_key(seed, salt);
     const unsigned int thresh = p_drop > 0.f ? (unsigned int)(p_drop * 4294967296.0) : 0u;
     const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-    float v[NM_MAXE];
+    float v[NG][V];
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NM_MAXE; ++j) {
-        v[j] = 0.f;
-        const int c = lane + 64 * j;
-        if (j < ne && c < C) {
+    for (int jj = 0; jj < NG; ++jj) {
+        const int c = (lane + 64 * jj) * V;
+#pragma unroll
+        for (int q = 0; q < V; ++q) v[jj][q] = 0.f;
+        if (c < C) {
             const long i = row * C + c;
-            float a = nm_ld(x, i);
-            if (thresh) a = nm_keep(key, (unsigned long long)i, thresh) ? a * scale : 0.f;
-            if (res) a = a + nm_ld(res, i);
-            v[j] = a;
-            sum = sum + a;
+            float a[V], r[V];
+            nm_ldv<V>(x, i, a);
+            if (res) nm_ldv<V>(res, i, r);
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                if (thresh) a[q] = nm_keep(key, (unsigned long long)(i + q), thresh) ? a[q] * scale : 0.f;
+                if (res) a[q] = a[q] + r[q];
+                v[jj][q] = a[q];
+                sum = sum + a[q];
+            }
         }
     }
     const float mean = nm_wave_sum(sum) / C;
     float sq = 0.f;
 #pragma unroll
-    for (int j = 0; j < NM_MAXE; ++j) {
-        const int c = lane + 64 * j;
-        if (j < ne && c < C) sq = fmaf(v[j] - mean, v[j] - mean, sq);
-    }
+    for (int jj = 0; jj < NG; ++jj)
+        if ((lane + 64 * jj) * V < C)
+#pragma unroll
+            for (int q = 0; q < V; ++q) sq = fmaf(v[jj][q] - mean, v[jj][q] - mean, sq);
     const float rstd = 1.f / sqrtf(nm_wave_sum(sq) / C + eps);
     const bool live = !keep_row || keep_row[row] != 0;
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 #pragma unroll
-    for (int j = 0; j < NM_MAXE; ++j) {
-        const int c = lane + 64 * j;
-        if (j < ne && c < C) {
+    for (int jj = 0; jj < NG; ++jj) {
+        const int c = (lane + 64 * jj) * V;
+        if (c < C) {
             const long i = row * C + c;
-            nm_st(v_out, i, v[j]);
-            nm_st(y, i, live ? (v[j] - mean) * rstd * gamma[c] + beta[c] : 0.f);
+            float gm[V], bt[V], o[V];
+            nm_ldv<V>(gamma, c, gm);
+            nm_ldv<V>(beta, c, bt);
+#pragma unroll
+            for (int q = 0; q < V; ++q) o[q] = live ? (v[jj][q] - mean) * rstd * gm[q] + bt[q] : 0.f;
+            nm_stv<V>(v_out, i, v[jj]);
+            nm_stv<V>(y, i, o);
         }
     }
 }
@@ -90,7 +144,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
 // backward: gy = g * live; dxhat = gy * gamma; dv = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat));
 // gres = dv; gx = dv * dropmask * scale.  Parameter-gradient partials per workgroup: part[block][0][c] = sum gy*xhat,
 // part[block][1][c] = sum gy (reduced in a fixed order by add_ln_param_kernel).
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ g, const T* __restrict__ v_in,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const float* __restrict__ gamma,
@@ -98,61 +152,75 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ g
                                                          T* __restrict__ gres, float* __restrict__ part, long N, int C,
                                                          float p_drop, const long long* seed, long long salt, int rows_per_block) {
     MSMC_DYN_LDS(smem);
+    constexpr int NG = NM_MAXE / V;
     float* acc = (float*)smem;                     // [4 waves][2][C]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int ne = (C + 63) / 64;
     const unsigned long long key = nm_key(seed, salt);
     const unsigned int thresh = p_drop > 0.f ? (unsigned int)(p_drop * 4294967296.0) : 0u;
     const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-    float dg[NM_MAXE], dbt[NM_MAXE], gm[NM_MAXE];
+    float dg[NG][V], dbt[NG][V], gm[NG][V];
 #pragma unroll
-    for (int j = 0; j < NM_MAXE; ++j) {
-        dg[j] = dbt[j] = 0.f;
-        const int c = lane + 64 * j;
-        gm[j] = (j < ne && c < C) ? gamma[c] : 0.f;
+    for (int jj = 0; jj < NG; ++jj) {
+        const int c = (lane + 64 * jj) * V;
+#pragma unroll
+        for (int q = 0; q < V; ++q) dg[jj][q] = dbt[jj][q] = gm[jj][q] = 0.f;
+        if (c < C) nm_ldv<V>(gamma, c, gm[jj]);
     }
     const long r0 = (long)blockIdx.x * rows_per_block;
     for (long row = r0 + w; row < r0 + rows_per_block && row < N; row += 4) {
         const bool live = !keep_row || keep_row[row] != 0;
         const float mean = mean_in[row], rstd = rstd_in[row];
-        float dx[NM_MAXE], xh[NM_MAXE];
+        float dx[NG][V], xh[NG][V];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < NM_MAXE; ++j) {
-            dx[j] = xh[j] = 0.f;
-            const int c = lane + 64 * j;
-            if (j < ne && c < C) {
+        for (int jj = 0; jj < NG; ++jj) {
+            const int c = (lane + 64 * jj) * V;
+#pragma unroll
+            for (int q = 0; q < V; ++q) dx[jj][q] = xh[jj][q] = 0.f;
+            if (c < C) {
                 const long i = row * C + c;
-                const float gy = live ? nm_ld(g, i) : 0.f;
-                xh[j] = (nm_ld(v_in, i) - mean) * rstd;
-                dx[j] = gy * gm[j];
-                s1 = s1 + dx[j];
-                s2 = fmaf(dx[j], xh[j], s2);
-                dg[j] = fmaf(gy, xh[j], dg[j]);
-                dbt[j] = dbt[j] + gy;
+                float gy[V], vv[V];
+                nm_ldv<V>(g, i, gy);
+                nm_ldv<V>(v_in, i, vv);
+#pragma unroll
+                for (int q = 0; q < V; ++q) {
+                    if (!live) gy[q] = 0.f;
+                    xh[jj][q] = (vv[q] - mean) * rstd;
+                    dx[jj][q] = gy[q] * gm[jj][q];
+                    s1 = s1 + dx[jj][q];
+                    s2 = fmaf(dx[jj][q], xh[jj][q], s2);
+                    dg[jj][q] = fmaf(gy[q], xh[jj][q], dg[jj][q]);
+                    dbt[jj][q] = dbt[jj][q] + gy[q];
+                }
             }
         }
         const float m1 = nm_wave_sum(s1) / C, m2 = nm_wave_sum(s2) / C;
 #pragma unroll
-        for (int j = 0; j < NM_MAXE; ++j) {
-            const int c = lane + 64 * j;
-            if (j < ne && c < C) {
+        for (int jj = 0; jj < NG; ++jj) {
+            const int c = (lane + 64 * jj) * V;
+            if (c < C) {
                 const long i = row * C + c;
-                const float dv = rstd * (dx[j] - m1 - xh[j] * m2);
-                if (gres) nm_st(gres, i, dv);
-                float d = dv;
-                if (thresh) d = nm_keep(key, (unsigned long long)i, thresh) ? dv * scale : 0.f;
-                nm_st(gx, i, d);
+                float dv[V], d[V];
+#pragma unroll
+                for (int q = 0; q < V; ++q) {
+                    dv[q] = rstd * (dx[jj][q] - m1 - xh[jj][q] * m2);
+                    d[q] = dv[q];
+                    if (thresh) d[q] = nm_keep(key, (unsigned long long)(i + q), thresh) ? dv[q] * scale : 0.f;
+                }
+                if (gres) nm_stv<V>(gres, i, dv);
+                nm_stv<V>(gx, i, d);
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < NM_MAXE; ++j) {
-        const int c = lane + 64 * j;
-        if (j < ne && c < C) {
-            acc[(w * 2 + 0) * C + c] = dg[j];
-            acc[(w * 2 + 1) * C + c] = dbt[j];
-        }
+    for (int jj = 0; jj < NG; ++jj) {
+        const int c = (lane + 64 * jj) * V;
+        if (c < C)
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                acc[(w * 2 + 0) * C + c + q] = dg[jj][q];
+                acc[(w * 2 + 1) * C + c + q] = dbt[jj][q];
+            }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * C; e += 256) {
@@ -162,24 +230,24 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ g
     }
 }
 
-// dgamma[c] (+)= sum_b part[b][0][c], dbeta[c] (+)= sum_b part[b][1][c].  A workgroup owns 32 columns of one of the two
-// vectors; its 8 slices each sum a contiguous range of blocks in order, then the slices are added in order (deterministic).
+// dgamma[c] (+)= sum_b part[b][0][c], dbeta[c] (+)= sum_b part[b][1][c].  A workgroup owns 16 columns of one of the two
+// vectors; its 16 slices each sum a contiguous range of blocks in order, then the slices are added in order (deterministic).
 __global__ __launch_bounds__(256) void add_ln_param_kernel(const float* __restrict__ part, int nblocks, int C,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            int accumulate) {
-    __shared__ float red[8][32];
-    const int groups = (C + 31) / 32;
-    const int k = blockIdx.x / groups, c = (blockIdx.x - k * groups) * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
-    const int per = (nblocks + 7) / 8, b0 = sl * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    __shared__ float red[16][16];
+    const int groups = (C + 15) / 16;
+    const int k = blockIdx.x / groups, c = (blockIdx.x - k * groups) * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+    const int per = (nblocks + 15) / 16, b0 = sl * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
     float s = 0.f;
     if (c < C)
         for (int b = b0; b < b1; ++b) s = s + part[((size_t)b * 2 + k) * C + c];
-    red[sl][threadIdx.x & 31] = s;
+    red[sl][threadIdx.x & 15] = s;
     __syncthreads();
     if (sl == 0 && c < C) {
         float t = red[0][threadIdx.x];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) t = t + red[q][threadIdx.x];
+        for (int q = 1; q < 16; ++q) t = t + red[q][threadIdx.x];
         float* dst = k == 0 ? dgamma : dbeta;
         dst[c] = accumulate ? dst[c] + t : t;
     }
@@ -249,14 +317,14 @@ int msmc_add_ln_fwd(const void* x, const void* res, const float* gamma, const fl
         return MSMC_E_SHAPE;
     if (N == 0) return 0;
     const dim3 grid((unsigned)((N + 3) / 4));
-    if (dtype == 0)
-        MSMC_LAUNCH(add_ln_fwd_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, (const float*)x, (const float*)res, gamma,
-                    beta, keep_row, (float*)y, (float*)v, mean, rstd, N, C, eps, p_drop, seed, salt);
-    else if (dtype == 1)
-        MSMC_LAUNCH(add_ln_fwd_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)x,
-                    (const unsigned short*)res, gamma, beta, keep_row, (unsigned short*)y, (unsigned short*)v, mean, rstd, N, C,
-                    eps, p_drop, seed, salt);
+#define NM_FWD(T_, V_)                                                                                                  \
+    MSMC_LAUNCH((add_ln_fwd_kernel<T_, V_>), grid, dim3(256), 0, (msmc_stream_t)stream, (const T_*)x, (const T_*)res, gamma, \
+                beta, keep_row, (T_*)y, (T_*)v, mean, rstd, N, C, eps, p_drop, seed, salt)
+    const bool vec = (C % 4) == 0;          // rows start 8 / 16-byte aligned: vector accesses
+    if (dtype == 0) { if (vec) NM_FWD(float, 4); else NM_FWD(float, 1); }
+    else if (dtype == 1) { if (vec) NM_FWD(unsigned short, 4); else NM_FWD(unsigned short, 1); }
     else return MSMC_E_SHAPE;
+#undef NM_FWD
     return msmc_check_launch();
 }
 
@@ -276,19 +344,18 @@ int msmc_add_ln_bwd(const void* g, const void* v, const float* mean, const float
     if (workspace_bytes < msmc_add_ln_bwd_workspace(N, C) || (nblocks && !workspace)) return MSMC_E_WORKSPACE;
     const size_t lds = (size_t)4 * 2 * C * sizeof(float);
     if (nblocks) {
-        if (dtype == 0)
-            MSMC_LAUNCH(add_ln_bwd_kernel<float>, dim3((unsigned)nblocks), dim3(256), lds, (msmc_stream_t)stream, (const float*)g,
-                        (const float*)v, mean, rstd, gamma, keep_row, (float*)gx, (float*)gres, (float*)workspace, N, C, p_drop,
-                        seed, salt, rows);
-        else if (dtype == 1)
-            MSMC_LAUNCH(add_ln_bwd_kernel<unsigned short>, dim3((unsigned)nblocks), dim3(256), lds, (msmc_stream_t)stream,
-                        (const unsigned short*)g, (const unsigned short*)v, mean, rstd, gamma, keep_row, (unsigned short*)gx,
-                        (unsigned short*)gres, (float*)workspace, N, C, p_drop, seed, salt, rows);
+#define NM_BWD(T_, V_)                                                                                                  \
+    MSMC_LAUNCH((add_ln_bwd_kernel<T_, V_>), dim3((unsigned)nblocks), dim3(256), lds, (msmc_stream_t)stream, (const T_*)g,   \
+                (const T_*)v, mean, rstd, gamma, keep_row, (T_*)gx, (T_*)gres, (float*)workspace, N, C, p_drop, seed, salt, rows)
+        const bool vec = (C % 4) == 0;
+        if (dtype == 0) { if (vec) NM_BWD(float, 4); else NM_BWD(float, 1); }
+        else if (dtype == 1) { if (vec) NM_BWD(unsigned short, 4); else NM_BWD(unsigned short, 1); }
         else return MSMC_E_SHAPE;
+#undef NM_BWD
         int rc = msmc_check_launch();
         if (rc) return rc;
     }
-    MSMC_LAUNCH(add_ln_param_kernel, dim3((unsigned)(2 * ((C + 31) / 32))), dim3(256), 0, (msmc_stream_t)stream,
+    MSMC_LAUNCH(add_ln_param_kernel, dim3((unsigned)(2 * ((C + 15) / 16))), dim3(256), 0, (msmc_stream_t)stream,
                 (const float*)workspace, nblocks, C, dgamma, dbeta, accumulate);
     return msmc_check_launch();
 }

@@ -481,6 +481,14 @@ __global__ __launch_bounds__(256) void vq_stats_kernel(const float* __restrict__
             if (ids[e] == k) sorted[p++] = e;
     }
     __syncthreads();
+    // the head's slice of every valid row of the tile -> LDS, all loads in flight at once (the ordered sums below walk the
+    // rows of one codeword after another: from global memory that is one exposed load latency per row)
+    float* xs = (float*)(ids + ((2 * TN + 2 * K + 1 + 3) & ~3));   // [TN][d], 16-byte aligned
+    for (int e = threadIdx.x; e < TN * (d / 4); e += blockDim.x) {
+        const int r = e / (d / 4), c4 = e - r * (d / 4);
+        if (ids[r] >= 0) *(f32x4*)(xs + (size_t)r * d + 4 * c4) = *(const f32x4*)(x + (size_t)(n0 + r) * D + h * d + 4 * c4);
+    }
+    __syncthreads();
     // ordered sums: a "slot" of min(d, 64) lanes owns one codeword at a time
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int lanes_per_code = d < 64 ? d : 64;
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(256) void vq_stats_kernel(const float* __restrict__
         for (int q = 0; q < 8; ++q) acc[q] = 0.f;
         const int r1 = off[k + 1];
         for (int r = off[k]; r < r1; ++r) {
-            const float* row = x + (size_t)(n0 + sorted[r]) * D + h * d + j0;
+            const float* row = xs + (size_t)sorted[r] * d + j0;
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 if (j0 + 64 * q < d) acc[q] = acc[q] + row[64 * q];
@@ -510,9 +518,24 @@ __global__ __launch_bounds__(256) void vq_stats_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// EMA statistics, stage 2: fixed-order reduction over tiles + buffer update (one workgroup per head)
+// EMA statistics, stage 2: fixed-order reduction over tiles + buffer update.
+//   vq_ema_cs_kernel : new cluster sizes of every (head, codeword) into scratch (cluster_size itself is not written, so
+//                      every workgroup of the next launch sees the same values)
+//   vq_ema_kernel    : grid (head, slice): each workgroup re-derives n = sum_k cluster size of its head (same summation
+//                      order everywhere), updates its slice of embed_avg / embed; slice 0 publishes cluster_size
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vq_ema_kernel(const float* __restrict__ part, const float* __restrict__ pcnt,
+__global__ __launch_bounds__(256) void vq_ema_cs_kernel(const float* __restrict__ pcnt, const float* __restrict__ cluster_size,
+                                                       float* __restrict__ cs_new, int ntiles, int HK, float decay,
+                                                       float omd) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= HK) return;
+    float c = 0.f;
+    for (int t = 0; t < ntiles; ++t) c = c + pcnt[(size_t)t * HK + e];
+    float v = cluster_size[e] * decay;
+    cs_new[e] = fmaf(c, omd, v);
+}
+
+__global__ __launch_bounds__(256) void vq_ema_kernel(const float* __restrict__ part, const float* __restrict__ cs_new,
                                                     float* __restrict__ embed, float* __restrict__ cluster_size,
                                                     float* __restrict__ embed_avg, int ntiles, int H, int d, int K,
                                                     float decay, float omd, float eps, float keps) {
@@ -521,12 +544,9 @@ __global__ __launch_bounds__(256) void vq_ema_kernel(const float* __restrict__ p
     float* red = cs + K;                // [256]
     const int h = blockIdx.x;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        float c = 0.f;
-        for (int t = 0; t < ntiles; ++t) c = c + pcnt[((size_t)t * H + h) * K + k];
-        float v = cluster_size[(size_t)h * K + k] * decay;
-        v = fmaf(c, omd, v);
-        cluster_size[(size_t)h * K + k] = v;
+        const float v = cs_new[(size_t)h * K + k];
         cs[k] = v;
+        if (blockIdx.y == 0) cluster_size[(size_t)h * K + k] = v;
     }
     __syncthreads();
     float p = 0.f;
@@ -539,7 +559,9 @@ __global__ __launch_bounds__(256) void vq_ema_kernel(const float* __restrict__ p
     }
     const float n = red[0];
     const float den = n + keps;
-    for (int e = threadIdx.x; e < d * K; e += blockDim.x) {
+    const int per = (d * K + gridDim.y - 1) / gridDim.y;
+    const int e1 = min(d * K, (int)(blockIdx.y + 1) * per);
+    for (int e = blockIdx.y * per + threadIdx.x; e < e1; e += blockDim.x) {
         const int j = e / K, k = e - j * K;
         float s = 0.f;
         for (int t = 0; t < ntiles; ++t) s = s + part[(((size_t)t * H + h) * K + k) * d + j];
@@ -667,18 +689,47 @@ int msmc_vq_search(const float* x, const float* embed_t, const float* enorm, flo
     return msmc_check_launch();
 }
 
-static inline int vq_stats_tile(int N) {
-    int TN = 256;
-    while (TN < 4096 && (N + TN - 1) / TN > 64) TN <<= 1;
+static inline int vq_stats_tile(int N, int d) {
+    int cap = 16384 / d;                    // the tile's rows of one head are staged in LDS: TN * d floats <= 64 KB
+    if (cap > 4096) cap = 4096;
+    int TN = cap < 256 ? cap : 256;
+    while (TN < cap && (N + TN - 1) / TN > 64) TN <<= 1;
     return TN;
+}
+
+static int vq_ema_launch(const float* part, const float* pcnt, float* cs_new, float* embed, float* cluster_size,
+                         float* embed_avg, int ntiles, int H, int d, int K, float decay, float eps, msmc_stream stream) {
+    const float omd = (float)(1.0 - (double)decay);
+    const float keps = (float)((double)K * (double)eps);
+    MSMC_LAUNCH(vq_ema_cs_kernel, dim3((H * K + 255) / 256), dim3(256), 0, (msmc_stream_t)stream, pcnt,
+                (const float*)cluster_size, cs_new, ntiles, H * K, decay, omd);
+    int rc = msmc_check_launch();
+    if (rc) return rc;
+    int slices = (d * K + 2047) / 2048;     // ~8 elements per work-item
+    if (slices > 64) slices = 64;
+    const size_t lds2 = (size_t)(K + 256) * sizeof(float);
+    MSMC_LAUNCH(vq_ema_kernel, dim3(H, slices), dim3(256), lds2, (msmc_stream_t)stream, part, (const float*)cs_new, embed,
+                cluster_size, embed_avg, ntiles, H, d, K, decay, omd, eps, keps);
+    return msmc_check_launch();
+}
+
+static int vq_stats_launch(const float* x, const int64_t* ind, const int64_t* length, float* part, float* pcnt, int N,
+                           int T, int D, int H, int K, int TN, int ntiles, msmc_stream stream) {
+    const int d = D / H;
+    const size_t lds1 = (size_t)((2 * TN + 2 * K + 1 + 3) & ~3) * sizeof(int) + (size_t)TN * d * sizeof(float);
+    int rc = msmc_allow_lds((const void*)vq_stats_kernel, (int)lds1);
+    if (rc) return rc;
+    MSMC_LAUNCH(vq_stats_kernel, dim3(ntiles, H), dim3(256), lds1, (msmc_stream_t)stream, x, ind, length, part, pcnt, N,
+                T, D, H, K, TN);
+    return msmc_check_launch();
 }
 
 size_t msmc_vq_ema_workspace(int N, int D, int H, int K) {
     if (N <= 0 || H <= 0 || D % H) return 0;
     const int d = D / H;
-    const int TN = vq_stats_tile(N);
+    const int TN = vq_stats_tile(N, d);
     const size_t ntiles = (size_t)(N + TN - 1) / TN;
-    return ntiles * H * K * (size_t)(d + 1) * sizeof(float);
+    return (ntiles * H * K * (size_t)(d + 1) + (size_t)H * K) * sizeof(float);
 }
 
 int msmc_vq_ema_update(const float* x, const int64_t* ind, const int64_t* length, float* embed, float* cluster_size,
@@ -687,23 +738,16 @@ int msmc_vq_ema_update(const float* x, const int64_t* ind, const int64_t* length
     const int N = B * T;
     if (N <= 0 || H <= 0 || D % H || K <= 0) return MSMC_E_SHAPE;
     const int d = D / H;
-    if (d > 512) return MSMC_E_SHAPE;
+    if (d > 512 || d % 4) return MSMC_E_SHAPE;
     if (workspace_bytes < msmc_vq_ema_workspace(N, D, H, K)) return MSMC_E_WORKSPACE;
-    const int TN = vq_stats_tile(N);
+    const int TN = vq_stats_tile(N, d);
     const int ntiles = (N + TN - 1) / TN;
     float* part = (float*)workspace;
     float* pcnt = part + (size_t)ntiles * H * K * d;
-    const size_t lds1 = (size_t)(2 * TN + 2 * K + 1) * sizeof(int);
-    MSMC_LAUNCH(vq_stats_kernel, dim3(ntiles, H), dim3(256), lds1, (msmc_stream_t)stream, x, ind, length, part, pcnt, N,
-                T, D, H, K, TN);
-    int rc = msmc_check_launch();
+    float* cs_new = pcnt + (size_t)ntiles * H * K;
+    int rc = vq_stats_launch(x, ind, length, part, pcnt, N, T, D, H, K, TN, ntiles, stream);
     if (rc) return rc;
-    const float omd = (float)(1.0 - (double)decay);
-    const float keps = (float)((double)K * (double)eps);
-    const size_t lds2 = (size_t)(K + 256) * sizeof(float);
-    MSMC_LAUNCH(vq_ema_kernel, dim3(H), dim3(256), lds2, (msmc_stream_t)stream, (const float*)part, (const float*)pcnt,
-                embed, cluster_size, embed_avg, ntiles, H, d, K, decay, omd, eps, keps);
-    return msmc_check_launch();
+    return vq_ema_launch(part, pcnt, cs_new, embed, cluster_size, embed_avg, ntiles, H, d, K, decay, eps, stream);
 }
 
 int msmc_vq_ema_stats(const float* x, const int64_t* ind, const int64_t* length, float* stats, void* workspace,
@@ -711,16 +755,13 @@ int msmc_vq_ema_stats(const float* x, const int64_t* ind, const int64_t* length,
     const int N = B * T;
     if (N <= 0 || H <= 0 || D % H || K <= 0) return MSMC_E_SHAPE;
     const int d = D / H;
-    if (d > 512) return MSMC_E_SHAPE;
+    if (d > 512 || d % 4) return MSMC_E_SHAPE;
     if (workspace_bytes < msmc_vq_ema_workspace(N, D, H, K)) return MSMC_E_WORKSPACE;
-    const int TN = vq_stats_tile(N);
+    const int TN = vq_stats_tile(N, d);
     const int ntiles = (N + TN - 1) / TN;
     float* part = (float*)workspace;
     float* pcnt = part + (size_t)ntiles * H * K * d;
-    const size_t lds1 = (size_t)(2 * TN + 2 * K + 1) * sizeof(int);
-    MSMC_LAUNCH(vq_stats_kernel, dim3(ntiles, H), dim3(256), lds1, (msmc_stream_t)stream, x, ind, length, part, pcnt, N,
-                T, D, H, K, TN);
-    int rc = msmc_check_launch();
+    int rc = vq_stats_launch(x, ind, length, part, pcnt, N, T, D, H, K, TN, ntiles, stream);
     if (rc) return rc;
     const long nsum = (long)H * K * d, ncnt = (long)H * K;
     long blocks = (nsum + ncnt + 255) / 256;
@@ -730,16 +771,12 @@ int msmc_vq_ema_stats(const float* x, const int64_t* ind, const int64_t* length,
     return msmc_check_launch();
 }
 
-int msmc_vq_ema_apply(const float* stats, float* embed, float* cluster_size, float* embed_avg, int D, int H, int K,
-                      float decay, float eps, msmc_stream stream) {
+int msmc_vq_ema_apply(float* stats, float* embed, float* cluster_size, float* embed_avg, int D, int H, int K, float decay,
+                      float eps, msmc_stream stream) {
     if (H <= 0 || D % H || K <= 0) return MSMC_E_SHAPE;
     const int d = D / H;
-    const float omd = (float)(1.0 - (double)decay);
-    const float keps = (float)((double)K * (double)eps);
-    const size_t lds2 = (size_t)(K + 256) * sizeof(float);
-    MSMC_LAUNCH(vq_ema_kernel, dim3(H), dim3(256), lds2, (msmc_stream_t)stream, stats, stats + (size_t)H * K * d, embed,
-                cluster_size, embed_avg, 1, H, d, K, decay, omd, eps, keps);
-    return msmc_check_launch();
+    float* pcnt = stats + (size_t)H * K * d;
+    return vq_ema_launch(stats, pcnt, pcnt + (size_t)H * K, embed, cluster_size, embed_avg, 1, H, d, K, decay, eps, stream);
 }
 
 int msmc_vq_backward(const float* g_quant, const float* g_diff, const float* x, const float* quant, float* gx, int N,

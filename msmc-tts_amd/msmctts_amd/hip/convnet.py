@@ -4,7 +4,7 @@
 UnivNet discriminator):
   * the kernel-layout weights (forward slices ``[T, Cout, Cin]`` and data-gradient slices
     ``[T, Cin, Cout]`` in the compute dtype), refreshed from ``weight_v / weight_g`` by ONE
-    ``msmc_wn_prepare_multi`` launch per forward pass of the network;
+    ``msmc_wn_prepare_multi_tiled`` call (two launches) per forward pass of the network;
   * fp32 weight-gradient accumulators in kernel layout, filled by ``msmc_conv_wgrad`` from each
     convolution's backward, and turned into ``weight_v.grad / weight_g.grad / bias.grad`` by ONE
     ``msmc_wn_backward_multi`` launch at the end of the backward pass (autograd engine callback).
@@ -12,6 +12,7 @@ UnivNet discriminator):
     out = lrelu_out( (res2 + ((conv(lrelu_in(x)) + bias) + res)) / div ).
 Activations are channels-last ``[B, H, W, C]`` (1-D signals: H == 1), float32 or bfloat16.
 """
+import contextlib
 import ctypes
 
 import os
@@ -67,6 +68,23 @@ def fork_join(streams, thunks, inputs=()):
     return outs
 
 
+# Weight gradients are off the critical path of a backward pass (only the optimizer reads them): MSMC_WGRAD_STREAMS=n > 0
+# issues them on n side streams -- parallel branches of the captured hipGraph -- while the data-gradient chain continues on
+# the calling stream.  Branches of a hipGraph DO run concurrently on this runtime (tools/graph_overlap_probe.py: two chains
+# of 64-workgroup GEMMs replay 1.6x, four chains 2x faster forked than serial), but every kernel of this step already
+# occupies all 256 CUs (>= 256 workgroups bounded by LDS), so a second branch only gets the tails: measured 30.9 (n = 2)
+# vs 31.1 ms/step (n = 0) -- within noise.  Default off; kept for workloads whose grids under-fill the chip.
+WGRAD_STREAMS = int(os.environ.get('MSMC_WGRAD_STREAMS', '0'))
+_SIDE = {}
+
+
+def _side_streams(device):
+    st = _SIDE.get(device)
+    if st is None:
+        st = _SIDE[device] = [torch.cuda.Stream(device=device) for _ in range(max(1, WGRAD_STREAMS))]
+    return st
+
+
 def make_streams(device, n):
     """n side streams on a CUDA/HIP device; [] on the CPU (kernel-interpreter tests run sequentially)."""
     if device.type != 'cuda' or n <= 1 or os.environ.get('MSMC_STREAMS', '1') == '0' or GROUPED:
@@ -118,6 +136,28 @@ class ConvBank(object):
         self._touched = set()           # layers whose weight gradient was accumulated in the running backward pass
         self._hold = []                 # gradients shared by several consumers, pinned until the backward ends
         self.streams = []               # side streams whose backward launches write this bank's accumulators
+        self._side_used = []            # weight-gradient side streams to join at the end of the backward pass
+        self._side_rr = 0
+
+    @contextlib.contextmanager
+    def wgrad_side(self, *tensors):
+        """Context for the weight-gradient launches of one backward node: a side stream ordered after everything the
+        calling stream has issued so far.  ``tensors`` (the node's inputs to those launches) stay referenced until the
+        join in ``_finish_backward``, so the caching allocator -- eagerly and inside a capture -- cannot hand their
+        memory to a later allocation of the calling stream while the side stream still reads it."""
+        dev = self.w1.device
+        if dev.type != 'cuda' or WGRAD_STREAMS <= 0 or not STREAMS_ENABLED:
+            yield
+            return
+        sts = _side_streams(dev)
+        st = sts[self._side_rr % len(sts)]
+        self._side_rr += 1
+        st.wait_stream(torch.cuda.current_stream(dev))
+        self._hold.extend(t for t in tensors if t is not None)
+        if not any(st is u for u in self._side_used):
+            self._side_used.append(st)
+        with torch.cuda.stream(st):
+            yield
 
     # -- (re)build device buffers whenever parameters moved / changed dtype ------------------------
     def _signature(self, dtype):
@@ -143,7 +183,7 @@ class ConvBank(object):
         self.db = torch.zeros(tot_db, dtype=torch.float32, device=dev)
         self.gb = torch.empty(tot_b, dtype=torch.float32, device=dev)
         items = (lib.WnItem * len(self.layers))()
-        ow = oa = ob = blk = odw = odb = 0
+        ow = oa = ob = blk = odw = odb = tblk = 0
         esz = self.w1.element_size()
         for l, it in zip(self.layers, items):
             v, g = l.weight, (None if l.plain else l.module.weight_g)
@@ -159,6 +199,8 @@ class ConvBank(object):
             it.A, it.Bc, it.T = A, v.shape[1], l.taps
             it.dtype = 0 if dtype == torch.float32 else 1
             it.block0 = blk
+            it.tblock0 = tblk                      # tiles of 64 (dim 0) x 16 (dim 1) of the transposing pass
+            tblk += ((A + 63) // 64) * ((v.shape[1] + 15) // 16)
             it.nbias = l.cout
             it.db, it.gb = self.db.data_ptr() + odb * 4, self.gb.data_ptr() + ob * 4
             w1 = self.w1[ow:ow + n]
@@ -180,7 +222,7 @@ class ConvBank(object):
             l.gg_view = self.gg[oa:oa + A].view_as(g) if g is not None else None
             ow, oa, ob, blk = ow + pad8(n), oa + A, ob + l.cout, blk + A
             odw, odb = odw + pad8(n * R), odb + pad8(l.cout * R)
-        self.total_blocks = blk
+        self.total_blocks, self.total_tile_blocks = blk, tblk
         raw = bytes(items)
         self.items_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.dtype = dtype
@@ -191,8 +233,9 @@ class ConvBank(object):
         if sig != self._sig:
             self._build(dtype)
             self._sig = sig
-        lib.check(lib.get().msmc_wn_prepare_multi(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
-                                                  lib.stream(self.w1)), 'msmc_wn_prepare_multi')
+        lib.check(lib.get().msmc_wn_prepare_multi_tiled(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
+                                                        self.total_tile_blocks, lib.stream(self.w1)),
+                  'msmc_wn_prepare_multi_tiled')
 
     # -- end-of-backward: kernel-layout dW -> parameter gradients --------------------------------------
     def _queue_finish(self):
@@ -208,6 +251,11 @@ class ConvBank(object):
 
     def _finish_backward(self):
         self._queued = False
+        if self._side_used:             # weight-gradient branches join here, before their inputs are released
+            cur = torch.cuda.current_stream(self.w1.device)
+            for st in self._side_used:
+                cur.wait_stream(st)
+            self._side_used = []
         del self._hold[:]
         touched, self._touched = self._touched, set()
         if not touched:                 # a pass that only propagated through this network (frozen D in the G step)
@@ -287,13 +335,14 @@ class _HipConv(torch.autograd.Function):
                 gx = K.conv_transpose1d_dgrad(g, layer.wb, layer.kernel[1], layer.stride[1], layer.padding[1],
                                               x.shape[2], mask_src=mask, mask_slope=ctx.in_slope)
         if ctx.need_w:
-            if layer.kind == 'conv':
-                K.conv_wgrad(x, g, layer.geom(x.shape[1], x.shape[2]), layer.taps, in_slope=ctx.in_slope, dw=layer.dw,
-                             db=layer.db, copies=layer.dw_copies)
-            else:
-                K.conv_transpose1d_wgrad(x, g, layer.kernel[1], layer.stride[1], layer.padding[1],
-                                         in_slope=ctx.in_slope, dw=layer.dw, copies=layer.dw_copies)
-                layer.db.add_(K.colsum(g.reshape(-1, g.shape[-1])))
+            with bank.wgrad_side(x, g):
+                if layer.kind == 'conv':
+                    K.conv_wgrad(x, g, layer.geom(x.shape[1], x.shape[2]), layer.taps, in_slope=ctx.in_slope,
+                                 dw=layer.dw, db=layer.db, copies=layer.dw_copies)
+                else:
+                    K.conv_transpose1d_wgrad(x, g, layer.kernel[1], layer.stride[1], layer.padding[1],
+                                             in_slope=ctx.in_slope, dw=layer.dw, copies=layer.dw_copies)
+                    layer.db.add_(K.colsum(g.reshape(-1, g.shape[-1])))
             bank._touched.add(layer.index)
             bank._queue_finish()
         if ctx.has_res or ctx.has_res2:
@@ -387,7 +436,8 @@ class _HipConvGroup(torch.autograd.Function):
                 for (k, _), gx in zip(members, K.reflect_fold_group([m[1] for m in members], pad, in_slope)):
                     grads[ctx.xpos[k]] = gx
         if w_items:
-            K.conv_wgrad_group(w_items)
+            with bank.wgrad_side(*([it['x'] for it in w_items] + [it['g'] for it in w_items])):
+                K.conv_wgrad_group(w_items)
         bank._queue_finish()
         return (None, None) + tuple(grads)
 

@@ -50,7 +50,7 @@ class WnItem(ctypes.Structure):
     """msmc_wn_item of include/msmc_hip.h."""
     _fields_ = [('v', _vp), ('g', _vp), ('dst1', _vp), ('dst2', _vp), ('inv_norm', _vp), ('dw', _vp), ('gv', _vp),
                 ('gg', _vp), ('s1', ctypes.c_long * 3), ('s2', ctypes.c_long * 3), ('A', _i), ('Bc', _i), ('T', _i),
-                ('dtype', _i), ('block0', _i), ('nbias', _i), ('db', _vp), ('gb', _vp), ('copies', _i), ('pad_', _i),
+                ('dtype', _i), ('block0', _i), ('nbias', _i), ('db', _vp), ('gb', _vp), ('copies', _i), ('tblock0', _i),
                 ('dw_copy_stride', ctypes.c_long), ('db_copy_stride', ctypes.c_long)]
 
 
@@ -99,6 +99,7 @@ _SIGNATURES.update({
     'msmc_conv_wgrad_group_ws': (_i, [ctypes.POINTER(ConvDesc), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                  _i, _vp, _sz, _vp]),
     'msmc_wn_prepare_multi': (_i, [_vp, _i, _i, _vp]),
+    'msmc_wn_prepare_multi_tiled': (_i, [_vp, _i, _i, _i, _vp]),
     'msmc_wn_backward_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_wn_backward_multi_acc': (_i, [_vp, _i, _i, _i, _vp]),
     'msmc_reflect_fold_multi': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i),

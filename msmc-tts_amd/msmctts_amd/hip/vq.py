@@ -88,7 +88,7 @@ class CodebookSync(object):
     def __init__(self, embed, cluster_size, embed_avg, decay, eps):
         H, d, K = embed.shape
         self.embed, self.cluster_size, self.embed_avg, self.decay, self.eps = embed, cluster_size, embed_avg, decay, eps
-        self.stats = torch.zeros(H * K * (d + 1), dtype=torch.float32, device=embed.device)
+        self.stats = torch.zeros(H * K * (d + 2), dtype=torch.float32, device=embed.device)   # sums, counts, scratch
         self.workspace = None
 
     def matches(self, embed):
