@@ -200,6 +200,8 @@ def main():
                     help='extra eager steps of the warm-up phase (no vocoder / discriminator) timed after the headline')
     ap.add_argument('--cpu-threads', type=int, default=0, help='0 = min(available cores, 32)')
     ap.add_argument('--no-microbench', action='store_true')
+    ap.add_argument('--microbench-only', action='store_true',
+                    help='only the VQ argmin micro-benchmarks at N = 2^20 frames (the PMC passes of tools/profile_round.sh)')
     ap.add_argument('--no-autocast', action='store_true',
                     help='bf16 only inside the HIP conv stacks; the transformer encoder/decoder stay fp32')
     ap.add_argument('--exec', dest='exec_mode', default='auto', choices=['auto', 'graph', 'eager'],
@@ -225,6 +227,10 @@ def main():
     from msmctts_amd.hip import lib, vq as hipvq
     from msmctts_amd.synthetic import make_batch
     assert lib.backend() == 'gfx950'
+    if args.microbench_only:
+        print(json.dumps({'vq_microbench': [vq_microbench(device, args.heads, args.codewords, iters=5),
+                                            vq_microbench(device, 4, 64, iters=5), vq_microbench(device, 8, 512, iters=5)]}))
+        return
     cfg, trainer = build(args, device, rank, world)
     state0 = {k: v.detach().clone() for k, v in trainer.model.state_dict().items()} if rank == 0 and world == 1 else None
     batch = make_batch(args.batch, args.frames, 80, 300, seed=1234, rank=rank, device='cpu')

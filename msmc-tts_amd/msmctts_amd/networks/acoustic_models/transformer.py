@@ -74,6 +74,23 @@ class ScaledDotProductAttention(nn.Module):
         return torch.bmm(attn, v), attn
 
 
+class _SplitHeads(torch.autograd.Function):
+    """q, k, v as strided views of the fused projection [bs, H, T, 2*dk + dv]; the backward pass writes the three
+    gradients side by side in ONE concatenation (slicing's own backward zero-fills and copies a full-size tensor per
+    slice: six launches per attention layer)."""
+
+    @staticmethod
+    def forward(ctx, qkv, dk):
+        ctx.dk = dk
+        return qkv[..., :dk], qkv[..., dk:2 * dk], qkv[..., 2 * dk:]
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        # assembled in the memory order of the projection's output ([bs, T, H, E]) and handed back as the transposed view,
+        # so the projection's backward reads it without a layout copy
+        return torch.cat((gq.transpose(1, 2), gk.transpose(1, 2), gv.transpose(1, 2)), dim=-1).transpose(1, 2), None
+
+
 class MultiHeadAttention(nn.Module):
     def __init__(self, n_head, d_model, d_k, d_v, dropout, name, attn_dropout=0.1, fused_layernorm=False):
         super().__init__()
@@ -93,7 +110,7 @@ class MultiHeadAttention(nn.Module):
         return [ConvLayer(m, 'conv', (1, 1), plain=True) for m in (self.linear, self.fc)]
 
     def forward_hip(self, x, keep_row, key_keep, hip):
-        """x [B, T, C] in the compute dtype; key_keep [B, 1, 1, T] bool (True = attend); returns the masked sub-layer
+        """x [B, T, C] in the compute dtype; key_keep [B, 1, 1, T] additive bias (0 = attend, -inf = padding); returns the masked sub-layer
         output layer_norm(dropout(fc(attention)) + x) * non_pad_mask"""
         bank, (l_qkv, l_fc) = hip
         bs, T, _ = x.shape
@@ -101,8 +118,8 @@ class MultiHeadAttention(nn.Module):
         qkv = hip_conv(bank, l_qkv, x.unsqueeze(1)).view(bs, T, H, 2 * dk + dv).transpose(1, 2)       # [bs, H, T, 2dk+dv]
         att = self.attention
         p = att.dropout.p if (hasattr(att, 'dropout') and att.training) else 0.0
-        out = F.scaled_dot_product_attention(qkv[..., :dk], qkv[..., dk:2 * dk], qkv[..., 2 * dk:], attn_mask=key_keep,
-                                             dropout_p=p, scale=1.0 / att.temperature)
+        q, k, v = _SplitHeads.apply(qkv, dk)
+        out = F.scaled_dot_product_attention(q, k, v, attn_mask=key_keep, dropout_p=p, scale=1.0 / att.temperature)
         out = out.transpose(1, 2).reshape(bs, 1, T, H * dv)
         h = hip_conv(bank, l_fc, out).squeeze(1)
         pd = self.dropout.p if self.training else 0.0
@@ -217,7 +234,10 @@ class FFTBlocks(nn.Module):
             bank, layers = self._hip()
             bank.prepare(self.hip_dtype)          # one launch: kernel-layout weights of the 4 x n_layers GEMMs / convolutions
             keep_row = pos.ne(0).to(torch.uint8).reshape(-1)
-            key_keep = pos.ne(0).view(pos.shape[0], 1, 1, pos.shape[1])       # broadcast over heads and queries
+            # additive key-padding bias, built ONCE per stack in the compute dtype and broadcast over heads and queries (a
+            # boolean mask is converted to this by every attention call: a where + fills per layer)
+            key_keep = torch.zeros(pos.shape[0], 1, 1, pos.shape[1], dtype=self.hip_dtype, device=pos.device).masked_fill_(
+                pos.eq(0).view(pos.shape[0], 1, 1, pos.shape[1]), float('-inf'))
             out = out.to(self.hip_dtype)
             for layer, (attn, ffn) in zip(self.layer_stack, layers):
                 out = layer.forward_hip(out, keep_row, key_keep, (bank, attn), (bank, ffn))

@@ -14,8 +14,13 @@ SHORT="--steps 2 --warmup 2 --no-microbench --cpu-steps 0 --kernel-timing-steps 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python $REPO/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- python $REPO/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_write.log
 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d /tmp/prof_mfma -- python $REPO/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_mfma.log
+# the VQ argmin micro-benchmark at N = 2^20 frames (the half of the BASELINE metric the step does not exercise at size)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_vq_fetch -- python $REPO/bench.py --microbench-only > /dev/null 2> $OUT/${TAG}_pmc_vq_fetch.log
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_vq_write -- python $REPO/bench.py --microbench-only > /dev/null 2> $OUT/${TAG}_pmc_vq_write.log
+python $REPO/tools/pmc_summary.py $OUT/${TAG}_pmc_vq_traffic.json FETCH=/tmp/prof_vq_fetch WRITE=/tmp/prof_vq_write > $OUT/${TAG}_pmc_vq_summary.txt 2>&1
 python $REPO/tools/pmc_summary.py $OUT/${TAG}_pmc_traffic.json FETCH=/tmp/prof_fetch WRITE=/tmp/prof_write MFMA=/tmp/prof_mfma > $OUT/${TAG}_pmc_summary.txt 2>&1
 cd $REPO
+cp $OUT/${TAG}_pmc_traffic.json $REPO/profiles/pmc_traffic.json      # the line below reports roofline.traffic from this run's passes
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.log
 tail -c 1500 $OUT/${TAG}_bench.json
 head -12 $OUT/${TAG}_pmc_summary.txt
