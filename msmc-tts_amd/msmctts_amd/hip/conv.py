@@ -117,6 +117,44 @@ def _signature(desc):
             tuple(desc.tap_dx[:desc.ntaps]), desc.pad_mode, bool(desc.res), bool(desc.res2), bool(desc.mask_src))
 
 
+# Variable-length batches: every new padded length T is a new signature.  Timing launches are a per-process BUDGET of
+# new shapes (MSMC_TUNE_BUDGET); a shape outside the cache first borrows the choice of the nearest tuned shape of its
+# CLASS (everything but batch and spatial extents: channels, taps, strides, dilation, padding rule, epilogue operands) --
+# kernel preferences follow the channel / tap configuration far more than the length -- and is timed only when its class
+# has no entry and budget is left.  Ranks of a data-parallel job therefore stop issuing timing launches after the same
+# bounded number of shapes instead of stalling each other at the collectives whenever one of them meets a new length.
+TUNE_BUDGET = [int(os.environ.get('MSMC_TUNE_BUDGET', '256'))]
+_CLASS_INDEX = {}                             # (kind, class) -> [(pixels, signature)]
+_CLASS_INDEXED = [0]
+
+
+def _class_of(sig):
+    """signature (kind, dtype, B, Hin, Win, Cin, Hout, Wout, Cout, QH, QW, ...) -> (class key, output pixels)"""
+    return (sig[0], sig[1], sig[5], sig[8]) + tuple(sig[11:]), sig[2] * sig[9] * sig[10]
+
+
+def _nearest_tuned(sig):
+    if _CLASS_INDEXED[0] != len(TUNED):      # (re)index lazily: TUNED only grows
+        _CLASS_INDEX.clear()
+        for k in TUNED:
+            c, px = _class_of(k)
+            _CLASS_INDEX.setdefault(c, []).append((px, k))
+        _CLASS_INDEXED[0] = len(TUNED)
+    c, px = _class_of(sig)
+    rows = _CLASS_INDEX.get(c)
+    if not rows:
+        return None
+    import math
+    k = min(rows, key=lambda r: abs(math.log(max(1, r[0])) - math.log(max(1, px))))[1]
+    return TUNED[k]
+
+
+def _bounded(cache, limit=4096):
+    """plan / geometry caches are keyed by shape: a long run over variable-length batches must not grow them for ever"""
+    if len(cache) > limit:
+        cache.clear()
+
+
 def _tune(kind, desc, launch, candidates):
     """Time ``launch()`` under every candidate (variant, split_shift); leave the fastest in the descriptor."""
     desc._tuned = True
@@ -124,9 +162,18 @@ def _tune(kind, desc, launch, candidates):
         return
     sig = (kind,) + _signature(desc)
     hit = TUNED.get(sig)
-    if hit is None and (not AUTOTUNE or torch.cuda.is_current_stream_capturing()):
+    if hit is None:
+        near = _nearest_tuned(sig)
+        if near is not None:        # borrowed from the nearest tuned shape of the same class (validated below)
+            keep = (desc.variant, desc.split_shift)
+            desc.variant, desc.split_shift = near[0], near[1]
+            if launch() == 0:
+                return
+            desc.variant, desc.split_shift = keep
+    if hit is None and (not AUTOTUNE or TUNE_BUDGET[0] <= 0 or torch.cuda.is_current_stream_capturing()):
         return                      # no timing launches now: library heuristic for this shape
     if hit is None:
+        TUNE_BUDGET[0] -= 1
         times = {}
         for variant, shift in candidates:
             desc.variant, desc.split_shift = variant, shift
@@ -176,9 +223,14 @@ def _wgrad(desc, g_ptr, dw, db, stream, what):
     dbp = db.data_ptr() if db is not None else None
     if not getattr(desc, '_tuned', False):
         cached = TUNED.get(('wgrad',) + _signature(desc)) if not lib._host_pointers_ok else None
+        if cached is None and not lib._host_pointers_ok:
+            cached = _nearest_tuned(('wgrad',) + _signature(desc))
+            if cached is not None and cached[0] == 3 and desc.dtype != 1:
+                cached = None                 # (the third generation is bf16-only)
         if cached is not None:
+            desc._borrowed = ('wgrad',) + _signature(desc) not in TUNED
             desc.variant, desc.split_shift, desc._tuned = cached[0], cached[1], True
-        elif AUTOTUNE and not lib._host_pointers_ok and not torch.cuda.is_current_stream_capturing():
+        elif AUTOTUNE and TUNE_BUDGET[0] > 0 and not lib._host_pointers_ok and not torch.cuda.is_current_stream_capturing():
             R = max(1, desc.dw_copies)                       # candidates accumulate into scratch, not into dW
             sdw = torch.zeros(R * desc.ntaps * desc.Cout * desc.Cin, dtype=torch.float32, device=dw.device)
             sdb = torch.zeros(R * desc.Cout, dtype=torch.float32, device=dw.device) if db is not None else None
@@ -187,6 +239,9 @@ def _wgrad(desc, g_ptr, dw, db, stream, what):
         else:
             desc._tuned = True
     rc = fn(ctypes.byref(desc), g_ptr, dw.data_ptr(), dbp, stream)
+    if rc != 0 and getattr(desc, '_borrowed', False):        # a neighbour's choice this shape cannot run: library heuristic
+        desc.variant, desc.split_shift, desc._borrowed = 0, 0, False
+        rc = fn(ctypes.byref(desc), g_ptr, dw.data_ptr(), dbp, stream)
     if rc != 0:
         raise RuntimeError('%s failed with code %d (dtype %d variant %d split_shift %d copies %d, x %dx%dx%dx%d -> %dx%dx%d, '
                            '%d taps)' % (what, rc, desc.dtype, desc.variant, desc.split_shift, desc.dw_copies, desc.B, desc.Hin,
@@ -219,6 +274,7 @@ def _fill(desc_unused, x, w, out, B, Hin, Win, Cin, Hout, Wout, Cout, lattice, t
            out_slope)
     desc = _PLANS.get(key)
     if desc is None:
+        _bounded(_PLANS)
         desc = _PLANS[key] = _build_desc(x.dtype, B, Hin, Win, Cin, Hout, Wout, Cout, lattice, taps, pad_mode,
                                          in_slope, mask_slope, out_div, out_slope)
     desc.x, desc.w, desc.out = _ptr(x), _ptr(w), _ptr(out)

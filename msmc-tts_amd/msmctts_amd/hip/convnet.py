@@ -122,6 +122,7 @@ class ConvLayer(object):
         key = (H, W)
         g = self._geoms.get(key)
         if g is None:
+            K._bounded(self._geoms, 1024)         # one entry per input extent: bounded under variable-length batches
             g = self._geoms[key] = K.Geometry(H, W, self.kernel, self.stride, self.dilation, self.padding, self.reflect)
         return g
 

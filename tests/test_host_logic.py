@@ -114,3 +114,27 @@ def test_synthetic_batch_contract():
         assert bool((b['mel'][i, l:] == -4).all()) and bool((b['wav'][i, l * 300:] == 0).all())
     b2 = make_batch(8, 40, 80, 300, seed=1, rank=1)
     assert not torch.equal(b['mel'], b2['mel'])
+
+
+def test_tuner_borrows_the_nearest_tuned_shape_of_the_same_class():
+    """variable-length batches: a new padded length does not trigger timing launches when a shape of the same
+    channel / tap / stride class is already tuned; the nearest pixel count wins; another class does not match"""
+    from msmctts_amd.hip import conv as K
+    keep = dict(K.TUNED)
+    try:
+        K.TUNED.clear()
+        taps = ((0, 0, 0), (0, 1, 2))
+        sig = lambda T, cin=256: ('gather', 1, 16, 1, T, cin, 1, T, 1024, 1, T, 1, 1, 1, 1, 3, taps[0], taps[1], 0, False,
+                                  False, False)
+        K.TUNED[sig(400)] = (19, 0, {})
+        K.TUNED[sig(100)] = (9, 0, {})
+        assert K._nearest_tuned(sig(380))[0] == 19
+        assert K._nearest_tuned(sig(120))[0] == 9
+        assert K._nearest_tuned(sig(380, cin=128)) is None
+        cache = {i: i for i in range(5000)}
+        K._bounded(cache, 4096)
+        assert not cache
+    finally:
+        K.TUNED.clear()
+        K.TUNED.update(keep)
+        K._CLASS_INDEXED[0] = -1
