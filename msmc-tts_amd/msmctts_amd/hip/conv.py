@@ -137,9 +137,13 @@ def _nearest_tuned(sig):
     if _CLASS_INDEXED[0] != len(TUNED):      # (re)index lazily: TUNED only grows
         _CLASS_INDEX.clear()
         for k in TUNED:
+            if k[0] not in ('gather', 'wgrad') or len(k) < 12:     # (grouping decisions are keyed by member lists)
+                continue
             c, px = _class_of(k)
             _CLASS_INDEX.setdefault(c, []).append((px, k))
         _CLASS_INDEXED[0] = len(TUNED)
+    if sig[0] not in ('gather', 'wgrad') or len(sig) < 12:
+        return None
     c, px = _class_of(sig)
     rows = _CLASS_INDEX.get(c)
     if not rows:
