@@ -229,6 +229,11 @@ int msmc_lrelu_bwd(const void* g, const void* y, void* gx, long n, float slope, 
  * sub-discriminators), 16-byte channel vectors where every member allows. */
 int msmc_reflect_fold_multi(const void* const* gp, const void* const* mask_src, void* const* gx, const int* B, const int* H,
                             const int* W, const int* C, int n, int p, float slope, int dtype, msmc_stream stream);
+/* as msmc_reflect_fold_multi with a third input per tensor: gx = fold(gp) * lrelu'(mask_src) + res  (res[k] may be NULL):
+ * the gradient of a second consumer of the padded layer's input (a feature-matching tap) without a separate add. */
+int msmc_reflect_fold_multi_res(const void* const* gp, const void* const* mask_src, const void* const* res, void* const* gx,
+                                const int* B, const int* H, const int* W, const int* C, int n, int p, float slope, int dtype,
+                                msmc_stream stream);
 int msmc_lrelu_bwd_multi(const void* const* g, const void* const* y, void* const* gx, const long* nelem, int n, float slope,
                          int dtype, msmc_stream stream);
 

@@ -3041,6 +3041,7 @@ struct FoldMultiArgs {
     int first[MSMC_GROUP_MAX + 1];
     const void* gp[MSMC_GROUP_MAX];
     const void* mask[MSMC_GROUP_MAX];
+    const void* res[MSMC_GROUP_MAX];    // NULL, or [B][H][W][C] added after the mask (a second consumer's gradient)
     void* gx[MSMC_GROUP_MAX];
     int H[MSMC_GROUP_MAX], W[MSMC_GROUP_MAX], C[MSMC_GROUP_MAX];
     long items[MSMC_GROUP_MAX];         // B * H * W * (C / V)
@@ -3052,6 +3053,7 @@ __global__ __launch_bounds__(256) void reflect_fold_multi_kernel(FoldMultiArgs a
     const int H = a.H[k], W = a.W[k], C = a.C[k], CV = C / V, Hp = H + 2 * p, Wp = W + 2 * p;
     const T* gp = (const T*)a.gp[k];
     const T* mask = (const T*)a.mask[k];
+    const T* res = (const T*)a.res[k];
     T* gx = (T*)a.gx[k];
     for (long e = (long)(blockIdx.x - a.first[k]) * 256 + threadIdx.x; e < a.items[k]; e += (long)nb * 256) {
         const int c = (int)(e % CV) * V;
@@ -3080,15 +3082,20 @@ __global__ __launch_bounds__(256) void reflect_fold_multi_kernel(FoldMultiArgs a
                 for (int q = 0; q < V; ++q) sacc[q] = sacc[q] + Elt<T>::ld(&v[q]);
             }
         const size_t o = (((size_t)b * H + y) * W + x) * C + c;
-        alignas(16) T mv[V], ov[V];
+        alignas(16) T mv[V], rv[V], ov[V];
         if (mask) {
             if (V * sizeof(T) == 16) *(u32x4*)mv = *(const u32x4*)(mask + o);
             else mv[0] = mask[o];
+        }
+        if (res) {
+            if (V * sizeof(T) == 16) *(u32x4*)rv = *(const u32x4*)(res + o);
+            else rv[0] = res[o];
         }
 #pragma unroll
         for (int q = 0; q < V; ++q) {
             float sv = sacc[q];
             if (mask) sv = sv * (Elt<T>::ld(&mv[q]) > 0.f ? 1.f : a.slope);
+            if (res) sv = sv + Elt<T>::ld(&rv[q]);
             Elt<T>::st(&ov[q], sv);
         }
         if (V * sizeof(T) == 16) *(u32x4*)(gx + o) = *(const u32x4*)ov;
@@ -3214,6 +3221,12 @@ int msmc_lrelu_bwd(const void* g, const void* y, void* gx, long n, float slope, 
 
 int msmc_reflect_fold_multi(const void* const* gp, const void* const* mask_src, void* const* gx, const int* B, const int* H,
                             const int* W, const int* C, int n, int p, float slope, int dtype, msmc_stream stream) {
+    return msmc_reflect_fold_multi_res(gp, mask_src, nullptr, gx, B, H, W, C, n, p, slope, dtype, stream);
+}
+
+int msmc_reflect_fold_multi_res(const void* const* gp, const void* const* mask_src, const void* const* res, void* const* gx,
+                                const int* B, const int* H, const int* W, const int* C, int n, int p, float slope, int dtype,
+                                msmc_stream stream) {
     if (!gp || !gx || !B || !H || !W || !C || n <= 0 || n > MSMC_GROUP_MAX || p < 0 || dtype < 0 || dtype > 1)
         return MSMC_E_SHAPE;
     const int VEC = dtype == 0 ? 4 : 8;
@@ -3230,6 +3243,7 @@ int msmc_reflect_fold_multi(const void* const* gp, const void* const* mask_src, 
     for (int k = 0; k < n; ++k) {
         a.gp[k] = gp[k];
         a.mask[k] = mask_src ? mask_src[k] : nullptr;
+        a.res[k] = res ? res[k] : nullptr;
         a.gx[k] = gx[k];
         a.H[k] = H[k];
         a.W[k] = W[k];

@@ -119,7 +119,7 @@ def _signature(desc):
 
 # Variable-length batches: every new padded length T is a new signature.  Timing launches are a per-process BUDGET of
 # new shapes (MSMC_TUNE_BUDGET); a shape outside the cache first borrows the choice of the nearest tuned shape of its
-# CLASS (everything but batch and spatial extents: channels, taps, strides, dilation, padding rule, epilogue operands) --
+# CLASS (everything but batch, spatial extents and epilogue operands: channels, taps, strides, dilation, padding rule) --
 # kernel preferences follow the channel / tap configuration far more than the length -- and is timed only when its class
 # has no entry and budget is left.  Ranks of a data-parallel job therefore stop issuing timing launches after the same
 # bounded number of shapes instead of stalling each other at the collectives whenever one of them meets a new length.
@@ -130,7 +130,7 @@ _CLASS_INDEXED = [0]
 
 def _class_of(sig):
     """signature (kind, dtype, B, Hin, Win, Cin, Hout, Wout, Cout, QH, QW, ...) -> (class key, output pixels)"""
-    return (sig[0], sig[1], sig[5], sig[8]) + tuple(sig[11:]), sig[2] * sig[9] * sig[10]
+    return (sig[0], sig[1], sig[5], sig[8]) + tuple(sig[11:-3]), sig[2] * sig[9] * sig[10]
 
 
 def _nearest_tuned(sig):
@@ -516,15 +516,16 @@ def conv_transpose1d_forward(x, w, k, stride, padding, bias=None, in_slope=1.0):
     return out
 
 
-def conv_transpose1d_dgrad(g, wb, k, stride, padding, Lin, mask_src=None, mask_slope=1.0):
-    """g [B,1,Lout,Cout] -> gx [B,1,Lin,Cin];  wb [k, Cin, Cout]:  gx[q] = sum_k g[q*stride + k - padding] wb[k]."""
-    _check(g, wb, mask_src)
+def conv_transpose1d_dgrad(g, wb, k, stride, padding, Lin, mask_src=None, mask_slope=1.0, res=None):
+    """g [B,1,Lout,Cout] -> gx [B,1,Lin,Cin];  wb [k, Cin, Cout]:  gx[q] = sum_k g[q*stride + k - padding] wb[k]
+    (epilogue: * lrelu'(mask_src) + res)."""
+    _check(g, wb, mask_src, res)
     B, _, Lout, Cout = g.shape
     Cin = wb.shape[1]
     gx = torch.empty((B, 1, Lin, Cin), dtype=g.dtype, device=g.device)
     taps = [(0, kk, kk) for kk in range(k)]
     lattice = (1, Lin, 0, 1, 0, 1, 1, stride, 0, -padding)
-    d = _fill(None, g, wb, gx, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, mask_src=mask_src,
+    d = _fill(None, g, wb, gx, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, mask_src=mask_src, res=res,
               mask_slope=mask_slope)
     _gather(d, lib.stream(g), 'msmc_conv_gather(convT dgrad)')
     return gx
@@ -691,26 +692,38 @@ def lrelu_bwd_group(pairs, slope):
 
 
 def reflect_fold_group(items, p=1, slope=1.0):
-    """[(gp, H, W, mask_src or None), ...] -> folded gradients, up to six tensors per launch (msmc_reflect_fold_multi)."""
+    """[(gp, H, W, mask_src or None[, res or None]), ...] -> folded gradients (* lrelu'(mask_src) + res), up to six tensors
+    per launch (msmc_reflect_fold_multi_res)."""
+    items = [tuple(it) + (None,) * (5 - len(it)) for it in items]
     if not _G['FOLD']:
-        return [reflect_fold(gp, H, W, p, mask_src=mask, slope=slope) for gp, H, W, mask in items]
+        outs = []
+        for gp, H, W, mask, res in items:
+            gx = reflect_fold(gp, H, W, p, mask_src=mask, slope=slope)
+            outs.append(gx if res is None else gx + res)
+        return outs
     outs = []
     L = lib.get()
     for i in range(0, len(items), 6):
         part = items[i:i + 6]
         n = len(part)
-        gxs, masks = [], []
-        for gp, H, W, mask in part:
+        gxs, masks, ress = [], [], []
+        for gp, H, W, mask, res in part:
             assert gp.shape[1:3] == (H + 2 * p, W + 2 * p) and gp.is_contiguous() and gp.dtype == part[0][0].dtype
             _dev_ok(gp)
-            if mask is not None:
-                _dev_ok(mask)
-            gxs.append(torch.empty((gp.shape[0], H, W, gp.shape[3]), dtype=gp.dtype, device=gp.device))
+            gx = torch.empty((gp.shape[0], H, W, gp.shape[3]), dtype=gp.dtype, device=gp.device)
+            for aux in (mask, res):
+                if aux is not None:
+                    _dev_ok(aux)
+                    assert aux.shape == gx.shape and aux.dtype == gp.dtype and aux.is_contiguous()
+            gxs.append(gx)
             masks.append(mask.data_ptr() if mask is not None else None)
+            ress.append(res.data_ptr() if res is not None else None)
         vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
-        lib.check(L.msmc_reflect_fold_multi(vp(*[t[0].data_ptr() for t in part]), vp(*masks), vp(*[t.data_ptr() for t in gxs]),
-                                            ip(*[t[0].shape[0] for t in part]), ip(*[t[1] for t in part]),
-                                            ip(*[t[2] for t in part]), ip(*[t[0].shape[3] for t in part]), n, p, float(slope),
-                                            _DT[part[0][0].dtype], lib.stream(part[0][0])), 'msmc_reflect_fold_multi')
+        lib.check(L.msmc_reflect_fold_multi_res(vp(*[t[0].data_ptr() for t in part]), vp(*masks), vp(*ress),
+                                                vp(*[t.data_ptr() for t in gxs]), ip(*[t[0].shape[0] for t in part]),
+                                                ip(*[t[1] for t in part]), ip(*[t[2] for t in part]),
+                                                ip(*[t[0].shape[3] for t in part]), n, p, float(slope), _DT[part[0][0].dtype],
+                                                lib.stream(part[0][0])), 'msmc_reflect_fold_multi_res')
         outs.extend(gxs)
     return outs
+

@@ -293,9 +293,19 @@ class ConvBank(object):
                         GRAD_READY_HOOK(p)
 
 
+def _tap_grad(g_tap, like):
+    """gradient that arrived through a tap (an alias of a convolution's input handed to another consumer): contiguous,
+    in the dtype of the data gradient it is added to"""
+    if g_tap is None:
+        return None
+    if g_tap.dtype != like.dtype:
+        g_tap = g_tap.to(like.dtype)
+    return g_tap.contiguous()
+
+
 class _HipConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, res2, weight_token, bank, layer, in_slope, out_slope, out_div):
+    def forward(ctx, x, res, res2, weight_token, bank, layer, in_slope, out_slope, out_div, tap=False):
         m = layer.module
         if layer.kind == 'conv':
             geom = layer.geom(x.shape[1], x.shape[2])
@@ -310,13 +320,20 @@ class _HipConv(torch.autograd.Function):
         ctx.has_res, ctx.has_res2 = res is not None, res2 is not None
         ctx.need_w = layer.weight.requires_grad
         ctx.save_for_backward(x, out if out_slope != 1.0 else None)
-        return out
+        ctx.set_materialize_grads(False)
+        # ``tap``: also return an alias of x for x's OTHER consumer (a residual add, a feature-matching loss, a fused
+        # LayerNorm's residual input).  Its gradient then arrives HERE and is added in the data-gradient launch's epilogue
+        # instead of by a stock add_ of the autograd engine (one launch and one read-modify-write of the tensor less).
+        return (out, x.view_as(x)) if tap else out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_tap=None):
         x, out = ctx.saved_tensors
         layer, bank = ctx.layer, ctx.bank
+        if g is None:                                  # only the tap was used
+            return (g_tap,) + (None,) * 9
         g = g.contiguous()
+        g_tap = _tap_grad(g_tap, g)
         if ctx.out_slope != 1.0:                       # y = lrelu(z): dz = dy * (y > 0 ? 1 : slope)
             g = K.lrelu_bwd(g, out, ctx.out_slope)
         if ctx.out_div != 1.0:
@@ -330,11 +347,18 @@ class _HipConv(torch.autograd.Function):
                     gp = K.conv_dgrad(g, layer.wb, geom)
                     gx = K.reflect_fold(gp, x.shape[1], x.shape[2], layer.padding[0], mask_src=mask,
                                         slope=ctx.in_slope)
+                    if g_tap is not None:
+                        gx = gx + g_tap
                 else:
-                    gx = K.conv_dgrad(g, layer.wb, geom, mask_src=mask, mask_slope=ctx.in_slope)
+                    gx = K.conv_dgrad(g, layer.wb, geom, mask_src=mask, mask_slope=ctx.in_slope, res=g_tap)
             else:
                 gx = K.conv_transpose1d_dgrad(g, layer.wb, layer.kernel[1], layer.stride[1], layer.padding[1],
-                                              x.shape[2], mask_src=mask, mask_slope=ctx.in_slope)
+                                              x.shape[2], mask_src=mask, mask_slope=ctx.in_slope, res=g_tap)
+            if g_tap is not None:
+                bank._hold.append(g_tap)               # (read by a launch that may replay on another stream)
+                bank._queue_finish()
+        elif g_tap is not None:
+            gx = g_tap
         if ctx.need_w:
             with bank.wgrad_side(x, g):
                 if layer.kind == 'conv':
@@ -355,7 +379,7 @@ class _HipConv(torch.autograd.Function):
             bank._queue_finish()
         # weight_token (the layer's weight_v) only ties the output to the parameters in the autograd graph;
         # parameter gradients are produced in kernel layout and delivered by ConvBank._finish_backward.
-        return gx, (g if ctx.has_res else None), (g if ctx.has_res2 else None), None, None, None, None, None, None
+        return gx, (g if ctx.has_res else None), (g if ctx.has_res2 else None), None, None, None, None, None, None, None
 
 
 class _HipConvGroup(torch.autograd.Function):
@@ -367,7 +391,7 @@ class _HipConvGroup(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bank, specs, *tensors):
         items, pos, members = [], 0, []
-        for layer, in_slope, out_slope, out_div, has_res, has_res2 in specs:
+        for layer, in_slope, out_slope, out_div, has_res, has_res2, tap in specs:
             x = tensors[pos]
             res = tensors[pos + 1] if has_res else None
             res2 = tensors[pos + 1 + has_res] if has_res2 else None
@@ -382,7 +406,10 @@ class _HipConvGroup(torch.autograd.Function):
         ctx.xpos = [m[0] for m in members]
         saved = [m[1] for m in members] + [o if sp[2] != 1.0 else None for o, sp in zip(outs, specs)]
         ctx.save_for_backward(*saved)
-        return tuple(outs)
+        ctx.set_materialize_grads(False)
+        # members with ``tap``: an alias of their input follows the outputs (see _HipConv.forward)
+        ctx.tapped = [k for k, sp in enumerate(specs) if sp[6]]
+        return tuple(outs) + tuple(members[k][1].view_as(members[k][1]) for k in ctx.tapped)
 
     @staticmethod
     def backward(ctx, *gs):
@@ -392,13 +419,20 @@ class _HipConvGroup(torch.autograd.Function):
         bank = ctx.bank
         grads = [None] * ctx.ntensors
         gl, d_items, d_members, w_items = [], [], [], []
+        g_taps = dict(zip(ctx.tapped, gs[n:]))
+        gs = list(gs[:n])
+        for k in range(n):
+            if gs[k] is None:                          # an output nobody used: zero gradient
+                gs[k] = torch.zeros_like(outs[k]) if outs[k] is not None else None
+        if any(g is None for g in gs):
+            raise RuntimeError('grouped convolution: an output without gradient (not expected on the training path)')
         gs = [g.contiguous() for g in gs]
         # y = lrelu(z): dz = dy * (y > 0 ? 1 : slope) -- one multi-tensor launch per slope value
         for slope in sorted(set(sp[2] for sp in ctx.specs if sp[2] != 1.0)):
             ks = [k for k, sp in enumerate(ctx.specs) if sp[2] == slope]
             for k, gm in zip(ks, K.lrelu_bwd_group([(gs[k], outs[k]) for k in ks], slope)):
                 gs[k] = gm
-        for k, (layer, in_slope, out_slope, out_div, has_res, has_res2) in enumerate(ctx.specs):
+        for k, (layer, in_slope, out_slope, out_div, has_res, has_res2, tap) in enumerate(ctx.specs):
             g = gs[k]
             if out_div != 1.0:
                 g = g / out_div
@@ -408,10 +442,13 @@ class _HipConvGroup(torch.autograd.Function):
             pos = ctx.xpos[k]
             if ctx.needs_input_grad[2 + pos]:
                 mask = x if in_slope != 1.0 else None
+                g_tap = _tap_grad(g_taps.get(k), g)
                 if layer.reflect:
                     d_items.append(dict(g=g, wb=layer.wb, geom=geom))
                 else:
-                    d_items.append(dict(g=g, wb=layer.wb, geom=geom, mask_src=mask, mask_slope=in_slope))
+                    d_items.append(dict(g=g, wb=layer.wb, geom=geom, mask_src=mask, mask_slope=in_slope, res=g_tap))
+                    if g_tap is not None:
+                        bank._hold.append(g_tap)
                 d_members.append(k)
             if ctx.need_w[k]:
                 w_items.append(dict(x=x, g=g, geom=geom, n_slices=layer.taps, in_slope=in_slope, dw=layer.dw, db=layer.db,
@@ -429,8 +466,11 @@ class _HipConvGroup(torch.autograd.Function):
                 layer, in_slope = ctx.specs[k][0], ctx.specs[k][1]
                 if layer.reflect:           # gradient on the padded grid: fold the border back (multi-tensor launch)
                     x = xs[k]
+                    g_tap = _tap_grad(g_taps.get(k), gx)
+                    if g_tap is not None:
+                        bank._hold.append(g_tap)
                     folds.setdefault((layer.padding[0], in_slope), []).append(
-                        (k, (gx, x.shape[1], x.shape[2], x if in_slope != 1.0 else None)))
+                        (k, (gx, x.shape[1], x.shape[2], x if in_slope != 1.0 else None, g_tap)))
                 else:
                     grads[ctx.xpos[k]] = gx
             for (pad, in_slope), members in folds.items():
@@ -450,20 +490,27 @@ def hip_conv_group(bank, members):
     for m in members:
         res, res2 = m.get('res'), m.get('res2')
         specs.append((m['layer'], float(m.get('in_slope', 1.0)), float(m.get('out_slope', 1.0)),
-                      float(m.get('out_div', 1.0)), int(res is not None), int(res2 is not None)))
+                      float(m.get('out_div', 1.0)), int(res is not None), int(res2 is not None), bool(m.get('tap', False))))
         tensors.append(m['x'])
         if res is not None:
             tensors.append(res)
         if res2 is not None:
             tensors.append(res2)
         tensors.append(m['layer'].weight)
-    return list(_HipConvGroup.apply(bank, tuple(specs), *tensors))
+    outs = list(_HipConvGroup.apply(bank, tuple(specs), *tensors))
+    n = len(members)
+    if len(outs) == n:
+        return outs
+    taps = iter(outs[n:])                      # members with tap=True return (out, tap) instead of out
+    return [(outs[k], next(taps)) if specs[k][6] else outs[k] for k in range(n)]
 
 
 # grouped launches replace the fork/join streams (forked hipGraph branches do not overlap; one grid does)
 GROUPED = os.environ.get('MSMC_GROUPED', '1') != '0'
 
 
-def hip_conv(bank, layer, x, res=None, res2=None, in_slope=1.0, out_slope=1.0, out_div=1.0):
+def hip_conv(bank, layer, x, res=None, res2=None, in_slope=1.0, out_slope=1.0, out_div=1.0, tap=False):
+    """``tap=True``: returns (out, x_tap) -- x_tap aliases x and is what x's other consumer should read, so that its
+    gradient is added inside this convolution's data-gradient launch (see _HipConv.forward)."""
     return _HipConv.apply(x, res, res2, layer.weight, bank, layer, float(in_slope), float(out_slope),
-                          float(out_div))
+                          float(out_div), bool(tap))

@@ -115,7 +115,9 @@ class MultiHeadAttention(nn.Module):
         bank, (l_qkv, l_fc) = hip
         bs, T, _ = x.shape
         H, dk, dv = self.n_head, self.d_k, self.d_v
-        qkv = hip_conv(bank, l_qkv, x.unsqueeze(1)).view(bs, T, H, 2 * dk + dv).transpose(1, 2)       # [bs, H, T, 2dk+dv]
+        qkv, x_res = hip_conv(bank, l_qkv, x.unsqueeze(1), tap=True)        # (tap: see PositionwiseFeedForward.forward_hip)
+        x = x_res.squeeze(1)
+        qkv = qkv.view(bs, T, H, 2 * dk + dv).transpose(1, 2)               # [bs, H, T, 2dk+dv]
         att = self.attention
         p = att.dropout.p if (hasattr(att, 'dropout') and att.training) else 0.0
         q, k, v = _SplitHeads.apply(qkv, dk)
@@ -170,7 +172,11 @@ class PositionwiseFeedForward(nn.Module):
         bank, (l1, l2) = hip
         # [B, T, C] IS the channels-last layout of a 1-D convolution: no transposes; the ReLU between the two
         # convolutions is the second one's input activation (leaky slope 0)
-        h = hip_conv(bank, l2, hip_conv(bank, l1, x.unsqueeze(1)), in_slope=0.0).squeeze(1)
+        # (tap: the residual input of the fused LayerNorm reads the alias the first convolution hands back, so the residual
+        # gradient is added in that convolution's data-gradient epilogue)
+        h1, x_res = hip_conv(bank, l1, x.unsqueeze(1), tap=True)
+        h = hip_conv(bank, l2, h1, in_slope=0.0).squeeze(1)
+        x = x_res.squeeze(1)
         pd = self.dropout.p if self.training else 0.0
         return hipnorm.add_layer_norm(h, x, self.layer_norm.weight, self.layer_norm.bias, keep_row=keep_row, p_drop=pd,
                                       salt=self._salt, eps=self.layer_norm.eps)

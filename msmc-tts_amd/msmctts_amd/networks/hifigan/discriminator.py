@@ -54,9 +54,11 @@ class DiscriminatorR(nn.Module):
         fmaps = []
         last = len(layers) - 1
         for i, layer in enumerate(layers):
-            x = hip_conv(bank, layer, x, out_slope=LRELU_SLOPE if i < last else 1.0)
-            if i < last:
-                fmaps.append(x.permute(0, 3, 1, 2))      # aliased post-activation map, see module docstring
+            if i == 0:
+                x = hip_conv(bank, layer, x, out_slope=LRELU_SLOPE)
+            else:               # (tap: the feature-matching loss reads the alias of the map the next layer hands back)
+                x, tap = hip_conv(bank, layer, x, out_slope=LRELU_SLOPE if i < last else 1.0, tap=True)
+                fmaps.append(tap.permute(0, 3, 1, 2))    # aliased post-activation map, see module docstring
         return x.permute(0, 3, 1, 2), fmaps
 
 
@@ -103,10 +105,16 @@ class DiscriminatorP(nn.Module):
             x = F.pad(x, (0, n_pad), 'reflect')
             t = t + n_pad
         x = x.reshape(b, t // self.period, self.period, 1).to(dtype)        # C == 1: NCHW and NHWC coincide
+        # every feature map has two consumers (the next layer and the feature-matching loss): the loss reads the alias the
+        # next layer hands back (tap), so its gradient is added in that layer's data-gradient epilogue
         for i, layer in enumerate(layers[:-1]):
-            x = hip_conv(bank, layer, x, in_slope=LRELU_SLOPE if i > 0 else 1.0)
-            fmap.append(x.permute(0, 3, 1, 2))
-        x = hip_conv(bank, layers[-1], x, in_slope=LRELU_SLOPE)
+            if i == 0:
+                x = hip_conv(bank, layer, x)
+            else:
+                x, tap = hip_conv(bank, layer, x, in_slope=LRELU_SLOPE, tap=True)
+                fmap.append(tap.permute(0, 3, 1, 2))
+        x, tap = hip_conv(bank, layers[-1], x, in_slope=LRELU_SLOPE, tap=True)
+        fmap.append(tap.permute(0, 3, 1, 2))
         return torch.flatten(x, 1, -1), fmap
 
 
@@ -158,12 +166,15 @@ class Discriminator(nn.Module):
         xs = [stft.image_cl(wav).to(dtype) for stft in self.mrd.stfts]
         r_fmaps = [[] for _ in xs]
         last = len(mrd[0]) - 1
-        for i in range(last + 1):
-            xs = hip_conv_group(bank, [dict(layer=mrd[j][i], x=xs[j], out_slope=LRELU_SLOPE if i < last else 1.0)
+        xs = hip_conv_group(bank, [dict(layer=mrd[j][0], x=xs[j], out_slope=LRELU_SLOPE) for j in range(len(xs))])
+        for i in range(1, last + 1):
+            # (tap: the feature-matching loss reads the alias of map i-1 that layer i hands back, so its gradient is added
+            # in layer i's data-gradient fold instead of by a stock add_)
+            xt = hip_conv_group(bank, [dict(layer=mrd[j][i], x=xs[j], out_slope=LRELU_SLOPE if i < last else 1.0, tap=True)
                                        for j in range(len(xs))])
-            if i < last:
-                for j, x in enumerate(xs):
-                    r_fmaps[j].append(x.permute(0, 3, 1, 2))    # aliased post-activation map, see module docstring
+            for j, (x, tap) in enumerate(xt):
+                r_fmaps[j].append(tap.permute(0, 3, 1, 2))      # aliased post-activation map, see module docstring
+            xs = [x for x, _ in xt]
         r_scores = [x.permute(0, 3, 1, 2) for x in xs]
         ps = []
         for d in self.mpd.discriminators:
@@ -175,11 +186,14 @@ class Discriminator(nn.Module):
             ps.append(x.reshape(b, t // d.period, d.period, 1).to(dtype))      # C == 1: NCHW and NHWC coincide
         p_fmaps = [[] for _ in ps]
         nl = len(mpd[0]) - 1
-        for i in range(nl):
-            ps = hip_conv_group(bank, [dict(layer=mpd[j][i], x=ps[j], in_slope=LRELU_SLOPE if i > 0 else 1.0)
+        # every feature map has two consumers (the next layer and the feature-matching loss): the loss reads the alias the
+        # next layer hands back (tap), so its gradient is added in that layer's data-gradient epilogue
+        ps = hip_conv_group(bank, [dict(layer=mpd[j][0], x=ps[j]) for j in range(len(ps))])
+        for i in range(1, nl + 1):
+            pt = hip_conv_group(bank, [dict(layer=mpd[j][i], x=ps[j], in_slope=LRELU_SLOPE, tap=True)
                                        for j in range(len(ps))])
-            for j, x in enumerate(ps):
-                p_fmaps[j].append(x.permute(0, 3, 1, 2))
-        ps = hip_conv_group(bank, [dict(layer=mpd[j][nl], x=ps[j], in_slope=LRELU_SLOPE) for j in range(len(ps))])
+            for j, (x, tap) in enumerate(pt):
+                p_fmaps[j].append(tap.permute(0, 3, 1, 2))
+            ps = [x for x, _ in pt]
         p_scores = [torch.flatten(x, 1, -1) for x in ps]
         return r_scores + p_scores, r_fmaps + p_fmaps

@@ -63,22 +63,25 @@ class Generator(nn.Module):
                 c1s, c2s = L['rb'][i * nk + j]
                 y = x
                 for m in range(len(c1s) - 1):
-                    t = hip_conv(bank, c1s[m], y, in_slope=LRELU_SLOPE)
+                    t, y = hip_conv(bank, c1s[m], y, in_slope=LRELU_SLOPE, tap=True)   # (the residual edge reads the tap)
                     y = hip_conv(bank, c2s[m], t, res=y, in_slope=LRELU_SLOPE)
-                return y, hip_conv(bank, c1s[-1], y, in_slope=LRELU_SLOPE)
+                t, y = hip_conv(bank, c1s[-1], y, in_slope=LRELU_SLOPE, tap=True)
+                return y, t
 
             if convnet.GROUPED:
                 # the nk parallel ResBlocks advance in lock step: one grouped launch per convolution position
                 ys = [x] * nk
                 nu = len(L['rb'][i * nk][0])
+                # tap=True: the residual edge of a unit reads an alias of the unit's input handed back by its first
+                # convolution, so the residual gradient is added in that convolution's data-gradient epilogue
                 for m in range(nu - 1):
-                    ts = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][0][m], x=ys[j], in_slope=LRELU_SLOPE)
+                    tt = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][0][m], x=ys[j], in_slope=LRELU_SLOPE, tap=True)
                                                for j in range(nk)])
-                    ys = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][1][m], x=ts[j], res=ys[j],
+                    ys = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][1][m], x=tt[j][0], res=tt[j][1],
                                                     in_slope=LRELU_SLOPE) for j in range(nk)])
-                ts = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][0][nu - 1], x=ys[j], in_slope=LRELU_SLOPE)
+                tt = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][0][nu - 1], x=ys[j], in_slope=LRELU_SLOPE, tap=True)
                                            for j in range(nk)])
-                parts = list(zip(ys, ts))
+                parts = [(t_[1], t_[0]) for t_ in tt]
             else:
                 parts = fork_join(self._streams, [lambda j=j: block_body(j) for j in range(nk)], inputs=(x,))
             xs = None
