@@ -73,7 +73,7 @@ def fork_join(streams, thunks, inputs=()):
 # the calling stream.  Branches of a hipGraph DO run concurrently on this runtime (tools/graph_overlap_probe.py: two chains
 # of 64-workgroup GEMMs replay 1.6x, four chains 2x faster forked than serial), but every kernel of this step already
 # occupies all 256 CUs (>= 256 workgroups bounded by LDS), so a second branch only gets the tails: measured 30.9 (n = 2)
-# vs 31.1 ms/step (n = 0) -- within noise.  Default off; kept for workloads whose grids under-fill the chip.
+# vs 31.1 ms/step (n = 0), later 28.8 vs 29.1 with half the pixel splits per weight gradient -- within noise.  Default off; kept for workloads whose grids under-fill the chip.
 WGRAD_STREAMS = int(os.environ.get('MSMC_WGRAD_STREAMS', '0'))
 _SIDE = {}
 
