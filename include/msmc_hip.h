@@ -127,7 +127,9 @@ typedef struct msmc_conv_desc {
                                where a configuration does not apply), 9 = 32-point tiles with the channel
                                chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation (fp32 atomics), 3 = third (split partials + fixed-order reduce).  The host layer times the candidates once per layer shape.       */
-    int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative)                */
+    int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative).  msmc_conv_gather
+                               variants 16..23 only: DIAGNOSTICS mask, 0 in production (1 skip the MFMAs, 2 the weight stream,
+                               4 the halo loads, 8 the epilogue: tools/bench_gather3.py ABLATE=...; results are then garbage) */
     int dw_copies;          /* msmc_conv_wgrad: R > 1 = dw is [R][ntaps][Cout][Cin] and db [R][Cout]; workgroup i adds
                                into copy i % R (same-address atomics retire serially; R copies shorten the chain R
                                times); the consumer sums the copies (msmc_wn_backward_multi does)                      */

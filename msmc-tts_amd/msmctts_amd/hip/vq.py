@@ -71,8 +71,9 @@ def vq_ema_update(x, ind, length, embed, cluster_size, embed_avg, decay, eps, wo
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
     xc = x.detach().contiguous().float()
+    indc = ind.contiguous()                 # (named: a temporary would be released before the launch reads it)
     length = length.to(device=x.device, dtype=torch.int64).contiguous()
-    lib.check(L.msmc_vq_ema_update(lib.ptr(xc), lib.ptr(ind.contiguous(), torch.int64), lib.ptr(length),
+    lib.check(L.msmc_vq_ema_update(lib.ptr(xc), lib.ptr(indc, torch.int64), lib.ptr(length),
                                    lib.ptr(embed, torch.float32), lib.ptr(cluster_size, torch.float32),
                                    lib.ptr(embed_avg, torch.float32), lib.ptr(workspace),
                                    workspace.numel() * workspace.element_size(), B, T, D, H, K, float(decay),

@@ -252,6 +252,122 @@ def check_predictor_step(device):
             close(sd[k[len('post.'):]], v, 1e-5, what=k)
 
 
+def check_norm_kernels(dev, dtype, tol):
+    """csrc/norm.hip against the stock operator chains they replace (forward and every gradient), ragged row counts,
+    row mask; dropout: the backward pass regenerates exactly the forward's mask and the keep rate is right"""
+    from msmctts_amd.hip import norm
+    torch.manual_seed(0)
+    for N, C in ((37, 256), (5, 96), (130, 32)):
+        x = torch.randn(N, C, device=dev).to(dtype).requires_grad_(True)
+        r = torch.randn(N, C, device=dev).to(dtype).requires_grad_(True)
+        gm = (torch.rand(C, device=dev) + 0.5).requires_grad_(True)
+        bt = torch.randn(C, device=dev).requires_grad_(True)
+        keep = (torch.rand(N, device=dev) > 0.3).to(torch.uint8)
+        y = norm.add_layer_norm(x, r, gm, bt, keep_row=keep)
+        go = torch.randn(N, C, device=dev)
+        (y.float() * go).sum().backward()
+        xr, rr = x.detach().float().requires_grad_(True), r.detach().float().requires_grad_(True)
+        gr, br = gm.detach().clone().requires_grad_(True), bt.detach().clone().requires_grad_(True)
+        yr = torch.nn.functional.layer_norm(xr + rr, (C,), gr, br) * keep.float().unsqueeze(1)
+        (yr * (go.to(dtype).float() if dtype != torch.float32 else go)).sum().backward()
+        scale = lambda t: max(1.0, float(t.abs().max()))
+        assert (y.float() - yr).abs().max() <= tol * scale(yr)
+        assert (x.grad.float() - xr.grad).abs().max() <= tol * scale(xr.grad)
+        assert (r.grad.float() - rr.grad).abs().max() <= tol * scale(rr.grad)
+        assert (gm.grad - gr.grad).abs().max() <= tol * scale(gr.grad) * (4 if dtype != torch.float32 else 1)
+        assert (bt.grad - br.grad).abs().max() <= tol * scale(br.grad) * (4 if dtype != torch.float32 else 1)
+    # gate and tanh
+    x = torch.randn(23, 2 * 48, device=dev).to(dtype).requires_grad_(True)
+    y = norm.gate(x)
+    go = torch.randn(23, 48, device=dev)
+    (y.float() * go).sum().backward()
+    xr = x.detach().float().requires_grad_(True)
+    yr = torch.tanh(xr[:, :48]) * torch.sigmoid(xr[:, 48:])
+    (yr * go).sum().backward()
+    assert (y.float() - yr).abs().max() <= tol and (x.grad.float() - xr.grad).abs().max() <= tol * 4
+    x = torch.randn(1000, device=dev).to(dtype).requires_grad_(True)
+    y = norm.tanh(x)
+    y.float().sum().backward()
+    assert (y.float() - torch.tanh(x.detach().float())).abs().max() <= tol
+    assert (x.grad.float() - (1 - torch.tanh(x.detach().float()) ** 2)).abs().max() <= tol * 2
+    # dropout: same mask in both passes, keep rate ~ 1 - p, fresh mask after advance_seed
+    p = 0.25
+    x = torch.ones(64, 256, device=dev).to(dtype).requires_grad_(True)
+    one, zero = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+    salt = norm.new_salt()
+    y = norm.gate(torch.full((64, 512), 3.0, device=dev).to(dtype).requires_grad_(True), p_drop=p, salt=salt)
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 0.03, kept
+    xg = torch.full((64, 512), 3.0, device=dev).to(dtype).requires_grad_(True)
+    yg = norm.gate(xg, p_drop=p, salt=salt)
+    yg.float().sum().backward()
+    assert torch.equal(yg != 0, y != 0)                                   # same seed, same salt: same mask
+    assert torch.equal(xg.grad[:, :256] != 0, yg != 0)                    # backward regenerated it
+    norm.advance_seed(xg.device)
+    y2 = norm.gate(xg.detach(), p_drop=p, salt=salt)
+    assert not torch.equal(y2 != 0, y != 0)
+
+
+def check_hip_adamw(dev):
+    """csrc/optim.hip (grad-norm clip + AdamW of all tensors in three launches) against clip_grad_norm_ + torch.optim.AdamW
+    over several steps, odd sizes and unaligned views; state_dict round trip both ways"""
+    from msmctts_amd.trainers.optimizers.hip_adamw import HipAdamW
+    torch.manual_seed(0)
+    shapes = [(7,), (33, 5), (4096,), (5000,), (3, 3, 3)]
+    base = torch.randn(20000, device=dev)
+    mine = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    a = HipAdamW(mine, lr=2e-3, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01)
+    b = torch.optim.AdamW(ref, lr=2e-3, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01)
+    for step in range(4):
+        for p, q in zip(mine, ref):
+            g = torch.randn_like(p) * (3.0 if step % 2 == 0 else 0.01)
+            p.grad = g.clone() if step != 2 else base[1:1 + g.numel()].view_as(g).clone()
+            q.grad = p.grad.clone()
+        norm = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        b.step()
+        a.step(max_norm=1.0)
+        assert abs(float(a.grad_norm) - float(norm)) <= 1e-5 * max(1.0, float(norm))
+        for p, q in zip(mine, ref):
+            assert (p - q).abs().max() <= 2e-6, step
+            assert (p.grad - q.grad).abs().max() <= 1e-6 * max(1.0, float(q.grad.abs().max()))       # clipped in place
+    sd = a.state_dict()
+    assert set(sd['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'} and float(sd['state'][0]['step']) == 4.0
+    b2 = torch.optim.AdamW([torch.nn.Parameter(p.detach().clone()) for p in mine], lr=2e-3, betas=(0.8, 0.99), weight_decay=0.01)
+    b2.load_state_dict(sd)                                  # our checkpoint into torch's optimizer
+    a2 = HipAdamW([torch.nn.Parameter(p.detach().clone()) for p in mine], lr=2e-3, betas=(0.8, 0.99), weight_decay=0.01)
+    a2.load_state_dict(b.state_dict())                      # torch's checkpoint into ours
+    for opt in (a2, b2):
+        for p in opt.param_groups[0]['params']:
+            p.grad = torch.ones_like(p) * 0.1
+    a2.step()
+    b2.step()
+    for p, q in zip(a2.param_groups[0]['params'], b2.param_groups[0]['params']):
+        assert (p - q).abs().max() <= 2e-6
+
+
+def check_codebook_split_update(dev):
+    """msmc_vq_ema_stats + msmc_vq_ema_apply (the two halves around the cross-rank sum of sync_codebook_stats) are, on
+    one rank, bit for bit the fused msmc_vq_ema_update"""
+    from msmctts_amd.hip import vq as hipvq
+    from msmctts_amd.networks.vqgantts.modules import MultiHeadQuantize
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 137, 64, generator=g).to(dev)
+    ln = torch.tensor([137, 20, 5, 131]).to(dev)
+    torch.manual_seed(3)
+    q1 = MultiHeadQuantize(64, 32, 4).to(dev).train()
+    torch.manual_seed(3)
+    q2 = MultiHeadQuantize(64, 32, 4).to(dev).train()
+    q2.sync_stats = True
+    for _ in range(3):
+        q1(x, ln, update=True)
+        q2(x, ln, update=True)
+        assert len(hipvq.PENDING) == 1
+        hipvq.flush_codebook_sync()
+    for (k, a), b in zip(q1.state_dict().items(), q2.state_dict().values()):
+        assert torch.equal(a, b), k
+
+
 def check_mr_stft(device):
     """MultiResolutionSTFTLoss of the product against the reference values in frontends.npz."""
     from msmctts_amd.trainers.criterions.stft_loss import MultiResolutionSTFTLoss

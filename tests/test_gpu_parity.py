@@ -231,3 +231,17 @@ def test_multi_resolution_stft_loss_matches_reference():
 
 def test_vq_edge_cases_empty_single_frame_zero_length_ragged():
     _parity.check_vq_edge_cases(DEV)
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+def test_fused_add_layernorm_gate_tanh_match_torch(dtype, tol):
+    """csrc/norm.hip on the device against the stock operator chains (PyTorch-ROCm is the checker here)"""
+    _parity.check_norm_kernels(DEV, dtype, tol)
+
+
+def test_hip_adamw_matches_torch_adamw_with_clipping():
+    _parity.check_hip_adamw(DEV)
+
+
+def test_codebook_statistics_split_update_is_the_fused_update():
+    _parity.check_codebook_split_update(DEV)
