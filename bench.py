@@ -44,13 +44,27 @@ def vq_bytes_per_frame(D, H):
 
 
 class KernelTimer(object):
-    """HIP-event timing of the hand-written launches on the stream they are launched on, attributed to the kernel
-    symbol the C library reports (the names rocprofv3 prints), with the algorithmic flops and bytes of each call."""
+    """Per-kernel timing of the hand-written launches through the library's own launch log (msmc_prof_*): every launch
+    is bracketed by a HIP event pair recorded on the stream it is launched on and logged under the symbol rocprofv3
+    prints.  The Python-level calls are wrapped only to attach their algorithmic flops / bytes to the launches they issue:
+    a call's work goes to its convolution / search kernels (helper launches such as the partial-sum reduce are listed with
+    zero work); when one grouped call resolves to several kernel instantiations its work is split in proportion to their
+    measured durations."""
+    HELPERS = ('conv_wgrad_reduce_kernel', 'colsum_kernel', 'reflect_fold', 'lrelu_bwd')
 
     def __init__(self):
-        self.records = {}
+        self.calls = []
         self.enabled = False
-        self.count = lambda: 0
+        self.lib = None
+
+    def start(self, L):
+        self.lib = L
+        L.msmc_prof_enable(1)
+        self.enabled = True
+
+    def stop(self):
+        self.enabled = False
+        self.lib.msmc_prof_enable(0)
 
     def wrap(self, module, fn_name, label, work):
         inner = getattr(module, fn_name)
@@ -59,23 +73,38 @@ class KernelTimer(object):
         def timed(*args, **kw):
             if not timer.enabled:
                 return inner(*args, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n0 = timer.count()
-            s.record()
+            i0 = timer.lib.msmc_prof_count()
             out = inner(*args, **kw)
-            e.record()
-            # one call can be several kernels (a strided data gradient / transposed convolution launches one per phase)
-            timer.records.setdefault(label(), []).append((s, e) + tuple(work(*args, **kw)) + (max(1, timer.count() - n0),))
+            timer.calls.append((i0, timer.lib.msmc_prof_count()) + tuple(work(*args, **kw)))
             return out
 
         setattr(module, fn_name, timed)
 
     def summary(self):
+        if self.lib is None:
+            return {}
+        import ctypes
+        n = self.lib.msmc_prof_count()
+        buf, ms = ctypes.create_string_buffer(128), ctypes.c_float()
+        recs = []
+        for i in range(n):
+            if self.lib.msmc_prof_read(i, buf, 128, ctypes.byref(ms)) != 0:
+                raise RuntimeError('msmc_prof_read(%d) failed' % i)
+            recs.append([buf.value.decode(), float(ms.value), 0.0, 0.0])
+        for i0, i1, flops, byts in self.calls:
+            main = [r for r in recs[i0:i1] if not r[0].startswith(self.HELPERS)]
+            tot = sum(r[1] for r in main)
+            for r in main:
+                share = r[1] / tot if tot > 0 else 1.0 / len(main)
+                r[2] += flops * share
+                r[3] += byts * share
         out = {}
-        for label, recs in self.records.items():
-            ms = [r[0].elapsed_time(r[1]) for r in recs]
-            out[label] = dict(launches=sum(r[4] for r in recs), calls=len(ms), total_ms=sum(ms),
-                              flops=sum(r[2] for r in recs), bytes=sum(r[3] for r in recs))
+        for name, t, f, b in recs:
+            o = out.setdefault(name, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+            o['launches'] += 1
+            o['total_ms'] += t
+            o['flops'] += f
+            o['bytes'] += b
         return out
 
 
@@ -250,7 +279,6 @@ def main():
         return 2.0 * n * x.shape[-1] * et.shape[1], n * vq_bytes_per_frame(x.shape[-1], et.shape[0])
 
     timer.wrap(hipvq, 'vq_search', lambda: 'vq_search_reg_kernel', vq_work)
-    timer.count = lambda: lib.get().msmc_conv_launch_count()
 
     # algorithmic work of one call: flops = 2 * output points * Cout * Cin * taps; bytes = every operand once
     def conv_work(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, **k):
@@ -337,7 +365,7 @@ def main():
         from msmctts_amd.hip import convnet
         convnet.STREAMS_ENABLED = False          # ... and one stream, so that an event pair brackets exactly one kernel
         trainer.model.zero_grad()
-        timer.enabled = True
+        timer.start(lib.get())
         t1 = time.perf_counter()
         for i in range(args.kernel_timing_steps):
             # park the GPU while the host enqueues the step: with the queue full, an event pair brackets kernel
@@ -347,7 +375,7 @@ def main():
             step(args.warmup + args.steps + i)
         torch.cuda.synchronize()
         ms_instr = (time.perf_counter() - t1) / args.kernel_timing_steps * 1e3
-        timer.enabled = False
+        timer.stop()
         convnet.STREAMS_ENABLED = True
         trainer.use_graphs = graphs_were
     # warm-up phase (iteration < warmup_steps: autoencoder + frame decoder only), SURVEY.md 8d asks for it separately
@@ -389,7 +417,7 @@ def main():
         # fp32 kernels (spectral DFT projections, VQ search) are priced against the fp32 MFMA peak
         peak = MFMA_PEAK_TFLOPS['fp32'] if ('float' in label or label.startswith('vq_')) else mfma_peak
         t_mfma, t_hbm = rec['flops'] / (peak * 1e12), rec['bytes'] / (HBM_PEAK_GBS * 1e9)
-        sec = rec['total_ms'] * 1e-3
+        sec = max(rec['total_ms'] * 1e-3, 1e-12)
         kernels[label] = dict(launches=rec['launches'], avg_us=rec['total_ms'] * 1e3 / rec['launches'],
                               ms_per_step=rec['total_ms'] / nst, tflops=rec['flops'] / sec / 1e12,
                               gbps=rec['bytes'] / sec / 1e9, bound='mfma' if t_mfma >= t_hbm else 'hbm',
@@ -397,7 +425,8 @@ def main():
                               bytes_per_launch=rec['bytes'] / rec['launches'],
                               flops_per_launch=rec['flops'] / rec['launches'])
     if kernels:
-        label = max(kernels, key=lambda k: kernels[k]['ms_per_step'])
+        # (helper kernels carry no algorithmic work of their own: the roofline object is about a kernel that does)
+        label = max((k for k in kernels if kernels[k]['flops_per_launch'] > 0), key=lambda k: kernels[k]['ms_per_step'])
         k = kernels[label]
         traffic = mfma_util = None
         try:
@@ -414,7 +443,8 @@ def main():
                         traffic=traffic)
         roof.update(mfma_util_percent_pmc=mfma_util, kernel=label, launches=k['launches'], avg_us=k['avg_us'], ms_per_step=k['ms_per_step'],
                     bytes_per_launch=k['bytes_per_launch'], flops_per_launch=k['flops_per_launch'])
-        roof['note'] = ('dominant hand-written kernel by summed HIP-event time over %d instrumented single-stream steps; achieved = '
+        roof['note'] = ('dominant hand-written kernel by summed HIP-event time (one event pair per launch, recorded on the '
+                        'launch stream by the library: msmc_prof_*) over %d instrumented single-stream steps; achieved = '
                         'algorithmic flops (or bytes) of its launches / their summed durations; bound = the roofline '
                         'that prices those launches higher; traffic = PMC HBM bytes per launch from '
                         'profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command), null if not collected'

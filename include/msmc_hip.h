@@ -144,6 +144,15 @@ void msmc_conv_set_wgrad_generation(int n);
 /* 2 (default) = second-generation forward / data-gradient gather kernel, 1 = first generation (A/B tests) */
 void msmc_conv_set_gather_generation(int n);
 void msmc_conv_set_narrow(int on);
+/* Per-launch profiling log (process-wide; bench.py's kernel table): while enabled, every kernel this library launches
+ * -- from any thread: the backward pass runs on the autograd engine's -- is bracketed by a HIP event pair recorded on the launch's own stream and logged under the
+ * symbol rocprofv3 prints for it (template arguments included where the launcher knows the instantiation, the template's
+ * name otherwise).  msmc_prof_enable(1) clears the log and starts recording, (0) stops; msmc_prof_read synchronises
+ * on the record's end event and returns its duration in milliseconds (0 on success).  At most 16384 records; off by
+ * default (cost when off: one thread-local flag test per launch). */
+void msmc_prof_enable(int on);
+int msmc_prof_count(void);
+int msmc_prof_read(int i, char* name, int cap, float* ms);
 /* Symbol of the kernel the calling thread's most recent msmc_conv_gather / msmc_conv_wgrad launched (profiling aid). */
 const char* msmc_conv_last_kernel(void);
 /* Number of kernels the calling thread's msmc_conv_gather / msmc_conv_wgrad calls have launched so far. */

@@ -819,7 +819,7 @@ static int cv_try_pipe(const msmc_conv_desc* d, msmc_stream stream, bool* done) 
     rc = msmc_allow_lds((const void*)conv_gather_pipe_kernel<T, NT, MT>, (int)lds);
     if (rc) return rc;
     MSMC_LAUNCH((conv_gather_pipe_kernel<T, NT, MT>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, G);
-    msmc_conv_last = msmc_kname("conv_gather_pipe_kernel", EltName<T>::v, NT, MT);
+    msmc_conv_last = msmc_prof_name(msmc_kname("conv_gather_pipe_kernel", EltName<T>::v, NT, MT));
     *done = true;
     return msmc_check_launch();
 }
@@ -954,7 +954,7 @@ static int cv2_dispatch(int nt, int ckm, int sb, dim3 grid, size_t lds, msmc_str
     else if (ckm == 2) CV2_SB(1, 2);
     else CV2_SB(1, 1);
 #undef CV2_SB
-    msmc_conv_last = msmc_kname2(grp ? "conv_gather2_group_kernel" : "conv_gather2_kernel", EltName<T>::v, nt, ckm, sb);
+    msmc_conv_last = msmc_prof_name(msmc_kname2(grp ? "conv_gather2_group_kernel" : "conv_gather2_kernel", EltName<T>::v, nt, ckm, sb));
     return msmc_check_launch();
 }
 
@@ -1007,12 +1007,12 @@ static int cv_launch(const msmc_conv_desc* d, msmc_stream stream) {
         rc = msmc_allow_lds((const void*)conv_gather_kernel<T, 2>, (int)lds);
         if (rc) return rc;
         MSMC_LAUNCH((conv_gather_kernel<T, 2>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, G);
-        msmc_conv_last = msmc_kname("conv_gather_kernel", EltName<T>::v, 2, -1);
+        msmc_conv_last = msmc_prof_name(msmc_kname("conv_gather_kernel", EltName<T>::v, 2, -1));
     } else {
         rc = msmc_allow_lds((const void*)conv_gather_kernel<T, 1>, (int)lds);
         if (rc) return rc;
         MSMC_LAUNCH((conv_gather_kernel<T, 1>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, G);
-        msmc_conv_last = msmc_kname("conv_gather_kernel", EltName<T>::v, 1, -1);
+        msmc_conv_last = msmc_prof_name(msmc_kname("conv_gather_kernel", EltName<T>::v, 1, -1));
     }
     return msmc_check_launch();
 }
@@ -1252,7 +1252,7 @@ static int cv_direct_launch(const msmc_conv_desc* d, msmc_stream stream) {
         else DIR_CO(8);
 #undef DIR_CO
 #undef DIR_GO
-        msmc_conv_last = msmc_kname2("conv_direct_small_kernel", EltName<T>::v, CI, CO, 0);
+        msmc_conv_last = msmc_prof_name(msmc_kname2("conv_direct_small_kernel", EltName<T>::v, CI, CO, 0));
         rc = msmc_check_launch();
         return rc ? rc : 1;
     }
@@ -1265,7 +1265,7 @@ static int cv_direct_launch(const msmc_conv_desc* d, msmc_stream stream) {
         if (b > 8L * MSMC_NUM_CU) b = 8L * MSMC_NUM_CU;
         MSMC_LAUNCH((conv_direct_dot_kernel<T>), dim3((unsigned)(b < 1 ? 1 : b)), dim3(256), lds, (msmc_stream_t)stream, *d,
                     npoints);
-        msmc_conv_last = msmc_kname("conv_direct_dot_kernel", EltName<T>::v, 0, -1);
+        msmc_conv_last = msmc_prof_name(msmc_kname("conv_direct_dot_kernel", EltName<T>::v, 0, -1));
         rc = msmc_check_launch();
         return rc ? rc : 1;
     }
@@ -1276,7 +1276,7 @@ static int cv_direct_launch(const msmc_conv_desc* d, msmc_stream stream) {
         rc = msmc_allow_lds((const void*)conv_direct_outer_kernel<T>, (int)lds);
         if (rc) return rc;
         MSMC_LAUNCH((conv_direct_outer_kernel<T>), dim3(blocks(nitems)), dim3(256), lds, (msmc_stream_t)stream, *d, nitems);
-        msmc_conv_last = msmc_kname("conv_direct_outer_kernel", EltName<T>::v, 0, -1);
+        msmc_conv_last = msmc_prof_name(msmc_kname("conv_direct_outer_kernel", EltName<T>::v, 0, -1));
         rc = msmc_check_launch();
         return rc ? rc : 1;
     }
@@ -1513,7 +1513,7 @@ static int cv_ks_launch(const msmc_conv_desc* d, msmc_stream stream) {
     else if (ckm == 2) KS_GO(1, 2);
     else KS_GO(1, 1);
 #undef KS_GO
-    msmc_conv_last = msmc_kname("conv_gather_ks_kernel", EltName<T>::v, nt, ckm);
+    msmc_conv_last = msmc_prof_name(msmc_kname("conv_gather_ks_kernel", EltName<T>::v, nt, ckm));
     rc = msmc_check_launch();
     return rc ? rc : 1;
 }
@@ -1600,17 +1600,17 @@ static int cv_direct_group_launch(const msmc_conv_desc* const* members, int m, D
         else DIRG_CO(8);
 #undef DIRG_CO
 #undef DIRG_GO
-        msmc_conv_last = msmc_kname2("conv_direct_small_group_kernel", EltName<T>::v, key.ci, key.co, 0);
+        msmc_conv_last = msmc_prof_name(msmc_kname2("conv_direct_small_group_kernel", EltName<T>::v, key.ci, key.co, 0));
     } else if (key.kind == 2) {
         rc = msmc_allow_lds((const void*)conv_direct_dot_group_kernel<T>, (int)lds);
         if (rc) return rc;
         MSMC_LAUNCH((conv_direct_dot_group_kernel<T>), grid, dim3(256), lds, (msmc_stream_t)stream, a);
-        msmc_conv_last = msmc_kname("conv_direct_dot_group_kernel", EltName<T>::v, 0, -1);
+        msmc_conv_last = msmc_prof_name(msmc_kname("conv_direct_dot_group_kernel", EltName<T>::v, 0, -1));
     } else {
         rc = msmc_allow_lds((const void*)conv_direct_outer_group_kernel<T>, (int)lds);
         if (rc) return rc;
         MSMC_LAUNCH((conv_direct_outer_group_kernel<T>), grid, dim3(256), lds, (msmc_stream_t)stream, a);
-        msmc_conv_last = msmc_kname("conv_direct_outer_group_kernel", EltName<T>::v, 0, -1);
+        msmc_conv_last = msmc_prof_name(msmc_kname("conv_direct_outer_group_kernel", EltName<T>::v, 0, -1));
     }
     return msmc_check_launch();
 }
@@ -2137,8 +2137,8 @@ static int wg_launch(const msmc_conv_desc* d, const void* g, float* dw, float* d
     else if (d->ntaps <= 12) WG_GO(12);
     else WG_GO(16);
 #undef WG_GO
-    msmc_conv_last = msmc_kname("conv_wgrad_kernel", EltName<T>::v, d->ntaps <= 4 ? 4 : d->ntaps <= 8 ? 8 : d->ntaps <= 12 ? 12 : 16,
-                                fast ? 1 : 0);
+    msmc_conv_last = msmc_prof_name(msmc_kname("conv_wgrad_kernel", EltName<T>::v,
+                                               d->ntaps <= 4 ? 4 : d->ntaps <= 8 ? 8 : d->ntaps <= 12 ? 12 : 16, fast ? 1 : 0));
     return msmc_check_launch();
 }
 
@@ -2674,7 +2674,7 @@ static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* 
     else if (pl.tpw == 4) WG2_GO(4);
     else WG2_GO(5);
 #undef WG2_GO
-    msmc_conv_last = msmc_kname("conv_wgrad2_kernel", nullptr, pl.tpw, -1);
+    msmc_conv_last = msmc_prof_name(msmc_kname("conv_wgrad2_kernel", nullptr, pl.tpw, -1));
     rc = msmc_check_launch();
     if (rc || !pl.P.ws) return rc;
     const long n_dw = (long)d->ntaps * d->Cout * d->Cin;
@@ -2795,7 +2795,7 @@ extern "C" int msmc_conv_wgrad_group_ws(const msmc_conv_desc* descs, const void*
         else if (tpw == 4) WG2G_GO(4);
         else WG2G_GO(5);
 #undef WG2G_GO
-        msmc_conv_last = msmc_kname("conv_wgrad2_group_kernel", nullptr, tpw, -1);
+        msmc_conv_last = msmc_prof_name(msmc_kname("conv_wgrad2_group_kernel", nullptr, tpw, -1));
         rc = msmc_check_launch();
         if (rc) return rc;
         for (int level = 0; level < 2 && nmembers; ++level) {

@@ -22,10 +22,83 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define MSMC_DEV static __device__ __forceinline__
 #define MSMC_DEV_INLINE __device__ __forceinline__
 #define MSMC_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
-#define MSMC_LAUNCH(kernel, grid, block, lds, stream, ...) \
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__)
-
 typedef hipStream_t msmc_stream_t;
+
+// ---- per-launch profiling log (msmc_prof_* of include/msmc_hip.h) ------------------------------------------
+// Off by default: one thread-local flag test per launch.  On: every launch of the calling thread is bracketed by a HIP
+// event pair ON THE STREAM IT IS LAUNCHED ON and logged under the kernel's symbol -- the launch macro supplies the
+// template's name, launchers that know the instantiation (msmc_conv_gather / _wgrad ...) overwrite it through
+// msmc_prof_name with the text rocprofv3 prints.  bench.py reads the log after a device synchronisation.
+struct MsmcProfRec {
+    char name[120];
+    hipEvent_t e0, e1;
+};
+#define MSMC_PROF_MAX 16384
+// ONE log per process: a training step launches from two threads (the forward pass from the caller's, the backward pass
+// from the autograd engine's), one after the other; slots are claimed with an atomic counter.
+struct MsmcProfLog {
+    volatile int on = 0;
+    int n = 0;                       // claimed slots (atomic increments)
+    MsmcProfRec* rec = nullptr;
+};
+inline MsmcProfLog msmc_prof_log;
+inline thread_local int msmc_prof_mine = -1;          // slot of the calling thread's most recent launch
+static inline void msmc_prof_pre(hipStream_t st) {
+    MsmcProfLog& L = msmc_prof_log;
+    const int i = __atomic_fetch_add(&L.n, 1, __ATOMIC_RELAXED);
+    msmc_prof_mine = i < MSMC_PROF_MAX ? i : -1;
+    if (msmc_prof_mine < 0) return;
+    MsmcProfRec& r = L.rec[i];
+    r.name[0] = 0;
+    hipEventCreate(&r.e0);
+    hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, st);
+}
+static inline void msmc_prof_post(hipStream_t st, const char* text) {
+    if (msmc_prof_mine < 0) return;
+    MsmcProfRec& r = msmc_prof_log.rec[msmc_prof_mine];
+    hipEventRecord(r.e1, st);
+    int j = 0;                                        // "(kernel<T, 4>)" -> "kernel"
+    for (const char* c = text; *c && *c != '<' && j < (int)sizeof(r.name) - 1; ++c)
+        if (*c != '(' && *c != ' ') r.name[j++] = *c;
+    r.name[j] = 0;
+}
+// the launcher knows the instantiation of the launch it just issued
+static inline const char* msmc_prof_name(const char* name) {
+    if (msmc_prof_log.on && msmc_prof_mine >= 0) {
+        MsmcProfRec& r = msmc_prof_log.rec[msmc_prof_mine];
+        int j = 0;
+        for (; name[j] && j < (int)sizeof(r.name) - 1; ++j) r.name[j] = name[j];
+        r.name[j] = 0;
+    }
+    return name;
+}
+static inline int msmc_prof_used() { return msmc_prof_log.n < MSMC_PROF_MAX ? msmc_prof_log.n : MSMC_PROF_MAX; }
+static inline void msmc_prof_reset_impl() {
+    MsmcProfLog& L = msmc_prof_log;
+    for (int i = 0; i < msmc_prof_used(); ++i) {
+        hipEventDestroy(L.rec[i].e0);
+        hipEventDestroy(L.rec[i].e1);
+    }
+    L.n = 0;
+    msmc_prof_mine = -1;
+}
+static inline int msmc_prof_read_impl(int i, char* name, int cap, float* ms) {
+    MsmcProfLog& L = msmc_prof_log;
+    if (i < 0 || i >= msmc_prof_used() || !name || cap <= 0 || !ms) return -1;
+    MsmcProfRec& r = L.rec[i];
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(ms, r.e0, r.e1) != hipSuccess) return -2;
+    int j = 0;
+    for (; r.name[j] && j < cap - 1; ++j) name[j] = r.name[j];
+    name[j] = 0;
+    return 0;
+}
+#define MSMC_LAUNCH(kernel, grid, block, lds, stream, ...)                    \
+    do {                                                                      \
+        if (msmc_prof_log.on) msmc_prof_pre(stream);                          \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);    \
+        if (msmc_prof_log.on) msmc_prof_post(stream, #kernel);                \
+    } while (0)
 
 // ---- 64-lane cross-lane moves ------------------------------------------------------------
 // value known to be identical in every lane of the wave -> scalar register

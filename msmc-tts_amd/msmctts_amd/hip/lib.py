@@ -98,6 +98,9 @@ _SIGNATURES.update({
     'msmc_conv_wgrad_ws': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _sz, _vp]),
     'msmc_conv_wgrad_group_ws': (_i, [ctypes.POINTER(ConvDesc), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                  _i, _vp, _sz, _vp]),
+    'msmc_prof_enable': (None, [_i]),
+    'msmc_prof_count': (_i, []),
+    'msmc_prof_read': (_i, [_i, ctypes.c_char_p, _i, ctypes.POINTER(ctypes.c_float)]),
     'msmc_wn_prepare_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_wn_prepare_multi_tiled': (_i, [_vp, _i, _i, _i, _vp]),
     'msmc_wn_backward_multi': (_i, [_vp, _i, _i, _vp]),

@@ -239,4 +239,13 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 static inline int msmc_emu_num_cu() { const char* e = getenv("MSMC_EMU_CUS"); return e ? atoi(e) : 3; }
 #define MSMC_NUM_CU (msmc_emu_num_cu())
 static inline int msmc_check_launch() { return 0; }
+// (the per-launch profiling log of the device build: nothing to time on the interpreter)
+struct MsmcProfRec { char name[120]; };
+struct MsmcProfLog { int on = 0, n = 0; MsmcProfRec* rec = nullptr; };
+inline MsmcProfLog msmc_prof_log;
+static inline int msmc_prof_used() { return 0; }
+static inline const char* msmc_prof_name(const char* name) { return name; }
+#define MSMC_PROF_MAX 1
+static inline void msmc_prof_reset_impl() {}
+static inline int msmc_prof_read_impl(int, char*, int, float*) { return -1; }
 static inline int msmc_allow_lds(const void*, int) { return 0; }
