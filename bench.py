@@ -480,7 +480,7 @@ def main():
         sys.exit(3)
     if not args.no_microbench:
         out['vq_microbench'] = [vq_microbench(device, args.heads, args.codewords), vq_microbench(device, 4, 64),
-                                vq_microbench(device, 8, 512),
+                                vq_microbench(device, 8, 512), vq_microbench(device, 1, 64),
                                 vq_microbench(device, args.heads, args.codewords, variant=0),
                                 vq_microbench(device, 4, 64, variant=0)]
         say('vq microbench done')
