@@ -124,6 +124,7 @@ def _signature(desc):
 # has no entry and budget is left.  Ranks of a data-parallel job therefore stop issuing timing launches after the same
 # bounded number of shapes instead of stalling each other at the collectives whenever one of them meets a new length.
 TUNE_BUDGET = [int(os.environ.get('MSMC_TUNE_BUDGET', '256'))]
+TUNE_BORROW = os.environ.get('MSMC_TUNE_BORROW', '1') != '0'       # 0: time every shape (tools/tune_bench_shapes.py)
 _CLASS_INDEX = {}                             # (kind, class) -> [(pixels, signature)]
 _CLASS_INDEXED = [0]
 
@@ -134,6 +135,8 @@ def _class_of(sig):
 
 
 def _nearest_tuned(sig):
+    if not TUNE_BORROW:
+        return None
     if _CLASS_INDEXED[0] != len(TUNED):      # (re)index lazily: TUNED only grows
         _CLASS_INDEX.clear()
         for k in TUNED:

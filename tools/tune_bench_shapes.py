@@ -5,6 +5,8 @@ import os, sys, random, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd'), os.path.join(ROOT, 'tests')]
 os.environ['MSMC_TUNE_CACHE'] = '/nonexistent'            # start from scratch
+os.environ['MSMC_TUNE_BUDGET'] = '1000000'                # ... and time every shape itself (no borrowing from neighbours)
+os.environ['MSMC_TUNE_BORROW'] = '0'
 import torch
 import bench
 from msmctts_amd.hip import conv
