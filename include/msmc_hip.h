@@ -139,6 +139,9 @@ typedef struct msmc_conv_desc {
 void msmc_conv_set_pipeline(int on);
 /* Perf-sweep switches: force the weight-gradient pixel split (0 = model), allow 32-channel N tiles for small grids. */
 void msmc_conv_set_wgrad_split(int n);
+/* Perf-sweep switch: accumulators (32x32 output blocks) per wave of the second-generation weight gradient, 1..5 (default 5:
+ * fewest re-reads of the staged tiles; fewer = more workgroups per CU). */
+void msmc_conv_set_wgrad_tpw(int n);
 /* 2 (default) = second-generation bf16 weight-gradient kernel, 1 = first generation (A/B tests) */
 void msmc_conv_set_wgrad_generation(int n);
 /* 2 (default) = second-generation forward / data-gradient gather kernel, 1 = first generation (A/B tests) */

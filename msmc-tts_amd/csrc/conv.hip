@@ -59,6 +59,8 @@ static int msmc_gather_generation = 2;          // 1 = first-generation forward 
 extern "C" void msmc_conv_set_gather_generation(int n) { msmc_gather_generation = n; }
 static int msmc_wgrad_generation = 2;           // 1 = first-generation bf16 weight-gradient kernel (A/B tests)
 extern "C" void msmc_conv_set_wgrad_generation(int n) { msmc_wgrad_generation = n; }
+static int msmc_wgrad_tpw_cap = 5;              // accumulators per wave of the second-generation weight gradient (perf sweeps)
+extern "C" void msmc_conv_set_wgrad_tpw(int n) { msmc_wgrad_tpw_cap = n < 1 ? 1 : n > 5 ? 5 : n; }
 static int msmc_wgrad_split_override = 0;       // tests / perf sweeps: force the pixel-split factor
 extern "C" void msmc_conv_set_wgrad_split(int n) { msmc_wgrad_split_override = n; }
 
@@ -2599,7 +2601,8 @@ static int wg2_plan(const msmc_conv_desc* d, const void* g, Wg2Plan* pl, bool ge
     if (lds < 1024) lds = 1024;                  // the bias reduction reuses the first KiB
     // taps per workgroup: a wave carries at most 5 accumulators (6 would spill at two waves per SIMD)
     const int ncb = d->Cout > 32 ? 2 : 1, nib = d->Cin > 32 ? 2 : 1, wpc = 4 / ncb;
-    int tgmax = 5 * wpc / nib;
+    int tgmax = msmc_wgrad_tpw_cap * wpc / nib;
+    if (tgmax < 1) tgmax = 1;
     P.ntg = (d->ntaps + tgmax - 1) / tgmax;
     P.TG = (d->ntaps + P.ntg - 1) / P.ntg;
     const int tpw = (P.TG * nib + wpc - 1) / wpc;

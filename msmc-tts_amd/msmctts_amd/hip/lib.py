@@ -98,6 +98,7 @@ _SIGNATURES.update({
     'msmc_conv_wgrad_ws': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _sz, _vp]),
     'msmc_conv_wgrad_group_ws': (_i, [ctypes.POINTER(ConvDesc), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                  _i, _vp, _sz, _vp]),
+    'msmc_conv_set_wgrad_tpw': (None, [_i]),
     'msmc_prof_enable': (None, [_i]),
     'msmc_prof_count': (_i, []),
     'msmc_prof_read': (_i, [_i, ctypes.c_char_p, _i, ctypes.POINTER(ctypes.c_float)]),
@@ -153,6 +154,9 @@ def get():
     global _lib
     if _lib is None:
         _lib = load()
+        cap = os.environ.get('MSMC_WGRAD_TPW')          # perf sweeps (tools/): accumulators per wave of the weight gradient
+        if cap:
+            _lib.msmc_conv_set_wgrad_tpw(int(cap))
     return _lib
 
 
