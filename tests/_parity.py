@@ -346,6 +346,33 @@ def check_hip_adamw(dev):
         assert (p - q).abs().max() <= 2e-6
 
 
+def check_resblock_standalone(dev):
+    """ResBlock1 called on its own (reference hifigan/common.py:44-51) against the stock operator chain: output, input
+    gradient and every parameter gradient"""
+    import torch.nn.functional as F
+    from msmctts_amd.networks.hifigan.common import ResBlock1
+    torch.manual_seed(5)
+    for C, k, L in ((32, 3, 77), (16, 7, 40)):
+        rb = ResBlock1(C, k, (1, 3, 5)).to(dev)
+        x = torch.randn(2, C, L, device=dev, requires_grad=True)
+        y = rb(x)
+        go = torch.randn_like(y)
+        (y * go).sum().backward()
+        got = {n: p.grad.clone() for n, p in rb.named_parameters()}
+        gx = x.grad.clone()
+        rb.zero_grad()
+        xr = x.detach().clone().requires_grad_(True)
+        h = xr
+        for c1, c2 in zip(rb.convs1, rb.convs2):
+            t = F.conv1d(F.leaky_relu(h, 0.1), c1.weight(), c1.bias, 1, c1.padding, c1.dilation)
+            h = F.conv1d(F.leaky_relu(t, 0.1), c2.weight(), c2.bias, 1, c2.padding, c2.dilation) + h
+        (h * go).sum().backward()
+        close(y, h, 2e-4, what='resblock out')
+        close(gx, xr.grad, 2e-4, 1e-3, what='resblock gx')
+        for n, p in rb.named_parameters():
+            close(got[n], p.grad, 2e-4, 2e-3, what=n)
+
+
 def check_codebook_split_update(dev):
     """msmc_vq_ema_stats + msmc_vq_ema_apply (the two halves around the cross-rank sum of sync_codebook_stats) are, on
     one rank, bit for bit the fused msmc_vq_ema_update"""

@@ -245,3 +245,7 @@ def test_hip_adamw_matches_torch_adamw_with_clipping():
 
 def test_codebook_statistics_split_update_is_the_fused_update():
     _parity.check_codebook_split_update(DEV)
+
+
+def test_resblock_standalone_matches_stock_operators():
+    _parity.check_resblock_standalone(DEV)
