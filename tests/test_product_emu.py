@@ -265,3 +265,15 @@ def test_codebook_statistics_split_update_is_the_fused_update():
 
 def test_resblock_standalone_matches_stock_operators():
     _parity.check_resblock_standalone('cpu')
+
+
+def test_train_steps_match_reference_with_ungrouped_launches():
+    """MSMC_GROUPED=0 path (one launch per convolution; tap gradients through _HipConv, incl. the reflect-padded MRD
+    layers' fold + add) against the same reference fixture"""
+    from msmctts_amd.hip import convnet
+    keep = convnet.GROUPED
+    convnet.GROUPED = False
+    try:
+        _parity.check_train_steps('cpu')
+    finally:
+        convnet.GROUPED = keep
