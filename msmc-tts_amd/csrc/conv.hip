@@ -679,74 +679,45 @@ MSMC_DEV void cv2_body(const msmc_conv_desc& d, const CvGeom& G, const int block
     T* out = (T*)d.out;
     const bool ovec = (d.Cout % VEC) == 0;
     const size_t img = (size_t)b * d.Hout * d.Wout;
-    if (ovec) {
-        // EB output vectors per work-item at a time: every mask / residual load of the batch is in flight before the first
-        // use (one global-load latency per batch instead of one per vector)
-        constexpr int EB = 4;
-        const float mslope = d.mask_slope, odiv = d.out_div, oslope = d.out_slope;
-        for (int e0 = tid; e0 < 128 * BNV; e0 += 256 * EB) {
-            u32x4 mk[EB], r1[EB], r2[EB];
-            size_t oo[EB];
-            int mm[EB], vc[EB];
-            bool ok[EB];
-#pragma unroll
-            for (int u = 0; u < EB; ++u) {
-                const int e = e0 + 256 * u;
-                const int m = e / BNV;
-                vc[u] = (e - m * BNV) * VEC;
-                mm[u] = m;
-                const int po = e < 128 * BNV ? out_off[m] : -1, co = co0 + vc[u];
-                ok[u] = po >= 0 && co < d.Cout;
-                oo[u] = ok[u] ? (img + po) * d.Cout + co : 0;
-                if (ok[u]) {
-                    if (mask) mk[u] = *(const u32x4*)(mask + oo[u]);
-                    if (res) r1[u] = *(const u32x4*)(res + oo[u]);
-                    if (res2) r2[u] = *(const u32x4*)(res2 + oo[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < EB; ++u) {
-                if (!ok[u]) continue;
-                const int co = co0 + vc[u];
-                alignas(16) T mkv[VEC], r1v[VEC], r2v[VEC], ov[VEC];
-                if (mask) *(u32x4*)mkv = mk[u];
-                if (res) *(u32x4*)r1v = r1[u];
-                if (res2) *(u32x4*)r2v = r2[u];
-#pragma unroll
-                for (int q = 0; q < VEC; ++q) {
-                    float x = ot[mm[u] * OS + vc[u] + q] + (d.bias ? d.bias[co + q] : 0.f);
-                    if (mask) x = x * (Elt<T>::ld(&mkv[q]) > 0.f ? 1.f : mslope);
-                    if (res) x = x + Elt<T>::ld(&r1v[q]);
-                    if (res2) x = Elt<T>::ld(&r2v[q]) + x;
-                    if (odiv != 1.f) x = x / odiv;
-                    if (oslope != 1.f) x = x > 0.f ? x : x * oslope;
-                    Elt<T>::st(&ov[q], x);
-                }
-                *(u32x4*)(out + oo[u]) = *(const u32x4*)ov;
-            }
-        }
-        return;
-    }
     for (int e = tid; e < 128 * BNV; e += 256) {
         const int m = e / BNV, vcol = (e - m * BNV) * VEC;
         const int po = out_off[m], co = co0 + vcol;
         if (po < 0 || co >= d.Cout) continue;
         const size_t o = (img + po) * d.Cout + co;
-        alignas(16) T ov[VEC];
+        float v[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) v[q] = ot[m * OS + vcol + q] + ((d.bias && co + q < d.Cout) ? d.bias[co + q] : 0.f);
+        alignas(16) T mk[VEC], r1[VEC], r2[VEC], ov[VEC];
+        if (ovec) {
+            if (mask) *(u32x4*)mk = *(const u32x4*)(mask + o);
+            if (res) *(u32x4*)r1 = *(const u32x4*)(res + o);
+            if (res2) *(u32x4*)r2 = *(const u32x4*)(res2 + o);
+        } else {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const bool in = co + q < d.Cout;
+                if (mask) mk[q] = in ? mask[o + q] : (T)0;
+                if (res) r1[q] = in ? res[o + q] : (T)0;
+                if (res2) r2[q] = in ? res2[o + q] : (T)0;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            const bool in = co + q < d.Cout;
-            float x = ot[m * OS + vcol + q] + ((d.bias && in) ? d.bias[co + q] : 0.f);
-            if (mask) x = x * (Elt<T>::ld(in ? mask + o + q : mask) > 0.f ? 1.f : d.mask_slope);
-            if (res && in) x = x + Elt<T>::ld(res + o + q);
-            if (res2 && in) x = Elt<T>::ld(res2 + o + q) + x;
+            float x = v[q];
+            if (mask) x = x * (Elt<T>::ld(&mk[q]) > 0.f ? 1.f : d.mask_slope);
+            if (res) x = x + Elt<T>::ld(&r1[q]);
+            if (res2) x = Elt<T>::ld(&r2[q]) + x;
             if (d.out_div != 1.f) x = x / d.out_div;
             if (d.out_slope != 1.f) x = x > 0.f ? x : x * d.out_slope;
             Elt<T>::st(&ov[q], x);
         }
+        if (ovec) {
+            *(u32x4*)(out + o) = *(const u32x4*)ov;
+        } else {
 #pragma unroll
-        for (int q = 0; q < VEC; ++q)
-            if (co + q < d.Cout) out[o + q] = ov[q];
+            for (int q = 0; q < VEC; ++q)
+                if (co + q < d.Cout) out[o + q] = ov[q];
+        }
     }
 }
 
