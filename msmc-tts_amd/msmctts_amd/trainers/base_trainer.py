@@ -48,15 +48,33 @@ class BaseTrainer(object):
             reducer.finish()
 
     # -- loop ------------------------------------------------------------------------------
-    def train(self, data_loader, logger=None):
-        """Run until ``config.training_steps``; ``data_loader`` is re-iterated as epochs."""
+    def train(self, data_loader=None, logger=None):
+        """Run until ``config.training_steps``; ``data_loader`` is re-iterated as epochs.  Without one the loader is built
+        from ``config.dataset`` / ``config.dataloader`` like the reference's loop does (base_trainer.py:40-41), sharded per
+        rank under data parallelism, and wrapped in a ``DeviceLoader`` (one batch ahead on the GPU; with ``use_graphs``
+        and a fixed ``segment_length`` every batch is padded to that many frames, i.e. static shapes)."""
         graphs = getattr(self, 'use_graphs', False)
+        sampler = None
+        if data_loader is None:
+            from ..datasets import DeviceLoader, build_dataloader
+            dataset, sampler, host_loader = build_dataloader(self.config.dataset, self.config.dataloader,
+                                                             bool(getattr(self, 'distributed', False)))
+            device = next(self.model.parameters()).device
+            hop = getattr(dataset, 'frameshift', {}).get('mel')
+            seg = getattr(dataset, 'segment_length', -1)
+            pad = seg // hop if (graphs and hop and seg and seg > 0) else None
+            data_loader = DeviceLoader(host_loader, device, pad_frames=pad, hop=hop,
+                                       mel_pad=getattr(dataset, 'padding_value', {}).get('mel', 0.0))
         if self.optimizer is None:
             self.optimizer = build_optimizer(self.model, self.config.optimizer, capturable=graphs)
         scheduler = build_lr_scheduler(self.config.lr_scheduler) if 'lr_scheduler' in self.config else None
         iteration = self.attempt_load_checkpoint()
         self.model.train()
+        epoch = 0
         while True:
+            if sampler is not None:
+                sampler.set_epoch(epoch)
+            epoch += 1
             for batch in data_loader:
                 if scheduler is not None:
                     scheduler.step(self.optimizer, iteration)

@@ -2,7 +2,7 @@
 
 Mirrors the parts of reference msmctts/utils/utils.py that the train step touches:
 ``get_mask_from_lengths`` (:154-158), ``module_search`` (:276-316), ``load_checkpoint`` (:207-250),
-``to_model`` (:137-151).  Feature IO (npy/wav readers) is out of scope.
+``to_model`` (:137-151).  Feature IO (npy / wav readers) lives in msmctts_amd/datasets/readers.py.
 """
 import glob
 import importlib
@@ -25,7 +25,8 @@ def to_model(batch, device=None):
     if isinstance(batch, (list, tuple)):
         return [to_model(b, device) for b in batch]
     if isinstance(batch, dict):
-        return {k: to_model(v, device) for k, v in batch.items()}
+        # ('*_host' entries are host-side copies kept on purpose, e.g. DeviceLoader's mel_length_host)
+        return {k: (v if k.endswith('_host') else to_model(v, device)) for k, v in batch.items()}
     t = torch.as_tensor(batch).contiguous()
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else t.device
