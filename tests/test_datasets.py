@@ -184,3 +184,41 @@ def test_training_loop_from_feature_files_to_checkpoint(tmp_path):
     assert seen2 == [2]                                   # resumed after the checkpointed iteration
     for (k, a), b in zip(tr.model.state_dict().items(), torch.load(root + '/ckpt/model_1', weights_only=False)['model'].values()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.gpu
+def test_graph_replayed_training_from_feature_files_on_the_gpu(tmp_path):
+    """the whole chain on the device: feature files -> MelDataset -> DeviceLoader (static shapes) -> VQGANTrainer with
+    hipGraph replay across warm-up and GAN phase; losses finite, parameters move, graphs were replayed"""
+    import _parity
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.utils.config import ConfigItem
+    root = str(tmp_path)
+    os.makedirs(root + '/mel')
+    os.makedirs(root + '/wav')
+    rng = np.random.default_rng(0)
+    ids = []
+    for i, T in enumerate((30, 41, 26, 35, 50, 24)):
+        ids.append('u%d' % i)
+        np.save(root + '/mel/u%d.npy' % i, rng.standard_normal((T, 80)).astype(np.float32))
+        np.save(root + '/wav/u%d.npy' % i, rng.uniform(-1, 1, (T * 300, 1)).astype(np.float32))
+    with open(root + '/id.list', 'w') as f:
+        f.write('\n'.join(ids) + '\n')
+    cfg, task = _parity.build_small('cuda:0')
+    cfg.dataset = ConfigItem(dict(_name='MelDataset', id_list=root + '/id.list', feature=['mel', 'wav'], samplerate=24000,
+                                  dimension=[80, 1], frameshift=[300, 1],
+                                  feature_path=[root + '/mel/{}.npy', root + '/wav/{}.npy'], padding_value=[-4.0, 0.0],
+                                  segment_length=24 * 300, pre_load=True))
+    cfg.dataloader = ConfigItem(dict(batch_size=3, num_workers=0))
+    cfg.save_checkpoint_dir, cfg.iters_per_checkpoint, cfg.training_steps = root + '/ckpt', 100, 12
+    cfg.trainer.warmup_steps = 3
+    tr = build_trainer(cfg, task, num_gpus=1, rank=0)
+    tr.use_graphs = True
+    before = {k: v.detach().clone() for k, v in tr.model.state_dict().items()}
+    seen = []
+    assert tr.train(logger=lambda i, log: seen.append({k: float(v) for k, v in log['loss'].items()})) == 12
+    assert len(seen) == 13 and all(np.isfinite(list(l.values())).all() for l in seen)
+    assert 'g_loss' in seen[-1] and 'g_loss' not in seen[0]
+    assert tr._graphs is not None
+    moved = sum(int(not torch.equal(v, before[k])) for k, v in tr.model.state_dict().items())
+    assert moved > 100
