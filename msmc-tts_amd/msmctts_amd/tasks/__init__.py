@@ -1,6 +1,6 @@
 """Task container: the module whose children (``autoencoder``, ``discriminator``) key optimizers and
-checkpoints (reference msmctts/tasks/__init__.py:9-43, base_task.py:6-33).  Inference glue is out of
-scope for this path."""
+checkpoints (reference msmctts/tasks/__init__.py:9-43, base_task.py:6-33), built from a configuration or restored
+from a checkpoint (``infer.py``)."""
 from os.path import dirname
 
 import torch

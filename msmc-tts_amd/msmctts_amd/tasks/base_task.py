@@ -20,7 +20,7 @@ class BaseTask(torch.nn.Module):
         pass
 
     def infer_step(self, features):
-        raise NotImplementedError('inference is outside the training hot path (SURVEY.md 8f row 4)')
+        raise NotImplementedError
 
     def debug_step(self, features):
         pass

@@ -346,6 +346,41 @@ def check_hip_adamw(dev):
         assert (p - q).abs().max() <= 2e-6
 
 
+def check_inference(device):
+    """the task's inference glue (analysis-synthesis; text -> predictor -> synthesis with teacher durations) in evaluation
+    mode against the reference's MSMCTTS.infer_step (tests/golden/small_infer.npz)"""
+    from msmctts_amd.tasks import build_task
+    from msmctts_amd.utils.config import Config
+    z, zp, zb = load_npz('small_infer.npz'), load_npz('small_predictor.npz'), load_npz('small_modules.npz')
+
+    def check(tag, wavs):
+        for i, w in enumerate(wavs):
+            want = z['%s.wav.%d' % (tag, i)]
+            w = w.detach().double().reshape(-1).cpu()
+            assert w.numel() == int(want[0]), (tag, i, w.numel(), want[0])
+            assert abs(w.mean().item() - want[1]) <= TOL and abs(w.abs().mean().item() - want[2]) <= TOL
+            close(w[:3000:3], want[3:], what='%s wav %d' % (tag, i))
+
+    _, atask = build_small(device)
+    atask.eval()
+    mel, ml = t(zb['batch.mel']).to(device), t(zb['batch.mel_length']).to(device)
+    with torch.no_grad():
+        res = atask.infer_step({'mel': mel, 'mel_length': ml}, mode='train_autoencoder')
+    check('ae', res['wav'])
+    cfg = Config({'id': 'small_infer', 'task': {'_name': 'MSMCTTS', '_mode': 'train_predictor', 'predictor': small_predictor_cfg()},
+                  'dataset': dict(samplerate=24000, feature=['mel', 'wav'], frameshift=[300, 1])})
+    task = build_task(cfg, mode='infer')
+    task.load_state_dict({k[len('state.'):]: t(v) for k, v in zp.items() if k.startswith('state.')})
+    task = task.to(device).eval()
+    task.autoencoder, task.load_modules = atask.autoencoder, True
+    feed = {k: t(zp['batch.' + k]).to(device) for k in ('text', 'text_length', 'dur')}
+    with torch.no_grad():
+        res = task(feed)                                # mode 'infer' -> infer_step -> predict
+    check('tts', res['wav'])
+    close(res['embedding'], z['tts.embedding'], what='embedding')
+    assert np.array_equal(res['duration'].cpu().numpy(), z['tts.duration'])
+
+
 def check_resblock_standalone(dev):
     """ResBlock1 called on its own (reference hifigan/common.py:44-51) against the stock operator chain: output, input
     gradient and every parameter gradient"""

@@ -222,3 +222,42 @@ def test_graph_replayed_training_from_feature_files_on_the_gpu(tmp_path):
     assert tr._graphs is not None
     moved = sum(int(not torch.equal(v, before[k])) for k, v in tr.model.state_dict().items())
     assert moved > 100
+
+
+def test_infer_entry_point_writes_waveforms_from_a_checkpoint(tmp_path):
+    """infer.py: checkpoint -> task (its stored configuration) -> evaluation dataset -> analysis-synthesis -> one 16-bit
+    PCM file per utterance with hop * frames samples, and the raw-float copy requested beside it"""
+    import subprocess
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'tests', 'emu')])
+    from msmctts_amd.hip import lib
+    lib.use_library_for_tests(os.path.join(ROOT, 'tests', 'emu', 'libmsmc_emu.so'))
+    import importlib.util
+    import _parity
+    root = str(tmp_path)
+    os.makedirs(root + '/mel')
+    rng = np.random.default_rng(3)
+    for uid, T in (('a', 12), ('b', 20)):
+        np.save(root + '/mel/%s.npy' % uid, rng.standard_normal((T, 80)).astype(np.float32))
+    with open(root + '/id.list', 'w') as f:
+        f.write('a\nb\n')
+    cfg, task = _parity.build_small('cpu')
+    conf = cfg.to_dict()
+    conf['dataset'] = dict(_name='MelDataset', id_list=root + '/id.list', feature=['mel'], samplerate=24000, dimension=[80],
+                           frameshift=[300], feature_path=[root + '/mel/{}.npy'], padding_value=[-4.0])
+    conf['save_features'] = [['wav', '.wav', 24000], ['wav', '.dat', 24000]]
+    torch.save({'model': task.state_dict(), 'iteration': 7, 'config': conf}, root + '/model_7')
+    spec = importlib.util.spec_from_file_location('infer_entry', os.path.join(ROOT, 'infer.py'))
+    entry = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(entry)
+    argv, sys.argv = sys.argv, ['infer.py', '-m', root + '/model_7', '-j', '2']
+    try:
+        entry.main()
+    finally:
+        sys.argv = argv
+    out = root + '/eval-7/wav'
+    assert sorted(os.listdir(out)) == ['a.dat', 'a.wav', 'b.dat', 'b.wav']
+    with wave.open(out + '/b.wav', 'rb') as w:
+        assert (w.getnframes(), w.getframerate(), w.getsampwidth()) == (20 * 300, 24000, 2)
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype='<i2')
+    raw = np.fromfile(out + '/b.dat', dtype=np.float32)
+    assert raw.shape == (6000,) and np.abs(pcm / 32767.0 - np.clip(raw, -1, 1)).max() < 1e-4

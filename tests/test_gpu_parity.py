@@ -249,3 +249,7 @@ def test_codebook_statistics_split_update_is_the_fused_update():
 
 def test_resblock_standalone_matches_stock_operators():
     _parity.check_resblock_standalone(DEV)
+
+
+def test_inference_glue_matches_reference():
+    _parity.check_inference(DEV)

@@ -277,3 +277,7 @@ def test_train_steps_match_reference_with_ungrouped_launches():
         _parity.check_train_steps('cpu')
     finally:
         convnet.GROUPED = keep
+
+
+def test_inference_glue_matches_reference():
+    _parity.check_inference('cpu')
