@@ -147,6 +147,24 @@ void msmc_conv_set_wgrad_generation(int n);
 /* 2 (default) = second-generation forward / data-gradient gather kernel, 1 = first generation (A/B tests) */
 void msmc_conv_set_gather_generation(int n);
 void msmc_conv_set_narrow(int on);
+/* ---------------------------------------------------------------------------------------------
+ * Attention core of the FFT blocks (bf16, head size 64): softmax(q k^T * scale + bias) (dropout) v per (batch, head),
+ * q / k / v read in place from the fused projection, heads merged on the way out.  Replaces
+ *   ScaledDotProductAttention.forward + head split / merge   reference acoustic_models/transformer.py:237-259,296-315
+ * qkv [B][T][H][192] bf16 (q | k | v, 64 each); bias [B][Tp] fp32 additive key bias (0 = attend, -inf = padding), Tp = T
+ * rounded up to a multiple of 32 with a -inf tail; out [B][T][H*64] bf16; lse [B*H][T] fp32 (log-sum-exp of the scaled,
+ * biased scores: the backward pass recomputes the probabilities from it).  Dropout (p_drop) acts on the probabilities
+ * after the softmax; masks are a counter hash of (seed word on the device, salt, (b, h, query, key)).
+ * ------------------------------------------------------------------------------------------- */
+int msmc_attn_fwd(const void* qkv, const float* bias, void* out, float* lse, int B, int T, int H, int Tp, float scale,
+                  float p_drop, const long long* seed, long long salt, msmc_stream stream);
+/* Backward: dqkv [B][T][H][192] (dq | dk | dv, every element written) from dout [B][T][H*64]; the probabilities are
+ * recomputed from lse and the same dropout hash (same seed word and salt as the forward call).  dsum [B*H][T] fp32 scratch
+ * (dO . O per query, written by the first of the two launches, read by the second). */
+int msmc_attn_bwd(const void* qkv, const float* bias, const void* out, const float* lse, const void* dout, void* dqkv,
+                  float* dsum, int B, int T, int H, int Tp, float scale, float p_drop, const long long* seed, long long salt,
+                  msmc_stream stream);
+
 /* Per-launch profiling log (process-wide; bench.py's kernel table): while enabled, every kernel this library launches
  * -- from any thread: the backward pass runs on the autograd engine's -- is bracketed by a HIP event pair recorded on the launch's own stream and logged under the
  * symbol rocprofv3 prints for it (template arguments included where the launcher knows the instantiation, the template's

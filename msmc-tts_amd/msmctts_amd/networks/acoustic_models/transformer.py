@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...hip import attn as hipattn
 from ...hip import norm as hipnorm
 from ...hip.convnet import ConvBank, ConvLayer, hip_conv
 
@@ -46,6 +47,7 @@ def get_non_pad_mask(seq):
 
 # fused scaled_dot_product_attention for the FFT blocks (stock PyTorch-ROCm operator); MSMC_SDPA=0 keeps the bmm chain
 USE_SDPA = os.environ.get('MSMC_SDPA', '1') != '0'
+USE_HIP_ATTENTION = os.environ.get('MSMC_HIP_ATTENTION', '1') != '0'     # 0: stock fused attention also in bf16 (A/B)
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -103,6 +105,7 @@ class MultiHeadAttention(nn.Module):
         nn.init.xavier_normal_(self.fc.weight)
         self.dropout = nn.Dropout(dropout)
         self._salt = hipnorm.new_salt()
+        self._salt_attn = hipnorm.new_salt()
 
     def hip_layers(self):
         """the two projections as 1-tap convolutions of the block stack's ConvBank (a Linear weight (out, in) is the
@@ -117,12 +120,16 @@ class MultiHeadAttention(nn.Module):
         H, dk, dv = self.n_head, self.d_k, self.d_v
         qkv, x_res = hip_conv(bank, l_qkv, x.unsqueeze(1), tap=True)        # (tap: see PositionwiseFeedForward.forward_hip)
         x = x_res.squeeze(1)
-        qkv = qkv.view(bs, T, H, 2 * dk + dv).transpose(1, 2)               # [bs, H, T, 2dk+dv]
+        qkv = qkv.view(bs, T, H, 2 * dk + dv).transpose(1, 2)               # [bs, H, T, 2dk+dv] (a view)
         att = self.attention
         p = att.dropout.p if (hasattr(att, 'dropout') and att.training) else 0.0
-        q, k, v = _SplitHeads.apply(qkv, dk)
-        out = F.scaled_dot_product_attention(q, k, v, attn_mask=key_keep, dropout_p=p, scale=1.0 / att.temperature)
-        out = out.transpose(1, 2).reshape(bs, 1, T, H * dv)
+        if torch.is_tensor(key_keep):
+            q, k, v = _SplitHeads.apply(qkv, dk)
+            out = F.scaled_dot_product_attention(q, k, v, attn_mask=key_keep, dropout_p=p, scale=1.0 / att.temperature)
+            out = out.transpose(1, 2).reshape(bs, 1, T, H * dv)
+        else:       # padded key bias (hip/attn.py): the attention core on the kernels, q / k / v read in place
+            out = hipattn.attention(qkv.transpose(1, 2).reshape(bs, T, H * (2 * dk + dv)), key_keep[0], H,
+                                    1.0 / att.temperature, p, self._salt_attn).unsqueeze(1)
         h = hip_conv(bank, l_fc, out).squeeze(1)
         pd = self.dropout.p if self.training else 0.0
         return hipnorm.add_layer_norm(h, x, self.layer_norm.weight, self.layer_norm.bias, keep_row=keep_row, p_drop=pd,
@@ -242,8 +249,12 @@ class FFTBlocks(nn.Module):
             keep_row = pos.ne(0).to(torch.uint8).reshape(-1)
             # additive key-padding bias, built ONCE per stack in the compute dtype and broadcast over heads and queries (a
             # boolean mask is converted to this by every attention call: a where + fills per layer)
-            key_keep = torch.zeros(pos.shape[0], 1, 1, pos.shape[1], dtype=self.hip_dtype, device=pos.device).masked_fill_(
-                pos.eq(0).view(pos.shape[0], 1, 1, pos.shape[1]), float('-inf'))
+            att0 = self.layer_stack[0].slf_attn
+            if USE_HIP_ATTENTION and hipattn.supported(self.hip_dtype, att0.d_k, att0.d_v):
+                key_keep = (hipattn.pad_key_bias(pos),)      # csrc/attn.hip (bf16, head size 64)
+            else:                                            # the stock fused operator (fp32 parity runs, other head sizes)
+                key_keep = torch.zeros(pos.shape[0], 1, 1, pos.shape[1], dtype=self.hip_dtype, device=pos.device).masked_fill_(
+                    pos.eq(0).view(pos.shape[0], 1, 1, pos.shape[1]), float('-inf'))
             out = out.to(self.hip_dtype)
             for layer, (attn, ffn) in zip(self.layer_stack, layers):
                 out = layer.forward_hip(out, keep_row, key_keep, (bank, attn), (bank, ffn))

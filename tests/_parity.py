@@ -381,6 +381,44 @@ def check_inference(device):
     assert np.array_equal(res['duration'].cpu().numpy(), z['tts.duration'])
 
 
+def check_attention(dev):
+    """csrc/attn.hip (bf16, head size 64) against the reference's chain -- softmax(q k^T / sqrt(d) + key-padding mask),
+    dropout, times v -- in fp32: output and the gradient of the fused projection (dq | dk | dv), ragged lengths, key tiles
+    that are not multiples of 32, and with dropout: the kernel's own mask is recovered by a probe call (uniform
+    probabilities, one-hot values) and the backward pass must have regenerated exactly that mask"""
+    from msmctts_amd.hip import attn, norm
+    torch.manual_seed(0)
+    for (B, T, H, pd) in ((2, 45, 2, 0.0), (1, 64, 1, 0.0), (3, 33, 2, 0.0), (2, 50, 2, 0.25)):
+        qkv = (torch.randn(B, T, H * 192, device=dev) * 0.7).bfloat16().requires_grad_(True)
+        pos = torch.arange(1, T + 1, device=dev).repeat(B, 1)
+        if B > 1:
+            pos[1, T - 13:] = 0
+        bias = attn.pad_key_bias(pos)
+        assert bias.shape[1] % 32 == 0 and bool(torch.isinf(bias[:, T:]).all())
+        salt = norm.new_salt()
+        out = attn.attention(qkv, bias, H, 0.125, pd, salt)
+        go = torch.randn(B, T, H * 64, device=dev)
+        (out.float() * go).sum().backward()
+        mask = torch.ones(B, H, T, T, device=dev)
+        if pd > 0:
+            probe = torch.zeros(B, T, H, 192, device=dev)
+            for k in range(T):
+                probe[:, k, :, 128 + k] = 1.0
+            flat = torch.zeros_like(bias)
+            flat[:, T:] = float('-inf')
+            o = attn.attention(probe.reshape(B, T, H * 192).bfloat16(), flat, H, 0.0, pd, salt)
+            mask = (o.float().reshape(B, T, H, 64)[..., :T].permute(0, 2, 1, 3) > 0).float()
+            assert abs(mask.mean().item() - (1 - pd)) < 0.03
+        x = qkv.detach().float().reshape(B, T, H, 192).requires_grad_(True)
+        s = torch.einsum('bqhd,bkhd->bhqk', x[..., :64], x[..., 64:128]) * 0.125 + bias[:, None, None, :T]
+        ref = torch.einsum('bhqk,bkhd->bqhd', torch.softmax(s, -1) * mask / (1 - pd), x[..., 128:]).reshape(B, T, H * 64)
+        (ref * go).sum().backward()
+        close(out, ref, 2e-2, what='attention out')
+        g, gr = qkv.grad.float().reshape(B, T, H, 192), x.grad
+        for name, a, b in (('dq', 0, 64), ('dk', 64, 128), ('dv', 128, 192)):
+            close(g[..., a:b], gr[..., a:b], 2e-2 * max(1.0, float(gr[..., a:b].abs().max())), what=name)
+
+
 def check_resblock_standalone(dev):
     """ResBlock1 called on its own (reference hifigan/common.py:44-51) against the stock operator chain: output, input
     gradient and every parameter gradient"""

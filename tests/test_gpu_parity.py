@@ -253,3 +253,7 @@ def test_resblock_standalone_matches_stock_operators():
 
 def test_inference_glue_matches_reference():
     _parity.check_inference(DEV)
+
+
+def test_attention_kernels_match_the_reference_chain():
+    _parity.check_attention(DEV)

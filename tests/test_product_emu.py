@@ -281,3 +281,7 @@ def test_train_steps_match_reference_with_ungrouped_launches():
 
 def test_inference_glue_matches_reference():
     _parity.check_inference('cpu')
+
+
+def test_attention_kernels_match_the_reference_chain():
+    _parity.check_attention('cpu')
