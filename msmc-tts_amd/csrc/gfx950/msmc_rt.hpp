@@ -185,6 +185,9 @@ MSMC_DEV void lds_wait() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// hardware exponential (v_exp_f32 after a multiply by log2 e): ~1e-6 relative, exp(-inf) = 0
+MSMC_DEV float fast_exp(float x) { return __expf(x); }
+
 // ---- bf16 <-> f32 (round to nearest even), bit-level so host and device agree ---------------
 MSMC_DEV unsigned short f32_to_bf16_bits(float f) {
     unsigned int u = __float_as_uint(f);

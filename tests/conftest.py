@@ -26,3 +26,12 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _unbounded_tuning_budget():
+    """the per-process budget of kernel-timing launches (hip/conv.py TUNE_BUDGET) protects long training runs; a test
+    session touches more layer shapes than any of them and tests that force a kernel generation rely on the timing pass"""
+    from msmctts_amd.hip import conv
+    conv.TUNE_BUDGET[0] = 10 ** 9
+    yield
