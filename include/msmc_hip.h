@@ -300,6 +300,10 @@ int msmc_spec_mag_bwd(const float* spec, const float* mag, const float* gmag, fl
 /* MRD image, channels-last [B][F][T][2] from mel [B*T][FP]: ch0 = mel, ch1 = clamp((20 log10(mel) - ref + 100)/100, 0, 1)
  * (audio.py:411-419 'double' domain, ref_level_db = 20, min_level_db = -100). */
 int msmc_mrd_image_fwd(const float* mel, float* img, int B, int T, int F, int FP, msmc_stream stream);
+/* the same with the image (and its gradient) in the discriminator stack's compute dtype: 0 fp32, 1 bf16 */
+int msmc_mrd_image_fwd_dt(const float* mel, void* img, int B, int T, int F, int FP, int dtype, msmc_stream stream);
+int msmc_mrd_image_bwd_dt(const float* mel, const void* gimg, float* gmel, int B, int T, int F, int FP, int dtype,
+                          msmc_stream stream);
 int msmc_mrd_image_bwd(const float* mel, const float* gimg, float* gmel, int B, int T, int F, int FP,
                        msmc_stream stream);
 

@@ -92,7 +92,19 @@ __global__ __launch_bounds__(256) void spec_mag_bwd_kernel(const float* __restri
 }
 
 // img[b][f][t][0..1] <- mel[(b*T + t)][f]   (transposed write; reads are the strided side, tiny tensors)
-__global__ __launch_bounds__(256) void mrd_image_fwd_kernel(const float* __restrict__ mel, float* __restrict__ img, int T,
+// (image element type O: float, or bf16 bits when the discriminator stack computes in bf16 -- no separate cast launch)
+MSMC_DEV void sp_store2(float* p, float a, float b) { f32x2 o = {a, b}; *(f32x2*)p = o; }
+MSMC_DEV void sp_store2(unsigned short* p, float a, float b) {
+    *(unsigned int*)p = (unsigned int)f32_to_bf16_bits(a) | ((unsigned int)f32_to_bf16_bits(b) << 16);
+}
+MSMC_DEV void sp_load2(const float* p, float& a, float& b) { const f32x2 v = *(const f32x2*)p; a = v[0]; b = v[1]; }
+MSMC_DEV void sp_load2(const unsigned short* p, float& a, float& b) {
+    const unsigned int v = *(const unsigned int*)p;
+    a = __uint_as_float(v << 16);
+    b = __uint_as_float(v & 0xffff0000u);
+}
+template <typename O>
+__global__ __launch_bounds__(256) void mrd_image_fwd_kernel(const float* __restrict__ mel, O* __restrict__ img, int T,
                                                            int F, int FP, long total) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int t = (int)(e % T);
@@ -102,12 +114,12 @@ __global__ __launch_bounds__(256) void mrd_image_fwd_kernel(const float* __restr
         const float m = mel[(b * T + t) * FP + f];
         float lg = (20.f * log10f(m) - 20.f + 100.f) / 100.f;
         lg = lg < 0.f ? 0.f : (lg > 1.f ? 1.f : lg);
-        f32x2 o = {m, lg};
-        *(f32x2*)(img + e * 2) = o;
+        sp_store2(img + e * 2, m, lg);
     }
 }
 
-__global__ __launch_bounds__(256) void mrd_image_bwd_kernel(const float* __restrict__ mel, const float* __restrict__ gimg,
+template <typename O>
+__global__ __launch_bounds__(256) void mrd_image_bwd_kernel(const float* __restrict__ mel, const O* __restrict__ gimg,
                                                            float* __restrict__ gmel, int T, int F, int FP, long total) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int f = (int)(e % FP);
@@ -117,10 +129,11 @@ __global__ __launch_bounds__(256) void mrd_image_bwd_kernel(const float* __restr
         float g = 0.f;
         if (f < F) {
             const float m = mel[e];
-            const f32x2 gi = *(const f32x2*)(gimg + (((b * F + f) * (long)T) + t) * 2);
+            float g0, g1;
+            sp_load2(gimg + (((b * F + f) * (long)T) + t) * 2, g0, g1);
             const float lg = (20.f * log10f(m) - 20.f + 100.f) / 100.f;
-            g = gi[0];
-            if (lg > 0.f && lg < 1.f) g = g + gi[1] * (0.2f / (2.302585092994046f * m));
+            g = g0;
+            if (lg > 0.f && lg < 1.f) g = g + g1 * (0.2f / (2.302585092994046f * m));
         }
         gmel[e] = g;
     }
@@ -182,19 +195,35 @@ int msmc_spec_mag_bwd(const float* spec, const float* mag, const float* gmag, fl
                 FP, lo, clamp_mode, total);
     return msmc_check_launch();
 }
-int msmc_mrd_image_fwd(const float* mel, float* img, int B, int T, int F, int FP, msmc_stream stream) {
-    if (!mel || !img || B <= 0 || T <= 0 || F <= 0 || FP < F) return MSMC_E_SHAPE;
+int msmc_mrd_image_fwd_dt(const float* mel, void* img, int B, int T, int F, int FP, int dtype, msmc_stream stream) {
+    if (!mel || !img || B <= 0 || T <= 0 || F <= 0 || FP < F || dtype < 0 || dtype > 1) return MSMC_E_SHAPE;
     const long total = (long)B * F * T;
-    MSMC_LAUNCH(mrd_image_fwd_kernel, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, mel, img, T, F, FP, total);
+    if (dtype == 0)
+        MSMC_LAUNCH(mrd_image_fwd_kernel<float>, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, mel, (float*)img, T, F, FP,
+                    total);
+    else
+        MSMC_LAUNCH(mrd_image_fwd_kernel<unsigned short>, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, mel,
+                    (unsigned short*)img, T, F, FP, total);
     return msmc_check_launch();
+}
+int msmc_mrd_image_bwd_dt(const float* mel, const void* gimg, float* gmel, int B, int T, int F, int FP, int dtype,
+                          msmc_stream stream) {
+    if (!mel || !gimg || !gmel || B <= 0 || T <= 0 || F <= 0 || FP < F || dtype < 0 || dtype > 1) return MSMC_E_SHAPE;
+    const long total = (long)B * T * FP;
+    if (dtype == 0)
+        MSMC_LAUNCH(mrd_image_bwd_kernel<float>, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, mel, (const float*)gimg,
+                    gmel, T, F, FP, total);
+    else
+        MSMC_LAUNCH(mrd_image_bwd_kernel<unsigned short>, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, mel,
+                    (const unsigned short*)gimg, gmel, T, F, FP, total);
+    return msmc_check_launch();
+}
+int msmc_mrd_image_fwd(const float* mel, float* img, int B, int T, int F, int FP, msmc_stream stream) {
+    return msmc_mrd_image_fwd_dt(mel, img, B, T, F, FP, 0, stream);
 }
 int msmc_mrd_image_bwd(const float* mel, const float* gimg, float* gmel, int B, int T, int F, int FP,
                        msmc_stream stream) {
-    if (!mel || !gimg || !gmel || B <= 0 || T <= 0 || F <= 0 || FP < F) return MSMC_E_SHAPE;
-    const long total = (long)B * T * FP;
-    MSMC_LAUNCH(mrd_image_bwd_kernel, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, mel, gimg, gmel, T, F, FP,
-                total);
-    return msmc_check_launch();
+    return msmc_mrd_image_bwd_dt(mel, gimg, gmel, B, T, F, FP, 0, stream);
 }
 int msmc_log_clamp_fwd(const float* x, float* y, long n, float lo, msmc_stream stream) {
     if (!x || !y || n <= 0) return MSMC_E_SHAPE;

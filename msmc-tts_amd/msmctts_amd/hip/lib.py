@@ -75,6 +75,8 @@ _SIGNATURES.update({
     'msmc_spec_mag_bwd': (_i, [_vp, _vp, _vp, _vp, ctypes.c_long, _i, _i, _i, _f, _i, _vp]),
     'msmc_mrd_image_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'msmc_mrd_image_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'msmc_mrd_image_fwd_dt': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'msmc_mrd_image_bwd_dt': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msmc_log_clamp_fwd': (_i, [_vp, _vp, ctypes.c_long, _f, _vp]),
     'msmc_log_clamp_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _f, _vp]),
     'msmc_l1_multi_fwd': (_i, [ctypes.POINTER(TensorTable), _vp, _vp]),

@@ -77,15 +77,18 @@ class _SpecMag(torch.autograd.Function):
         return gs, None, None, None, None
 
 
+_IMG_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
 class _MrdImage(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mel, F):
+    def forward(ctx, mel, F, dtype=torch.float32):
         B, _, T, FP = mel.shape
-        img = torch.empty((B, F, T, 2), dtype=torch.float32, device=mel.device)
-        lib.check(lib.get().msmc_mrd_image_fwd(lib.ptr(mel), lib.ptr(img), B, T, F, FP, lib.stream(mel)),
-                  'msmc_mrd_image_fwd')
+        img = torch.empty((B, F, T, 2), dtype=dtype, device=mel.device)
+        lib.check(lib.get().msmc_mrd_image_fwd_dt(lib.ptr(mel), lib.ptr(img), B, T, F, FP, _IMG_DT[dtype], lib.stream(mel)),
+                  'msmc_mrd_image_fwd_dt')
         ctx.save_for_backward(mel)
-        ctx.F = F
+        ctx.F, ctx.dtype = F, dtype
         return img
 
     @staticmethod
@@ -93,10 +96,12 @@ class _MrdImage(torch.autograd.Function):
         (mel,) = ctx.saved_tensors
         B, _, T, FP = mel.shape
         g = g.contiguous()
+        if g.dtype != ctx.dtype:
+            g = g.to(ctx.dtype)
         gm = torch.empty_like(mel)
-        lib.check(lib.get().msmc_mrd_image_bwd(lib.ptr(mel), lib.ptr(g), lib.ptr(gm), B, T, ctx.F, FP, lib.stream(g)),
-                  'msmc_mrd_image_bwd')
-        return gm, None
+        lib.check(lib.get().msmc_mrd_image_bwd_dt(lib.ptr(mel), lib.ptr(g), lib.ptr(gm), B, T, ctx.F, FP, _IMG_DT[ctx.dtype],
+                                                  lib.stream(g)), 'msmc_mrd_image_bwd_dt')
+        return gm, None, None
 
 
 class _LogClamp(torch.autograd.Function):
@@ -150,8 +155,9 @@ def projection(mat, device):
     return W.unsqueeze(0).contiguous().to(device), W.t().unsqueeze(0).contiguous().to(device)
 
 
-def mrd_image(x, n_fft, hop, dft, fb):
-    """x (B, L) -> MRD input image, channels-last [B, F, T', 2] (ch0 mel-scaled magnitude, ch1 normalised log)."""
+def mrd_image(x, n_fft, hop, dft, fb, dtype=torch.float32):
+    """x (B, L) -> MRD input image, channels-last [B, F, T', 2] (ch0 mel-scaled magnitude, ch1 normalised log), written
+    in ``dtype`` (the discriminator stack's compute dtype: the spectra themselves stay fp32)."""
     B, L = x.shape
     F = n_fft // 2 + 1
     T = L // hop + 1
@@ -161,7 +167,7 @@ def mrd_image(x, n_fft, hop, dft, fb):
     mag = _SpecMag.apply(spec, F, _pad4(F), 1e-7, 1)
     if fb is not None:
         mag = _ConstGemm.apply(mag, fb[0], fb[1])
-    return _MrdImage.apply(mag, F)
+    return _MrdImage.apply(mag, F, dtype)
 
 
 def stft_magnitude(x, n_fft, hop, dft, lo):

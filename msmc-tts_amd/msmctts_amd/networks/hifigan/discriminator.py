@@ -76,7 +76,7 @@ class MultiResolutionDiscriminator(nn.Module):
     def thunks(self, bank, layers, x, dtype):
         assert self.domain == 'double', 'every shipped config uses the two-channel (mag, log-mag) image'
         wav = x.squeeze(1) if x.dim() == 3 else x
-        return [lambda stft=stft, disc=disc, ls=ls: disc.forward_hip(bank, ls, stft.image_cl(wav), dtype)
+        return [lambda stft=stft, disc=disc, ls=ls: disc.forward_hip(bank, ls, stft.image_cl(wav, dtype), dtype)
                 for stft, disc, ls in zip(self.stfts, self.discriminators, layers)]
 
 
@@ -163,7 +163,7 @@ class Discriminator(nn.Module):
         dtype = self.hip_dtype
         assert self.mrd.domain == 'double', 'every shipped config uses the two-channel (mag, log-mag) image'
         wav = y.squeeze(1)
-        xs = [stft.image_cl(wav).to(dtype) for stft in self.mrd.stfts]
+        xs = [stft.image_cl(wav, dtype) for stft in self.mrd.stfts]      # (images written in the compute dtype: no cast launches)
         r_fmaps = [[] for _ in xs]
         last = len(mrd[0]) - 1
         xs = hip_conv_group(bank, [dict(layer=mrd[j][0], x=xs[j], out_slope=LRELU_SLOPE) for j in range(len(xs))])
@@ -177,13 +177,14 @@ class Discriminator(nn.Module):
             xs = [x for x, _ in xt]
         r_scores = [x.permute(0, 3, 1, 2) for x in xs]
         ps = []
+        yc = y.to(dtype)                                  # ONE cast of the waveform; padding and folding in the compute dtype
         for d in self.mpd.discriminators:
-            b, c, t = y.shape
-            x = y
+            b, c, t = yc.shape
+            x = yc
             if t % d.period != 0:
                 x = F.pad(x, (0, d.period - (t % d.period)), 'reflect')
                 t = x.shape[2]
-            ps.append(x.reshape(b, t // d.period, d.period, 1).to(dtype))      # C == 1: NCHW and NHWC coincide
+            ps.append(x.reshape(b, t // d.period, d.period, 1))                # C == 1: NCHW and NHWC coincide
         p_fmaps = [[] for _ in ps]
         nl = len(mpd[0]) - 1
         # every feature map has two consumers (the next layer and the feature-matching loss): the loss reads the alias the

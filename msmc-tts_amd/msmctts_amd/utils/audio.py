@@ -84,12 +84,12 @@ class TorchSTFT(nn.Module):
             self._consts[key] = (dft, fb)
         return self._consts[key]
 
-    def image_cl(self, x):
-        """x (B, L) -> channels-last [B, F, T', 2]: ch0 (mel-scaled) magnitude, ch1 normalised log-magnitude."""
+    def image_cl(self, x, dtype=torch.float32):
+        """x (B, L) -> channels-last [B, F, T', 2] in ``dtype``: ch0 (mel-scaled) magnitude, ch1 normalised log-magnitude."""
         from ..hip import spectral
         dft, fb = self.consts(x.device)
         with torch.autocast(device_type=x.device.type, enabled=False):
-            return spectral.mrd_image(x.float(), self.fft_size, self.hop_size, dft, fb)
+            return spectral.mrd_image(x.float(), self.fft_size, self.hop_size, dft, fb, dtype)
 
     def transform(self, x):
         img = self.image_cl(x)                       # [B, F, T, 2]
