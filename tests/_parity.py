@@ -417,6 +417,22 @@ def check_attention(dev):
         g, gr = qkv.grad.float().reshape(B, T, H, 192), x.grad
         for name, a, b in (('dq', 0, 64), ('dk', 64, 128), ('dv', 128, 192)):
             close(g[..., a:b], gr[..., a:b], 2e-2 * max(1.0, float(gr[..., a:b].abs().max())), what=name)
+    # edge cases: a single frame, exactly one / one-plus-one key tile, four heads, an utterance with ONE valid key
+    for (B, T, H) in ((1, 1, 1), (2, 32, 4), (2, 33, 1), (2, 129, 2)):
+        qkv = torch.randn(B, T, H * 192, device=dev).bfloat16().requires_grad_(True)
+        pos = torch.arange(1, T + 1, device=dev).repeat(B, 1)
+        if B > 1:
+            pos[1, 1:] = 0
+        bias = attn.pad_key_bias(pos)
+        out = attn.attention(qkv, bias, H, 0.125)
+        out.float().sum().backward()
+        assert bool(torch.isfinite(out.float()).all()) and bool(torch.isfinite(qkv.grad.float()).all()), (B, T, H)
+        x = qkv.detach().float().reshape(B, T, H, 192)
+        s = torch.einsum('bqhd,bkhd->bhqk', x[..., :64], x[..., 64:128]) * 0.125 + bias[:, None, None, :T]
+        ref = torch.einsum('bhqk,bkhd->bqhd', torch.softmax(s, -1), x[..., 128:]).reshape(B, T, H * 64)
+        close(out, ref, 2e-2, what='attention edge %s' % ((B, T, H),))
+        if B > 1:               # every query of the one-key utterance returns that key's value
+            close(out[1].float().reshape(T, H, 64), x[1, :1, :, 128:].expand(T, H, 64), 1e-2, what='single key')
 
 
 def check_resblock_standalone(dev):
