@@ -126,7 +126,10 @@ typedef struct msmc_conv_desc {
                                2*(64- instead of 32-column wave tiles) + 4*(128- instead of 64-byte chunks); MSMC_E_SHAPE
                                where a configuration does not apply), 9 = 32-point tiles with the channel
                                chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
-                               2 = second generation (fp32 atomics), 3 = third (split partials + fixed-order reduce).  The host layer times the candidates once per layer shape.       */
+                               2 = second generation (fp32 atomics), 3 = third (split partials + fixed-order reduce), 4 / 5 / 6 = fourth (the
+                               third's result contract; pixel tiles flow through an LDS-DMA ring of three / two / four stages;
+                               MSMC_E_SHAPE outside its scope: unit strides, zero padding, channel counts multiples of 64,
+                               taps along one axis).  The host layer times the candidates once per layer shape.       */
     int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative).  msmc_conv_gather
                                variants 16..23 only: DIAGNOSTICS mask, 0 in production (1 skip the MFMAs, 2 the weight stream,
                                4 the halo loads, 8 the epilogue: tools/bench_gather3.py ABLATE=...; results are then garbage) */
@@ -202,7 +205,11 @@ int msmc_conv_wgrad_group(const msmc_conv_desc* descs, const void* const* g, flo
  * the chip; every split stores its partial dW (and db) into its own region of a caller-provided workspace with plain
  * stores, and a second launch adds the regions to dw / db in split order (bit-reproducible).  With a single split the
  * kernel accumulates straight into dw and needs no workspace.  msmc_conv_wgrad_workspace: bytes this descriptor needs
- * (0 for other variants / dtypes); a group needs the sum over its members.  MSMC_E_WORKSPACE when it is too small. */
+ * (0 for other variants / dtypes); a group needs the sum over its members.  MSMC_E_WORKSPACE when it is too small.
+ * Fourth generation (desc->variant 4 / 5 / 6, msmc-tts_amd/csrc/wgrad4.inc): same contract and second stage; the
+ * workgroup's pixel tiles (output gradient rows + the x rows all its taps touch) stream global -> LDS through a ring
+ * filled by global_load_lds_dwordx4 while the matrix cores work on the previous tile.  Inside msmc_conv_wgrad_group_ws
+ * such members join the shared grid as third-generation members. */
 size_t msmc_conv_wgrad_workspace(const msmc_conv_desc* desc, const void* g);
 int msmc_conv_wgrad_ws(const msmc_conv_desc* desc, const void* g, float* dw, float* db, void* workspace,
                        size_t workspace_bytes, msmc_stream stream);

@@ -159,6 +159,15 @@ MSMC_DEV void lds_dma16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 MSMC_DEV void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// at most N younger pieces (or other vector-memory loads) of the calling wave still in flight: pieces land in issue order
+template <int N>
+MSMC_DEV void lds_dma_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release fence, which makes
+// hipcc retire EVERY outstanding vector-memory operation (s_waitcnt vmcnt(0)) -- including LDS-DMA pieces of later ring
+// stages that are meant to stay in flight across the barrier.  The caller retires the pieces it needs first
+// (lds_dma_wait_n) and must not rely on this barrier for the visibility of global-memory writes.
+MSMC_DEV void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // The machine scheduler must not move instructions across this point (software pipelines written in source order:
 // hipcc otherwise sinks prefetching LDS reads down to their first use and waits with lgkmcnt(0)).
@@ -177,6 +186,15 @@ MSMC_DEV u16x8 lds_read128_async(const void* p) {
 MSMC_DEV int lds_read32_async(const void* p) {
     int v;
     asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"((__attribute__((address_space(3))) const char*)p));
+    return v;
+}
+// transposing read (see lds_read_tr16) at p + OFF bytes, hand-counted like the two above
+template <int OFF>
+MSMC_DEV u32x2 lds_read_tr16_async(const void* p) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"
+                 : "=v"(v)
+                 : "v"((__attribute__((address_space(3))) const char*)p), "n"(OFF));
     return v;
 }
 template <int N>

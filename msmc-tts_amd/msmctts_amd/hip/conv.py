@@ -68,7 +68,7 @@ _PLANS = {}
 # that differ by 2x between layers of equal arithmetic.  Off inside hipGraph capture and on the interpreter.
 AUTOTUNE = os.environ.get('MSMC_AUTOTUNE', '1') != '0'
 _GATHER_CANDIDATES = tuple((int(v), 0) for v in os.environ.get('MSMC_GATHER_VARIANTS', '1,2,3,4,5,8,9,16,17,18,19,20,21,22,23').split(','))
-_WGRAD_CANDIDATES = ((3, 0), (3, -1), (3, -2), (3, 1), (2, 0), (2, -1), (2, 1), (1, 0))
+_WGRAD_CANDIDATES = ((4, 0), (4, -1), (3, 0), (3, -1), (3, -2), (3, 1), (2, 0), (2, -1), (2, 1), (1, 0))
 TUNED = {}                                    # (kind, shape signature) -> (variant, split_shift, {candidate: ms})
 TUNE_CACHE = os.environ.get('MSMC_TUNE_CACHE', os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                                             'tuned_gfx950.json'))
@@ -232,8 +232,8 @@ def _wgrad(desc, g_ptr, dw, db, stream, what):
         cached = TUNED.get(('wgrad',) + _signature(desc)) if not lib._host_pointers_ok else None
         if cached is None and not lib._host_pointers_ok:
             cached = _nearest_tuned(('wgrad',) + _signature(desc))
-            if cached is not None and cached[0] == 3 and desc.dtype != 1:
-                cached = None                 # (the third generation is bf16-only)
+            if cached is not None and cached[0] >= 3 and desc.dtype != 1:
+                cached = None                 # (the third and fourth generations are bf16-only)
         if cached is not None:
             desc._borrowed = ('wgrad',) + _signature(desc) not in TUNED
             desc.variant, desc.split_shift, desc._tuned = cached[0], cached[1], True

@@ -213,9 +213,14 @@ MSMC_DEV u16x4 lds_read_tr16(const unsigned short* p) {
 // LDS-DMA: destination = wave-uniform base + 16 * lane (fibers copy at once; the wait is a no-op)
 MSMC_DEV void lds_dma16(const void* gsrc, void* lds_wave_base) { memcpy((char*)lds_wave_base + 16 * emu::lane(), gsrc, 16); }
 MSMC_DEV void lds_dma_wait() {}
+template <int N> MSMC_DEV void lds_dma_wait_n() {}
+MSMC_DEV void block_sync_lds() { emu::block_barrier(); }
 MSMC_DEV void sched_fence() {}
 MSMC_DEV u16x8 lds_read128_async(const void* p) { u16x8 v; memcpy(&v, p, 16); return v; }
 MSMC_DEV int lds_read32_async(const void* p) { int v; memcpy(&v, p, 4); return v; }
+template <int OFF> MSMC_DEV u32x2 lds_read_tr16_async(const void* p) {
+    return __builtin_bit_cast(u32x2, lds_read_tr16((const unsigned short*)((const char*)p + OFF)));
+}
 template <int N> MSMC_DEV void lds_wait() {}
 
 static inline unsigned int __float_as_uint(float f) { unsigned int u; memcpy(&u, &f, 4); return u; }

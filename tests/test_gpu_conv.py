@@ -55,6 +55,46 @@ def test_wgrad_generations_agree(gen):
         conv.TUNED.update(saved[1])
 
 
+WG4_LAYERS = [
+    # (name, B, Cin, Cout, H, W, kernel, stride, dilation, padding, reflect, in_slope)
+    ('ffn w1 256->1024 k3', 16, 256, 1024, 1, 400, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
+    ('ffn w2 1024->256 k3 T100', 16, 1024, 256, 1, 100, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
+    ('gen rb0 k11 d5 C256', 16, 256, 256, 1, 240, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
+    ('gen rb1 k7 d3 C128', 16, 128, 128, 1, 1200, (1, 7), (1, 1), (1, 3), (0, 9), False, 0.1),
+    ('gen rb2 k3 d1 C64', 16, 64, 64, 1, 6000, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
+    ('mpd p7 conv4 512->512 s1', 16, 512, 512, 22, 7, (5, 1), (1, 1), (1, 1), (2, 0), False, 0.2),
+]
+
+
+@pytest.mark.parametrize('variant', [4, 5, 6])
+def test_wgrad_fourth_generation_matches_pytorch(variant):
+    """fourth generation of the bf16 weight gradient (wgrad4.inc: LDS-DMA ring of three / two / four pixel-tile stages)
+    forced through the descriptor on the layer families it serves, against PyTorch; bit-reproducible like the third"""
+    from msmctts_amd.hip import conv, lib
+    saved = (conv._WGRAD_CANDIDATES, dict(conv.TUNED))
+    conv._WGRAD_CANDIDATES = ((variant, 0),)
+    try:
+        for case in WG4_LAYERS:
+            conv.TUNED.clear()
+            conv._PLANS.clear()
+            check_conv_case((case[0] + ' v%d' % variant,) + tuple(case[1:]), torch.bfloat16, 2e-2, DEV, parts=('wgrad',))
+        name, B, Cin, Cout, H, W, k, s, dil, pad, reflect, slope = WG4_LAYERS[3]
+        geom = conv.Geometry(H, W, k, s, dil, pad, reflect)
+        x = torch.randn(B, H, W, Cin, device=DEV).bfloat16()
+        g = torch.randn(B, geom.Hout, geom.Wout, Cout, device=DEV).bfloat16()
+        outs = []
+        for _ in range(3):
+            dw, db = torch.zeros(k[0] * k[1], Cout, Cin, device=DEV), torch.zeros(Cout, device=DEV)
+            conv.conv_wgrad(x, g, geom, k[0] * k[1], in_slope=slope, dw=dw, db=db)
+            outs.append((dw, db))
+        assert b'conv_wgrad4_kernel' in lib.get().msmc_conv_last_kernel()
+        assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
+    finally:
+        conv._WGRAD_CANDIDATES = saved[0]
+        conv.TUNED.clear()
+        conv.TUNED.update(saved[1])
+
+
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize('Cin,Cout,k,u,L', [(512, 256, 12, 6, 40), (256, 128, 11, 5, 240), (128, 64, 11, 5, 1200),
                                             (64, 32, 4, 2, 6000)])

@@ -250,6 +250,47 @@ def test_wgrad_third_generation_split_partials():
         L.msmc_conv_set_wgrad_split(0)
 
 
+WG4_CASES = [
+    # (name, B, Cin, Cout, H, W, kernel, stride, dilation, padding, reflect, in_slope)
+    ('ffn k3 128->64', 2, 128, 64, 1, 100, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
+    ('gen k11 d5 C64', 2, 64, 64, 1, 70, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
+    ('gen k7 d3 C64 long', 1, 64, 64, 1, 400, (1, 7), (1, 1), (1, 3), (0, 9), False, 0.1),
+    ('mpd 64->128 p3 s1', 2, 64, 128, 22, 3, (5, 1), (1, 1), (1, 1), (2, 0), False, 0.2),
+    ('valid k3 64->64', 1, 64, 64, 1, 37, (1, 3), (1, 1), (1, 1), (0, 0), False, 1.0),
+    ('wide pad k3 64->64', 1, 64, 64, 1, 20, (1, 3), (1, 1), (1, 1), (0, 2), False, 1.0),
+    ('tiny L3 k11 d5 C64', 1, 64, 64, 1, 3, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
+]
+
+
+@pytest.mark.parametrize('gen', [4, 5, 6])
+def test_wgrad_fourth_generation_ring(gen):
+    """generation 4 of the bf16 weight gradient (wgrad4.inc: LDS-DMA ring of 3 / 2 / 4 pixel-tile stages, source-side
+    swizzle, flattened pixel axis) against PyTorch on the interpreter: model split, one split (direct accumulation, the
+    ring wraps) and forced splits; shapes outside its scope fall back to the third generation"""
+    from msmctts_amd.hip import conv, lib
+    L = lib.get()
+    L.msmc_conv_set_wgrad_generation(gen)
+    try:
+        for split in (0, 1, 3):
+            L.msmc_conv_set_wgrad_split(split)
+            for case in WG4_CASES:
+                conv._PLANS.clear()
+                _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=('wgrad',))
+        L.msmc_conv_set_wgrad_split(0)
+        # the kernel that ran last for an in-scope layer is the fourth generation; out of scope (stride 3) it is not
+        name, B, Cin, Cout, H, W, k, s, dil, pad, reflect, slope = WG4_CASES[0]
+        geom = conv.Geometry(H, W, k, s, dil, pad, reflect)
+        x, g = torch.randn(B, H, W, Cin).bfloat16(), torch.randn(B, geom.Hout, geom.Wout, Cout).bfloat16()
+        conv.conv_wgrad(x, g, geom, k[0] * k[1], db=torch.zeros(Cout))
+        assert b'conv_wgrad4_kernel' in L.msmc_conv_last_kernel()
+        conv._PLANS.clear()
+        _convcases.check_conv_case(_convcases.SMALL[5], torch.bfloat16, 2e-2, 'cpu', parts=('wgrad',))
+        assert b'conv_wgrad4_kernel' not in L.msmc_conv_last_kernel()
+    finally:
+        L.msmc_conv_set_wgrad_generation(2)
+        L.msmc_conv_set_wgrad_split(0)
+
+
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 def test_fused_add_layernorm_gate_tanh_match_torch(dtype, tol):
     _parity.check_norm_kernels('cpu', dtype, tol)

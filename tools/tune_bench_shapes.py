@@ -1,10 +1,14 @@
 #!/usr/bin/env python
 """Runs ON the GPU box: time the kernel candidates of every convolution shape of the bench configuration (and of the
-GPU test-suite's layer cases) and write the choices to msmctts_amd/hip/tuned_gfx950.json (copied back via gpurun_out)."""
+GPU test-suite's layer cases) and write the choices to msmctts_amd/hip/tuned_gfx950.json (copied back via gpurun_out).
+RETUNE=wgrad4 keeps the committed table and re-times only the single-launch bf16 weight gradients the fourth-generation
+kernel can serve (one pass)."""
 import os, sys, random, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd'), os.path.join(ROOT, 'tests')]
-os.environ['MSMC_TUNE_CACHE'] = '/nonexistent'            # start from scratch
+RETUNE = os.environ.get('RETUNE', '')
+if not RETUNE:
+    os.environ['MSMC_TUNE_CACHE'] = '/nonexistent'        # start from scratch
 os.environ['MSMC_TUNE_BUDGET'] = '1000000'                # ... and time every shape itself (no borrowing from neighbours)
 os.environ['MSMC_TUNE_BORROW'] = '0'
 import torch
@@ -17,11 +21,29 @@ class A(object):
     codewords, heads, batch, frames, graph, dtype, no_autocast = 256, 4, 16, 400, False, 'bf16', False
 
 
+def _wgrad4_scope(key):
+    """signature of a single-launch weight gradient inside wgrad4.inc's scope (see wg4_plan)"""
+    if key[0] != 'wgrad':
+        return False
+    (dtype, B, Hin, Win, Cin, Hout, Wout, Cout, QH, QW, osy, osx, isy, isx, ntaps, dys, dxs, pad_mode) = key[1:19]
+    if dtype != 1 or Cin % 64 or Cout % 64 or pad_mode != 0 or (osy, osx, isy, isx) != (1, 1, 1, 1):
+        return False
+    if (QH, QW) != (Hout, Wout):
+        return False
+    return (Hin == 1 and Hout == 1 and not any(dys)) or (Win == Wout and not any(dxs))
+
+
 dev = torch.device('cuda:0')
 torch.cuda.set_device(0)
-for rep in range(2):                                      # two passes: keep the faster measurement of each candidate
+if RETUNE == 'wgrad4':
+    dropped = [k for k in conv.TUNED if _wgrad4_scope(k)]
+    for k in dropped:
+        del conv.TUNED[k]
+    print('re-timing %d weight-gradient shapes' % len(dropped))
+for rep in range(1 if RETUNE else 2):                     # two passes: keep the faster measurement of each candidate
     saved = dict(conv.TUNED)
-    conv.TUNED.clear()
+    if not RETUNE:
+        conv.TUNED.clear()
     cfg, trainer = bench.build(A, dev, 0, 1)
     batch = make_batch(A.batch, A.frames, 80, 300, seed=1234, rank=0, device='cpu')
     lengths = batch['mel_length'].tolist()
