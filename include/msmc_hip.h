@@ -127,7 +127,8 @@ typedef struct msmc_conv_desc {
                                where a configuration does not apply), 9 = 32-point tiles with the channel
                                chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation (fp32 atomics), 3 = third (split partials + fixed-order reduce), 4 / 5 / 6 = fourth (the
-                               third's result contract; pixel tiles flow through an LDS-DMA ring of three / two / four stages;
+                               third's result contract; pixel tiles flow through an LDS-DMA ring: 4 = three stages, fragment reads two
+                               steps ahead of the MFMAs, 5 = one step ahead, 6 = two stages, one step ahead;
                                MSMC_E_SHAPE outside its scope: unit strides, zero padding, channel counts multiples of 64,
                                taps along one axis).  The host layer times the candidates once per layer shape.       */
     int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative).  msmc_conv_gather
@@ -209,7 +210,10 @@ int msmc_conv_wgrad_group(const msmc_conv_desc* descs, const void* const* g, flo
  * Fourth generation (desc->variant 4 / 5 / 6, msmc-tts_amd/csrc/wgrad4.inc): same contract and second stage; the
  * workgroup's pixel tiles (output gradient rows + the x rows all its taps touch) stream global -> LDS through a ring
  * filled by global_load_lds_dwordx4 while the matrix cores work on the previous tile.  Inside msmc_conv_wgrad_group_ws
- * such members join the shared grid as third-generation members. */
+ * such members join the shared grid as third-generation members.
+ * msmc_conv_set_wgrad4_ablate: DIAGNOSTICS (tools/bench_wgrad_splits.py ABLATE=...), 0 in production: 1 skips the MFMA
+ * steps, 2 the LDS-DMA stream; results are then garbage. */
+void msmc_conv_set_wgrad4_ablate(int mask);
 size_t msmc_conv_wgrad_workspace(const msmc_conv_desc* desc, const void* g);
 int msmc_conv_wgrad_ws(const msmc_conv_desc* desc, const void* g, float* dw, float* db, void* workspace,
                        size_t workspace_bytes, msmc_stream stream);

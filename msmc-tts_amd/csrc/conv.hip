@@ -48,7 +48,8 @@ static const char* msmc_kname2(const char* base, const char* elt, int a, int b, 
 }
 static const char* msmc_kname(const char* base, const char* elt, int a, int b) {
     static thread_local char buf[96];
-    if (b >= 0) snprintf(buf, sizeof(buf), "%s<%s, %d, %d>", base, elt, a, b);
+    if (b >= 0 && !elt) snprintf(buf, sizeof(buf), "%s<%d, %d>", base, a, b);
+    else if (b >= 0) snprintf(buf, sizeof(buf), "%s<%s, %d, %d>", base, elt, a, b);
     else if (elt) snprintf(buf, sizeof(buf), "%s<%s, %d>", base, elt, a);
     else snprintf(buf, sizeof(buf), "%s<%d>", base, a);
     return buf;
@@ -2668,7 +2669,7 @@ static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* 
 
 #include "wgrad4.inc"
 
-// fourth generation (variants 4 / 5 / 6 = ring of 3 / 2 / 4 stages): MSMC_E_SHAPE where it does not apply
+// fourth generation (variants 4 / 5 / 6, see wg4_plan): MSMC_E_SHAPE where it does not apply
 static int wg4_launch(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream, float* ws,
                       size_t ws_floats) {
     Wg4Plan pl;
@@ -2680,19 +2681,20 @@ static int wg4_launch(const msmc_conv_desc* d, const void* g, float* dw, float* 
     }
     const dim3 grid(pl.gx, pl.gy, pl.gz);
     const unsigned short* gp = (const unsigned short*)g;
-#define WG4_GO(TP)                                                                                           \
+#define WG4_GO(TP, DD)                                                                                       \
     do {                                                                                                     \
-        rc = msmc_allow_lds((const void*)conv_wgrad4_kernel<TP>, (int)pl.lds);                               \
+        rc = msmc_allow_lds((const void*)conv_wgrad4_kernel<TP, DD>, (int)pl.lds);                           \
         if (rc) return rc;                                                                                   \
-        MSMC_LAUNCH((conv_wgrad4_kernel<TP>), grid, dim3(256), pl.lds, (msmc_stream_t)stream, *d, gp, dw, db, pl.P); \
+        MSMC_LAUNCH((conv_wgrad4_kernel<TP, DD>), grid, dim3(256), pl.lds, (msmc_stream_t)stream, *d, gp, dw, db, pl.P); \
     } while (0)
-    if (pl.tpw == 1) WG4_GO(1);
-    else if (pl.tpw == 2) WG4_GO(2);
-    else if (pl.tpw == 3) WG4_GO(3);
-    else if (pl.tpw == 4) WG4_GO(4);
-    else WG4_GO(5);
+    const bool ahead2 = d->variant == 4;
+    if (pl.tpw == 1) { if (ahead2) WG4_GO(1, 2); else WG4_GO(1, 1); }
+    else if (pl.tpw == 2) { if (ahead2) WG4_GO(2, 2); else WG4_GO(2, 1); }
+    else if (pl.tpw == 3) { if (ahead2) WG4_GO(3, 2); else WG4_GO(3, 1); }
+    else if (pl.tpw == 4) { if (ahead2) WG4_GO(4, 2); else WG4_GO(4, 1); }
+    else WG4_GO(5, 1);
 #undef WG4_GO
-    msmc_conv_last = msmc_prof_name(msmc_kname("conv_wgrad4_kernel", nullptr, pl.tpw, -1));
+    msmc_conv_last = msmc_prof_name(msmc_kname("conv_wgrad4_kernel", nullptr, pl.tpw, (ahead2 && pl.tpw < 5) ? 2 : 1));
     rc = msmc_check_launch();
     if (rc || !pl.P.ws) return rc;
     const long n_dw = (long)d->ntaps * d->Cout * d->Cin;

@@ -215,6 +215,16 @@ MSMC_DEV unsigned short f32_to_bf16_bits(float f) {
 }
 MSMC_DEV float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
+// leaky ReLU of two packed bf16 values, slope in [0, 1]: max(x, slope * x) in fp32 (x for x > 0, slope * x otherwise),
+// rounded back to bf16 by v_cvt_pk_bf16_f32 (round to nearest even, as f32_to_bf16_bits)
+MSMC_DEV unsigned int bf16x2_leaky(unsigned int w, float slope) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const float f0 = __uint_as_float(w << 16), f1 = __uint_as_float(w & 0xffff0000u);
+    const f32x2_ r = {fmaxf(f0, f0 * slope), fmaxf(f1, f1 * slope)};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(r, bf16x2_));
+}
+
 // ---- host-side helpers used by the C-ABI launchers ------------------------------------------
 #define MSMC_BACKEND_NAME "gfx950"
 #define MSMC_NUM_CU 256              // MI355X: 8 XCDs x 32 CUs

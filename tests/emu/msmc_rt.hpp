@@ -232,6 +232,11 @@ MSMC_DEV unsigned short f32_to_bf16_bits(float f) {
     return (unsigned short)(u >> 16);
 }
 MSMC_DEV float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+MSMC_DEV unsigned int bf16x2_leaky(unsigned int w, float slope) {
+    const float f0 = __uint_as_float(w << 16), f1 = __uint_as_float(w & 0xffff0000u);
+    const float r0 = f0 > 0.f ? f0 : f0 * slope, r1 = f1 > 0.f ? f1 : f1 * slope;
+    return (unsigned int)f32_to_bf16_bits(r0) | ((unsigned int)f32_to_bf16_bits(r1) << 16);
+}
 
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }

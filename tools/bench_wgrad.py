@@ -83,5 +83,7 @@ for name, B, Cin, Cout, H, W, k, s_, dil, pad, reflect, slope in SHAPES:
         if best is None or t < best[0]:
             best = (t, v, sh)
     gflop = 2.0 * B * geom.Hout * geom.Wout * Cout * Cin * T / 1e9
+    if best is None:
+        best = (float('inf'), 0, 0)
     print('%-28s %8.2f | %s | best v%d/%+d %.1f us %.0f TF/s' % (name, gflop, ' '.join(cells), best[1], best[2], best[0],
                                                                 gflop / best[0] * 1e-3), flush=True)
