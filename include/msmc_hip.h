@@ -219,6 +219,11 @@ int msmc_conv_wgrad_ws(const msmc_conv_desc* desc, const void* g, float* dw, flo
                        size_t workspace_bytes, msmc_stream stream);
 int msmc_conv_wgrad_group_ws(const msmc_conv_desc* descs, const void* const* g, float* const* dw, float* const* db, int n,
                              void* workspace, size_t workspace_bytes, msmc_stream stream);
+/* As msmc_conv_wgrad_group_ws; group4 != 0: the fourth-generation members of the call share grids of their own kernel
+ * (every member planned for its share of the chip, one second-stage launch for all of them) and the rest is issued as
+ * msmc_conv_wgrad_group_ws would; 0 = msmc_conv_wgrad_group_ws. */
+int msmc_conv_wgrad_group_ws4(const msmc_conv_desc* descs, const void* const* g, float* const* dw, float* const* db, int n,
+                              void* workspace, size_t workspace_bytes, msmc_stream stream, int group4);
 
 /* Weight-norm (torch weight_norm, dim=0) for MANY convolutions in one launch.
  * Item i: v [A][Bc][T] fp32 contiguous (A = dim 0, the normalised axis; T = taps), g [A] fp32.

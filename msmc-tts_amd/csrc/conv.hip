@@ -2755,14 +2755,123 @@ extern "C" size_t msmc_conv_wgrad_workspace(const msmc_conv_desc* d, const void*
 // n independent weight gradients (msmc_conv_wgrad semantics each): bf16 second- / third-generation members share grids.
 // Third-generation members (variant 3) take consecutive regions of the workspace; one grouped second-stage launch
 // folds the partial results of all of them.
-extern "C" int msmc_conv_wgrad_group_ws(const msmc_conv_desc* descs, const void* const* g, float* const* dw,
-                                        float* const* db, int n, void* workspace, size_t workspace_bytes,
-                                        msmc_stream stream) {
+// group4 != 0: fourth-generation members (variants 4 / 5 / 6 inside wgrad4.inc's scope) share grids of their own kernel
+// (conv_wgrad4_group_kernel, every member planned for its share of the chip); 0: they join the shared grid of the
+// second / third generation as third-generation members.  The host layer times both against one launch per member.
+extern "C" int msmc_conv_wgrad_group_ws4(const msmc_conv_desc* descs, const void* const* g, float* const* dw,
+                                         float* const* db, int n, void* workspace, size_t workspace_bytes,
+                                         msmc_stream stream, int group4) {
     if (!descs || !g || !dw || n <= 0 || n > MSMC_GROUP_LIMIT) return MSMC_E_SHAPE;
     Wg2Plan plans[MSMC_GROUP_LIMIT];
     bool pending[MSMC_GROUP_LIMIT];
     float* wsp = (float*)workspace;
     size_t ws_left = workspace_bytes / sizeof(float);
+    if (group4 && msmc_conv_grouping && n > 1) {
+        Wg4Plan p4[MSMC_GROUP_LIMIT];
+        bool mine[MSMC_GROUP_LIMIT], took[MSMC_GROUP_LIMIT];
+        int count = 0;
+        for (int i = 0; i < n; ++i) {
+            const msmc_conv_desc* d = &descs[i];
+            const int gen = d->variant > 0 ? d->variant : msmc_wgrad_generation;
+            took[i] = false;
+            mine[i] = d->dtype == 1 && gen >= 4 && gen <= 6 && g[i] && dw[i] && d->B > 0 && d->ntaps > 0 &&
+                      d->ntaps <= MSMC_CONV_MAX_TAPS;
+            if (mine[i]) ++count;
+        }
+        if (count > 1) {
+            const int share = count < MSMC_GROUP_MAX ? count : MSMC_GROUP_MAX;
+            for (int i = 0; i < n; ++i) {
+                if (!mine[i]) continue;
+                const msmc_conv_desc* d = &descs[i];
+                const int gen = d->variant > 0 ? d->variant : msmc_wgrad_generation;
+                if (wg4_plan(d, g[i], &p4[i], gen - 4, share)) { mine[i] = false; continue; }
+                if (p4[i].ws_floats) {
+                    if (p4[i].ws_floats > ws_left) return MSMC_E_WORKSPACE;
+                    p4[i].P.ws = wsp;
+                    wsp += p4[i].ws_floats;
+                    ws_left -= p4[i].ws_floats;
+                }
+            }
+            for (int i = 0; i < n; ++i) {
+                if (!mine[i]) continue;
+                Wg4GroupArgs a;
+                a.n = 0;
+                int members[MSMC_GROUP_MAX], nmembers = 0;
+                int blocks = 0, tpw = 1;
+                size_t lds = 0;
+                for (int j = i; j < n && a.n < MSMC_GROUP_MAX; ++j) {
+                    if (!mine[j]) continue;
+                    const int k = a.n++;
+                    a.first[k] = blocks;
+                    a.nx[k] = (int)p4[j].gx;
+                    a.ny[k] = (int)p4[j].gy;
+                    a.g[k] = (const unsigned short*)g[j];
+                    a.dw[k] = dw[j];
+                    a.db[k] = db ? db[j] : nullptr;
+                    a.d[k] = descs[j];
+                    a.P[k] = p4[j].P;
+                    blocks += (int)(p4[j].gx * p4[j].gy * p4[j].gz);
+                    if (p4[j].lds > lds) lds = p4[j].lds;
+                    if (p4[j].tpw > tpw) tpw = p4[j].tpw;      // the widest member sets the accumulator budget
+                    if (p4[j].P.ws) members[nmembers++] = j;
+                    mine[j] = false;
+                    took[j] = true;
+                }
+                a.first[a.n] = blocks;
+                ++msmc_conv_launches;
+                int rc;
+                const dim3 grid((unsigned)blocks);
+#define WG4G_GO(TP)                                                                                          \
+    do {                                                                                                     \
+        rc = msmc_allow_lds((const void*)conv_wgrad4_group_kernel<TP, 1>, (int)lds);                         \
+        if (rc) return rc;                                                                                   \
+        MSMC_LAUNCH((conv_wgrad4_group_kernel<TP, 1>), grid, dim3(256), lds, (msmc_stream_t)stream, a);      \
+    } while (0)
+                if (tpw == 1) WG4G_GO(1);
+                else if (tpw == 2) WG4G_GO(2);
+                else if (tpw == 3) WG4G_GO(3);
+                else if (tpw == 4) WG4G_GO(4);
+                else WG4G_GO(5);
+#undef WG4G_GO
+                msmc_conv_last = msmc_prof_name(msmc_kname("conv_wgrad4_group_kernel", nullptr, tpw, 1));
+                rc = msmc_check_launch();
+                if (rc) return rc;
+                for (int level = 0; level < 2 && nmembers; ++level) {
+                    WgReduceArgs r;
+                    r.n = 0;
+                    int rblocks = 0;
+                    for (int q = 0; q < nmembers; ++q) {
+                        const int j = members[q];
+                        const msmc_conv_desc& dj = descs[j];
+                        float* wsj = p4[j].P.ws;
+                        wg3_reduce_add(r, &rblocks, wsj, p4[j].P.ws_stride, (long)dj.ntaps * dj.Cout * dj.Cin,
+                                       (db && db[j]) ? dj.Cout : 0, (int)p4[j].gx,
+                                       wsj + (size_t)p4[j].gx * p4[j].P.ws_stride, dw[j], db ? db[j] : nullptr, level);
+                    }
+                    if (!r.n) continue;
+                    r.first[r.n] = rblocks;
+                    rc = wg3_reduce_launch(r, rblocks, stream);
+                    if (rc) return rc;
+                }
+            }
+            // the rest of the call: everything the fourth generation did not take
+            int nrest = 0;
+            msmc_conv_desc rest_d[MSMC_GROUP_LIMIT];
+            const void* rest_g[MSMC_GROUP_LIMIT];
+            float* rest_dw[MSMC_GROUP_LIMIT];
+            float* rest_db[MSMC_GROUP_LIMIT];
+            for (int i = 0; i < n; ++i) {
+                if (took[i]) continue;
+                rest_d[nrest] = descs[i];
+                rest_g[nrest] = g[i];
+                rest_dw[nrest] = dw[i];
+                rest_db[nrest] = db ? db[i] : nullptr;
+                ++nrest;
+            }
+            if (!nrest) return 0;
+            return msmc_conv_wgrad_group_ws4(rest_d, rest_g, rest_dw, rest_db, nrest, wsp, ws_left * sizeof(float), stream, 0);
+        }
+    }
     for (int i = 0; i < n; ++i) {
         const msmc_conv_desc* d = &descs[i];
         pending[i] = false;
@@ -2854,6 +2963,11 @@ extern "C" int msmc_conv_wgrad_group_ws(const msmc_conv_desc* descs, const void*
         }
     }
     return 0;
+}
+extern "C" int msmc_conv_wgrad_group_ws(const msmc_conv_desc* descs, const void* const* g, float* const* dw,
+                                        float* const* db, int n, void* workspace, size_t workspace_bytes,
+                                        msmc_stream stream) {
+    return msmc_conv_wgrad_group_ws4(descs, g, dw, db, n, workspace, workspace_bytes, stream, 0);
 }
 extern "C" int msmc_conv_wgrad_group(const msmc_conv_desc* descs, const void* const* g, float* const* dw, float* const* db,
                                      int n, msmc_stream stream) {

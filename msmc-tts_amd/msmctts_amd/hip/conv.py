@@ -365,9 +365,13 @@ def _snapshot(desc, stream):
     return lib.ConvDesc.from_buffer_copy(desc)
 
 
-def _group_choice(kind, snaps, grouped_fn, single_fn):
-    """1: issue the members as one grouped call, 0: one by one.  Timed once per member-shape combination (grouping
-    fills the chip for small grids but imposes one kernel instantiation on all members)."""
+_GROUP_CODES = {'single': 0, 'group': 1, 'group4': 2}
+
+
+def _group_choice(kind, snaps, grouped_fn, single_fn, group4_fn=None):
+    """1: issue the members as one grouped call, 0: one by one, 2: grouped with the fourth-generation weight-gradient
+    members on grids of their own (``group4_fn``, weight gradients only).  Timed once per member-shape combination
+    (grouping fills the chip for small grids but imposes one kernel instantiation on all members)."""
     if len(snaps) == 1:
         return 0
     if lib._host_pointers_ok:
@@ -378,7 +382,9 @@ def _group_choice(kind, snaps, grouped_fn, single_fn):
         return 1
     if hit is None:
         times = {}
-        for name, fn in (('group', grouped_fn), ('single', single_fn)):
+        for name, fn in (('group', grouped_fn), ('single', single_fn), ('group4', group4_fn)):
+            if fn is None:
+                continue
             fn()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -387,7 +393,8 @@ def _group_choice(kind, snaps, grouped_fn, single_fn):
             e.record()
             e.synchronize()
             times[(name, 0)] = s.elapsed_time(e) / 3.0
-        hit = TUNED[sig] = (1 if times[('group', 0)] <= times[('single', 0)] else 0, 0, times)
+        best = min(times, key=times.get)
+        hit = TUNED[sig] = (_GROUP_CODES[best[0]], 0, times)
     return hit[0]
 
 
@@ -598,6 +605,11 @@ def conv_wgrad_group(items):
         def grouped():
             lib.check(L.msmc_conv_wgrad_group_ws(arr, ga, dwa, dba, n, wsp, wsb, stream), 'msmc_conv_wgrad_group_ws')
 
+        def grouped4():
+            lib.check(L.msmc_conv_wgrad_group_ws4(arr, ga, dwa, dba, n, wsp, wsb, stream, 1), 'msmc_conv_wgrad_group_ws4')
+
+        g4 = grouped4 if sum(1 for d in part if d.variant >= 4) > 1 else None
+
         def single():
             for k in range(n):
                 lib.check(L.msmc_conv_wgrad_ws(ctypes.byref(part[k]), ga[k], dwa[k], dba[k], wsp, wsb, stream),
@@ -616,9 +628,9 @@ def conv_wgrad_group(items):
                 sb = [torch.zeros(max(1, d.dw_copies) * d.Cout, dtype=torch.float32, device=items[0]['x'].device)
                       for d in part]
                 dwa, dba = vp(*[t.data_ptr() for t in scratch]), vp(*[t.data_ptr() for t in sb])
-                _group_choice('wgrad-group', part, grouped, single)
+                _group_choice('wgrad-group', part, grouped, single, g4)
                 dwa, dba = keep
-        (grouped if _group_choice('wgrad-group', part, grouped, single) else single)()
+        (single, grouped, g4 or grouped)[_group_choice('wgrad-group', part, grouped, single, g4)]()
 
 
 def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None, copies=1):

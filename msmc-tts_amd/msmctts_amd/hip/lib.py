@@ -101,6 +101,8 @@ _SIGNATURES.update({
     'msmc_conv_wgrad_ws': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _sz, _vp]),
     'msmc_conv_wgrad_group_ws': (_i, [ctypes.POINTER(ConvDesc), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                  _i, _vp, _sz, _vp]),
+    'msmc_conv_wgrad_group_ws4': (_i, [ctypes.POINTER(ConvDesc), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                  _i, _vp, _sz, _vp, _i]),
     'msmc_conv_set_wgrad_tpw': (None, [_i]),
     'msmc_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, ctypes.c_longlong, _vp]),
     'msmc_attn_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, ctypes.c_longlong, _vp]),

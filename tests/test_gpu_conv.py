@@ -95,6 +95,41 @@ def test_wgrad_fourth_generation_matches_pytorch(variant):
         conv.TUNED.update(saved[1])
 
 
+def test_wgrad_fourth_generation_grouped_matches_single_launches():
+    """msmc_conv_wgrad_group_ws4(group4 = 1) on the three parallel ResBlock convolutions of a generator stage (k = 3, 7,
+    11: one shared grid, the widest member sets the accumulator budget) against one launch per member"""
+    import ctypes
+    from msmctts_amd.hip import conv, lib
+    L = lib.get()
+    torch.manual_seed(0)
+    B, C, Lx = 16, 128, 1200
+    x = torch.randn(B, 1, Lx, C, device=DEV).bfloat16()
+    descs, gs, refs, outs = [], [], [], []
+    for k, dil in ((3, 1), (7, 3), (11, 1)):
+        geom = conv.Geometry(1, Lx, (1, k), (1, 1), (1, dil), (0, dil * (k - 1) // 2), False)
+        g = torch.randn(B, 1, Lx, C, device=DEV).bfloat16()
+        d = conv._build_desc(x.dtype, B, 1, Lx, C, 1, Lx, C, geom.fwd_lattice, geom.fwd_taps, 0, 0.1, 1.0, 1.0, 1.0)
+        d.x = d.w = d.out = x.data_ptr()
+        d.variant, d.dw_copies = 4, 1
+        need = L.msmc_conv_wgrad_workspace(ctypes.byref(d), g.data_ptr())
+        ws = torch.zeros(max(1, need // 4), device=DEV)
+        dw_ref, db_ref = torch.zeros(k, C, C, device=DEV), torch.zeros(C, device=DEV)
+        assert L.msmc_conv_wgrad_ws(ctypes.byref(d), g.data_ptr(), dw_ref.data_ptr(), db_ref.data_ptr(), ws.data_ptr(),
+                                    need, lib.stream(x)) == 0
+        descs.append(d); gs.append(g); refs.append((dw_ref, db_ref))
+        outs.append((torch.zeros(k, C, C, device=DEV), torch.zeros(C, device=DEV)))
+    arr = (lib.ConvDesc * 3)(*descs)
+    vp = ctypes.c_void_p * 3
+    need = sum(L.msmc_conv_wgrad_workspace(ctypes.byref(d), g.data_ptr()) for d, g in zip(descs, gs))
+    ws = torch.zeros(max(1, need // 4), device=DEV)
+    rc = L.msmc_conv_wgrad_group_ws4(arr, vp(*[g.data_ptr() for g in gs]), vp(*[o[0].data_ptr() for o in outs]),
+                                     vp(*[o[1].data_ptr() for o in outs]), 3, ws.data_ptr(), need, lib.stream(x), 1)
+    assert rc == 0 and b'conv_wgrad4_group_kernel' in L.msmc_conv_last_kernel()
+    torch.cuda.synchronize()
+    for (dw_ref, db_ref), (dw, db) in zip(refs, outs):
+        assert rel(dw, dw_ref) < 1e-4 and rel(db, db_ref) < 1e-4
+
+
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize('Cin,Cout,k,u,L', [(512, 256, 12, 6, 40), (256, 128, 11, 5, 240), (128, 64, 11, 5, 1200),
                                             (64, 32, 4, 2, 6000)])

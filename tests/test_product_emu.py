@@ -291,6 +291,53 @@ def test_wgrad_fourth_generation_ring(gen):
         L.msmc_conv_set_wgrad_split(0)
 
 
+def test_wgrad_fourth_generation_grouped():
+    """msmc_conv_wgrad_group_ws4(group4 = 1): the fourth-generation members of a grouped call share one grid of their own
+    kernel (members of different tap counts: the widest sets the accumulator budget), a member outside the scope goes the
+    old way; bit-identical to one launch per member with the same split"""
+    import ctypes
+    from msmctts_amd.hip import conv, lib
+    L = lib.get()
+    torch.manual_seed(0)
+    B, C, Lx = 2, 64, 90
+    x = torch.randn(B, 1, Lx, C).bfloat16()
+    for split in (1, 2):
+        L.msmc_conv_set_wgrad_split(split)
+        descs, gs, refs, outs = [], [], [], []
+        for k, dil, cout, variant in ((3, 1, 64, 4), (7, 3, 128, 4), (11, 1, 64, 5), (3, 1, 40, 4)):
+            geom = conv.Geometry(1, Lx, (1, k), (1, 1), (1, dil), (0, dil * (k - 1) // 2), False)
+            g = torch.randn(B, 1, Lx, cout).bfloat16()
+            d = conv._build_desc(x.dtype, B, 1, Lx, C, 1, Lx, cout, geom.fwd_lattice, geom.fwd_taps, 0, 0.1, 1.0, 1.0, 1.0)
+            d.x = d.w = d.out = x.data_ptr()
+            d.variant, d.dw_copies = variant, 1
+            if cout == 40:
+                d.variant = 3                     # outside the fourth generation's scope (Cout % 64)
+            need = L.msmc_conv_wgrad_workspace(ctypes.byref(d), g.data_ptr())
+            ws = torch.zeros(max(1, need // 4))
+            dw_ref, db_ref = torch.zeros(k, cout, C), torch.zeros(cout)
+            assert L.msmc_conv_wgrad_ws(ctypes.byref(d), g.data_ptr(), dw_ref.data_ptr(), db_ref.data_ptr(), ws.data_ptr(),
+                                        need, None) == 0
+            descs.append(d); gs.append(g); refs.append((dw_ref, db_ref))
+            outs.append((torch.zeros(k, cout, C), torch.zeros(cout)))
+        n = len(descs)
+        arr = (lib.ConvDesc * n)(*descs)
+        vp = ctypes.c_void_p * n
+        need = sum(L.msmc_conv_wgrad_workspace(ctypes.byref(d), g.data_ptr()) for d, g in zip(descs, gs))
+        ws = torch.zeros(max(1, need // 4))
+        rc = L.msmc_conv_wgrad_group_ws4(arr, vp(*[g.data_ptr() for g in gs]), vp(*[o[0].data_ptr() for o in outs]),
+                                         vp(*[o[1].data_ptr() for o in outs]), n, ws.data_ptr(), need, None, 1)
+        assert rc == 0, rc
+        for (dw_ref, db_ref), (dw, db) in zip(refs, outs):
+            assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+        # the in-scope members alone: the last launch is the second stage of the shared fourth-generation grid
+        arr3 = (lib.ConvDesc * 3)(*descs[:3])
+        vp3 = ctypes.c_void_p * 3
+        rc = L.msmc_conv_wgrad_group_ws4(arr3, vp3(*[g.data_ptr() for g in gs[:3]]), vp3(*[o[0].data_ptr() for o in outs[:3]]),
+                                         vp3(*[o[1].data_ptr() for o in outs[:3]]), 3, ws.data_ptr(), need, None, 1)
+        assert rc == 0 and b'conv_wgrad4_group_kernel<4, 1>' in L.msmc_conv_last_kernel(), L.msmc_conv_last_kernel()
+    L.msmc_conv_set_wgrad_split(0)
+
+
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 def test_fused_add_layernorm_gate_tanh_match_torch(dtype, tol):
     _parity.check_norm_kernels('cpu', dtype, tol)

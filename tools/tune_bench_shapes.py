@@ -37,6 +37,8 @@ dev = torch.device('cuda:0')
 torch.cuda.set_device(0)
 if RETUNE == 'wgrad4':
     dropped = [k for k in conv.TUNED if _wgrad4_scope(k)]
+    # ... and the grouped calls with two or more fourth-generation members (grids of their own: a third alternative)
+    dropped += [k for k in conv.TUNED if k[0] == 'wgrad-group' and sum(1 for m in k[1:] if m[21] >= 4) > 1]
     for k in dropped:
         del conv.TUNED[k]
     print('re-timing %d weight-gradient shapes' % len(dropped))
@@ -59,7 +61,7 @@ for rep in range(1 if RETUNE else 2):                     # two passes: keep the
         if k in conv.TUNED:
             times = {c: min(t, v[2].get(c, t)) for c, t in conv.TUNED[k][2].items()}
             best = min(times, key=times.get)
-            conv.TUNED[k] = ((1 if best[0] == 'group' else 0) if isinstance(best[0], str) else best[0], best[1], times)
+            conv.TUNED[k] = (conv._GROUP_CODES[best[0]] if isinstance(best[0], str) else best[0], best[1], times)
         else:
             conv.TUNED[k] = v
     del trainer
