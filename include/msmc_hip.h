@@ -124,7 +124,9 @@ typedef struct msmc_conv_desc {
                                C -> 1 and 1 -> C layers (MSMC_E_SHAPE otherwise), 16..23 = third generation (bf16: 64-row wave
                                tiles, LDS-DMA weight stream, one barrier per chunk; 16 + (256- instead of 128-point tiles) +
                                2*(64- instead of 32-column wave tiles) + 4*(128- instead of 64-byte chunks); MSMC_E_SHAPE
-                               where a configuration does not apply), 9 = 32-point tiles with the channel
+                               where a configuration does not apply), 24..31 = 16..23 with the halo tile by LDS-DMA as well (no staging
+                               registers; unpadded source-swizzled rows, zero chunk for padding pixels, in-place input activation,
+                               0 <= in_slope <= 1), 9 = 32-point tiles with the channel
                                chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation (fp32 atomics), 3 = third (split partials + fixed-order reduce), 4 / 5 / 6 = fourth (the
                                third's result contract; pixel tiles flow through an LDS-DMA ring: 4 = three stages, fragment reads two

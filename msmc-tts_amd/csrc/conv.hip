@@ -1614,7 +1614,8 @@ static int cv_group_launch(const msmc_conv_desc* descs, int n, msmc_stream strea
         int blocks = 0;
         size_t lds = 0;
         for (int j = i; j < n && a.n < MSMC_GROUP_MAX; ++j) {
-            if (!gen3[j] || p3[j].wm != p3[i].wm || p3[j].ntw != p3[i].ntw || p3[j].ckm != p3[i].ckm || p3[j].xv != p3[i].xv)
+            if (!gen3[j] || p3[j].wm != p3[i].wm || p3[j].ntw != p3[i].ntw || p3[j].ckm != p3[i].ckm || p3[j].xv != p3[i].xv ||
+                p3[j].xdma != p3[i].xdma)
                 continue;
             a.first[a.n] = blocks;
             a.nx[a.n] = (int)p3[j].gx;

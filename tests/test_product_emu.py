@@ -172,7 +172,7 @@ def test_vq_edge_cases_empty_single_frame_zero_length_ragged():
     _parity.check_vq_edge_cases('cpu')
 
 
-@pytest.mark.parametrize('variant', [16, 17, 18, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize('variant', [16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31])
 def test_gather_third_generation_variants(variant):
     """variants 16..23 (gather3.inc: 64-row wave tiles, LDS-DMA weight stream with source-side swizzle, one barrier per
     channel chunk): every tile shape / chunk width where it applies, forward and data gradient, ragged tiles,

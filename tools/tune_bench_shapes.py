@@ -2,7 +2,8 @@
 """Runs ON the GPU box: time the kernel candidates of every convolution shape of the bench configuration (and of the
 GPU test-suite's layer cases) and write the choices to msmctts_amd/hip/tuned_gfx950.json (copied back via gpurun_out).
 RETUNE=wgrad4 keeps the committed table and re-times only the single-launch bf16 weight gradients the fourth-generation
-kernel can serve (one pass)."""
+kernel can serve (one pass).  RETUNE=gather3x keeps it too and times only the LDS-DMA halo variants (24..31) of every bf16
+forward / data-gradient shape, merging them with the committed timings of the other candidates."""
 import os, sys, random, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd'), os.path.join(ROOT, 'tests')]
@@ -42,6 +43,11 @@ if RETUNE == 'wgrad4':
     for k in dropped:
         del conv.TUNED[k]
     print('re-timing %d weight-gradient shapes' % len(dropped))
+kept = {}
+if RETUNE == 'gather3x':
+    conv._GATHER_CANDIDATES = tuple((v, 0) for v in range(24, 32))
+    kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED) if k[0] == 'gather' and k[1] == 1}
+    print('timing the LDS-DMA halo variants of %d forward / data-gradient shapes' % len(kept))
 for rep in range(1 if RETUNE else 2):                     # two passes: keep the faster measurement of each candidate
     saved = dict(conv.TUNED)
     if not RETUNE:
@@ -65,6 +71,12 @@ for rep in range(1 if RETUNE else 2):                     # two passes: keep the
         else:
             conv.TUNED[k] = v
     del trainer
+for k, v in kept.items():                                 # committed candidates + the new ones; shapes the run did not meet stay
+    times = dict(v[2])
+    for c, t in (conv.TUNED[k][2] if k in conv.TUNED else {}).items():
+        times[c] = min(t, times.get(c, t))
+    best = min(times, key=times.get) if times else (v[0], v[1])
+    conv.TUNED[k] = (best[0], best[1], times)
 out = os.path.join(ROOT, 'gpurun_out', 'tuned_gfx950.json')
 conv.save_tuned(out)
 print('shapes tuned:', len(conv.TUNED))
