@@ -126,7 +126,9 @@ typedef struct msmc_conv_desc {
                                2*(64- instead of 32-column wave tiles) + 4*(128- instead of 64-byte chunks); MSMC_E_SHAPE
                                where a configuration does not apply), 24..31 = 16..23 with the halo tile by LDS-DMA as well (no staging
                                registers; unpadded source-swizzled rows, zero chunk for padding pixels, in-place input activation,
-                               0 <= in_slope <= 1), 9 = 32-point tiles with the channel
+                               0 <= in_slope <= 1), 32 = persistent thin-layer kernel (csrc/gather4.inc: Cin, Cout in {32, 64}, unit strides, zero
+                               padding, taps along one axis; weights of all taps resident in LDS, halo tiles by LDS-DMA, epilogue in
+                               registers; MSMC_E_SHAPE outside that scope), 9 = 32-point tiles with the channel
                                chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation (fp32 atomics), 3 = third (split partials + fixed-order reduce), 4 / 5 / 6 = fourth (the
                                third's result contract; pixel tiles flow through an LDS-DMA ring: 4 = three stages, fragment reads two
@@ -141,6 +143,8 @@ typedef struct msmc_conv_desc {
                                times); the consumer sums the copies (msmc_wn_backward_multi does)                      */
 } msmc_conv_desc;
 
+/* Tests / sweeps: workgroups of the persistent grid of msmc_conv_gather variant 32 (0 = one or two per CU). */
+void msmc_conv_set_gather4_grid(int n);
 /* Perf-experiment switch: 0 selects the simple (un-pipelined) gather kernel everywhere; default 1. */
 void msmc_conv_set_pipeline(int on);
 /* Perf-sweep switches: force the weight-gradient pixel split (0 = model), allow 32-channel N tiles for small grids. */

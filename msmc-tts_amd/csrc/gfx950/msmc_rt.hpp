@@ -169,6 +169,18 @@ MSMC_DEV void lds_dma_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "
 // (lds_dma_wait_n) and must not rely on this barrier for the visibility of global-memory writes.
 MSMC_DEV void block_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- hand-counted global loads beside an LDS-DMA ring: an ordinary load inside such a loop makes hipcc drain the whole
+// vector-memory queue (s_waitcnt vmcnt(0)) BEFORE issuing it, i.e. right after the ring's next stage was requested.
+// These 8-byte loads are invisible to its wait insertion: the caller retires them with lds_dma_wait() (vmcnt(0)) and then
+// passes every destination through vm_pin() before the first use (volatile asm statements keep their order, so the uses
+// cannot be scheduled above the wait).
+MSMC_DEV u32x2 global_load8_async(const void* p) {
+    u32x2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p));
+    return v;
+}
+MSMC_DEV void vm_pin(u32x2& v) { asm volatile("" : "+v"(v)); }
+
 // The machine scheduler must not move instructions across this point (software pipelines written in source order:
 // hipcc otherwise sinks prefetching LDS reads down to their first use and waits with lgkmcnt(0)).
 MSMC_DEV void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

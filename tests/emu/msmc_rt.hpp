@@ -215,6 +215,8 @@ MSMC_DEV void lds_dma16(const void* gsrc, void* lds_wave_base) { memcpy((char*)l
 MSMC_DEV void lds_dma_wait() {}
 template <int N> MSMC_DEV void lds_dma_wait_n() {}
 MSMC_DEV void block_sync_lds() { emu::block_barrier(); }
+MSMC_DEV u32x2 global_load8_async(const void* p) { return *(const u32x2*)p; }
+MSMC_DEV void vm_pin(u32x2&) {}
 MSMC_DEV void sched_fence() {}
 MSMC_DEV u16x8 lds_read128_async(const void* p) { u16x8 v; memcpy(&v, p, 16); return v; }
 MSMC_DEV int lds_read32_async(const void* p) { int v; memcpy(&v, p, 4); return v; }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """GPU microbench: forward convolutions of the bench configuration -- the tuned second-generation choice against every
-third-generation configuration (desc.variant 16..23; 24..31 = the same with the halo tile by LDS-DMA), checked against
-the second-generation output.
+third-generation configuration (desc.variant 16..23; 24..31 = the same with the halo tile by LDS-DMA) and the persistent
+thin-layer kernel (32), checked against the second-generation output.  VARIANTS="24 25 32" selects the columns.
 
     python tools/bench_gather3.py [filter]
 """
@@ -62,7 +62,8 @@ def timed(desc, stream, iters=20):
     return s.elapsed_time(e) / iters * 1e3
 
 
-print('%-28s %9s %7s | %s' % ('layer', 'GFLOP', 'gen2 us', ' '.join('v%-6d' % v for v in range(16, 32))))
+VARIANTS = [int(v) for v in os.environ.get('VARIANTS', ' '.join(str(v) for v in range(16, 33))).split()]
+print('%-28s %9s %7s | %s' % ('layer', 'GFLOP', 'gen2 us', ' '.join('v%-6d' % v for v in VARIANTS)))
 for name, B, Cin, Cout, H, W, k, s_, dil, pad, reflect, slope in SHAPES:
     if flt not in name:
         continue
@@ -81,7 +82,7 @@ for name, B, Cin, Cout, H, W, k, s_, dil, pad, reflect, slope in SHAPES:
     gflop = 2.0 * B * geom.Hout * geom.Wout * Cout * Cin * T / 1e9
     cells = []
     best = (t2, base_variant)
-    for v in range(16, 32):
+    for v in VARIANTS:
         d3 = lib.ConvDesc.from_buffer_copy(desc)
         d3.variant = v
         out.zero_()

@@ -3,7 +3,8 @@
 GPU test-suite's layer cases) and write the choices to msmctts_amd/hip/tuned_gfx950.json (copied back via gpurun_out).
 RETUNE=wgrad4 keeps the committed table and re-times only the single-launch bf16 weight gradients the fourth-generation
 kernel can serve (one pass).  RETUNE=gather3x keeps it too and times only the LDS-DMA halo variants (24..31) of every bf16
-forward / data-gradient shape, merging them with the committed timings of the other candidates."""
+forward / data-gradient shape, merging them with the committed timings of the other candidates; RETUNE=gather4 does the
+same for the persistent thin-layer kernel (variant 32)."""
 import os, sys, random, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd'), os.path.join(ROOT, 'tests')]
@@ -48,6 +49,11 @@ if RETUNE == 'gather3x':
     conv._GATHER_CANDIDATES = tuple((v, 0) for v in range(24, 32))
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED) if k[0] == 'gather' and k[1] == 1}
     print('timing the LDS-DMA halo variants of %d forward / data-gradient shapes' % len(kept))
+if RETUNE == 'gather4':                                   # the persistent thin-layer kernel: Cin, Cout in {32, 64}
+    conv._GATHER_CANDIDATES = ((32, 0),)
+    kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
+            if k[0] == 'gather' and k[1] == 1 and k[5] in (32, 64) and k[8] in (32, 64)}
+    print('timing the persistent thin-layer kernel on %d forward / data-gradient shapes' % len(kept))
 for rep in range(1 if RETUNE else 2):                     # two passes: keep the faster measurement of each candidate
     saved = dict(conv.TUNED)
     if not RETUNE:
