@@ -128,7 +128,8 @@ typedef struct msmc_conv_desc {
                                registers; unpadded source-swizzled rows, zero chunk for padding pixels, in-place input activation,
                                0 <= in_slope <= 1), 32 = persistent thin-layer kernel (csrc/gather4.inc: Cin, Cout in {32, 64}, unit strides, zero
                                padding, taps along one axis; weights of all taps resident in LDS, halo tiles by LDS-DMA, epilogue in
-                               registers; MSMC_E_SHAPE outside that scope), 9 = 32-point tiles with the channel
+                               registers; MSMC_E_SHAPE outside that scope), 33 = 32 with the epilogue of a tile deferred into the next
+                               iteration (interpreter-tested, not yet timed on the GPU: not a tuner candidate), 9 = 32-point tiles with the channel
                                chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation (fp32 atomics), 3 = third (split partials + fixed-order reduce), 4 / 5 / 6 = fourth (the
                                third's result contract; pixel tiles flow through an LDS-DMA ring: 4 = three stages, fragment reads two

@@ -210,8 +210,9 @@ def test_gather_third_generation_variants(variant):
     assert ran >= 2, (variant, ran)
 
 
-def test_gather_persistent_thin_layer_variant():
-    """variant 32 (gather4.inc: weights of all taps resident in LDS, halo tiles of consecutive pixel tiles by LDS-DMA,
+@pytest.mark.parametrize('variant', [32, 33])
+def test_gather_persistent_thin_layer_variant(variant):
+    """variant 32 / 33 = the same with the epilogue of a tile deferred into the next iteration (gather4.inc: weights of all taps resident in LDS, halo tiles of consecutive pixel tiles by LDS-DMA,
     accumulators [co][pixel] with the epilogue in registers) on the thin-layer family it serves: forward and data
     gradient (mask operand), residual operands / output division / output leaky-ReLU against the second generation,
     more tiles than workgroups, ragged last tile, taps along H, layers outside its scope refused"""
@@ -223,7 +224,7 @@ def test_gather_persistent_thin_layer_variant():
              ('g4 valid k3 64->64', 1, 64, 64, 1, 37, (1, 3), (1, 1), (1, 1), (0, 0), False, 1.0),
              ('g4 tiny L3 k11 d5', 1, 32, 32, 1, 3, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1)]
     real = conv._build_desc
-    state = {'variant': 32}
+    state = {'variant': variant}
 
     def forced(*a, **k):
         d = real(*a, **k)
@@ -238,7 +239,7 @@ def test_gather_persistent_thin_layer_variant():
                 for part in ('fwd', 'dgrad'):
                     conv._PLANS.clear()
                     _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=(part,))
-                    assert b'conv_gather4_kernel' in lib.get().msmc_conv_last_kernel(), (case[0], part)
+                    assert b'conv_gather4' in lib.get().msmc_conv_last_kernel(), (case[0], part)
         lib.get().msmc_conv_set_gather4_grid(0)
         # epilogue operands against the second generation on the same inputs
         torch.manual_seed(0)
@@ -248,14 +249,14 @@ def test_gather_persistent_thin_layer_variant():
         w = (torch.randn(k, C, C) / (C * k) ** 0.5).bfloat16()
         bias, res, res2 = torch.randn(C), torch.randn(B, 1, Lx, C).bfloat16(), torch.randn(B, 1, Lx, C).bfloat16()
         outs = []
-        for variant in (32, 2):
-            state['variant'] = variant
+        for v in (variant, 2):
+            state['variant'] = v
             conv._PLANS.clear()
             outs.append(conv.conv_forward(x, w, geom, bias=bias, in_slope=0.1, res=res, res2=res2, out_div=3.0,
                                           out_slope=0.2))
         assert _convcases.rel(outs[0], outs[1]) < 1e-2
         # outside the scope: stride 3 / 96 channels -> MSMC_E_SHAPE surfaces as an error, nothing is mis-computed
-        state['variant'] = 32
+        state['variant'] = variant
         conv._PLANS.clear()
         with pytest.raises(RuntimeError, match='msmc_conv_gather'):
             _convcases.check_conv_case(_convcases.SMALL[2], torch.bfloat16, 2e-2, 'cpu', parts=('fwd',))

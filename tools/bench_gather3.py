@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """GPU microbench: forward convolutions of the bench configuration -- the tuned second-generation choice against every
 third-generation configuration (desc.variant 16..23; 24..31 = the same with the halo tile by LDS-DMA) and the persistent
-thin-layer kernel (32), checked against the second-generation output.  VARIANTS="24 25 32" selects the columns.
+thin-layer kernel (32; 33 = its deferred-epilogue form), checked against the second-generation output.  VARIANTS="24 25 32" selects the columns.
 
     python tools/bench_gather3.py [filter]
 """
@@ -62,7 +62,7 @@ def timed(desc, stream, iters=20):
     return s.elapsed_time(e) / iters * 1e3
 
 
-VARIANTS = [int(v) for v in os.environ.get('VARIANTS', ' '.join(str(v) for v in range(16, 33))).split()]
+VARIANTS = [int(v) for v in os.environ.get('VARIANTS', ' '.join(str(v) for v in range(16, 34))).split()]
 print('%-28s %9s %7s | %s' % ('layer', 'GFLOP', 'gen2 us', ' '.join('v%-6d' % v for v in VARIANTS)))
 for name, B, Cin, Cout, H, W, k, s_, dil, pad, reflect, slope in SHAPES:
     if flt not in name:
