@@ -135,7 +135,10 @@ typedef struct msmc_conv_desc {
                                third's result contract; pixel tiles flow through an LDS-DMA ring: 4 = three stages, fragment reads two
                                steps ahead of the MFMAs, 5 = one step ahead, 6 = two stages, one step ahead;
                                MSMC_E_SHAPE outside its scope: unit strides, zero padding, channel counts multiples of 64,
-                               taps along one axis).  The host layer times the candidates once per layer shape.       */
+                               taps along one axis), 7 = the third generation's lattice tiles with both operands staged by LDS-DMA into
+                               a two-stage ring (csrc/wgrad5.inc: strided, 2-D and reflection-padded layers with channel counts that
+                               are multiples of 64; interpreter-tested, NOT yet timed on the GPU and not a tuner candidate).  The host
+                               layer times the candidates once per layer shape.       */
     int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative).  msmc_conv_gather
                                variants 16..23 only: DIAGNOSTICS mask, 0 in production (1 skip the MFMAs, 2 the weight stream,
                                4 the halo loads, 8 the epilogue: tools/bench_gather3.py ABLATE=...; results are then garbage) */

@@ -2718,6 +2718,50 @@ static int wg4_launch(const msmc_conv_desc* d, const void* g, float* dw, float* 
     return 0;
 }
 
+#include "wgrad5.inc"
+
+// general-lattice weight gradient with LDS-DMA staging (variant 7: interpreter-tested, not yet timed on the GPU)
+static int wg5_launch(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream, float* ws,
+                      size_t ws_floats) {
+    Wg5Plan pl;
+    int rc = wg5_plan(d, g, &pl);
+    if (rc) return rc;
+    if (pl.ws_floats) {
+        if (!ws || ws_floats < pl.ws_floats) return MSMC_E_WORKSPACE;
+        pl.P.ws = ws;
+    }
+    const dim3 grid(pl.gx, pl.gy, pl.gz);
+    const unsigned short* gp = (const unsigned short*)g;
+#define WG5_GO(TP)                                                                                           \
+    do {                                                                                                     \
+        rc = msmc_allow_lds((const void*)conv_wgrad5_kernel<TP>, (int)pl.lds);                               \
+        if (rc) return rc;                                                                                   \
+        MSMC_LAUNCH((conv_wgrad5_kernel<TP>), grid, dim3(256), pl.lds, (msmc_stream_t)stream, *d, gp, dw, db, pl.G, pl.P); \
+    } while (0)
+    if (pl.tpw == 1) WG5_GO(1);
+    else if (pl.tpw == 2) WG5_GO(2);
+    else if (pl.tpw == 3) WG5_GO(3);
+    else if (pl.tpw == 4) WG5_GO(4);
+    else WG5_GO(5);
+#undef WG5_GO
+    msmc_conv_last = msmc_prof_name(msmc_kname("conv_wgrad5_kernel", nullptr, pl.tpw, -1));
+    rc = msmc_check_launch();
+    if (rc || !pl.P.ws) return rc;
+    const long n_dw = (long)d->ntaps * d->Cout * d->Cin;
+    float* mid = ws + (size_t)pl.gx * pl.P.ws_stride;
+    for (int level = 0; level < 2; ++level) {
+        WgReduceArgs a;
+        a.n = 0;
+        int blocks = 0;
+        wg3_reduce_add(a, &blocks, ws, pl.P.ws_stride, n_dw, db ? d->Cout : 0, (int)pl.gx, mid, dw, db, level);
+        if (!a.n) continue;
+        a.first[a.n] = blocks;
+        rc = wg3_reduce_launch(a, blocks, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" int msmc_conv_wgrad_ws(const msmc_conv_desc* d, const void* g, float* dw, float* db, void* workspace,
                                   size_t workspace_bytes, msmc_stream stream) {
     if (!d || !g || !dw || d->B <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->QH <= 0 || d->QW <= 0) return MSMC_E_SHAPE;
@@ -2729,6 +2773,7 @@ extern "C" int msmc_conv_wgrad_ws(const msmc_conv_desc* d, const void* g, float*
         if (gen == 1) return wg_launch<unsigned short>(d, g, dw, db, stream);
         msmc_conv_desc e = *d;
         e.variant = gen;                                      // (the generation switch selects the third one too)
+        if (gen == 7) return wg5_launch(&e, g, dw, db, stream, (float*)workspace, workspace_bytes / sizeof(float));
         if (gen >= 4) {
             if (gen > 6) return MSMC_E_SHAPE;
             const int rc = wg4_launch(&e, g, dw, db, stream, (float*)workspace, workspace_bytes / sizeof(float));
@@ -2746,6 +2791,10 @@ extern "C" size_t msmc_conv_wgrad_workspace(const msmc_conv_desc* d, const void*
     if (!d || d->dtype != 1) return 0;
     const int gen = d->variant > 0 ? d->variant : msmc_wgrad_generation;
     size_t need4 = 0;
+    if (gen == 7) {
+        Wg5Plan p5;
+        return wg5_plan(d, g, &p5) == 0 ? p5.ws_floats * sizeof(float) : 0;
+    }
     if (gen >= 4 && gen <= 6) {                     // (inside a shared grid the member runs as third generation: the larger)
         Wg4Plan p4;
         if (wg4_plan(d, g, &p4, gen - 4) == 0) need4 = p4.ws_floats * sizeof(float);
@@ -2884,7 +2933,7 @@ extern "C" int msmc_conv_wgrad_group_ws4(const msmc_conv_desc* descs, const void
         const int gen = d->variant > 0 ? d->variant : msmc_wgrad_generation;
         // (fourth-generation members join a shared grid as third-generation members: the host layer times the shared
         //  grid against one launch per member, where each runs the kernel of its own choice)
-        if (!msmc_conv_grouping || d->dtype != 1 || gen == 1 || n == 1) {
+        if (!msmc_conv_grouping || d->dtype != 1 || gen == 1 || gen == 7 || n == 1) {
             size_t need = msmc_conv_wgrad_workspace(d, g[i]) / sizeof(float);
             if (need > ws_left) return MSMC_E_WORKSPACE;
             int rc = msmc_conv_wgrad_ws(d, g[i], dw[i], db ? db[i] : nullptr, wsp, need * sizeof(float), stream);

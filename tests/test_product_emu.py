@@ -347,6 +347,36 @@ def test_wgrad_fourth_generation_ring(gen):
         L.msmc_conv_set_wgrad_split(0)
 
 
+def test_wgrad_general_lattice_dma_staging():
+    """variant 7 (wgrad5.inc: the third generation's lattice tiles and table-driven fragment rows with both operands
+    staged by LDS-DMA into a two-stage ring) on strided, 2-D, reflection-padded and dilated layers, model split, one
+    split (the ring wraps) and forced splits, against PyTorch on the interpreter"""
+    from msmctts_amd.hip import conv, lib
+    L = lib.get()
+    cases = [('w5 mpd 64->128 s3 p3', 2, 64, 128, 40, 3, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
+             ('w5 mrd 64->64 s2 reflect', 1, 64, 64, 13, 18, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
+             ('w5 mrd 64->128 s1x2 reflect', 1, 64, 128, 9, 20, (3, 3), (1, 2), (1, 1), (1, 1), True, 0.2),
+             ('w5 gen k11 d5 C64', 2, 64, 64, 1, 70, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
+             ('w5 tiny 3x2 reflect s2', 2, 64, 64, 3, 2, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0)]
+    L.msmc_conv_set_wgrad_generation(7)
+    try:
+        for split in (0, 1, 3):
+            L.msmc_conv_set_wgrad_split(split)
+            for case in cases:
+                conv._PLANS.clear()
+                _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=('wgrad',))
+        L.msmc_conv_set_wgrad_split(0)
+        name, B, Cin, Cout, H, W, k, s, dil, pad, reflect, slope = cases[0]
+        geom = conv.Geometry(H, W, k, s, dil, pad, reflect)
+        x, g = torch.randn(B, H, W, Cin).bfloat16(), torch.randn(B, geom.Hout, geom.Wout, Cout).bfloat16()
+        conv._PLANS.clear()
+        conv.conv_wgrad(x, g, geom, k[0] * k[1], db=torch.zeros(Cout))
+        assert b'conv_wgrad5_kernel' in L.msmc_conv_last_kernel()
+    finally:
+        L.msmc_conv_set_wgrad_generation(2)
+        L.msmc_conv_set_wgrad_split(0)
+
+
 def test_wgrad_fourth_generation_grouped():
     """msmc_conv_wgrad_group_ws4(group4 = 1): the fourth-generation members of a grouped call share one grid of their own
     kernel (members of different tap counts: the widest sets the accumulator budget), a member outside the scope goes the

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """GPU microbench: bf16 weight gradients of the bench configuration -- generation 2 (fp32 atomics, tuned split) against
 generation 3 (split partials in a workspace + fixed-order second stage) and generation 4 (LDS-DMA ring of pixel tiles:
-variants 4 / 5 / 6 = three / two / four stages) at several split settings; results checked against generation 2.
+variants 4 / 5 / 6) and the general-lattice LDS-DMA form (variant 7, wgrad5.inc) at several split settings; results checked against generation 2.
 CANDS="2/0 3/-1 4/0" selects the columns.
 
     python tools/bench_wgrad.py [filter]
@@ -44,7 +44,7 @@ def timed(desc, gp, dw, db, stream, iters=10):
     return s.elapsed_time(e) / iters * 1e3
 
 
-cands = [(2, 0), (2, -1), (3, 0), (3, -1), (4, 0), (4, -1), (4, 1), (5, 0), (6, 0)]
+cands = [(2, 0), (2, -1), (3, 0), (3, -1), (4, 0), (4, -1), (4, 1), (5, 0), (6, 0), (7, 0), (7, -1)]
 if os.environ.get('CANDS'):
     cands = [tuple(int(v) for v in c.split('/')) for c in os.environ['CANDS'].split()]
 print('%-28s %8s | %s' % ('layer', 'GFLOP', ' '.join('v%d/%+d   ' % c for c in cands)))
