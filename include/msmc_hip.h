@@ -129,7 +129,7 @@ typedef struct msmc_conv_desc {
                                0 <= in_slope <= 1), 32 = persistent thin-layer kernel (csrc/gather4.inc: Cin, Cout in {32, 64}, unit strides, zero
                                padding, taps along one axis; weights of all taps resident in LDS, halo tiles by LDS-DMA, epilogue in
                                registers; MSMC_E_SHAPE outside that scope), 33 = 32 with the epilogue of a tile deferred into the next
-                               iteration (interpreter-tested, not yet timed on the GPU: not a tuner candidate), 9 = 32-point tiles with the channel
+                               iteration (measured no faster: not a tuner candidate), 9 = 32-point tiles with the channel
                                chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation (fp32 atomics), 3 = third (split partials + fixed-order reduce), 4 / 5 / 6 = fourth (the
                                third's result contract; pixel tiles flow through an LDS-DMA ring: 4 = three stages, fragment reads two
@@ -137,7 +137,8 @@ typedef struct msmc_conv_desc {
                                MSMC_E_SHAPE outside its scope: unit strides, zero padding, channel counts multiples of 64,
                                taps along one axis), 7 = the third generation's lattice tiles with both operands staged by LDS-DMA into
                                a two-stage ring (csrc/wgrad5.inc: strided, 2-D and reflection-padded layers with channel counts that
-                               are multiples of 64; interpreter-tested, NOT yet timed on the GPU and not a tuner candidate).  The host
+                               are multiples of 64; interpreter-tested, first GPU timing 15 % ahead of generation 3 on the stride-3 period-
+                               discriminator layers, not a tuner candidate yet).  The host
                                layer times the candidates once per layer shape.       */
     int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative).  msmc_conv_gather
                                variants 16..23 only: DIAGNOSTICS mask, 0 in production (1 skip the MFMAs, 2 the weight stream,
