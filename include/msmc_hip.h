@@ -137,8 +137,8 @@ typedef struct msmc_conv_desc {
                                MSMC_E_SHAPE outside its scope: unit strides, zero padding, channel counts multiples of 64,
                                taps along one axis), 7 = the third generation's lattice tiles with both operands staged by LDS-DMA into
                                a two-stage ring (csrc/wgrad5.inc: strided, 2-D and reflection-padded layers with channel counts that
-                               are multiples of 64; interpreter-tested, first GPU timing 15 % ahead of generation 3 on the stride-3 period-
-                               discriminator layers, not a tuner candidate yet).  The host
+                               are multiples of 64; interpreter-tested, first GPU timings 1.15-1.57 x ahead of generations 2 / 3 on the strided period- /
+                               resolution-discriminator layers, not a tuner candidate yet).  The host
                                layer times the candidates once per layer shape.       */
     int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative).  msmc_conv_gather
                                variants 16..23 only: DIAGNOSTICS mask, 0 in production (1 skip the MFMAs, 2 the weight stream,
