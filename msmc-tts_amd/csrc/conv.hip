@@ -2821,6 +2821,109 @@ extern "C" int msmc_conv_wgrad_group_ws4(const msmc_conv_desc* descs, const void
     bool pending[MSMC_GROUP_LIMIT];
     float* wsp = (float*)workspace;
     size_t ws_left = workspace_bytes / sizeof(float);
+    if (group4 && msmc_conv_grouping && n > 1) {                // general-lattice LDS-DMA members (variant 7) first
+        Wg5Plan p5[MSMC_GROUP_LIMIT];
+        bool mine5[MSMC_GROUP_LIMIT], took5[MSMC_GROUP_LIMIT];
+        int count5 = 0;
+        for (int i = 0; i < n; ++i) {
+            const msmc_conv_desc* d = &descs[i];
+            const int gen = d->variant > 0 ? d->variant : msmc_wgrad_generation;
+            took5[i] = false;
+            mine5[i] = d->dtype == 1 && gen == 7 && g[i] && dw[i] && d->B > 0 && d->ntaps > 0 && d->ntaps <= MSMC_CONV_MAX_TAPS;
+            if (mine5[i]) ++count5;
+        }
+        if (count5 > 1) {
+            const int share = count5 < MSMC_GROUP_MAX ? count5 : MSMC_GROUP_MAX;
+            for (int i = 0; i < n; ++i) {
+                if (!mine5[i]) continue;
+                if (wg5_plan(&descs[i], g[i], &p5[i], share)) { mine5[i] = false; continue; }
+                if (p5[i].ws_floats) {
+                    if (p5[i].ws_floats > ws_left) return MSMC_E_WORKSPACE;
+                    p5[i].P.ws = wsp;
+                    wsp += p5[i].ws_floats;
+                    ws_left -= p5[i].ws_floats;
+                }
+            }
+            for (int i = 0; i < n; ++i) {
+                if (!mine5[i]) continue;
+                Wg5GroupArgs a;
+                a.n = 0;
+                int members[MSMC_GROUP_MAX], nmembers = 0;
+                int blocks = 0, tpw = 1;
+                size_t lds = 0;
+                for (int j = i; j < n && a.n < MSMC_GROUP_MAX; ++j) {
+                    if (!mine5[j]) continue;
+                    const int k = a.n++;
+                    a.first[k] = blocks;
+                    a.nx[k] = (int)p5[j].gx;
+                    a.ny[k] = (int)p5[j].gy;
+                    a.g[k] = (const unsigned short*)g[j];
+                    a.dw[k] = dw[j];
+                    a.db[k] = db ? db[j] : nullptr;
+                    a.d[k] = descs[j];
+                    a.G[k] = p5[j].G;
+                    a.P[k] = p5[j].P;
+                    blocks += (int)(p5[j].gx * p5[j].gy * p5[j].gz);
+                    if (p5[j].lds > lds) lds = p5[j].lds;
+                    if (p5[j].tpw > tpw) tpw = p5[j].tpw;
+                    if (p5[j].P.ws) members[nmembers++] = j;
+                    mine5[j] = false;
+                    took5[j] = true;
+                }
+                a.first[a.n] = blocks;
+                ++msmc_conv_launches;
+                int rc;
+                const dim3 grid((unsigned)blocks);
+#define WG5G_GO(TP)                                                                                          \
+    do {                                                                                                     \
+        rc = msmc_allow_lds((const void*)conv_wgrad5_group_kernel<TP>, (int)lds);                            \
+        if (rc) return rc;                                                                                   \
+        MSMC_LAUNCH((conv_wgrad5_group_kernel<TP>), grid, dim3(256), lds, (msmc_stream_t)stream, a);         \
+    } while (0)
+                if (tpw == 1) WG5G_GO(1);
+                else if (tpw == 2) WG5G_GO(2);
+                else if (tpw == 3) WG5G_GO(3);
+                else if (tpw == 4) WG5G_GO(4);
+                else WG5G_GO(5);
+#undef WG5G_GO
+                msmc_conv_last = msmc_prof_name(msmc_kname("conv_wgrad5_group_kernel", nullptr, tpw, -1));
+                rc = msmc_check_launch();
+                if (rc) return rc;
+                for (int level = 0; level < 2 && nmembers; ++level) {
+                    WgReduceArgs r;
+                    r.n = 0;
+                    int rblocks = 0;
+                    for (int q = 0; q < nmembers; ++q) {
+                        const int j = members[q];
+                        const msmc_conv_desc& dj = descs[j];
+                        float* wsj = p5[j].P.ws;
+                        wg3_reduce_add(r, &rblocks, wsj, p5[j].P.ws_stride, (long)dj.ntaps * dj.Cout * dj.Cin,
+                                       (db && db[j]) ? dj.Cout : 0, (int)p5[j].gx,
+                                       wsj + (size_t)p5[j].gx * p5[j].P.ws_stride, dw[j], db ? db[j] : nullptr, level);
+                    }
+                    if (!r.n) continue;
+                    r.first[r.n] = rblocks;
+                    rc = wg3_reduce_launch(r, rblocks, stream);
+                    if (rc) return rc;
+                }
+            }
+            int nrest = 0;
+            msmc_conv_desc rest_d[MSMC_GROUP_LIMIT];
+            const void* rest_g[MSMC_GROUP_LIMIT];
+            float* rest_dw[MSMC_GROUP_LIMIT];
+            float* rest_db[MSMC_GROUP_LIMIT];
+            for (int i = 0; i < n; ++i) {
+                if (took5[i]) continue;
+                rest_d[nrest] = descs[i];
+                rest_g[nrest] = g[i];
+                rest_dw[nrest] = dw[i];
+                rest_db[nrest] = db ? db[i] : nullptr;
+                ++nrest;
+            }
+            if (!nrest) return 0;
+            return msmc_conv_wgrad_group_ws4(rest_d, rest_g, rest_dw, rest_db, nrest, wsp, ws_left * sizeof(float), stream, 1);
+        }
+    }
     if (group4 && msmc_conv_grouping && n > 1) {
         Wg4Plan p4[MSMC_GROUP_LIMIT];
         bool mine[MSMC_GROUP_LIMIT], took[MSMC_GROUP_LIMIT];

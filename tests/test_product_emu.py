@@ -372,6 +372,45 @@ def test_wgrad_general_lattice_dma_staging():
         conv._PLANS.clear()
         conv.conv_wgrad(x, g, geom, k[0] * k[1], db=torch.zeros(Cout))
         assert b'conv_wgrad5_kernel' in L.msmc_conv_last_kernel()
+        # grouped: two strided members of different tap counts on one grid, a third member the old way; bit-identical to
+        # one launch per member at the same split
+        import ctypes
+        L.msmc_conv_set_wgrad_generation(2)
+        L.msmc_conv_set_wgrad_split(2)
+        torch.manual_seed(0)
+        descs, gs, refs, outs = [], [], [], []
+        for (H, W, k, s, pad, reflect, cout, variant) in ((40, 3, (5, 1), (3, 1), (2, 0), False, 64, 7),
+                                                          (13, 18, (3, 3), (2, 2), (1, 1), True, 128, 7),
+                                                          (9, 20, (3, 3), (1, 2), (1, 1), True, 64, 3)):
+            geom = conv.Geometry(H, W, k, s, (1, 1), pad, reflect)
+            x = torch.randn(2, H, W, 64).bfloat16()
+            g = torch.randn(2, geom.Hout, geom.Wout, cout).bfloat16()
+            d = conv._build_desc(x.dtype, 2, H, W, 64, geom.Hout, geom.Wout, cout, geom.fwd_lattice, geom.fwd_taps,
+                                 1 if reflect else 0, 0.2, 1.0, 1.0, 1.0)
+            d.x = d.w = d.out = x.data_ptr()
+            d.variant, d.dw_copies = variant, 1
+            T = k[0] * k[1]
+            need = L.msmc_conv_wgrad_workspace(ctypes.byref(d), g.data_ptr())
+            ws = torch.zeros(max(1, need // 4))
+            dw_ref, db_ref = torch.zeros(T, cout, 64), torch.zeros(cout)
+            assert L.msmc_conv_wgrad_ws(ctypes.byref(d), g.data_ptr(), dw_ref.data_ptr(), db_ref.data_ptr(), ws.data_ptr(),
+                                        need, None) == 0
+            descs.append(d); gs.append((x, g)); refs.append((dw_ref, db_ref))
+            outs.append((torch.zeros(T, cout, 64), torch.zeros(cout)))
+        arr = (lib.ConvDesc * 3)(*descs)
+        vp = ctypes.c_void_p * 3
+        need = sum(L.msmc_conv_wgrad_workspace(ctypes.byref(d), xg[1].data_ptr()) for d, xg in zip(descs, gs))
+        ws = torch.zeros(max(1, need // 4))
+        rc = L.msmc_conv_wgrad_group_ws4(arr, vp(*[xg[1].data_ptr() for xg in gs]), vp(*[o[0].data_ptr() for o in outs]),
+                                         vp(*[o[1].data_ptr() for o in outs]), 3, ws.data_ptr(), need, None, 1)
+        assert rc == 0, rc
+        for (dw_ref, db_ref), (dw, db) in zip(refs, outs):
+            assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+        arr2 = (lib.ConvDesc * 2)(*descs[:2])
+        vp2 = ctypes.c_void_p * 2
+        rc = L.msmc_conv_wgrad_group_ws4(arr2, vp2(*[xg[1].data_ptr() for xg in gs[:2]]), vp2(*[o[0].data_ptr() for o in outs[:2]]),
+                                         vp2(*[o[1].data_ptr() for o in outs[:2]]), 2, ws.data_ptr(), need, None, 1)
+        assert rc == 0 and b'conv_wgrad5_group_kernel' in L.msmc_conv_last_kernel(), L.msmc_conv_last_kernel()
     finally:
         L.msmc_conv_set_wgrad_generation(2)
         L.msmc_conv_set_wgrad_split(0)
