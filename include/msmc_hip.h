@@ -150,6 +150,9 @@ typedef struct msmc_conv_desc {
 
 /* Tests / sweeps: workgroups of the persistent grid of msmc_conv_gather variant 32 (0 = one or two per CU). */
 void msmc_conv_set_gather4_grid(int n);
+/* 1: the variant-32 members of msmc_conv_gather_group share ONE persistent grid (interpreter-tested, not yet timed on the
+ * GPU); default 0: one launch per member. */
+void msmc_conv_set_gather4_grouping(int on);
 /* Perf-experiment switch: 0 selects the simple (un-pipelined) gather kernel everywhere; default 1. */
 void msmc_conv_set_pipeline(int on);
 /* Perf-sweep switches: force the weight-gradient pixel split (0 = model), allow 32-channel N tiles for small grids. */

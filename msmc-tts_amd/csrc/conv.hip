@@ -1637,10 +1637,15 @@ static int cv_group_launch(const msmc_conv_desc* descs, int n, msmc_stream strea
                           : cv3_dispatch(p3[i], dim3((unsigned)blocks), lds, stream, nullptr, nullptr, &a);
         if (rc) return rc;
     }
+    bool done4[MSMC_GROUP_LIMIT];                               // persistent thin-layer members on one grid (off by default)
+    {
+        const int rc = cv4_group_launch(descs, n, stream, done4);
+        if (rc) return rc;
+    }
     for (int i = 0; i < n; ++i) {
         pending[i] = direct[i] = false;
         const msmc_conv_desc* d = &descs[i];
-        if (cv3_is_variant(d->variant)) continue;
+        if (cv3_is_variant(d->variant) || done4[i]) continue;
         int nt_unused;
         int rc = (cv_takes_direct(d) || d->variant == 9 || cv4_is_variant(d->variant)) ? 0 : cv2_plan<T>(d, &plans[i], &nt_unused);
         if (rc) return rc;

@@ -91,6 +91,7 @@ _SIGNATURES.update({
     'msmc_conv_set_wgrad_generation': (None, [_i]),
     'msmc_conv_set_wgrad4_ablate': (None, [_i]),
     'msmc_conv_set_gather4_grid': (None, [_i]),
+    'msmc_conv_set_gather4_grouping': (None, [_i]),
     'msmc_conv_set_gather_generation': (None, [_i]),
     'msmc_conv_last_kernel': (ctypes.c_char_p, []),
     'msmc_conv_launch_count': (ctypes.c_long, []),

@@ -255,6 +255,28 @@ def test_gather_persistent_thin_layer_variant(variant):
             outs.append(conv.conv_forward(x, w, geom, bias=bias, in_slope=0.1, res=res, res2=res2, out_div=3.0,
                                           out_slope=0.2))
         assert _convcases.rel(outs[0], outs[1]) < 1e-2
+        # grouped: three members on one persistent grid (msmc_conv_set_gather4_grouping(1)), six + six + three tiles on
+        # a capped number of workgroups, equal to one launch per member
+        if variant == 32:
+            state['variant'] = 32
+            items, singles = [], []
+            for kk, dd in ((3, 1), (7, 3), (11, 1)):
+                gm = conv.Geometry(1, Lx, (1, kk), (1, 1), (1, dd), (0, dd * (kk - 1) // 2), False)
+                ww = (torch.randn(kk, C, C) / (C * kk) ** 0.5).bfloat16()
+                items.append(dict(x=x, w=ww, geom=gm, bias=bias, in_slope=0.1, res=res))
+                conv._PLANS.clear()
+                singles.append(conv.conv_forward(x, ww, gm, bias=bias, in_slope=0.1, res=res))
+            lib.get().msmc_conv_set_gather4_grouping(1)
+            try:
+                for grid in (0, 2):
+                    lib.get().msmc_conv_set_gather4_grid(grid)
+                    conv._PLANS.clear()
+                    outs_g = conv.conv_forward_group(items)
+                    assert b'conv_gather4_group_kernel' in lib.get().msmc_conv_last_kernel()
+                    assert all(torch.equal(a, b) for a, b in zip(outs_g, singles))
+            finally:
+                lib.get().msmc_conv_set_gather4_grouping(0)
+                lib.get().msmc_conv_set_gather4_grid(0)
         # outside the scope: stride 3 / 96 channels -> MSMC_E_SHAPE surfaces as an error, nothing is mis-computed
         state['variant'] = variant
         conv._PLANS.clear()
