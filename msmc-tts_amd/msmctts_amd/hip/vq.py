@@ -117,6 +117,7 @@ class CodebookSync(object):
                   'msmc_vq_ema_apply')
 
 
+_FLAT = {}            # (device, elements) -> persistent exchange buffer of flush_codebook_sync
 PENDING = []          # CodebookSync objects whose statistics were collected by a forward and not yet applied
 
 
@@ -129,9 +130,19 @@ def flush_codebook_sync(pending=None, group=None, local=False):
     if not items:
         return
     if not local and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        flat = torch.cat([it.stats for it in items])
+        # only the statistics travel: [H][K][d] sums + [H][K] counts of each stage (the trailing H*K words of a
+        # stage's buffer are msmc_vq_ema_apply's scratch), through ONE persistent flat buffer
+        views = [it.stats[:it.stats.numel() - it.embed.shape[0] * it.embed.shape[2]] for it in items]
+        total = sum(v.numel() for v in views)
+        key = (views[0].device, total)
+        flat = _FLAT.get(key)
+        if flat is None:
+            _FLAT.clear()
+            flat = _FLAT[key] = torch.empty(total, dtype=torch.float32, device=views[0].device)
+        parts = list(flat.split([v.numel() for v in views]))
+        torch._foreach_copy_(parts, views)
         dist.all_reduce(flat, group=group)
-        torch._foreach_copy_([it.stats for it in items], list(flat.split([it.stats.numel() for it in items])))
+        torch._foreach_copy_(views, parts)
     for it in items:
         it.apply()
     if pending is None:

@@ -285,6 +285,9 @@ class VQGANTrainer(BaseTrainer):
         codebooks into one tensor), so tensor identities taken before the warm-up can go stale"""
         opt = []
         for o in self.optimizer.optimizers.values():
+            if hasattr(o, '_ensure_state'):        # HipAdamW: the flat state must exist (and be what is recorded)
+                for group in o.param_groups:       # before the warm-up, or the roll-back restores into orphans
+                    o._ensure_state(group)
             for st in o.state.values():
                 opt.extend(v for v in st.values() if torch.is_tensor(v))
         return {'model': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
@@ -444,6 +447,11 @@ class PredictorTrainer(BaseTrainer):
             qs = self.autoencoder.analysis(batch.pop('mel'), batch.pop('mel_length').int())
         batch['feat'] = [f.float() for f in qs['quantizer_outputs']]
         batch['feat_length'] = qs['quantizer_lengths']
+        # fresh dropout masks for the fused kernels of this step: the masks are hash(seed word, salt, element) and
+        # only MSMCVQGAN.forward in training mode advances the word -- the autoencoder here is frozen in eval mode
+        # (analysis only), so without this every predictor step would draw the SAME masks
+        from ..hip import norm as hipnorm
+        hipnorm.advance_seed(batch['feat'][0].device)
         output = self.model.predictor(**batch)
         losses = {'total_loss': 0}
         emb = self.autoencoder.compute_embedding_loss(output['feat'], output['feat_length'], qs,

@@ -3,6 +3,10 @@
 the autoencoder first).  Same arithmetic and the same ``state_dict`` layout as ``torch.optim.AdamW`` (per-parameter
 ``step`` / ``exp_avg`` / ``exp_avg_sq``), so checkpoints move both ways.  Learning rate, step count and clip
 coefficient live on the device: the step replays from a hipGraph unchanged.
+
+Deviation from ``torch.optim.AdamW``: the step count is ONE device word per group, not one per parameter.  A parameter
+that first receives a gradient at step k > 1 (none of the shipped models has one: every trainable tensor of a child gets a
+gradient on every backward of that child) is bias-corrected with the group's count, not with its own.
 """
 import ctypes
 
@@ -24,6 +28,8 @@ class HipAdamW(Optimizer):
     # -- flat state ---------------------------------------------------------------------------
     def _ensure_state(self, group):
         ps = [p for p in group['params'] if p.requires_grad]
+        if not ps:                  # a child frozen entirely (config.freeze / the optimizer's parameter regex): no-op
+            return ps
         if 'flat' in group and group['flat']['n'] == sum(p.numel() for p in ps):
             return ps
         dev = ps[0].device
@@ -48,6 +54,8 @@ class HipAdamW(Optimizer):
         return ps
 
     def _table(self, group, ps):
+        if not ps:
+            return None, None, 0, 0
         live = [p for p in ps if p.grad is not None]
         sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in live)
         cached = group.get('table')
@@ -101,12 +109,16 @@ class HipAdamW(Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        for group in self.param_groups:           # re-home the loaded moments in the flat buffers at the next step
+        for group in self.param_groups:
             group.pop('flat', None)
             group.pop('table', None)
             if not torch.is_tensor(group['lr']):
                 dev = group['params'][0].device
                 group['lr'] = torch.tensor(float(group['lr']), dtype=torch.float32, device=dev)
+            # re-home the loaded moments in the flat buffers NOW: a later re-homing (first step) would replace the state
+            # tensors, and anything that recorded them in between -- the trainer's capture snapshot / roll-back -- would
+            # restore into orphans and zero the live moments (resume + --graphs lost step / exp_avg that way)
+            self._ensure_state(group)
 
     def state_dict(self):
         sd = super().state_dict()

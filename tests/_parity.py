@@ -346,6 +346,79 @@ def check_hip_adamw(dev):
         assert (p - q).abs().max() <= 2e-6
 
 
+def check_hip_adamw_resume_then_capture_rollback(dev):
+    """a checkpoint loaded into HipAdamW and then put through the trainer's capture protocol (record the state tensors,
+    run warm-up steps, copy the recorded values back) must come out with the LOADED step count and moments: the flat
+    state is re-homed at load time, so the recorded tensors are the live ones (round-2 advisor finding: they were orphans,
+    and the roll-back zeroed the live moments)"""
+    from msmctts_amd.trainers.optimizers.hip_adamw import HipAdamW
+    torch.manual_seed(1)
+    shapes = [(9,), (17, 3), (4100,)]
+    ps = [torch.nn.Parameter(torch.randn(*s, device=dev)) for s in shapes]
+    a = HipAdamW(ps, lr=1e-3, betas=(0.8, 0.99))
+    for _ in range(3):
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        a.step(max_norm=1.0)
+    sd = a.state_dict()
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    b = HipAdamW(qs, lr=1e-3, betas=(0.8, 0.99))
+    b.load_state_dict(sd)
+    recorded = [(v, v.detach().clone()) for st in b.state.values() for v in st.values() if torch.is_tensor(v)]
+    assert recorded
+    for _ in range(2):                                        # the capture warm-up really trains ...
+        for q in qs:
+            q.grad = torch.randn_like(q)
+        b.step(max_norm=1.0)
+    live = set(id(v) for st in b.state.values() for v in st.values() if torch.is_tensor(v))
+    assert live == set(id(v) for v, _ in recorded), 'state tensors were replaced after load_state_dict'
+    with torch.no_grad():
+        for v, saved in recorded:                             # ... and is rolled back
+            v.copy_(saved)
+    for i, q in enumerate(qs):
+        assert float(b.state[q]['step']) == 3.0
+        assert torch.equal(b.state[q]['exp_avg'], sd['state'][i]['exp_avg'].to(dev))
+        assert torch.equal(b.state[q]['exp_avg_sq'], sd['state'][i]['exp_avg_sq'].to(dev))
+    # a child without trainable parameters is a no-op, not an IndexError
+    frozen = [torch.nn.Parameter(torch.randn(5, device=dev), requires_grad=False)]
+    c = HipAdamW(frozen, lr=1e-3)
+    c.prepare()
+    c.step()
+
+
+def check_predictor_dropout_masks_advance(device):
+    """PredictorTrainer.train_step advances the seed word of the fused dropout kernels once per step (the frozen
+    autoencoder's analysis() does not), so consecutive steps draw different masks; with the word held fixed the same
+    call reproduces its masks (what backward relies on)"""
+    from msmctts_amd.hip import norm as hipnorm
+    from msmctts_amd.tasks import build_task
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    from msmctts_amd.utils.config import Config
+    z = load_npz('small_predictor.npz')
+    pc = small_predictor_cfg()
+    for part in ('encoder_config', 'decoder_config', 'adaptor_config'):
+        pc[part] = dict(pc[part], dropout=0.5, fused_layernorm=True)
+    cfg = Config({'id': 'small_predictor_dropout', 'task': {'_name': 'MSMCTTS', '_mode': 'train_predictor', 'predictor': pc},
+                  'trainer': dict(PREDICTOR_TRAINER, _name='PredictorTrainer'),
+                  'optimizer': {'_default': dict(_name='Adam', learning_rate=0.0, betas=[0.9, 0.98], eps=1e-9, weight_decay=0)},
+                  'dataset': dict(samplerate=24000, feature=['mel', 'wav'], frameshift=[300, 1])})
+    task = build_task(cfg, mode='train').to(device).train()
+    _, atask = build_small(device)
+    batch = {k[len('batch.'):]: t(v).to(device) for k, v in z.items() if k.startswith('batch.')}
+    tr = build_trainer(cfg, task, num_gpus=0, rank=0)
+    tr.autoencoder = atask.autoencoder
+    tr.optimizer = build_optimizer(task, cfg.optimizer)
+    dev = batch['mel'].device
+    w0 = int(hipnorm.seed_word(dev))
+    losses = []
+    for i in range(3):                                        # learning rate 0: only the masks differ between steps
+        log = tr.train_step({k: v.clone() for k, v in batch.items()}, i)
+        losses.append(float(log['loss']['total_loss']))
+    assert int(hipnorm.seed_word(dev)) == w0 + 3
+    assert len(set(losses)) == 3, ('identical dropout masks on consecutive predictor steps', losses)
+
+
 def check_inference(device):
     """the task's inference glue (analysis-synthesis; text -> predictor -> synthesis with teacher durations) in evaluation
     mode against the reference's MSMCTTS.infer_step (tests/golden/small_infer.npz)"""

@@ -243,6 +243,14 @@ def test_hip_adamw_matches_torch_adamw_with_clipping():
     _parity.check_hip_adamw(DEV)
 
 
+def test_hip_adamw_resume_then_capture_rollback_keeps_loaded_moments():
+    _parity.check_hip_adamw_resume_then_capture_rollback(DEV)
+
+
+def test_predictor_steps_draw_fresh_dropout_masks():
+    _parity.check_predictor_dropout_masks_advance(DEV)
+
+
 def test_codebook_statistics_split_update_is_the_fused_update():
     _parity.check_codebook_split_update(DEV)
 

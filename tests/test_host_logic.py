@@ -138,3 +138,26 @@ def test_tuner_borrows_the_nearest_tuned_shape_of_the_same_class():
         K.TUNED.clear()
         K.TUNED.update(keep)
         K._CLASS_INDEXED[0] = -1
+
+
+def test_bench_line_is_one_short_parseable_json_line(tmp_path):
+    """The driver parses ONE JSON line from bench.py's stdout; round 2's line (36 KB with the per-kernel table inline)
+    came back unparsed.  emit_line moves the table to a side file and keeps the line under 8 KB whatever the table's
+    size, without touching the contract keys, `roofline` or `cpu_baseline`."""
+    import bench
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r02_bench.json')))
+    assert len(json.dumps(full)) > 30000 and 'kernels' in full            # the line that did not parse
+    side = str(tmp_path / 'sub' / 'kernels.json')
+    line = bench.emit_line(full, side)
+    assert '\n' not in line and len(line) < 8192
+    got = json.loads(line)
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert got[key] == full[key], key
+    assert 'kernels' not in got and got['kernels_file']
+    assert json.load(open(side))['kernels'] == full['kernels']
+    # a pathologically long optional block is dropped before the line may exceed the limit
+    fat = dict(full, vq_microbench=[{'note': 'x' * 9000}])
+    slim = json.loads(bench.emit_line(fat, None))
+    assert 'vq_microbench' not in slim and slim['roofline'] == {k: v for k, v in full['roofline'].items() if k != 'note'}
+    assert slim['cpu_baseline']['value'] == full['cpu_baseline']['value']
