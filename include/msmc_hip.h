@@ -2,9 +2,12 @@
  *
  * The reference's drop-in boundary for this path is a Python plugin registry, not an FFI
  * (reference msmctts/networks/__init__.py:6-11).  This library sits *below* it:
- * every entry point takes plain device pointers, sizes and a HIP stream, allocates nothing, keeps no
- * global state, is stream-ordered and re-entrant per stream, and returns 0 (hipSuccess) or a
- * hipError_t / negative MSMC_E* code.  The Python host side (msmc-tts_amd/msmctts_amd) binds these with
+ * every entry point takes plain device pointers, sizes and a HIP stream, allocates nothing, is
+ * stream-ordered and re-entrant per stream, and returns 0 (hipSuccess) or a hipError_t / negative MSMC_E*
+ * code.  Process-global state, all of it: the msmc_*_set_* switches below (plain ints read at launch time;
+ * perf experiments and tests only -- a production caller never touches them, kernel choices that matter
+ * are per call: msmc_conv_desc.variant / split_shift), the per-thread msmc_conv_last_kernel /
+ * msmc_conv_launch_count / msmc_vq_last_kernel tags and the opt-in msmc_prof_* launch log.  The Python host side (msmc-tts_amd/msmctts_amd) binds these with
  * ctypes from modules that carry the reference's class names; INTEGRATION.md shows the stub a
  * reference maintainer would add.
  *
@@ -53,6 +56,8 @@ int msmc_vq_search(const float* x, const float* embed_t, const float* enorm, flo
 
 /* Perf-experiment switch: 0 selects the LDS-tile search kernel for every shape; default 1. */
 void msmc_vq_set_variant(int v);
+/* Symbol of the search kernel the calling thread's most recent msmc_vq_search launched (profiling aid). */
+const char* msmc_vq_last_kernel(void);
 
 /* Bytes of scratch msmc_vq_ema_update needs for these sizes. */
 size_t msmc_vq_ema_workspace(int N, int D, int H, int K);

@@ -24,6 +24,9 @@
 // A/B switch (msmc_vq_set_variant): 1 = register-resident search kernel where d % 16 == 0, 0 = LDS-tile kernel.
 static int vq_use_reg_kernel = 1;
 extern "C" void msmc_vq_set_variant(int v) { vq_use_reg_kernel = v; }
+// symbol of the search kernel the calling thread's most recent msmc_vq_search launched (bench.py's micro-benchmark table)
+static thread_local const char* msmc_vq_last = "";
+extern "C" const char* msmc_vq_last_kernel(void) { return msmc_vq_last; }
 
 // ------------------------------------------------------------------------------------------------
 // prepare: embed [H][d][K] -> embed_t [H][K][d], enorm [H][K]
@@ -656,6 +659,7 @@ int msmc_vq_search(const float* x, const float* embed_t, const float* enorm, flo
                 const int grid = numIters < wgs ? numIters : wgs;
                 MSMC_LAUNCH(rf, dim3(grid), dim3(64 * nw), lds, (msmc_stream_t)stream, x, embed_t, enorm, quant, diff,
                             ind, N, D, H, K, hpg);
+                msmc_vq_last = msmc_prof_name("vq_search_reg_kernel");
                 return msmc_check_launch();
             }
         }
@@ -686,6 +690,7 @@ int msmc_vq_search(const float* x, const float* embed_t, const float* enorm, flo
     const int grid = numIters < MSMC_NUM_CU ? numIters : MSMC_NUM_CU;
     MSMC_LAUNCH(fn, dim3(grid), dim3(64 * nw), (size_t)L.total, (msmc_stream_t)stream, x, embed_t, enorm, quant, diff,
                 ind, N, D, H, K, hpg, L);
+    msmc_vq_last = msmc_prof_name("vq_search_kernel");
     return msmc_check_launch();
 }
 

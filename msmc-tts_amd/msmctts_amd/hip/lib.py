@@ -24,6 +24,7 @@ _SIGNATURES = {
     'msmc_vq_prepare': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'msmc_vq_search': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'msmc_vq_set_variant': (None, [_i]),
+    'msmc_vq_last_kernel': (ctypes.c_char_p, []),
     'msmc_vq_ema_workspace': (_sz, [_i, _i, _i, _i]),
     'msmc_vq_ema_update': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _f, _f, _vp]),
     'msmc_vq_ema_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),

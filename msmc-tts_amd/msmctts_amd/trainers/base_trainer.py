@@ -3,8 +3,10 @@
 Keeps the reference's observable contract -- per-iteration order (LR schedule, batch to device,
 ``model.zero_grad``, ``train_step``, checkpoint cadence), checkpoint dictionary
 ``{'model', 'optimizer', 'iteration', 'config'}`` with the reference's key names, resume rules -- while
-the data source is any iterable of collated batches (the metric uses the synthetic generator in
-``msmctts_amd.synthetic``; dataset readers are out of scope).
+``train()`` builds its loader from the configuration's ``dataset:`` section (``msmctts_amd.datasets``: the
+reference's id-list / feature-path conventions and collation, behind a ``DeviceLoader`` that keeps one batch ahead on
+the GPU) or takes any iterable of collated batches (the metric uses the synthetic generator in
+``msmctts_amd.synthetic``).
 """
 import glob
 import os

@@ -58,6 +58,83 @@ SMALL = [
 ]
 
 
+def csmsc_layers(B=16):
+    """Every convolution layer shape of the CSMSC model's HifiGAN generator, period and resolution discriminators
+    (40-frame window = 12000 samples), as CONVS-style cases keyed by family."""
+    out = {'gen': [], 'mpd': [], 'mrd': []}
+    out['gen'].append(('gen conv_pre k7 256->512', B, 256, 512, 1, 40, (1, 7), (1, 1), (1, 1), (0, 3), False, 1.0))
+    for C, L in ((256, 240), (128, 1200), (64, 6000), (32, 12000)):
+        for k in (3, 7, 11):
+            for d in (1, 3, 5):
+                out['gen'].append(('gen rb C%d L%d k%d d%d' % (C, L, k, d), B, C, C, 1, L, (1, k), (1, 1), (1, d),
+                                   (0, d * (k - 1) // 2), False, 0.1))
+    out['gen'].append(('gen conv_post k7 32->1', B, 32, 1, 1, 12000, (1, 7), (1, 1), (1, 1), (0, 3), False, 0.01))
+    for p in (2, 3, 5, 7, 11):
+        H = -(-12000 // p)
+        chans = (1, 16, 64, 256, 512)
+        for i in range(4):
+            out['mpd'].append(('mpd p%d conv%d %d->%d s3' % (p, i, chans[i], chans[i + 1]), B, chans[i], chans[i + 1], H, p,
+                               (5, 1), (3, 1), (1, 1), (2, 0), False, 1.0 if i == 0 else 0.2))
+            H = (H + 4 - 5) // 3 + 1
+        out['mpd'].append(('mpd p%d conv4 512->512 s1' % p, B, 512, 512, H, p, (5, 1), (1, 1), (1, 1), (2, 0), False, 0.2))
+        out['mpd'].append(('mpd p%d post 512->1' % p, B, 512, 1, H, p, (3, 1), (1, 1), (1, 1), (1, 0), False, 0.2))
+    for hop, hidden in ((15, 128), (30, 128), (50, 256), (120, 256), (240, 512)):
+        F_, T_ = 2 * hop + 1, 12000 // hop + 1
+        chans = (2, hidden // 32, hidden // 16, hidden // 8, hidden // 4, hidden // 2, hidden, 1)
+        for i, st in enumerate((1, 2, 1, 2, 1, 2, 1)):
+            out['mrd'].append(('mrd h%d conv%d %d->%d s%d' % (hop, i, chans[i], chans[i + 1], st), B, chans[i], chans[i + 1],
+                               F_, T_, (3, 3), (st, st), (1, 1), (1, 1), True, 1.0 if i == 0 else 0.2))
+            F_, T_ = (F_ + 2 - 3) // st + 1, (T_ + 2 - 3) // st + 1
+    return out
+
+
+def conv_case_data(case, dtype, dev):
+    """operands in the kernels' layouts and PyTorch's results (forward, data gradient, weight / bias gradient) of one
+    layer: computed once per (case, dtype), checked against as many kernel variants as the caller forces"""
+    name, B, Cin, Cout, H, W, k, s, dil, pad, reflect, slope = case
+    g = torch.Generator(device='cpu').manual_seed(sum(ord(c) for c in name))
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, *k, generator=g) / (Cin * k[0] * k[1]) ** 0.5).to(dev).requires_grad_(True)
+    b = torch.randn(Cout, generator=g).to(dev).requires_grad_(True)
+    xa = F.leaky_relu(x, slope) if slope != 1.0 else x
+    if reflect:
+        ref = F.conv2d(F.pad(xa, (pad[1], pad[1], pad[0], pad[0]), mode='reflect'), w, b, s, 0, dil)
+    else:
+        ref = F.conv2d(xa, w, b, s, pad, dil)
+    go = torch.randn(ref.shape, generator=g).to(dev)
+    ref.backward(go)
+    T = k[0] * k[1]
+    d = dict(case=case, dtype=dtype, T=T, ref=ref.detach(), gx_ref=x.grad, b=b.detach(),
+             dw_ref=w.grad.permute(2, 3, 0, 1).reshape(T, Cout, Cin),
+             wf=w.detach().permute(2, 3, 0, 1).reshape(T, Cout, Cin).contiguous().to(dtype),
+             wb=w.detach().permute(2, 3, 1, 0).reshape(T, Cin, Cout).contiguous().to(dtype),
+             xc=cl(x.detach()).to(dtype), gc=cl(go).to(dtype))
+    d['db_ref'] = d['gc'].float().reshape(-1, Cout).sum(0)
+    d['db_scale'] = d['gc'].float().reshape(-1, Cout).abs().sum(0).max().item()
+    return d
+
+
+def conv_part_errors(d, part):
+    """relative error(s) of one part ('fwd' / 'dgrad' / 'wgrad') of a prepared case under the CURRENT kernel choices
+    (a fresh Geometry per call: descriptors, and with them forced variants, are cached per geometry object)"""
+    from msmctts_amd.hip import conv
+    name, B, Cin, Cout, H, W, k, s, dil, pad, reflect, slope = d['case']
+    geom = conv.Geometry(H, W, k, s, dil, pad, reflect)
+    if part == 'fwd':
+        out = conv.conv_forward(d['xc'], d['wf'], geom, bias=d['b'], in_slope=slope)
+        return {'fwd': rel(nchw(out), d['ref'])}
+    if part == 'dgrad':
+        if reflect:
+            gx = conv.reflect_fold(conv.conv_dgrad(d['gc'], d['wb'], geom), H, W, pad[0],
+                                   mask_src=d['xc'] if slope != 1.0 else None, slope=slope)
+        else:
+            gx = conv.conv_dgrad(d['gc'], d['wb'], geom, mask_src=d['xc'] if slope != 1.0 else None, mask_slope=slope)
+        return {'dgrad': rel(nchw(gx), d['gx_ref'])}
+    db = torch.zeros(Cout, device=d['xc'].device)
+    dw = conv.conv_wgrad(d['xc'], d['gc'], geom, d['T'], in_slope=slope, db=db)
+    return {'wgrad': rel(dw, d['dw_ref']), 'bias grad': (db - d['db_ref']).abs().max().item() / (d['db_scale'] + 1e-6) * 1e3}
+
+
 def check_conv_case(case, dtype, tol, dev, parts=('fwd', 'dgrad', 'wgrad'), batch_offset=0):
     """forward / data gradient / weight + bias gradient of one layer against PyTorch on ``dev``."""
     from msmctts_amd.hip import conv

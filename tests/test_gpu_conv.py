@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-from _convcases import CONVS, SMALL, check_conv_case, cl, nchw, rel
+from _convcases import CONVS, SMALL, check_conv_case, cl, conv_part_errors, nchw, rel
 
 
 @pytest.mark.parametrize('dtype,tol', [(torch.float32, 2e-4), (torch.bfloat16, 2e-2)])
@@ -292,3 +292,99 @@ def test_grouped_launches_equal_single_launches():
     conv.conv_wgrad_group(witems)
     for dw_ref, db_ref, dw, db in wrefs:
         assert rel(dw.sum(0), dw_ref) < 1e-4 and rel(db.sum(0), db_ref) < 1e-4
+
+
+def _forced(kind, variant_shift, data, parts, conv):
+    """run ``parts`` of a prepared case with ONE candidate forced through the tuner; returns (errors, ran) where ``ran``
+    counts the descriptors that really executed the candidate (a candidate outside its scope returns MSMC_E_SHAPE at the
+    validation launch and the library heuristic runs instead -- that proves nothing about the candidate)"""
+    conv.TUNED.clear()
+    conv._PLANS.clear()
+    conv._CLASS_INDEX.clear()
+    conv._CLASS_INDEXED[0] = -1
+    if kind == 'gather':
+        conv._GATHER_CANDIDATES = (variant_shift,)
+    else:
+        conv._WGRAD_CANDIDATES = (variant_shift,)
+    errs = {}
+    for part in parts:
+        errs.update(conv_part_errors(data, part))
+    ran = sum(1 for k, v in conv.TUNED.items() if k[0] == kind and (v[0], v[1]) == tuple(variant_shift) and v[2])
+    return errs, ran
+
+
+@pytest.mark.parametrize('family', ['gen', 'mpd', 'mrd'])
+def test_every_gather_candidate_forced_on_every_csmsc_layer(family):
+    """No forward / data-gradient kernel reaches hip/tuned_gfx950.json without a direct hardware test: every tuner
+    candidate (msmc_conv_desc.variant, hip/conv.py _GATHER_CANDIDATES: generations 1-2, direct, wave-split, third
+    generation 16-23, LDS-DMA halo 24-31, persistent thin-layer 32) is FORCED on every convolution shape of the CSMSC
+    generator / period / resolution discriminators it accepts, forward and data gradient, against PyTorch fp32 (2e-2,
+    bf16).  Shapes outside a candidate's scope are skipped (MSMC_E_SHAPE); each candidate must have run somewhere in
+    the model (asserted over the three families in test_every_candidate_ran_somewhere)."""
+    from msmctts_amd.hip import conv
+    from _convcases import conv_case_data, conv_part_errors, csmsc_layers
+    saved = (conv._GATHER_CANDIDATES, dict(conv.TUNED), conv.TUNE_BORROW)
+    conv.TUNE_BORROW = False            # time (= force) the one candidate on every shape, never borrow a neighbour's choice
+    bad = []
+    try:
+        for case in csmsc_layers()[family]:
+            data = conv_case_data(case, torch.bfloat16, DEV)
+            for cand in saved[0]:
+                errs, ran = _forced('gather', cand, data, ('fwd', 'dgrad'), conv)
+                _RAN[('gather', cand)] = _RAN.get(('gather', cand), 0) + ran
+                bad.extend((case[0], cand, part, e) for part, e in errs.items() if not e < 2e-2)
+    finally:
+        conv._GATHER_CANDIDATES, conv.TUNE_BORROW = saved[0], saved[2]
+        conv.TUNED.clear()
+        conv.TUNED.update(saved[1])
+    assert not bad, bad[:20]
+
+
+@pytest.mark.parametrize('family', ['gen', 'mpd', 'mrd'])
+def test_every_wgrad_candidate_forced_on_every_csmsc_layer(family):
+    """the same for the weight (+ bias) gradient candidates (_WGRAD_CANDIDATES: generations 1-4 with their pixel-split
+    shifts and the general-lattice LDS-DMA generation, variant 7) -- in particular variant 7 on every stride-3
+    period-discriminator layer and every reflect-padded 3x3 resolution-discriminator layer with channel counts it takes"""
+    from msmctts_amd.hip import conv
+    from _convcases import conv_case_data, conv_part_errors, csmsc_layers
+    saved = (conv._WGRAD_CANDIDATES, dict(conv.TUNED), conv.TUNE_BORROW)
+    conv.TUNE_BORROW = False
+    bad = []
+    try:
+        for case in csmsc_layers()[family]:
+            data = conv_case_data(case, torch.bfloat16, DEV)
+            for cand in saved[0]:
+                errs, ran = _forced('wgrad', cand, data, ('wgrad',), conv)
+                _RAN[('wgrad', cand)] = _RAN.get(('wgrad', cand), 0) + ran
+                if cand[0] == 7 and ran:
+                    _RAN.setdefault('wgrad5 layers', []).append(case[0])
+                bad.extend((case[0], cand, part, e) for part, e in errs.items() if not e < 2e-2)
+    finally:
+        conv._WGRAD_CANDIDATES, conv.TUNE_BORROW = saved[0], saved[2]
+        conv.TUNED.clear()
+        conv.TUNED.update(saved[1])
+    assert not bad, bad[:20]
+
+
+_RAN = {}
+
+
+def test_every_candidate_ran_somewhere():
+    """(after the two sweeps above, same process) every tuner candidate executed on at least one CSMSC layer; the
+    general-lattice weight gradient on all twenty strided / reflected discriminator layers with C % 64 == 0"""
+    from msmctts_amd.hip import conv
+    if not any(k[0] == 'gather' for k in _RAN if isinstance(k, tuple)):
+        pytest.skip('the sweeps did not run in this session')
+    missing = [k for k in [('gather', c) for c in conv._GATHER_CANDIDATES] + [('wgrad', c) for c in conv._WGRAD_CANDIDATES]
+               if not _RAN.get(k)]
+    assert not missing, missing
+    if (7, 0) in conv._WGRAD_CANDIDATES:
+        layers = set(_RAN.get('wgrad5 layers', []))
+        want = {c[0] for fam in ('mpd', 'mrd') for c in csmsc_layers_cached()[fam]
+                if c[2] % 64 == 0 and c[3] % 64 == 0 and (c[7] != (1, 1) or c[10])}
+        assert want <= layers, sorted(want - layers)
+
+
+def csmsc_layers_cached():
+    from _convcases import csmsc_layers
+    return csmsc_layers()

@@ -161,3 +161,53 @@ def test_bench_line_is_one_short_parseable_json_line(tmp_path):
     slim = json.loads(bench.emit_line(fat, None))
     assert 'vq_microbench' not in slim and slim['roofline'] == {k: v for k, v in full['roofline'].items() if k != 'note'}
     assert slim['cpu_baseline']['value'] == full['cpu_baseline']['value']
+
+
+def _header_struct_fields(name):
+    """[(field, kind)] of ``typedef struct <name> {...}`` in include/msmc_hip.h; kind: 'p' pointer, 'i' int, 'f' float,
+    'l' long, ('i', n) int array"""
+    header = open(os.path.join(ROOT, 'include', 'msmc_hip.h')).read()
+    body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (name, name), header, re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    out = []
+    for stmt in body.split(';'):
+        stmt = ' '.join(stmt.split())
+        if not stmt:
+            continue
+        m = re.match(r'(const )?(void|float|int|long)( ?\*)? ?(.*)', stmt)
+        assert m, stmt
+        base, ptr = m.group(2), bool(m.group(3))
+        for decl in m.group(4).split(','):
+            decl = decl.strip()
+            arr = re.match(r'(\w+)\[(\w+)\]', decl)
+            if ptr or decl.startswith('*'):
+                out.append((decl.lstrip('* '), 'p'))
+            elif arr:
+                n = {'MSMC_CONV_MAX_TAPS': 16, 'MSMC_MAX_TENSORS': 64}.get(arr.group(2)) or int(arr.group(2))
+                out.append((arr.group(1), (base[0], n)))
+            else:
+                out.append((decl, base[0]))
+    return out
+
+
+def test_conv_descriptor_is_the_same_in_header_binding_and_integration_doc():
+    """include/msmc_hip.h `msmc_conv_desc`, the ctypes binding (hip/lib.py ConvDesc) and the struct a maintainer would
+    copy from INTEGRATION.md route B agree field for field, in order (round 2: the doc block was three ints short)."""
+    from msmctts_amd.hip import lib
+    want = _header_struct_fields('msmc_conv_desc')
+    kinds = {ctypes.c_void_p: 'p', ctypes.c_int: 'i', ctypes.c_float: 'f', ctypes.c_long: 'l'}
+
+    def kind(ct):
+        return kinds[ct] if ct in kinds else (kinds[ct._type_], ct._length_)
+    assert [(n, kind(ct)) for n, ct in lib.ConvDesc._fields_] == want
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    block = re.search(r'class msmc_conv_desc\(ctypes\.Structure\):.*?_fields_ = \[(.*?)\]\n', doc, re.S).group(1)
+    got = []
+    for n, ct, arr in re.findall(r"\('(\w+)', ctypes\.c_(\w+)( \* \d+)?\)", block):
+        k = {'void_p': 'p', 'int': 'i', 'float': 'f', 'long': 'l'}[ct]
+        got.append((n, (k, int(arr.strip(' *'))) if arr else k))
+    assert got == want
+    assert ctypes.sizeof(lib.ConvDesc) == 360         # 7 pointers, 68 + 3 ints, 4 floats, padded to 8 bytes
+    # the other by-value structs of the ABI, binding against header
+    for cname, cls in (('msmc_opt_tensor', lib.OptTensor), ('msmc_wn_item', lib.WnItem)):
+        assert [n for n, _ in cls._fields_] == [n for n, _ in _header_struct_fields(cname)], cname
