@@ -109,6 +109,18 @@ MSMC_DEV float wave_down(float v, int delta) { return __shfl_down(v, delta, 64);
 MSMC_DEV float wave_bcast(float v, int lane) { return __shfl(v, lane, 64); }
 MSMC_DEV int wave_bcast(int v, int lane) { return __shfl(v, lane, 64); }
 
+// true in every lane when the predicate holds in at least one lane of the wave (wave-uniform branch conditions)
+MSMC_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// median of three (v_med3_f32): with lo <= hi, med3(hi, lo, x) is the second largest of {hi, lo, x}
+MSMC_DEV float fmed3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+// two floats -> packed bf16 pair (round to nearest even, v_cvt_pk_bf16_f32): a in bits 0..15, b in bits 16..31
+MSMC_DEV unsigned int pack_bf16x2(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ r = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(r, bf16x2_));
+}
+
 // Intra-wave LDS hand-off point: lanes of ONE wave exchange data through LDS (a wave executes its
 // LDS instructions in order, so no hardware barrier is needed); this only stops the compiler from
 // moving LDS accesses across the hand-off.

@@ -92,6 +92,16 @@ MSMC_DEV float wave_down(float v, int delta) {
 MSMC_DEV float wave_bcast(float v, int lane) { return emu_exchange(v, lane); }
 MSMC_DEV int wave_bcast(int v, int lane) { return emu_exchange(v, lane); }
 
+MSMC_DEV bool wave_any(bool p) {
+    int v = p ? 1 : 0;
+    for (int m = 1; m < 64; m <<= 1) v |= emu_exchange(v, emu::lane() ^ m);      // butterfly OR over the 64 lanes
+    return v != 0;
+}
+MSMC_DEV float fmed3(float a, float b, float c) {
+    const float lo = fminf(a, b), hi = fmaxf(a, b);
+    return fmaxf(lo, fminf(hi, c));
+}
+
 MSMC_DEV void wave_sync() { emu::wave_barrier(); }   // fibers are not lock-step: make it a real barrier
 
 // ---- MFMA, by the fragment layouts documented in csrc/gfx950/msmc_rt.hpp --------------------------
@@ -234,6 +244,9 @@ MSMC_DEV unsigned short f32_to_bf16_bits(float f) {
     return (unsigned short)(u >> 16);
 }
 MSMC_DEV float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+MSMC_DEV unsigned int pack_bf16x2(float a, float b) {
+    return (unsigned int)f32_to_bf16_bits(a) | ((unsigned int)f32_to_bf16_bits(b) << 16);
+}
 MSMC_DEV unsigned int bf16x2_leaky(unsigned int w, float slope) {
     const float f0 = __uint_as_float(w << 16), f1 = __uint_as_float(w & 0xffff0000u);
     const float r0 = f0 > 0.f ? f0 : f0 * slope, r1 = f1 > 0.f ? f1 : f1 * slope;
