@@ -222,29 +222,39 @@ def cpu_baseline(cfg, state_dict, batch, windows, steps, warmups, threads, sampl
     return out
 
 
-def vq_microbench(device, H, K, D=256, N=1 << 20, iters=20, variant=1):
+def vq_microbench(device, H, K, D=256, N=1 << 20, iters=20, shortlist=None):
+    """msmc_vq_search[_shortlist] at N = 2^20 frames.  ``shortlist``: None = what the product runs for this
+    shape (the bf16-shortlist kernel where it applies, bit-identical results), False = the exact register-resident kernel."""
     from msmctts_amd.hip import lib, vq
-    lib.get().msmc_vq_set_variant(variant)
     g = torch.Generator(device='cpu').manual_seed(0)
     x = torch.randn(N, D, generator=g).to(device)
     embed = torch.randn(H, D // H, K, generator=g).to(device)
     et, en = vq.vq_prepare(embed)
-    for _ in range(3):
-        vq.vq_search(x, et, en)
-    torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(iters):
-        vq.vq_search(x, et, en)
-    e.record()
-    torch.cuda.synchronize()
+    vq.SLOW_COUNT = torch.zeros(2, dtype=torch.int64, device=device)
+    try:
+        for _ in range(3):
+            vq.vq_search(x, et, en, shortlist=shortlist)
+        torch.cuda.synchronize()
+        vq.SLOW_COUNT.zero_()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            vq.vq_search(x, et, en, shortlist=shortlist)
+        e.record()
+        torch.cuda.synchronize()
+        slow = [v / float(iters) for v in vq.SLOW_COUNT.tolist()]
+    finally:
+        vq.SLOW_COUNT = None
     ms = s.elapsed_time(e) / iters          # includes three small output allocations per call (cached allocator)
     byts = N * vq_bytes_per_frame(D, H)
-    lib.get().msmc_vq_set_variant(1)
     r4 = lambda v: float('%.4g' % v)
-    return dict(kernel=lib.get().msmc_vq_last_kernel().decode(), N=N, D=D, H=H, K=K, ms=r4(ms), GBps=r4(byts / ms / 1e6),
-                frac_hbm=r4(byts / ms / 1e6 / HBM_PEAK_GBS), Mframes_per_s=r4(N / ms / 1e3),
-                fp32_TFLOPs=r4(2.0 * K * D * N / ms / 1e9))
+    out = dict(kernel=lib.get().msmc_vq_last_kernel().decode(), N=N, D=D, H=H, K=K, ms=r4(ms), GBps=r4(byts / ms / 1e6),
+               frac_hbm=r4(byts / ms / 1e6 / HBM_PEAK_GBS), Mframes_per_s=r4(N / ms / 1e3),
+               fp32_TFLOPs=r4(2.0 * K * D * N / ms / 1e9))
+    if out['kernel'] == 'vq_search_sl_kernel':
+        tiles = (N + 15) // 16 * H          # fractions of the 16-frame tiles (per head) that left the shortlist path
+        out.update(exact_rerank_frac=r4(slow[0] / tiles), exact_research_frac=r4(slow[1] / tiles))
+    return out
 
 
 def main():
@@ -317,7 +327,7 @@ def main():
         n = x.numel() // x.shape[-1]
         return 2.0 * n * x.shape[-1] * et.shape[1], n * vq_bytes_per_frame(x.shape[-1], et.shape[0])
 
-    timer.wrap(hipvq, 'vq_search', lambda: 'vq_search_reg_kernel', vq_work)
+    timer.wrap(hipvq, 'vq_search', lambda: 'vq_search_reg_kernel', lambda x, et, en, shortlist=None: vq_work(x, et, en))
 
     # algorithmic work of one call: flops = 2 * output points * Cout * Cin * taps; bytes = every operand once
     def conv_work(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, **k):
@@ -540,7 +550,9 @@ def main():
         sys.exit(3)
     if not args.no_microbench:
         out['vq_microbench'] = [vq_microbench(device, args.heads, args.codewords), vq_microbench(device, 4, 64),
-                                vq_microbench(device, 8, 512), vq_microbench(device, 1, 64)]
+                                vq_microbench(device, 8, 512), vq_microbench(device, 1, 64),
+                                vq_microbench(device, args.heads, args.codewords, shortlist=False),
+                                vq_microbench(device, 4, 64, shortlist=False)]
         say('vq microbench done')
     if world == 1 and args.cpu_steps > 0:
         cores = host_cores()

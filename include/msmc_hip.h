@@ -54,6 +54,22 @@ int msmc_vq_prepare(const float* embed, float* embed_t, float* enorm, int H, int
 int msmc_vq_search(const float* x, const float* embed_t, const float* enorm, float* quant, float* diff,
                    int64_t* ind, int N, int D, int H, int K, msmc_stream stream);
 
+/* The same search -- identical indices, quant and diff, bit for bit -- under the HBM roof for K >= 64
+ * (msmc-tts_amd/csrc/vq_shortlist.inc): all K distances approximately on the bf16 matrix cores (two-piece bf16 splits of
+ * x and e, three products), a running top-2 per frame, and a rigorous error bound that decides per (frame, head) whether
+ * the approximate winner IS the exact kernel's first minimum; where it is not (near-ties, duplicate codewords) the
+ * 16-frame tile is searched again with the exact fp32 chain.  The codebook comes as a prepared image
+ * (msmc_vq_prepare_shortlist, from embed_t / enorm of msmc_vq_prepare; msmc_vq_shortlist_bytes = its size, 0 when the
+ * kernel does not take the shape: d = D/H in {32, 64}, K % 16 == 0, one head's image <= 78 KiB).  slow_count (may be NULL):
+ * two counters, incremented once per 16-frame tile and head that took [0] the exact re-rank of the best two candidates,
+ * [1] the exact re-search over all K.  Finite inputs; magnitudes above bf16 underflow. */
+size_t msmc_vq_shortlist_bytes(int H, int d, int K);
+int msmc_vq_prepare_shortlist(const float* embed_t, const float* enorm, void* image, int H, int d, int K,
+                              msmc_stream stream);
+int msmc_vq_search_shortlist(const float* x, const float* embed_t, const float* enorm, const void* image, float* quant,
+                             float* diff, int64_t* ind, unsigned long long* slow_count, int N, int D, int H, int K,
+                             msmc_stream stream);
+
 /* Perf-experiment switch: 0 selects the LDS-tile search kernel for every shape; default 1. */
 void msmc_vq_set_variant(int v);
 /* Symbol of the search kernel the calling thread's most recent msmc_vq_search launched (profiling aid). */

@@ -108,6 +108,8 @@ MSMC_DEV int wave_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
 MSMC_DEV float wave_down(float v, int delta) { return __shfl_down(v, delta, 64); }
 MSMC_DEV float wave_bcast(float v, int lane) { return __shfl(v, lane, 64); }
 MSMC_DEV int wave_bcast(int v, int lane) { return __shfl(v, lane, 64); }
+// every lane reads the value of the lane IT names (ds_bpermute_b32)
+MSMC_DEV float wave_bcast_var(float v, int src_lane) { return __shfl(v, src_lane, 64); }
 
 // true in every lane when the predicate holds in at least one lane of the wave (wave-uniform branch conditions)
 MSMC_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }

@@ -435,6 +435,8 @@ __global__ __launch_bounds__(256, 2) void vq_search_reg_kernel(const float* __re
     }
 }
 
+#include "vq_shortlist.inc"
+
 typedef void (*vq_search_reg_fn)(const float*, const float*, const float*, float*, float*, int64_t*, int, int, int, int,
                                  int);
 
@@ -691,6 +693,50 @@ int msmc_vq_search(const float* x, const float* embed_t, const float* enorm, flo
     MSMC_LAUNCH(fn, dim3(grid), dim3(64 * nw), (size_t)L.total, (msmc_stream_t)stream, x, embed_t, enorm, quant, diff,
                 ind, N, D, H, K, hpg, L);
     msmc_vq_last = msmc_prof_name("vq_search_kernel");
+    return msmc_check_launch();
+}
+
+// ---- shortlist search (vq_shortlist.inc) ----------------------------------------------------------------------------
+size_t msmc_vq_shortlist_bytes(int H, int d, int K) {
+    if (H <= 0 || d <= 0 || K <= 0 || !vqs_mode(H, d, K)) return 0;
+    return (size_t)H * vqs_blob_bytes(d, K);
+}
+
+int msmc_vq_prepare_shortlist(const float* embed_t, const float* enorm, void* image, int H, int d, int K,
+                              msmc_stream stream) {
+    if (H <= 0 || d <= 0 || K <= 0 || !vqs_mode(H, d, K)) return MSMC_E_SHAPE;
+    MSMC_LAUNCH(vq_prepare_sl_kernel, dim3(H), dim3(256), 0, (msmc_stream_t)stream, embed_t, enorm, (char*)image, d, K,
+                (int)vqs_blob_bytes(d, K));
+    return msmc_check_launch();
+}
+
+int msmc_vq_search_shortlist(const float* x, const float* embed_t, const float* enorm, const void* image, float* quant,
+                             float* diff, int64_t* ind, unsigned long long* slow_count, int N, int D, int H, int K,
+                             msmc_stream stream) {
+    if (N < 0 || H <= 0 || D <= 0 || D % H) return MSMC_E_SHAPE;
+    const int d = D / H;
+    const int mode = vqs_mode(H, d, K);
+    if (!mode) return MSMC_E_SHAPE;
+    if (N == 0) return 0;
+    vq_search_sl_fn fn = d == 64 ? (vq_search_sl_fn)vq_search_sl_kernel<4> : (vq_search_sl_fn)vq_search_sl_kernel<2>;
+    const int blob = (int)vqs_blob_bytes(d, K);
+    const size_t lds = (size_t)(mode == 1 ? H : 2) * blob;
+    int rc = msmc_allow_lds((const void*)fn, (int)lds);
+    if (rc) return rc;
+    int bits = 0;
+    while ((1 << bits) < K / 4) ++bits;
+    const unsigned int ibmask = (1u << bits) - 1u;
+    // |key - u_k| <= c_approx * (|x| max|e| + max|e|^2 / 2): split residuals + dropped lo.lo products (3.02 * 2^-16), fp32
+    // accumulation of 3d products onto the initial value (one rounding of <= 2^-23 relative each), the index bits planted
+    // in the mantissa (2^(bits - 23)), and the exact chain's own d roundings (d * 2^-24)
+    const float c_approx = 3.02f / 65536.f + (float)(3 * d + 1) / 8388608.f + (float)(1u << bits) / 8388608.f +
+                           (float)d / 16777216.f;
+    const int numTiles = (N + VQS_FRAMES - 1) / VQS_FRAMES;
+    const int numIters = (numTiles + VQS_WAVES - 1) / VQS_WAVES;
+    const int grid = numIters < MSMC_NUM_CU ? numIters : MSMC_NUM_CU;
+    MSMC_LAUNCH(fn, dim3(grid), dim3(64 * VQS_WAVES), lds, (msmc_stream_t)stream, x, embed_t, enorm, (const char*)image,
+                quant, diff, ind, slow_count, N, D, H, K, mode == 1 ? 1 : 0, blob, ibmask, c_approx);
+    msmc_vq_last = msmc_prof_name("vq_search_sl_kernel");
     return msmc_check_launch();
 }
 

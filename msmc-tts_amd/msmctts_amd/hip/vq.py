@@ -3,25 +3,42 @@
 Replaces the arithmetic of ``Quantize.forward`` / ``MultiHeadQuantize.forward``
 (reference msmctts/networks/vqgantts/modules.py:24-67, :137-151).
 """
+import os
+
 import torch
 
 from . import lib
 
+# The shortlist search (csrc/vq_shortlist.inc: bf16 matrix-core shortlist + exact fp32 decision, bit-identical results)
+# serves the shapes it takes from SHORTLIST_MIN_FRAMES frames up; below that, and for every other shape, the exact
+# register-resident kernel runs.  MSMC_VQ_SHORTLIST=0 turns it off (A/B runs, tests of the exact kernel).
+SHORTLIST = os.environ.get('MSMC_VQ_SHORTLIST', '1') != '0'
+SHORTLIST_MIN_FRAMES = int(os.environ.get('MSMC_VQ_SHORTLIST_MIN', '0'))
+SLOW_COUNT = None           # tests / bench: an int64 [2] device tensor counting 16-frame tiles (per head) that took the
+                            # two-candidate exact re-rank [0] / the full exact re-search [1]
+
 
 def vq_prepare(embed):
-    """embed [H, d, K] -> (embed_t [H, K, d], enorm [H, K])."""
+    """embed [H, d, K] -> (embed_t [H, K, d], enorm [H, K]); where the shortlist kernel takes the shape its codebook
+    image rides along as ``embed_t.shortlist_image``."""
     H, d, K = embed.shape
     embed_t = torch.empty((H, K, d), dtype=torch.float32, device=embed.device)
     enorm = torch.empty((H, K), dtype=torch.float32, device=embed.device)
     L = lib.get()
     lib.check(L.msmc_vq_prepare(lib.ptr(embed, torch.float32), lib.ptr(embed_t), lib.ptr(enorm), H, d, K,
                                 lib.stream(embed)), 'msmc_vq_prepare')
+    nbytes = int(L.msmc_vq_shortlist_bytes(H, d, K)) if SHORTLIST else 0
+    if nbytes:
+        image = torch.empty(nbytes, dtype=torch.uint8, device=embed.device)
+        lib.check(L.msmc_vq_prepare_shortlist(lib.ptr(embed_t), lib.ptr(enorm), lib.ptr(image), H, d, K,
+                                              lib.stream(embed)), 'msmc_vq_prepare_shortlist')
+        embed_t.shortlist_image = image
     return embed_t, enorm
 
 
 class _VQSearch(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, embed_t, enorm):
+    def forward(ctx, x, embed_t, enorm, image=None):
         H, K, d = embed_t.shape
         D = H * d
         assert x.shape[-1] == D, (x.shape, embed_t.shape)
@@ -31,9 +48,15 @@ class _VQSearch(torch.autograd.Function):
         diff = torch.empty(xc.shape[:-1] + (d,), dtype=torch.float32, device=x.device)
         ind = torch.empty(xc.shape[:-1] + (H,), dtype=torch.int64, device=x.device)
         L = lib.get()
-        lib.check(L.msmc_vq_search(lib.ptr(xc), lib.ptr(embed_t, torch.float32), lib.ptr(enorm, torch.float32),
-                                   lib.ptr(quant), lib.ptr(diff), lib.ptr(ind), N, D, H, K, lib.stream(xc)),
-                  'msmc_vq_search')
+        if image is not None and N >= SHORTLIST_MIN_FRAMES:
+            lib.check(L.msmc_vq_search_shortlist(lib.ptr(xc), lib.ptr(embed_t, torch.float32), lib.ptr(enorm, torch.float32),
+                                                 lib.ptr(image, torch.uint8), lib.ptr(quant), lib.ptr(diff), lib.ptr(ind),
+                                                 lib.ptr(SLOW_COUNT, torch.int64), N, D, H, K, lib.stream(xc)),
+                      'msmc_vq_search_shortlist')
+        else:
+            lib.check(L.msmc_vq_search(lib.ptr(xc), lib.ptr(embed_t, torch.float32), lib.ptr(enorm, torch.float32),
+                                       lib.ptr(quant), lib.ptr(diff), lib.ptr(ind), N, D, H, K, lib.stream(xc)),
+                      'msmc_vq_search')
         ctx.save_for_backward(xc, quant)
         ctx.heads = H
         ctx.in_dtype = x.dtype
@@ -53,12 +76,14 @@ class _VQSearch(torch.autograd.Function):
         L = lib.get()
         lib.check(L.msmc_vq_backward(lib.ptr(g_quant), lib.ptr(g_diff), lib.ptr(xc), lib.ptr(quant), lib.ptr(gx),
                                      N, D, ctx.heads, lib.stream(xc)), 'msmc_vq_backward')
-        return gx.to(ctx.in_dtype), None, None
+        return gx.to(ctx.in_dtype), None, None, None
 
 
-def vq_search(x, embed_t, enorm):
-    """x [..., D] -> (quant [..., D] straight-through, diff [..., d], ind [..., H] int64)."""
-    return _VQSearch.apply(x, embed_t, enorm)
+def vq_search(x, embed_t, enorm, shortlist=None):
+    """x [..., D] -> (quant [..., D] straight-through, diff [..., d], ind [..., H] int64).  ``shortlist``: None = the
+    module default (``SHORTLIST``: shortlist kernel where ``vq_prepare`` attached an image), False = the exact kernel."""
+    image = getattr(embed_t, 'shortlist_image', None) if (SHORTLIST if shortlist is None else shortlist) else None
+    return _VQSearch.apply(x, embed_t, enorm, image)
 
 
 def vq_ema_update(x, ind, length, embed, cluster_size, embed_avg, decay, eps, workspace=None):

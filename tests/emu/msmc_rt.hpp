@@ -91,6 +91,7 @@ MSMC_DEV float wave_down(float v, int delta) {
 }
 MSMC_DEV float wave_bcast(float v, int lane) { return emu_exchange(v, lane); }
 MSMC_DEV int wave_bcast(int v, int lane) { return emu_exchange(v, lane); }
+MSMC_DEV float wave_bcast_var(float v, int src_lane) { return emu_exchange(v, src_lane); }
 
 MSMC_DEV bool wave_any(bool p) {
     int v = p ? 1 : 0;
@@ -256,6 +257,7 @@ MSMC_DEV unsigned int bf16x2_leaky(unsigned int w, float slope) {
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 #define MSMC_BACKEND_NAME "emu"

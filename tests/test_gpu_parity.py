@@ -39,9 +39,12 @@ def test_predictor_step_matches_reference():
     _parity.check_predictor_step(DEV)
 
 
+@pytest.mark.parametrize('shortlist', [None, False], ids=['product', 'exact-kernel'])
 @pytest.mark.parametrize('H,K,D,N', [(1, 64, 256, 777), (4, 64, 256, 6400), (4, 256, 256, 1600), (8, 512, 256, 530),
                                      (4, 16, 32, 51), (2, 48, 24, 1), (4, 64, 256, 16), (4, 64, 256, 17)])
-def test_vq_search_bit_exact_vs_c_oracle(H, K, D, N):
+def test_vq_search_bit_exact_vs_c_oracle(H, K, D, N, shortlist):
+    """``product``: the kernel the product runs for the shape (csrc/vq_shortlist.inc where d in {32, 64}); ``exact-kernel``:
+    the register-resident / LDS-tile exact kernels forced"""
     from msmctts_amd.hip import vq
     from oracle import cvq
     rng = np.random.default_rng(H * 1000 + K + N)
@@ -50,10 +53,59 @@ def test_vq_search_bit_exact_vs_c_oracle(H, K, D, N):
     want = cvq.search(x, e)
     et, en = vq.vq_prepare(torch.from_numpy(e).to(DEV))
     assert np.array_equal(et.cpu().numpy(), e.transpose(0, 2, 1))
-    q, d, i = vq.vq_search(torch.from_numpy(x).to(DEV), et, en)
+    q, d, i = vq.vq_search(torch.from_numpy(x).to(DEV), et, en, shortlist=shortlist)
     assert np.array_equal(i.cpu().numpy(), want['ind'])
     assert np.array_equal(q.cpu().numpy(), want['quant'])
     assert np.array_equal(d.cpu().numpy(), want['diff'])
+
+
+@pytest.mark.parametrize('H,K', [(4, 64), (4, 256), (8, 512), (2, 48)])
+def test_vq_shortlist_is_bit_identical_to_the_exact_kernel(H, K):
+    """csrc/vq_shortlist.inc against the exact kernel on 2^18 frames (every output, bit for bit): Gaussian frames,
+    frames that ARE codewords, runs of two and three duplicate codewords, a near-duplicate at relative distance 1e-7,
+    frames 1e-4 from a duplicated codeword; plus rows of it against the C oracle.  The planted ties must reach the exact
+    paths; Gaussian data must mostly be decided by the shortlist."""
+    from msmctts_amd.hip import lib, vq
+    from oracle import cvq
+    N, d = 1 << 18, 64 if H < 8 else 32
+    D = H * d
+    g = torch.Generator().manual_seed(K)
+    e = torch.randn(H, d, K, generator=g)
+    e[:, :, 7] = e[:, :, 3]
+    e[:, :, 11] = e[:, :, 3]
+    e[:, :, 9] = e[:, :, 5] * (1 + 1e-7)
+    x = torch.randn(N, D, generator=g)
+    x[:4096] = e[:, :, 3].reshape(1, D) + torch.randn(4096, D, generator=g) * 1e-4
+    x[8192:8192 + K] = e.permute(2, 0, 1).reshape(K, D)                    # every codeword (of all heads at once) as a frame
+    x[16384:16384 + 64] = e[:, :, 5].reshape(1, D)
+    e, x = e.to(DEV), x.to(DEV)
+    et, en = vq.vq_prepare(e)
+    assert getattr(et, 'shortlist_image', None) is not None
+    vq.SLOW_COUNT = torch.zeros(2, dtype=torch.int64, device=DEV)
+    try:
+        q, df, i = vq.vq_search(x, et, en)
+        assert lib.get().msmc_vq_last_kernel() == b'vq_search_sl_kernel'
+        slow = vq.SLOW_COUNT.tolist()
+        vq.SLOW_COUNT.zero_()
+        vq.vq_search(x[32768:], et, en)                                    # the Gaussian part alone
+        slow_gauss = vq.SLOW_COUNT.tolist()
+    finally:
+        vq.SLOW_COUNT = None
+    q0, df0, i0 = vq.vq_search(x, et, en, shortlist=False)
+    assert lib.get().msmc_vq_last_kernel() != b'vq_search_sl_kernel'
+    assert torch.equal(i, i0) and torch.equal(q, q0) and torch.equal(df, df0)
+    assert (i[:4096] == 3).all() and not ((i == 7) | (i == 11)).any()
+    own = torch.where(torch.isin(torch.arange(K), torch.tensor([7, 11])), 3, torch.arange(K)).to(DEV).unsqueeze(1)
+    clear = ~torch.isin(torch.arange(K), torch.tensor([5, 9])).to(DEV)     # (5 / 9: a 1e-7 pair, decided by fp32 rounding)
+    assert (i[8192:8192 + K][clear] == own[clear]).all()
+    rows = torch.cat((torch.arange(0, 4096, 37), torch.arange(8192, 8192 + K), torch.arange(16384, 16448),
+                      torch.arange(32768, N, 1031))).to(DEV)
+    w = cvq.search(x[rows].cpu().numpy(), e.cpu().numpy())
+    assert np.array_equal(i[rows].cpu().numpy(), w['ind']) and np.array_equal(q[rows].cpu().numpy(), w['quant'])
+    assert np.array_equal(df[rows].cpu().numpy(), w['diff'])
+    tiles = (N - 32768) // 16 * H
+    assert slow[1] >= 4096 // 16 * H and slow[0] >= 1
+    assert slow_gauss[0] <= 0.3 * tiles and slow_gauss[1] <= 0.02 * tiles, (slow_gauss, tiles)
 
 
 def test_vq_search_near_ties_and_duplicates():

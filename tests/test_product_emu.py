@@ -528,3 +528,64 @@ def test_inference_glue_matches_reference():
 
 def test_attention_kernels_match_the_reference_chain():
     _parity.check_attention('cpu')
+
+
+@pytest.mark.parametrize('H,K,D,N', [
+    (4, 64, 256, 100),     # all heads' images resident in LDS; ragged last tile
+    (4, 256, 256, 70),     # one head at a time, double-buffered LDS-DMA
+    (8, 512, 256, 45),     # d = 32: one 32-wide contraction step, nine index bits
+    (2, 48, 64, 33),       # codeword tiles that are not a power of two, two heads (index store of a partial head group)
+    (1, 16, 64, 300),      # single head, several persistent iterations per workgroup
+])
+def test_vq_shortlist_search_is_bit_identical_to_the_exact_kernel_and_the_oracle(H, K, D, N):
+    """csrc/vq_shortlist.inc on the interpreter: bf16 shortlist + error bound + exact re-search of unsure tiles gives the
+    exact kernel's indices / quant / diff on Gaussian data, on near-ties (gap 1e-7), on duplicate codewords and on frames
+    that ARE codewords; the exact path is taken for the adversarial frames and for few of the Gaussian ones."""
+    import numpy as np
+    from msmctts_amd.hip import vq
+    from oracle import cvq
+    rng = np.random.default_rng(H + K + N)
+    d = D // H
+    e = rng.standard_normal((H, d, K)).astype(np.float32)
+    e[:, :, 7] = e[:, :, 3]                                             # exact duplicates: the first minimum is 3
+    e[:, :, 11] = e[:, :, 3]                                            # ... a run of three (the two-candidate re-rank cannot settle it)
+    e[:, :, 9] = e[:, :, 5] * np.float32(1 + 1e-7)                      # near-duplicate pair
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    na = min(N // 2, 20)
+    x[:na] = np.tile(e[:, :, 3].transpose(0, 1).reshape(-1), (na, 1)) + rng.standard_normal((na, D)).astype(np.float32) * 1e-4
+    pp = 32 if N >= 35 else na                                          # (in a 16-frame tile of their own)
+    x[pp:pp + 3] = e[:, :, 5].reshape(-1)                               # a codeword itself (and its near-duplicate)
+    want = cvq.search(x, e)
+    et, en = vq.vq_prepare(torch.from_numpy(e))
+    assert getattr(et, 'shortlist_image', None) is not None
+    vq.SLOW_COUNT = torch.zeros(2, dtype=torch.int64)
+    try:
+        q, df, i = vq.vq_search(torch.from_numpy(x), et, en)
+        slow_adv = int(vq.SLOW_COUNT.sum())
+        slow_adv_full = int(vq.SLOW_COUNT[1])
+        assert lib_last() == 'vq_search_sl_kernel'
+        q0, df0, i0 = vq.vq_search(torch.from_numpy(x), et, en, shortlist=False)
+        assert lib_last() != 'vq_search_sl_kernel'
+        vq.SLOW_COUNT.zero_()
+        xg = rng.standard_normal((max(N, 64), D)).astype(np.float32)
+        e2 = rng.standard_normal((H, d, K)).astype(np.float32)
+        et2, en2 = vq.vq_prepare(torch.from_numpy(e2))
+        q2, df2, i2 = vq.vq_search(torch.from_numpy(xg), et2, en2)
+        slow_gauss, slow_gauss_full = int(vq.SLOW_COUNT.sum()), int(vq.SLOW_COUNT[1])
+    finally:
+        vq.SLOW_COUNT = None
+    for got, ref, name in ((i, want['ind'], 'ind'), (q, want['quant'], 'quant'), (df, want['diff'], 'diff')):
+        assert np.array_equal(got.numpy(), ref), name
+    assert torch.equal(i, i0) and torch.equal(q, q0) and torch.equal(df, df0)
+    w2 = cvq.search(xg, e2)
+    assert np.array_equal(i2.numpy(), w2['ind']) and np.array_equal(q2.numpy(), w2['quant']) and np.array_equal(df2.numpy(), w2['diff'])
+    assert slow_adv - slow_adv_full >= 1 and slow_adv_full >= 1         # the planted pairs / triples went through the two exact paths
+    assert (want['ind'][:na] == 3).all() and not np.isin(want['ind'], (7, 11)).any()
+    tiles = ((max(N, 64) + 15) // 16) * H
+    assert slow_gauss <= max(2, tiles // 3), (slow_gauss, tiles)        # Gaussian data: mostly decided by the shortlist
+    assert slow_gauss_full <= max(1, tiles // 20), (slow_gauss_full, tiles)
+
+
+def lib_last():
+    from msmctts_amd.hip import lib
+    return lib.get().msmc_vq_last_kernel().decode()
