@@ -70,6 +70,11 @@ int msmc_vq_search_shortlist(const float* x, const float* embed_t, const float* 
                              float* diff, int64_t* ind, unsigned long long* slow_count, int N, int D, int H, int K,
                              msmc_stream stream);
 
+/* DIAGNOSTICS (tools/bench_vq.py ABLATE=...), 0 in production (any other value selects a separate diagnostics build of the
+ * kernel; results are garbage for bits 0-4): bit 0 one codeword tile instead of K/16, 1 no exact paths, 2 no codeword-row
+ * gather, 3 no stores, 4 no frame loads, 5 phase timers: shader cycles per phase of a step of every wave of workgroup 0 into
+ * slow_count[2 + 8 w ..] (slow_count then holds 2 + 8 * 8 words). */
+void msmc_vq_set_shortlist_ablate(int mask);
 /* Perf-experiment switch: 0 selects the LDS-tile search kernel for every shape; default 1. */
 void msmc_vq_set_variant(int v);
 /* Symbol of the search kernel the calling thread's most recent msmc_vq_search launched (profiling aid). */

@@ -115,6 +115,19 @@ MSMC_DEV float wave_bcast_var(float v, int src_lane) { return __shfl(v, src_lane
 MSMC_DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 // median of three (v_med3_f32): with lo <= hi, med3(hi, lo, x) is the second largest of {hi, lo, x}
 MSMC_DEV float fmed3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+// max(a, b) of two non-NaN values in ONE operation: fmaxf would be preceded by a canonicalising v_max_f32 v, v, v per
+// operand whose origin the compiler cannot see (bit patterns assembled with integer operations)
+MSMC_DEV float fmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (bits(a) & keep) | ins in ONE operation (v_and_or_b32): plants the wave-uniform value `ins` in the low mantissa bits
+MSMC_DEV float bits_and_or(float a, unsigned int keep, unsigned int ins) {
+    unsigned int r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(keep), "s"(ins));
+    return __uint_as_float(r);
+}
 // two floats -> packed bf16 pair (round to nearest even, v_cvt_pk_bf16_f32): a in bits 0..15, b in bits 16..31
 MSMC_DEV unsigned int pack_bf16x2(float a, float b) {
     typedef float f32x2_ __attribute__((ext_vector_type(2)));
@@ -122,6 +135,23 @@ MSMC_DEV unsigned int pack_bf16x2(float a, float b) {
     const f32x2_ r = {a, b};
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(r, bf16x2_));
 }
+
+// value of lane l ^ 16 / l ^ 32 by the gfx950 row / half swaps (VALU: no LDS round trip, unlike ds_bpermute_b32).
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of its second,
+// v_permlane32_swap the upper half of the first with the lower half of the second (verified on MI355X by
+// tests/test_gpu_parity.py::test_wave_exchange_primitives).
+MSMC_DEV unsigned int wave_xor16_u(unsigned int v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 16u) ? r[0] : r[1];
+}
+MSMC_DEV unsigned int wave_xor32_u(unsigned int v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 32u) ? r[0] : r[1];
+}
+MSMC_DEV float wave_xor16(float v) { return __uint_as_float(wave_xor16_u(__float_as_uint(v))); }
+MSMC_DEV float wave_xor32(float v) { return __uint_as_float(wave_xor32_u(__float_as_uint(v))); }
+MSMC_DEV int wave_xor16(int v) { return (int)wave_xor16_u((unsigned int)v); }
+MSMC_DEV int wave_xor32(int v) { return (int)wave_xor32_u((unsigned int)v); }
 
 // Intra-wave LDS hand-off point: lanes of ONE wave exchange data through LDS (a wave executes its
 // LDS instructions in order, so no hardware barrier is needed); this only stops the compiler from
@@ -209,6 +239,20 @@ MSMC_DEV u16x8 lds_read128_async(const void* p) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((__attribute__((address_space(3))) const char*)p));
     return __builtin_bit_cast(u16x8, v);
 }
+// the same read as four dwords: a register quadruple that goes to an MFMA operand (or accumulator) as it is -- a 16-bit
+// element vector would be unpacked and re-packed by the compiler right after the read, i.e. BEFORE the caller's wait
+MSMC_DEV u32x4 lds_read128_async4(const void* p) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((__attribute__((address_space(3))) const char*)p));
+    return v;
+}
+// ... at p + OFF bytes (immediate offset field of the instruction, OFF < 65536: no address arithmetic per read)
+template <int OFF>
+MSMC_DEV u32x4 lds_read128_async4_off(const void* p) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((__attribute__((address_space(3))) const char*)p), "n"(OFF));
+    return v;
+}
 MSMC_DEV int lds_read32_async(const void* p) {
     int v;
     asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"((__attribute__((address_space(3))) const char*)p));
@@ -231,6 +275,10 @@ MSMC_DEV void lds_wait() {
 
 // hardware exponential (v_exp_f32 after a multiply by log2 e): ~1e-6 relative, exp(-inf) = 0
 MSMC_DEV float fast_exp(float x) { return __expf(x); }
+// shader clock (s_memtime): diagnostics only
+MSMC_DEV long long msmc_clock() { return (long long)__builtin_amdgcn_s_memtime(); }
+// hardware square root (v_sqrt_f32, ~1 ulp): for bounds and estimates, never for a reference-defined value
+MSMC_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // ---- bf16 <-> f32 (round to nearest even), bit-level so host and device agree ---------------
 MSMC_DEV unsigned short f32_to_bf16_bits(float f) {

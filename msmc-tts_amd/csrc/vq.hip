@@ -718,7 +718,13 @@ int msmc_vq_search_shortlist(const float* x, const float* embed_t, const float* 
     const int mode = vqs_mode(H, d, K);
     if (!mode) return MSMC_E_SHAPE;
     if (N == 0) return 0;
-    vq_search_sl_fn fn = d == 64 ? (vq_search_sl_fn)vq_search_sl_kernel<4> : (vq_search_sl_fn)vq_search_sl_kernel<2>;
+    // two 16-frame column tiles per wave, eight waves per workgroup (one column tile x sixteen waves measured slower:
+    // profiles/r03_vq_shortlist.md); the DIAG instantiations carry the ablation mask and the phase timers
+    const int nsub = 2, nw = 8;
+    if ((double)N * D * 4.0 >= 4294967296.0) return MSMC_E_SHAPE;     // (the kernel addresses frames with 32-bit byte offsets)
+    vq_search_sl_fn fn;
+    if (vqs_ablate) fn = d == 64 ? (vq_search_sl_fn)vq_search_sl_kernel<4, 2, 8, true> : (vq_search_sl_fn)vq_search_sl_kernel<2, 2, 8, true>;
+    else fn = d == 64 ? (vq_search_sl_fn)vq_search_sl_kernel<4, 2, 8, false> : (vq_search_sl_fn)vq_search_sl_kernel<2, 2, 8, false>;
     const int blob = (int)vqs_blob_bytes(d, K);
     const size_t lds = (size_t)(mode == 1 ? H : 2) * blob;
     int rc = msmc_allow_lds((const void*)fn, (int)lds);
@@ -731,11 +737,11 @@ int msmc_vq_search_shortlist(const float* x, const float* embed_t, const float* 
     // in the mantissa (2^(bits - 23)), and the exact chain's own d roundings (d * 2^-24)
     const float c_approx = 3.02f / 65536.f + (float)(3 * d + 1) / 8388608.f + (float)(1u << bits) / 8388608.f +
                            (float)d / 16777216.f;
-    const int numTiles = (N + VQS_FRAMES - 1) / VQS_FRAMES;
-    const int numIters = (numTiles + VQS_WAVES - 1) / VQS_WAVES;
+    const int numTiles = (N + 16 * nsub - 1) / (16 * nsub);
+    const int numIters = (numTiles + nw - 1) / nw;
     const int grid = numIters < MSMC_NUM_CU ? numIters : MSMC_NUM_CU;
-    MSMC_LAUNCH(fn, dim3(grid), dim3(64 * VQS_WAVES), lds, (msmc_stream_t)stream, x, embed_t, enorm, (const char*)image,
-                quant, diff, ind, slow_count, N, D, H, K, mode == 1 ? 1 : 0, blob, ibmask, c_approx);
+    MSMC_LAUNCH(fn, dim3(grid), dim3(64 * nw), lds, (msmc_stream_t)stream, x, embed_t, enorm, (const char*)image,
+                quant, diff, ind, slow_count, N, D, H, K, mode == 1 ? 1 : 0, blob, ibmask, c_approx, vqs_ablate);
     msmc_vq_last = msmc_prof_name("vq_search_sl_kernel");
     return msmc_check_launch();
 }

@@ -26,6 +26,7 @@ _SIGNATURES = {
     'msmc_vq_shortlist_bytes': (_sz, [_i, _i, _i]),
     'msmc_vq_prepare_shortlist': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'msmc_vq_search_shortlist': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'msmc_vq_set_shortlist_ablate': (None, [_i]),
     'msmc_vq_set_variant': (None, [_i]),
     'msmc_vq_last_kernel': (ctypes.c_char_p, []),
     'msmc_vq_ema_workspace': (_sz, [_i, _i, _i, _i]),

@@ -10,10 +10,12 @@ import torch
 from . import lib
 
 # The shortlist search (csrc/vq_shortlist.inc: bf16 matrix-core shortlist + exact fp32 decision, bit-identical results)
-# serves the shapes it takes from SHORTLIST_MIN_FRAMES frames up; below that, and for every other shape, the exact
-# register-resident kernel runs.  MSMC_VQ_SHORTLIST=0 turns it off (A/B runs, tests of the exact kernel).
+# serves the shapes it takes once frames x codewords reaches SHORTLIST_MIN_WORK -- measured cross-over against the exact
+# register-resident kernel on MI355X (profiles/r03_vq_shortlist.md: K = 64 from 131 072 frames, K = 256 from 32 768,
+# K = 512 from 16 384; below it the eight-wave workgroups leave most of the chip idle and the exact kernel's smaller tiles
+# win); below that, and for every other shape, the exact kernel runs.  MSMC_VQ_SHORTLIST=0 turns it off.
 SHORTLIST = os.environ.get('MSMC_VQ_SHORTLIST', '1') != '0'
-SHORTLIST_MIN_FRAMES = int(os.environ.get('MSMC_VQ_SHORTLIST_MIN', '0'))
+SHORTLIST_MIN_WORK = int(os.environ.get('MSMC_VQ_SHORTLIST_MIN_WORK', str(1 << 23)))
 SLOW_COUNT = None           # tests / bench: an int64 [2] device tensor counting 16-frame tiles (per head) that took the
                             # two-candidate exact re-rank [0] / the full exact re-search [1]
 
@@ -38,7 +40,7 @@ def vq_prepare(embed):
 
 class _VQSearch(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, embed_t, enorm, image=None):
+    def forward(ctx, x, embed_t, enorm, image=None, force_shortlist=False):
         H, K, d = embed_t.shape
         D = H * d
         assert x.shape[-1] == D, (x.shape, embed_t.shape)
@@ -48,7 +50,7 @@ class _VQSearch(torch.autograd.Function):
         diff = torch.empty(xc.shape[:-1] + (d,), dtype=torch.float32, device=x.device)
         ind = torch.empty(xc.shape[:-1] + (H,), dtype=torch.int64, device=x.device)
         L = lib.get()
-        if image is not None and N >= SHORTLIST_MIN_FRAMES:
+        if image is not None and (force_shortlist or N * K >= SHORTLIST_MIN_WORK):
             lib.check(L.msmc_vq_search_shortlist(lib.ptr(xc), lib.ptr(embed_t, torch.float32), lib.ptr(enorm, torch.float32),
                                                  lib.ptr(image, torch.uint8), lib.ptr(quant), lib.ptr(diff), lib.ptr(ind),
                                                  lib.ptr(SLOW_COUNT, torch.int64), N, D, H, K, lib.stream(xc)),
@@ -76,14 +78,17 @@ class _VQSearch(torch.autograd.Function):
         L = lib.get()
         lib.check(L.msmc_vq_backward(lib.ptr(g_quant), lib.ptr(g_diff), lib.ptr(xc), lib.ptr(quant), lib.ptr(gx),
                                      N, D, ctx.heads, lib.stream(xc)), 'msmc_vq_backward')
-        return gx.to(ctx.in_dtype), None, None, None
+        return gx.to(ctx.in_dtype), None, None, None, None
 
 
 def vq_search(x, embed_t, enorm, shortlist=None):
     """x [..., D] -> (quant [..., D] straight-through, diff [..., d], ind [..., H] int64).  ``shortlist``: None = the
-    module default (``SHORTLIST``: shortlist kernel where ``vq_prepare`` attached an image), False = the exact kernel."""
+    product's choice (the shortlist kernel where ``vq_prepare`` attached an image and the problem is large enough),
+    True = the shortlist kernel whatever the size (it must have an image), False = the exact kernel."""
     image = getattr(embed_t, 'shortlist_image', None) if (SHORTLIST if shortlist is None else shortlist) else None
-    return _VQSearch.apply(x, embed_t, enorm, image)
+    if shortlist and image is None:
+        raise RuntimeError('msmc_vq_search_shortlist does not take this shape (or MSMC_VQ_SHORTLIST=0)')
+    return _VQSearch.apply(x, embed_t, enorm, image, bool(shortlist))
 
 
 def vq_ema_update(x, ind, length, embed, cluster_size, embed_avg, decay, eps, workspace=None):

@@ -85,6 +85,10 @@ static inline T emu_exchange(T v, int src_lane) {
 static inline int wave_uniform(int v) { return v; }
 MSMC_DEV float wave_xor(float v, int mask) { return emu_exchange(v, emu::lane() ^ mask); }
 MSMC_DEV int wave_xor(int v, int mask) { return emu_exchange(v, emu::lane() ^ mask); }
+MSMC_DEV float wave_xor16(float v) { return emu_exchange(v, emu::lane() ^ 16); }
+MSMC_DEV float wave_xor32(float v) { return emu_exchange(v, emu::lane() ^ 32); }
+MSMC_DEV int wave_xor16(int v) { return emu_exchange(v, emu::lane() ^ 16); }
+MSMC_DEV int wave_xor32(int v) { return emu_exchange(v, emu::lane() ^ 32); }
 MSMC_DEV float wave_down(float v, int delta) {
     int s = emu::lane() + delta;
     return emu_exchange(v, s < 64 ? s : emu::lane());
@@ -97,6 +101,15 @@ MSMC_DEV bool wave_any(bool p) {
     int v = p ? 1 : 0;
     for (int m = 1; m < 64; m <<= 1) v |= emu_exchange(v, emu::lane() ^ m);      // butterfly OR over the 64 lanes
     return v != 0;
+}
+MSMC_DEV float fmax_raw(float a, float b) { return a > b ? a : b; }
+MSMC_DEV float bits_and_or(float a, unsigned int keep, unsigned int ins) {
+    unsigned int u;
+    memcpy(&u, &a, 4);
+    u = (u & keep) | ins;
+    float r;
+    memcpy(&r, &u, 4);
+    return r;
 }
 MSMC_DEV float fmed3(float a, float b, float c) {
     const float lo = fminf(a, b), hi = fmaxf(a, b);
@@ -230,6 +243,8 @@ MSMC_DEV u32x2 global_load8_async(const void* p) { return *(const u32x2*)p; }
 MSMC_DEV void vm_pin(u32x2&) {}
 MSMC_DEV void sched_fence() {}
 MSMC_DEV u16x8 lds_read128_async(const void* p) { u16x8 v; memcpy(&v, p, 16); return v; }
+MSMC_DEV u32x4 lds_read128_async4(const void* p) { u32x4 v; memcpy(&v, p, 16); return v; }
+template <int OFF> MSMC_DEV u32x4 lds_read128_async4_off(const void* p) { u32x4 v; memcpy(&v, (const char*)p + OFF, 16); return v; }
 MSMC_DEV int lds_read32_async(const void* p) { int v; memcpy(&v, p, 4); return v; }
 template <int OFF> MSMC_DEV u32x2 lds_read_tr16_async(const void* p) {
     return __builtin_bit_cast(u32x2, lds_read_tr16((const unsigned short*)((const char*)p + OFF)));
@@ -266,6 +281,8 @@ static inline int max(int a, int b) { return a > b ? a : b; }
 static inline int msmc_emu_num_cu() { const char* e = getenv("MSMC_EMU_CUS"); return e ? atoi(e) : 3; }
 #define MSMC_NUM_CU (msmc_emu_num_cu())
 MSMC_DEV float fast_exp(float x) { return expf(x); }
+MSMC_DEV long long msmc_clock() { return 0; }
+MSMC_DEV float fast_sqrt(float x) { return sqrtf(x); }
 static inline int msmc_check_launch() { return 0; }
 // (the per-launch profiling log of the device build: nothing to time on the interpreter)
 struct MsmcProfRec { char name[120]; };

@@ -39,12 +39,12 @@ def test_predictor_step_matches_reference():
     _parity.check_predictor_step(DEV)
 
 
-@pytest.mark.parametrize('shortlist', [None, False], ids=['product', 'exact-kernel'])
+@pytest.mark.parametrize('shortlist', [None, True, False], ids=['product', 'shortlist-kernel', 'exact-kernel'])
 @pytest.mark.parametrize('H,K,D,N', [(1, 64, 256, 777), (4, 64, 256, 6400), (4, 256, 256, 1600), (8, 512, 256, 530),
                                      (4, 16, 32, 51), (2, 48, 24, 1), (4, 64, 256, 16), (4, 64, 256, 17)])
 def test_vq_search_bit_exact_vs_c_oracle(H, K, D, N, shortlist):
-    """``product``: the kernel the product runs for the shape (csrc/vq_shortlist.inc where d in {32, 64}); ``exact-kernel``:
-    the register-resident / LDS-tile exact kernels forced"""
+    """``product``: the kernel the product picks for the shape and size; ``shortlist-kernel``: csrc/vq_shortlist.inc forced
+    (d in {32, 64}; skipped elsewhere); ``exact-kernel``: the register-resident / LDS-tile exact kernels forced"""
     from msmctts_amd.hip import vq
     from oracle import cvq
     rng = np.random.default_rng(H * 1000 + K + N)
@@ -53,6 +53,8 @@ def test_vq_search_bit_exact_vs_c_oracle(H, K, D, N, shortlist):
     want = cvq.search(x, e)
     et, en = vq.vq_prepare(torch.from_numpy(e).to(DEV))
     assert np.array_equal(et.cpu().numpy(), e.transpose(0, 2, 1))
+    if shortlist and getattr(et, 'shortlist_image', None) is None:
+        pytest.skip('the shortlist kernel does not take this shape')
     q, d, i = vq.vq_search(torch.from_numpy(x).to(DEV), et, en, shortlist=shortlist)
     assert np.array_equal(i.cpu().numpy(), want['ind'])
     assert np.array_equal(q.cpu().numpy(), want['quant'])
@@ -83,17 +85,21 @@ def test_vq_shortlist_is_bit_identical_to_the_exact_kernel(H, K):
     assert getattr(et, 'shortlist_image', None) is not None
     vq.SLOW_COUNT = torch.zeros(2, dtype=torch.int64, device=DEV)
     try:
-        q, df, i = vq.vq_search(x, et, en)
+        q, df, i = vq.vq_search(x, et, en, shortlist=True)
         assert lib.get().msmc_vq_last_kernel() == b'vq_search_sl_kernel'
         slow = vq.SLOW_COUNT.tolist()
         vq.SLOW_COUNT.zero_()
-        vq.vq_search(x[32768:], et, en)                                    # the Gaussian part alone
+        e_clean = torch.randn(H, d, K, generator=g).to(DEV)                # (no planted duplicates)
+        etc, enc = vq.vq_prepare(e_clean)
+        qc, dfc, ic = vq.vq_search(x[32768:], etc, enc, shortlist=True)    # the Gaussian part alone
         slow_gauss = vq.SLOW_COUNT.tolist()
     finally:
         vq.SLOW_COUNT = None
     q0, df0, i0 = vq.vq_search(x, et, en, shortlist=False)
     assert lib.get().msmc_vq_last_kernel() != b'vq_search_sl_kernel'
     assert torch.equal(i, i0) and torch.equal(q, q0) and torch.equal(df, df0)
+    qc0, dfc0, ic0 = vq.vq_search(x[32768:], etc, enc, shortlist=False)
+    assert torch.equal(ic, ic0) and torch.equal(qc, qc0) and torch.equal(dfc, dfc0)
     assert (i[:4096] == 3).all() and not ((i == 7) | (i == 11)).any()
     own = torch.where(torch.isin(torch.arange(K), torch.tensor([7, 11])), 3, torch.arange(K)).to(DEV).unsqueeze(1)
     clear = ~torch.isin(torch.arange(K), torch.tensor([5, 9])).to(DEV)     # (5 / 9: a 1e-7 pair, decided by fp32 rounding)
@@ -105,7 +111,7 @@ def test_vq_shortlist_is_bit_identical_to_the_exact_kernel(H, K):
     assert np.array_equal(df[rows].cpu().numpy(), w['diff'])
     tiles = (N - 32768) // 16 * H
     assert slow[1] >= 4096 // 16 * H and slow[0] >= 1
-    assert slow_gauss[0] <= 0.3 * tiles and slow_gauss[1] <= 0.02 * tiles, (slow_gauss, tiles)
+    assert slow_gauss[0] <= 0.3 * tiles and slow_gauss[1] <= 0.01 * tiles, (slow_gauss, tiles)
 
 
 def test_vq_search_near_ties_and_duplicates():
@@ -317,3 +323,24 @@ def test_inference_glue_matches_reference():
 
 def test_attention_kernels_match_the_reference_chain():
     _parity.check_attention(DEV)
+
+
+def test_wave_exchange_primitives():
+    """the shortlist search merges its per-lane candidates over lane groups with the gfx950 row / half swaps
+    (v_permlane16_swap / v_permlane32_swap behind wave_xor16 / wave_xor32): a search whose winner, runner-up and third
+    sit in DIFFERENT lane groups of every frame must still come out right -- codeword k belongs to lane group (k >> 2) & 3"""
+    from msmctts_amd.hip import vq
+    from oracle import cvq
+    H, K, d, N = 4, 64, 64, 4096
+    rng = np.random.default_rng(7)
+    e = (rng.standard_normal((H, d, K)) * 4).astype(np.float32)
+    x = np.empty((N, H * d), np.float32)
+    picks = rng.integers(0, K, size=(N, H, 3))
+    for h in range(H):                               # frame = mix of three codewords from (mostly) different lane groups
+        a, b, c = (e[h][:, picks[:, h, j]].T for j in range(3))
+        x[:, h * d:(h + 1) * d] = 0.5 * a + 0.3 * b + 0.2 * c + rng.standard_normal((N, d)).astype(np.float32) * 0.05
+    want = cvq.search(x, e)
+    et, en = vq.vq_prepare(torch.from_numpy(e).to(DEV))
+    q, df, i = vq.vq_search(torch.from_numpy(x).to(DEV), et, en, shortlist=True)
+    assert np.array_equal(i.cpu().numpy(), want['ind']) and np.array_equal(q.cpu().numpy(), want['quant'])
+    assert len(np.unique((want['ind'] >> 2) & 3)) == 4

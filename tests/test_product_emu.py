@@ -560,7 +560,7 @@ def test_vq_shortlist_search_is_bit_identical_to_the_exact_kernel_and_the_oracle
     assert getattr(et, 'shortlist_image', None) is not None
     vq.SLOW_COUNT = torch.zeros(2, dtype=torch.int64)
     try:
-        q, df, i = vq.vq_search(torch.from_numpy(x), et, en)
+        q, df, i = vq.vq_search(torch.from_numpy(x), et, en, shortlist=True)
         slow_adv = int(vq.SLOW_COUNT.sum())
         slow_adv_full = int(vq.SLOW_COUNT[1])
         assert lib_last() == 'vq_search_sl_kernel'
@@ -570,7 +570,7 @@ def test_vq_shortlist_search_is_bit_identical_to_the_exact_kernel_and_the_oracle
         xg = rng.standard_normal((max(N, 64), D)).astype(np.float32)
         e2 = rng.standard_normal((H, d, K)).astype(np.float32)
         et2, en2 = vq.vq_prepare(torch.from_numpy(e2))
-        q2, df2, i2 = vq.vq_search(torch.from_numpy(xg), et2, en2)
+        q2, df2, i2 = vq.vq_search(torch.from_numpy(xg), et2, en2, shortlist=True)
         slow_gauss, slow_gauss_full = int(vq.SLOW_COUNT.sum()), int(vq.SLOW_COUNT[1])
     finally:
         vq.SLOW_COUNT = None
