@@ -1,1 +1,2 @@
 from .msmc_vqgan import MSMCVQGAN
+from .msmc_vqgan_emb import MSMCVQGANEmb

@@ -16,6 +16,18 @@ from ...hip import vq as hipvq
 from ..layers import WNConv1d
 
 
+def _ranking(input, embed):
+    """``sort=True`` of the reference (modules.py:62-65): ALL codewords of every frame ordered by distance, nearest
+    first -- [..., K] per head.  No training or inference path of the reference asks for it; stock operators on the
+    expanded distance matrix, evaluated with the codebook the search used (before the EMA update)."""
+    H, d, K = embed.shape
+    flat = input.detach().reshape(-1, H, d).float()
+    dist = (flat.pow(2).sum(-1, keepdim=True) - 2 * torch.einsum('nhd,hdk->nhk', flat, embed)
+            + embed.pow(2).sum(1).unsqueeze(0))
+    order = (-dist).sort(dim=-1, descending=True)[1]                       # [N, H, K]
+    return order.reshape(*input.shape[:-1], H, K)
+
+
 def _ema(q, x3, ind, length, embed, cs, ea):
     """EMA codebook update of one stage: fused (reference semantics: this rank's frames only) or, with
     ``q.sync_stats`` (VQGANTrainer sync_codebook_stats=True), statistics now and the update after the cross-rank sum
@@ -47,15 +59,14 @@ class Quantize(nn.Module):
         return self.embed.unsqueeze(0), self.cluster_size.unsqueeze(0), self.embed_avg.unsqueeze(0)
 
     def forward(self, input, input_length=None, update=True, sort=False):
-        if sort:
-            raise NotImplementedError('sort=True (full ranking) is never used in training (modules.py:62-65)')
         embed, cs, ea = self._packed()
         embed_t, enorm = hipvq.vq_prepare(embed)
         quant, diff, ind = hipvq.vq_search(input, embed_t, enorm)
+        rank = _ranking(input, embed).squeeze(-2) if sort else None         # [..., K]
         if self.training and update and input.numel() > 0:          # (an empty batch has no statistics to add)
             x3 = input.detach().reshape(input.shape[0], -1, input.shape[-1])
             _ema(self, x3, ind.reshape(x3.shape[0], x3.shape[1], -1), input_length, embed, cs, ea)
-        return quant, diff, ind.squeeze(-1)
+        return quant, diff, rank if sort else ind.squeeze(-1)
 
     def embed_code(self, embed_id):
         return F.embedding(embed_id, self.embed.transpose(0, 1))
@@ -102,15 +113,14 @@ class MultiHeadQuantize(nn.Module):
         return p
 
     def forward(self, input, input_length=None, update=True, sort=False):
-        if sort:
-            raise NotImplementedError('sort=True (full ranking) is never used in training (modules.py:62-65)')
         embed, cs, ea = self._packed()
         embed_t, enorm = hipvq.vq_prepare(embed)
         quant, diff, ind = hipvq.vq_search(input, embed_t, enorm)
+        rank = _ranking(input, embed).transpose(-1, -2) if sort else None   # [..., K, H], as the reference's stack
         if self.training and update and input.numel() > 0:          # (an empty batch has no statistics to add)
             x3 = input.detach().reshape(input.shape[0], -1, input.shape[-1])
             _ema(self, x3, ind.reshape(x3.shape[0], x3.shape[1], -1), input_length, embed, cs, ea)
-        return quant, diff, ind
+        return quant, diff, rank if sort else ind
 
 
     def compute_triple_loss(self, prd_quant, trg_quant, reduction='mean', margin=1e-6, adaptive_margin=False):

@@ -79,6 +79,13 @@ def check_vq_cases(device):
         q.eval()
         qq, dd, ii = q(t(z['%s.s0.x' % name]).to(device), ln, update=True)
         assert np.array_equal(ii.cpu().numpy(), z['%s.eval.ind' % name])
+        # sort=True (reference modules.py:62-65): every codeword of every frame, nearest first; [.., K] / [.., K, H]
+        _, _, rank = q(t(z['%s.s0.x' % name]).to(device), ln, update=True, sort=True)
+        assert tuple(rank.shape) == tuple(ii.shape[:2]) + ((K,) if H == 1 else (K, H))
+        kdim = -1 if H == 1 else -2
+        assert torch.equal(rank.select(kdim, 0).cpu(), ii.cpu())
+        assert torch.equal(rank.sort(dim=kdim)[0].cpu(),
+                           torch.arange(K).view((K,) if H == 1 else (K, 1)).expand_as(rank))
 
 
 def check_state_dict_surface():
@@ -417,6 +424,81 @@ def check_predictor_dropout_masks_advance(device):
         losses.append(float(log['loss']['total_loss']))
     assert int(hipnorm.seed_word(dev)) == w0 + 3
     assert len(set(losses)) == 3, ('identical dropout masks on consecutive predictor steps', losses)
+
+
+def check_emb_autoencoder(device):
+    """MSMCVQGANEmb (the QS-TTS synthesiser over speech-embedding frames, with the pitch / energy side encoder) against the
+    reference's own module (tests/golden/small_emb.npz): state_dict surface, training-mode forward over windows (every
+    entry of the output dictionary 1e-3, VQ indices exact, the input gradient of a scalar of the outputs), the codebooks
+    after the EMA step, training-mode analysis, evaluation-mode analysis -> synthesis (both call forms) and window='full'."""
+    from msmctts_amd.networks import find_modules
+    z = load_npz('small_emb.npz')
+    cfg = json_field(z['cfg'])
+    (_, m), = find_modules({'autoencoder': dict(cfg, _name='MSMCVQGANEmb')})
+    want_keys = [k[len('state.'):] for k in z if k.startswith('state.')]
+    assert list(m.state_dict().keys()) == want_keys
+    m.load_state_dict({k: t(z['state.' + k]) for k in want_keys})
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    m = m.to(device).train()
+    b = {k[len('batch.'):]: t(v).to(device) for k, v in z.items() if k.startswith('batch.')}
+    windows = [tuple(int(v) for v in row) for row in z['windows']]
+
+    def compare(prefix, d, skip=()):
+        seen = 0
+        for k, v in d.items():
+            if k in skip:
+                continue
+            if torch.is_tensor(v):
+                items = [('%s.%s' % (prefix, k), v)]
+            elif isinstance(v, (tuple, list)):
+                items = [('%s.%s.%d' % (prefix, k, i), x) for i, x in enumerate(v) if torch.is_tensor(x)]
+            elif isinstance(v, dict):
+                seen += compare('%s.%s' % (prefix, k), v)
+                continue
+            else:
+                continue
+            for name, got in items:
+                want = z[name]
+                if 'indices' in name or 'lengths' in name:
+                    assert np.array_equal(got.cpu().numpy(), want), name
+                else:
+                    close(got, want, what=name)
+                seen += 1
+        return seen
+
+    e = b['emb'].clone().requires_grad_(True)
+    o = m(e, b['emb_length'], b['pitch'], b['energy'], window=windows)
+    assert compare('train', o) >= 13
+    scalar = (o['decoder_outputs'].pow(2).mean() + o['mel_outputs'].mean() + sum(d.mean() for d in o['encoder_diffs'])
+              + o['decoder_diffs']['total_loss'] + o['content_representations'].mean())
+    scalar.backward()
+    close(scalar, z['train.scalar'], what='scalar')
+    close(e.grad, z['train.grad_emb'], 1e-3 * max(1e-6, float(np.abs(z['train.grad_emb']).max())) + 1e-7, what='grad emb')
+    sd = m.state_dict()
+    for k in z:
+        if k.startswith('after.'):
+            ref = z[k]
+            close(sd[k[len('after.'):]], ref, 1e-5 * max(1.0, float(np.abs(ref).max())), 1e-5, what=k)
+    a = m.analysis(b['emb'], b['emb_length'], b['pitch'], b['energy'])
+    assert compare('train_analysis', a, skip=('quantizer_states',)) >= 8 and 'quantizer_states' in a
+    m.eval()
+    with torch.no_grad():
+        qs = m.analysis(b['emb'], b['emb_length'], b['pitch'], b['energy'])
+        assert compare('eval_analysis', qs) >= 8
+        close(m.synthesis(qs, qs['quantizer_lengths']), z['eval.wav'], what='synthesis(dict)')
+        close(m.synthesis(list(qs['quantizer_outputs']), qs['quantizer_lengths']), z['eval.wav_from_sequences'],
+              what='synthesis(sequences)')
+        close(m(b['emb'], b['emb_length'], b['pitch'], b['energy'])['decoder_outputs'], z['eval.full.decoder_outputs'],
+              what="window='full'")
+    with pytest_raises(NotImplementedError):
+        find_modules({'autoencoder': dict(cfg, _name='MSMCVQGANEmb', global_encoder_config={'_name': 'ECAPA_TDNN'})})
+
+
+def pytest_raises(exc):
+    import pytest
+    return pytest.raises(exc)
 
 
 def check_inference(device):

@@ -301,6 +301,11 @@ def test_hip_adamw_matches_torch_adamw_with_clipping():
     _parity.check_hip_adamw(DEV)
 
 
+def test_emb_autoencoder_matches_reference():
+    """the QS-TTS synthesiser MSMCVQGANEmb against the reference's own module"""
+    _parity.check_emb_autoencoder(DEV)
+
+
 def test_hip_adamw_resume_then_capture_rollback_keeps_loaded_moments():
     _parity.check_hip_adamw_resume_then_capture_rollback(DEV)
 

@@ -522,6 +522,11 @@ def test_train_steps_match_reference_with_ungrouped_launches():
         convnet.GROUPED = keep
 
 
+def test_emb_autoencoder_matches_reference():
+    """the QS-TTS synthesiser MSMCVQGANEmb against the reference's own module"""
+    _parity.check_emb_autoencoder('cpu')
+
+
 def test_inference_glue_matches_reference():
     _parity.check_inference('cpu')
 
