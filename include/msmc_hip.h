@@ -265,6 +265,25 @@ int msmc_conv_wgrad_group_ws(const msmc_conv_desc* descs, const void* const* g, 
 int msmc_conv_wgrad_group_ws4(const msmc_conv_desc* descs, const void* const* g, float* const* dw, float* const* db, int n,
                               void* workspace, size_t workspace_bytes, msmc_stream stream, int group4);
 
+/* Deferred second stage.  Between msmc_conv_wgrad_defer_begin(sink, capacity) and msmc_conv_wgrad_defer_end() the
+ * msmc_conv_wgrad_ws / _group_ws / _group_ws4 calls OF THE CALLING THREAD run their first stage only and append one record
+ * per partial-result set to `sink` (up to `capacity`; sets that do not fit are reduced at once, as without a sink);
+ * _defer_end returns the number recorded.  The workspace regions the records point into must stay untouched until
+ * msmc_conv_wgrad_reduce_pending has added them up: n records in ceil(n / 16) (+ the two-level members' first level)
+ * launches instead of one or two per weight gradient -- the host issues it once per backward pass of a network.  The
+ * sums and their order are those of the immediate second stage (bit-identical results). */
+typedef struct msmc_wg_pending {
+    const float* ws;        /* nsplit partial regions of `stride` floats: dW (n_dw) then db (n_db) */
+    float* mid;             /* intermediate regions of a two-level reduction (behind the partials) */
+    float* dw;              /* accumulated into */
+    float* db;              /* may be NULL */
+    long stride, n_dw;
+    int n_db, nsplit;
+} msmc_wg_pending;
+void msmc_conv_wgrad_defer_begin(msmc_wg_pending* sink, int capacity);
+int msmc_conv_wgrad_defer_end(void);
+int msmc_conv_wgrad_reduce_pending(const msmc_wg_pending* items, int n, msmc_stream stream);
+
 /* Weight-norm (torch weight_norm, dim=0) for MANY convolutions in one launch.
  * Item i: v [A][Bc][T] fp32 contiguous (A = dim 0, the normalised axis; T = taps), g [A] fp32.
  *   prepare : w = v * (g / ||v||) written to up to two kernel layouts

@@ -2484,8 +2484,27 @@ static Wg3Reduce wg3_reduce_plan(long total, int nsplit) {
 }
 // append the pass of one weight gradient at `level` (0: split groups -> intermediate regions, only when the plan has
 // several groups; 1: -> dw | db) to a launch; `mid` = the intermediate regions (groups * stride floats)
+// Deferred second stage (msmc_conv_wgrad_defer_begin / _end, include/msmc_hip.h): while the calling thread has a sink
+// armed, the weight-gradient launchers record what their second stage would add up instead of launching it; the caller
+// issues the recorded reductions of a whole backward pass together (msmc_conv_wgrad_reduce_pending).
+static thread_local msmc_wg_pending* wg_defer_sink = nullptr;
+static thread_local int wg_defer_cap = 0, wg_defer_n = 0;
 static void wg3_reduce_add(WgReduceArgs& a, int* blocks, const float* ws, long stride, long n_dw, int n_db, int nsplit,
                            float* mid, float* dw, float* db, int level) {
+    if (!ws) return;
+    if (wg_defer_sink) {
+        if (level == 0) {
+            if (wg_defer_n < wg_defer_cap) {
+                msmc_wg_pending& p = wg_defer_sink[wg_defer_n++];
+                p.ws = ws; p.mid = mid; p.dw = dw; p.db = db;
+                p.stride = stride; p.n_dw = n_dw; p.n_db = n_db; p.nsplit = nsplit;
+                return;
+            }
+        } else {
+            for (int i = 0; i < wg_defer_n; ++i)
+                if (wg_defer_sink[i].ws == ws) return;      // recorded at level 0: nothing to launch now
+        }
+    }
     const long total = n_dw + n_db;
     const Wg3Reduce r = wg3_reduce_plan(total, nsplit);
     if (level == 0 && r.groups == 1) return;
@@ -2633,6 +2652,41 @@ static int wg3_reduce_launch(WgReduceArgs& a, int blocks, msmc_stream stream) {
     MSMC_LAUNCH(conv_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
     ++msmc_conv_launches;
     return msmc_check_launch();
+}
+
+extern "C" void msmc_conv_wgrad_defer_begin(msmc_wg_pending* sink, int capacity) {
+    wg_defer_sink = capacity > 0 ? sink : nullptr;
+    wg_defer_cap = capacity;
+    wg_defer_n = 0;
+}
+extern "C" int msmc_conv_wgrad_defer_end(void) {
+    const int n = wg_defer_n;
+    wg_defer_sink = nullptr;
+    wg_defer_cap = wg_defer_n = 0;
+    return n;
+}
+extern "C" int msmc_conv_wgrad_reduce_pending(const msmc_wg_pending* items, int n, msmc_stream stream) {
+    if (n < 0 || (n && !items)) return MSMC_E_SHAPE;
+    msmc_wg_pending* keep = wg_defer_sink;                  // (the merged launches themselves are never deferred)
+    wg_defer_sink = nullptr;
+    int rc = 0;
+    for (int level = 0; level < 2 && !rc; ++level) {
+        int i = 0;
+        while (i < n && !rc) {
+            WgReduceArgs a;
+            a.n = 0;
+            int blocks = 0;
+            for (; i < n && a.n < MSMC_GROUP_MAX; ++i) {
+                const msmc_wg_pending& p = items[i];
+                wg3_reduce_add(a, &blocks, p.ws, p.stride, p.n_dw, p.n_db, p.nsplit, p.mid, p.dw, p.db, level);
+            }
+            if (!a.n) continue;
+            a.first[a.n] = blocks;
+            rc = wg3_reduce_launch(a, blocks, stream);
+        }
+    }
+    wg_defer_sink = keep;
+    return rc;
 }
 
 static int wg2_launch(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream,

@@ -205,6 +205,55 @@ def _gather(desc, stream, what):
     lib.check(fn(ctypes.byref(desc), stream), what)
 
 
+# -- deferred second stage of the no-atomics weight gradients ------------------------------------------------------------
+# A backward pass issues ~40 weight-gradient calls per network whose second stage (the fixed-order sum of the pixel
+# splits' partial results) used to be one or two launches EACH (77 launches, 1 ms per training step).  With a
+# ``DeferredReduce`` armed (``DEFER_TO``; hip/convnet.py arms the ConvBank's around its backward launches) the calls
+# run their first stage into an arena that lives until the end of the backward pass, and ``flush`` adds everything up in
+# ceil(records / 16) launches (msmc_conv_wgrad_reduce_pending) -- same sums, same order, bit-identical results.
+DEFER = os.environ.get('MSMC_WGRAD_DEFER', '1') != '0'
+DEFER_TO = None             # the DeferredReduce the running weight-gradient calls record into (None: reduce at once)
+
+
+class DeferredReduce(object):
+    CAPACITY = 1024                       # records per backward pass
+    CHUNK = 256 << 20                     # arena growth step (bytes); chunks persist and are reused every pass
+
+    def __init__(self):
+        self.records = (lib.WgPending * self.CAPACITY)()
+        self.n = 0
+        self.chunks = []                  # [tensor, bytes used]
+
+    def take(self, device, nbytes):
+        """``nbytes`` of partial-result storage that stays untouched until ``flush``"""
+        nbytes = (nbytes + 255) & ~255
+        for c in self.chunks:
+            if c[0].device == device and c[0].numel() * 4 - c[1] >= nbytes:
+                p = c[0].data_ptr() + c[1]
+                c[1] += nbytes
+                return p
+        t = torch.empty(max(nbytes, self.CHUNK) // 4, dtype=torch.float32, device=device)
+        self.chunks.append([t, nbytes])
+        return t.data_ptr()
+
+    def begin(self):
+        room = self.CAPACITY - self.n
+        lib.get().msmc_conv_wgrad_defer_begin(
+            ctypes.cast(ctypes.byref(self.records, self.n * ctypes.sizeof(lib.WgPending)), ctypes.POINTER(lib.WgPending)), room)
+
+    def end(self):
+        self.n += lib.get().msmc_conv_wgrad_defer_end()
+
+    def flush(self, stream):
+        """the merged second stage of everything recorded since the last flush (on ``stream``: the caller has ordered it
+        after the launches that wrote the partial results); the arena is free again afterwards"""
+        if self.n:
+            lib.check(lib.get().msmc_conv_wgrad_reduce_pending(self.records, self.n, stream), 'msmc_conv_wgrad_reduce_pending')
+        self.n = 0
+        for c in self.chunks:
+            c[1] = 0
+
+
 _WORKSPACES = {}            # (device, stream) -> fp32 scratch of the third-generation weight gradient (split partials)
 
 
@@ -223,11 +272,19 @@ def _workspace(device, stream, nbytes):
 def _wgrad(desc, g_ptr, dw, db, stream, what):
     L = lib.get()
 
-    def fn(dref, gp, dwp, dbp, st):
+    def fn(dref, gp, dwp, dbp, st, defer=None):
         need = L.msmc_conv_wgrad_workspace(dref, gp)
+        if defer is not None and need and defer.n < defer.CAPACITY:
+            wsp = defer.take(dw.device, need)
+            defer.begin()
+            try:
+                return L.msmc_conv_wgrad_ws(dref, gp, dwp, dbp, wsp, need, st)
+            finally:
+                defer.end()
         wsp, wsb = _workspace(dw.device, st, need) if need else (None, 0)
         return L.msmc_conv_wgrad_ws(dref, gp, dwp, dbp, wsp, wsb, st)
     dbp = db.data_ptr() if db is not None else None
+    defer = DEFER_TO if DEFER else None
     if not getattr(desc, '_tuned', False):
         cached = TUNED.get(('wgrad',) + _signature(desc)) if not lib._host_pointers_ok else None
         if cached is None and not lib._host_pointers_ok:
@@ -245,10 +302,10 @@ def _wgrad(desc, g_ptr, dw, db, stream, what):
             _tune('wgrad', desc, lambda: fn(ctypes.byref(desc), g_ptr, sdw.data_ptr(), sdbp, stream), _WGRAD_CANDIDATES)
         else:
             desc._tuned = True
-    rc = fn(ctypes.byref(desc), g_ptr, dw.data_ptr(), dbp, stream)
+    rc = fn(ctypes.byref(desc), g_ptr, dw.data_ptr(), dbp, stream, defer)
     if rc != 0 and getattr(desc, '_borrowed', False):        # a neighbour's choice this shape cannot run: library heuristic
         desc.variant, desc.split_shift, desc._borrowed = 0, 0, False
-        rc = fn(ctypes.byref(desc), g_ptr, dw.data_ptr(), dbp, stream)
+        rc = fn(ctypes.byref(desc), g_ptr, dw.data_ptr(), dbp, stream, defer)
     if rc != 0:
         raise RuntimeError('%s failed with code %d (dtype %d variant %d split_shift %d copies %d, x %dx%dx%dx%d -> %dx%dx%d, '
                            '%d taps)' % (what, rc, desc.dtype, desc.variant, desc.split_shift, desc.dw_copies, desc.B, desc.Hin,
@@ -599,8 +656,24 @@ def conv_wgrad_group(items):
         vp = ctypes.c_void_p * n
         ga, dwa, dba = vp(*gs[i:i + 16]), vp(*dws[i:i + 16]), vp(*dbs[i:i + 16])
 
-        need = sum(L.msmc_conv_wgrad_workspace(ctypes.byref(part[k]), ga[k]) for k in range(n))
+        needs = [L.msmc_conv_wgrad_workspace(ctypes.byref(part[k]), ga[k]) for k in range(n)]
+        need = sum(needs)
         wsp, wsb = _workspace(items[0]['x'].device, stream, need) if need else (None, 0)
+        defer = DEFER_TO if DEFER else None
+
+        def deferred(call):
+            """the real (not a timing) issue of this group: first stage only, partial results into the arena"""
+            nonlocal wsp, wsb
+            if defer is None or not need or defer.n + n > defer.CAPACITY:
+                return call()
+            keep = (wsp, wsb)
+            wsp, wsb = defer.take(items[0]['x'].device, need), need
+            defer.begin()
+            try:
+                return call()
+            finally:
+                defer.end()
+                wsp, wsb = keep
 
         def grouped():
             lib.check(L.msmc_conv_wgrad_group_ws(arr, ga, dwa, dba, n, wsp, wsb, stream), 'msmc_conv_wgrad_group_ws')
@@ -611,12 +684,14 @@ def conv_wgrad_group(items):
         g4 = grouped4 if sum(1 for d in part if d.variant >= 4) > 1 else None
 
         def single():
-            for k in range(n):
-                lib.check(L.msmc_conv_wgrad_ws(ctypes.byref(part[k]), ga[k], dwa[k], dba[k], wsp, wsb, stream),
-                          'msmc_conv_wgrad_ws')
+            off = 0                                   # (members get regions of their own: a deferred second stage reads
+            for k in range(n):                        #  them all at the end of the backward pass)
+                lib.check(L.msmc_conv_wgrad_ws(ctypes.byref(part[k]), ga[k], dwa[k], dba[k],
+                                               (wsp + off) if needs[k] else None, needs[k], stream), 'msmc_conv_wgrad_ws')
+                off += needs[k]
 
         if n == 1:
-            single()
+            deferred(single)
             continue
         # the timing launches accumulate into the real dW / db: harmless only on scratch, so time on copies
         if AUTOTUNE and not lib._host_pointers_ok and not torch.cuda.is_current_stream_capturing():
@@ -630,7 +705,7 @@ def conv_wgrad_group(items):
                 dwa, dba = vp(*[t.data_ptr() for t in scratch]), vp(*[t.data_ptr() for t in sb])
                 _group_choice('wgrad-group', part, grouped, single, g4)
                 dwa, dba = keep
-        (single, grouped, g4 or grouped)[_group_choice('wgrad-group', part, grouped, single, g4)]()
+        deferred((single, grouped, g4 or grouped)[_group_choice('wgrad-group', part, grouped, single, g4)])
 
 
 def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None, copies=1):

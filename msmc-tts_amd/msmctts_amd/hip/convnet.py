@@ -139,6 +139,7 @@ class ConvBank(object):
         self.streams = []               # side streams whose backward launches write this bank's accumulators
         self._side_used = []            # weight-gradient side streams to join at the end of the backward pass
         self._side_rr = 0
+        self.deferred = K.DeferredReduce()     # partial-result arena + pending second stages of the running backward pass
 
     @contextlib.contextmanager
     def wgrad_side(self, *tensors):
@@ -148,7 +149,11 @@ class ConvBank(object):
         memory to a later allocation of the calling stream while the side stream still reads it."""
         dev = self.w1.device
         if dev.type != 'cuda' or WGRAD_STREAMS <= 0 or not STREAMS_ENABLED:
-            yield
+            K.DEFER_TO = self.deferred          # (second stages of these launches: once, in _finish_backward)
+            try:
+                yield
+            finally:
+                K.DEFER_TO = None
             return
         sts = _side_streams(dev)
         st = sts[self._side_rr % len(sts)]
@@ -158,7 +163,11 @@ class ConvBank(object):
         if not any(st is u for u in self._side_used):
             self._side_used.append(st)
         with torch.cuda.stream(st):
-            yield
+            K.DEFER_TO = self.deferred
+            try:
+                yield
+            finally:
+                K.DEFER_TO = None
 
     # -- (re)build device buffers whenever parameters moved / changed dtype ------------------------
     def _signature(self, dtype):
@@ -260,11 +269,14 @@ class ConvBank(object):
         del self._hold[:]
         touched, self._touched = self._touched, set()
         if not touched:                 # a pass that only propagated through this network (frozen D in the G step)
+            self.deferred.flush(lib.stream(self.w1))
             return
         if self.streams:                # weight-gradient launches ran on the side streams of their forward
             cur = torch.cuda.current_stream()
             for st in self.streams:
                 cur.wait_stream(st)
+        # the second stage of every no-atomics weight gradient of this pass, merged (the partial results sat in the arena)
+        self.deferred.flush(lib.stream(self.w1))
         with torch.no_grad():
             # torch .grad semantics: a gradient that is still live (no zero_grad since the last backward) is added to.
             # The live gradients ARE the bank's output buffers, so the kernel accumulates in place; buffers of

@@ -51,6 +51,12 @@ class ConvDesc(ctypes.Structure):
                 ('variant', _i), ('split_shift', _i), ('dw_copies', _i)]
 
 
+class WgPending(ctypes.Structure):
+    """msmc_wg_pending of include/msmc_hip.h."""
+    _fields_ = [('ws', _vp), ('mid', _vp), ('dw', _vp), ('db', _vp), ('stride', ctypes.c_long), ('n_dw', ctypes.c_long),
+                ('n_db', _i), ('nsplit', _i)]
+
+
 class WnItem(ctypes.Structure):
     """msmc_wn_item of include/msmc_hip.h."""
     _fields_ = [('v', _vp), ('g', _vp), ('dst1', _vp), ('dst2', _vp), ('inv_norm', _vp), ('dw', _vp), ('gv', _vp),
@@ -111,6 +117,9 @@ _SIGNATURES.update({
     'msmc_conv_wgrad_group_ws4': (_i, [ctypes.POINTER(ConvDesc), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                   _i, _vp, _sz, _vp, _i]),
     'msmc_conv_set_wgrad_tpw': (None, [_i]),
+    'msmc_conv_wgrad_defer_begin': (None, [ctypes.POINTER(WgPending), _i]),
+    'msmc_conv_wgrad_defer_end': (_i, []),
+    'msmc_conv_wgrad_reduce_pending': (_i, [ctypes.POINTER(WgPending), _i, _vp]),
     'msmc_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, ctypes.c_longlong, _vp]),
     'msmc_attn_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, ctypes.c_longlong, _vp]),
     'msmc_prof_enable': (None, [_i]),

@@ -254,3 +254,113 @@ def test_config2_bf16_graphed_grouped_step_trains():
     # bf16 vs the reference's fp32 arithmetic: first step (same weights) and the 12-step trajectory
     assert dev_bf16_first <= 0.02, dev_bf16_first
     assert dev_bf16 <= 0.10, dev_bf16
+
+
+AM_TASK = {           # examples/csmsc/configs/msmc_vq_gan_am.yaml (BASELINE config #4), dropout zeroed for the comparison
+    '_name': 'MSMCTTS', '_mode': 'train_predictor',
+    'predictor': {
+        '_name': 'MultiStagePredictor', 'n_symbols': [100, 10, 2], 'n_model_size': 600, 'n_pred_size': 256,
+        'n_pred_scale': [4, 1],
+        'encoder_config': dict(max_seq_len=240, n_layers=6, n_head=2, d_k=64, d_v=64, d_model=600, d_inner=1536,
+                               fft_conv1d_kernel=3, fft_conv1d_padding=1, dropout=0.0, name='phoneme_side',
+                               fused_layernorm=False),
+        'adaptor_config': dict(input_size=600, duration_predictor_filter_size=256, duration_predictor_kernel_size=3,
+                               dropout=0.0, fused_layernorm=False),
+        'decoder_config': dict(max_seq_len=2400, n_layers=6, n_head=2, d_k=64, d_v=64, d_model=600, d_inner=1536,
+                               fft_conv1d_kernel=3, fft_conv1d_padding=1, dropout=0.0, name='mel_side',
+                               fused_layernorm=False),
+    },
+}
+AM_TRAINER = dict(grad_clip_thresh=10.0, training_methods=['mse', 'triple_sum'], loss_weights=[[1.0, 1.0], [1.0, 1.0]],
+                  lambda_dur=1.0)
+
+
+def test_fp32_predictor_step_matches_oracle_full_size():
+    """BASELINE config #4 at the sizes of msmc_vq_gan_am.yaml (600-wide, 6 + 6 FFT blocks, 256-wide per-stage predictions)
+    against the frozen CSMSC autoencoder (2 stages, 4 heads x 64): one fp32 PredictorTrainer.train_step of the product
+    against oracle/predictor.py on the same weights and batch (B = 6, ~50 phonemes -> <= 400 frames): teacher-forced
+    stage features 1e-3, every loss 1e-3 relative, every clipped gradient's norm 2e-3."""
+    from msmctts_amd.tasks import build_task
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    from msmctts_amd.utils.config import Config
+    from oracle import model as omodel
+    from oracle import predictor as op
+    from oracle.step import prepare_params
+    omodel.RESSTACK_DROPOUT = 0.0
+    B, T = 6, 400
+    acfg = _cfg(B, dropout=False)
+    atask = _build(acfg, dropout=False).model
+    atask.eval()
+    cfg = Config({'id': 'am_full', 'task': copy.deepcopy(AM_TASK), 'trainer': dict(AM_TRAINER, _name='PredictorTrainer'),
+                  'optimizer': {'_default': dict(_name='Adam', learning_rate=2e-4, betas=[0.9, 0.98], eps=1e-9, weight_decay=0)},
+                  'dataset': dict(samplerate=24000, feature=['mel', 'wav'], frameshift=[300, 1])})
+    torch.manual_seed(4)
+    task = build_task(cfg, mode='train')
+    for m in task.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    task = task.to(DEV).train()
+    cpu_mel, _ = _batch(B, T, 80)
+    g = torch.Generator().manual_seed(3)
+    text_length = torch.tensor([56, 52, 47, 41, 38, 30], dtype=torch.int64)
+    Tt = int(text_length.max())
+    text = torch.zeros(B, Tt, 3, dtype=torch.int64)
+    dur = torch.zeros(B, Tt, dtype=torch.int64)
+    for b, (tl, ml) in enumerate(zip(text_length.tolist(), cpu_mel['mel_length'].tolist())):
+        text[b, :tl, 0] = torch.randint(1, 100, (tl,), generator=g)
+        text[b, :tl, 1] = torch.randint(1, 10, (tl,), generator=g)
+        text[b, :tl, 2] = torch.randint(1, 2, (tl,), generator=g)
+        cuts = sorted(torch.randperm(ml - 1, generator=g)[:tl - 1].add(1).tolist())
+        edges = [0] + cuts + [ml]
+        dur[b, :tl] = torch.tensor([edges[i + 1] - edges[i] for i in range(tl)])
+    cpu_batch = {'text': text, 'text_length': text_length, 'dur': dur, 'mel': cpu_mel['mel'], 'mel_length': cpu_mel['mel_length']}
+    batch = {k: v.to(DEV) for k, v in cpu_batch.items()}
+
+    P = {k: v.detach().float().cpu().clone() for k, v in task.state_dict().items()}
+    for k, v in P.items():
+        if not k.endswith('position.weight'):
+            v.requires_grad_(True)
+    P_ae = prepare_params({k: v.detach().float().cpu() for k, v in atask.state_dict().items()})
+    losses, grads, out = op.predictor_step(P, AM_TASK['predictor'], P_ae, acfg.task.to_dict()['autoencoder'], cpu_batch,
+                                           AM_TRAINER['training_methods'], AM_TRAINER['loss_weights'],
+                                           AM_TRAINER['lambda_dur'], AM_TRAINER['grad_clip_thresh'])
+
+    tr = build_trainer(cfg, task, num_gpus=0, rank=0)
+    tr.autoencoder = atask.autoencoder
+    tr.optimizer = build_optimizer(task, cfg.optimizer)
+    # teacher-forced forward alone first (training mode, dropout zero)
+    with torch.no_grad():
+        qs = atask.autoencoder.analysis(batch['mel'], batch['mel_length'].int())
+        fo = task.predictor(text=batch['text'], text_length=batch['text_length'], dur=batch['dur'],
+                            feat=[f.float() for f in qs['quantizer_outputs']], feat_length=qs['quantizer_lengths'])
+    for i in range(2):
+        err = (fo['feat'][i].float().cpu() - out['feat'][i].detach()).abs().max().item()
+        assert err <= 1e-3, 'stage %d predictions: %.3e' % (i, err)
+    snaps = {}
+    real_step = tr.optimizer.step
+
+    def spy(names=None):
+        snaps['predictor'] = {n: p.grad.detach().float().cpu().clone() for n, p in task.named_parameters() if p.grad is not None}
+        return real_step(names)
+    tr.optimizer.step = spy
+    if hasattr(tr.optimizer, 'clip_and_step'):
+        real_clip_step = tr.optimizer.clip_and_step
+
+        def clip_spy(name, max_norm):
+            r = real_clip_step(name, max_norm)
+            snaps[name] = {n: p.grad.detach().float().cpu().clone() for n, p in task.named_parameters() if p.grad is not None}
+            return r
+        tr.optimizer.clip_and_step = clip_spy
+    log = tr.train_step({k: v.clone() for k, v in batch.items()}, 0)
+    got = {k: float(v) for k, v in log['loss'].items()}
+    assert set(got) == set(losses), (sorted(got), sorted(losses))
+    for k, w in losses.items():
+        assert _rel(got[k], float(w), 1e-3) <= 1e-3, 'loss %s: %.6g vs oracle %.6g' % (k, got[k], float(w))
+    scale = max(v.double().norm().item() for v in grads.values())
+    offenders = []
+    for n, gw in grads.items():
+        w, m = gw.double().norm().item(), snaps['predictor'][n].double().norm().item()
+        if abs(m - w) > 2e-3 * w + 1e-6 * scale:
+            offenders.append((n, m, w))
+    assert not offenders, '%d gradient norms off (name, got, oracle): %s' % (len(offenders), offenders[:8])

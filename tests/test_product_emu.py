@@ -594,3 +594,57 @@ def test_vq_shortlist_search_is_bit_identical_to_the_exact_kernel_and_the_oracle
 def lib_last():
     from msmctts_amd.hip import lib
     return lib.get().msmc_vq_last_kernel().decode()
+
+
+def test_wgrad_deferred_second_stage_equals_the_immediate_one():
+    """msmc_conv_wgrad_defer_* / _reduce_pending (hip/conv.py DeferredReduce): first stages of several no-atomics weight
+    gradients (single, two-level, grouped) into the arena, ONE merged second stage at the end -- bit-identical to the second
+    stage right behind every first stage; records are consumed, the arena is reused, nothing is deferred without a sink"""
+    from msmctts_amd.hip import conv, lib
+    L = lib.get()
+    L.msmc_conv_set_wgrad_generation(3)
+    try:
+        torch.manual_seed(1)
+        jobs = []
+        for split, (B, C, Lx, k, dil) in ((3, (2, 64, 90, 7, 3)), (47, (1, 32, 3000, 3, 1)), (2, (2, 64, 90, 11, 1))):
+            geom = conv.Geometry(1, Lx, (1, k), (1, 1), (1, dil), (0, dil * (k - 1) // 2), False)
+            x, g = torch.randn(B, 1, Lx, C).bfloat16(), torch.randn(B, 1, Lx, C).bfloat16()
+            jobs.append((split, geom, x, g, k, C))
+
+        def run(defer):
+            outs = []
+            conv.DEFER_TO = defer
+            try:
+                for split, geom, x, g, k, C in jobs:
+                    L.msmc_conv_set_wgrad_split(split)
+                    dw, db = torch.zeros(k, C, C), torch.zeros(C)
+                    conv.conv_wgrad(x, g, geom, k, in_slope=0.1, dw=dw, db=db)
+                    outs.append((dw, db))
+                L.msmc_conv_set_wgrad_split(2)
+                items = []
+                for split, geom, x, g, k, C in jobs[::2]:
+                    dw, db = torch.zeros(k, C, C), torch.zeros(C)
+                    items.append(dict(x=x, g=g, geom=geom, n_slices=k, in_slope=0.1, dw=dw.view(-1), db=db, copies=1))
+                    outs.append((dw, db))
+                conv.conv_wgrad_group(items)
+            finally:
+                conv.DEFER_TO = None
+            return outs
+
+        ref = run(None)
+        d = conv.DeferredReduce()
+        got = run(d)
+        assert d.n >= 5 and any(c[1] > 0 for c in d.chunks)
+        assert not all(torch.equal(a[0], b[0]) for a, b in zip(got, ref))          # (nothing added up yet)
+        d.flush(lib.stream(jobs[0][2]))
+        assert d.n == 0 and all(c[1] == 0 for c in d.chunks)
+        for (dw, db), (dw_ref, db_ref) in zip(got, ref):
+            assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+        got2 = run(d)                                                               # the arena is reused
+        d.flush(lib.stream(jobs[0][2]))
+        assert len(d.chunks) == 1
+        for (dw, db), (dw_ref, db_ref) in zip(got2, ref):
+            assert torch.equal(dw, dw_ref) and torch.equal(db, db_ref)
+    finally:
+        L.msmc_conv_set_wgrad_generation(2)
+        L.msmc_conv_set_wgrad_split(0)
