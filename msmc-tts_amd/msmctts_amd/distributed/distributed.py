@@ -17,10 +17,18 @@ back.  Here, for one process per GPU on a fully connected xGMI node:
 * VQ codebook statistics are, like the reference, NOT synchronised by default (each rank EMA-updates
   from its local batch; rank 0's codebook is checkpointed).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 DEFAULT_BUCKET_BYTES = 32 * 1024 * 1024
+# Wire format of the gradient exchange: fp32 (the reference's, default) or bf16 (MSMC_GRAD_EXCHANGE=bf16 / the
+# ``exchange_dtype`` argument): half the bytes on xGMI for ~3 significant digits per summand -- the sum is formed by
+# RCCL in bf16, the division by the world size and everything after it in fp32.  Budget per step at CSMSC sizes
+# (DESIGN.md section 6): 51 MB (D) + 147 MB (autoencoder) in fp32.
+_EXCHANGE = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16}
+DEFAULT_EXCHANGE_DTYPE = _EXCHANGE[os.environ.get('MSMC_GRAD_EXCHANGE', 'fp32')]
 
 
 def init_distributed(rank, num_gpus, group_name, dist_backend, dist_url):
@@ -58,8 +66,9 @@ class _Bucket(object):
 class GradReducer(object):
     """Bucketed, backward-overlapped gradient averaging."""
 
-    def __init__(self, module, bucket_bytes=DEFAULT_BUCKET_BYTES, group=None):
+    def __init__(self, module, bucket_bytes=DEFAULT_BUCKET_BYTES, group=None, exchange_dtype=None):
         self.group = group
+        self.exchange_dtype = exchange_dtype or DEFAULT_EXCHANGE_DTYPE
         self.world = dist.get_world_size(group)
         self.buckets = []
         self.hooks_enabled = True
@@ -103,7 +112,7 @@ class GradReducer(object):
     def _launch(self, b):
         ps = [p for p in b.params if any(p is r for r in b.ready)]   # fixed (registration) order on every rank
         if ps:
-            flat = torch.cat([p.grad.reshape(-1) for p in ps])
+            flat = torch.cat([p.grad.reshape(-1) for p in ps]).to(self.exchange_dtype)
             work = dist.all_reduce(flat, group=self.group, async_op=True)
             self._inflight.append((work, flat, ps))
         b.ready = []
@@ -120,13 +129,13 @@ class GradReducer(object):
             raise RuntimeError('gradient exchange found no gradients: ranks would silently diverge')
         flat = self._flat.get(id(child))
         total = sum(g.numel() for g in grads)
-        if flat is None or flat.numel() != total or flat.device != grads[0].device:
-            flat = self._flat[id(child)] = torch.empty(total, dtype=torch.float32, device=grads[0].device)
+        if flat is None or flat.numel() != total or flat.device != grads[0].device or flat.dtype != self.exchange_dtype:
+            flat = self._flat[id(child)] = torch.empty(total, dtype=self.exchange_dtype, device=grads[0].device)
         views = self._views(flat, grads)
         torch._foreach_copy_(views, grads)
         dist.all_reduce(flat, group=self.group)
-        flat.div_(self.world)
         torch._foreach_copy_(grads, views)
+        torch._foreach_div_(grads, float(self.world))           # (in the gradients' own fp32, whatever the wire format)
         for b in self.buckets:                      # drop hook state recorded while capturing
             b.ready = []
             b.pending = set(id(q) for q in b.params)
@@ -148,16 +157,16 @@ class GradReducer(object):
                 self._launch(b)
         for work, flat, ps in self._inflight:
             work.wait()
-            flat.div_(self.world)
             off = 0
             for p in ps:
                 n = p.numel()
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                p.grad.div_(self.world)
                 off += n
         self._inflight = []
 
 
-def apply_gradient_allreduce(module, bucket_bytes=DEFAULT_BUCKET_BYTES):
+def apply_gradient_allreduce(module, bucket_bytes=DEFAULT_BUCKET_BYTES, exchange_dtype=None):
     """Reference entry point: sync initial state from rank 0 and arm gradient averaging.
 
     Returns the same module (no wrapper class, like the reference) with ``module.grad_reducer`` set;
@@ -165,7 +174,7 @@ def apply_gradient_allreduce(module, bucket_bytes=DEFAULT_BUCKET_BYTES):
     """
     with torch.no_grad():
         broadcast_state(module, 0)
-    module.grad_reducer = GradReducer(module, bucket_bytes)
+    module.grad_reducer = GradReducer(module, bucket_bytes, exchange_dtype=exchange_dtype)
     from ..hip import convnet
     convnet.GRAD_READY_HOOK = module.grad_reducer._on_grad      # HIP conv stacks deliver their gradients by hand
     return module

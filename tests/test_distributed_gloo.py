@@ -35,7 +35,7 @@ class Toy(nn.Module):
         self.register_buffer('stat', torch.zeros(4))
 
 
-def _toy_worker(rank, world, port, out):
+def _toy_worker(rank, world, port, out, exchange=None):
     sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd')]
     from msmctts_amd.distributed.distributed import apply_gradient_allreduce, init_distributed
     torch.set_num_threads(1)
@@ -43,7 +43,7 @@ def _toy_worker(rank, world, port, out):
     torch.manual_seed(100 + rank)                      # different init per rank: broadcast must fix it
     m = Toy()
     m.stat.fill_(float(rank + 1))
-    apply_gradient_allreduce(m, bucket_bytes=600)      # tiny buckets -> several collectives per backward
+    apply_gradient_allreduce(m, bucket_bytes=600, exchange_dtype=exchange)   # tiny buckets -> several collectives per backward
     g = torch.Generator().manual_seed(7)
     x = torch.randn(8, 6, generator=g)
     y = torch.randn(8, 3, generator=g)
@@ -81,6 +81,29 @@ def _toy_worker(rank, world, port, out):
                      raised=raised, nbuckets=len(m.grad_reducer.buckets))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_bf16_wire_format_keeps_ranks_identical_and_close_to_fp32():
+    """``exchange_dtype=torch.bfloat16`` (MSMC_GRAD_EXCHANGE=bf16): half the bytes per exchange; every rank still ends
+    with the SAME gradients (the averaged values are what each rank reads back), within bf16 rounding of the full-batch
+    gradient -- bucketed path and graph-mode static exchange alike"""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_toy_worker, args=(2, port, out, torch.bfloat16), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    ref = Toy()
+    ref.load_state_dict(r0['state'])
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 6, generator=g)
+    (ref.b(ref.a(x)) ** 2).mean().backward()
+    for a, b, c in zip(r0['gb'], r1['gb'], [p.grad for p in ref.parameters()]):
+        assert torch.equal(a, b) and a.dtype == torch.float32
+        assert torch.allclose(a, c, atol=2e-2 * float(c.abs().max()) + 1e-6)
+        assert not torch.allclose(a, c, atol=1e-7) or float(c.abs().max()) == 0.0      # (it really went through bf16)
+    for a, b, c in zip(r0['gs'], r1['gs'], [p.grad for p in ref.b.parameters()]):
+        assert torch.equal(a, b)
+        assert torch.allclose(a, c, atol=2e-2 * float(c.abs().max()) + 1e-6)
 
 
 @pytest.mark.parametrize('world', [2, 4])

@@ -256,18 +256,19 @@ def test_config2_bf16_graphed_grouped_step_trains():
     assert dev_bf16 <= 0.10, dev_bf16
 
 
-AM_TASK = {           # examples/csmsc/configs/msmc_vq_gan_am.yaml (BASELINE config #4), dropout zeroed for the comparison
+AM_TASK = {           # examples/csmsc/configs/msmc_vq_gan_am.yaml (BASELINE config #4); every dropout (the attention's default
+                      # 0.1 included) zeroed for the comparison
     '_name': 'MSMCTTS', '_mode': 'train_predictor',
     'predictor': {
         '_name': 'MultiStagePredictor', 'n_symbols': [100, 10, 2], 'n_model_size': 600, 'n_pred_size': 256,
         'n_pred_scale': [4, 1],
         'encoder_config': dict(max_seq_len=240, n_layers=6, n_head=2, d_k=64, d_v=64, d_model=600, d_inner=1536,
-                               fft_conv1d_kernel=3, fft_conv1d_padding=1, dropout=0.0, name='phoneme_side',
+                               fft_conv1d_kernel=3, fft_conv1d_padding=1, dropout=0.0, attn_dropout=0.0, name='phoneme_side',
                                fused_layernorm=False),
         'adaptor_config': dict(input_size=600, duration_predictor_filter_size=256, duration_predictor_kernel_size=3,
                                dropout=0.0, fused_layernorm=False),
         'decoder_config': dict(max_seq_len=2400, n_layers=6, n_head=2, d_k=64, d_v=64, d_model=600, d_inner=1536,
-                               fft_conv1d_kernel=3, fft_conv1d_padding=1, dropout=0.0, name='mel_side',
+                               fft_conv1d_kernel=3, fft_conv1d_padding=1, dropout=0.0, attn_dropout=0.0, name='mel_side',
                                fused_layernorm=False),
     },
 }
