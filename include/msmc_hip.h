@@ -155,7 +155,10 @@ typedef struct msmc_conv_desc {
                                0 <= in_slope <= 1), 32 = persistent thin-layer kernel (csrc/gather4.inc: Cin, Cout in {32, 64}, unit strides, zero
                                padding, taps along one axis; weights of all taps resident in LDS, halo tiles by LDS-DMA, epilogue in
                                registers; MSMC_E_SHAPE outside that scope), 33 = 32 with the epilogue of a tile deferred into the next
-                               iteration (measured no faster: not a tuner candidate), 9 = 32-point tiles with the channel
+                               iteration (measured no faster: not a tuner candidate), 34 = 1-tap unit-stride layers as a plain channel GEMM
+                               (csrc/gemm1.inc: 128 x 128 tiles, both operands by LDS-DMA in 64-channel chunks, epilogue in
+                               registers; MSMC_E_SHAPE for anything but a bf16 kernel-size-1 layer on the identity lattice with
+                               Cin % 8 == 0, Cout % 4 == 0), 9 = 32-point tiles with the channel
                                chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation (fp32 atomics), 3 = third (split partials + fixed-order reduce), 4 / 5 / 6 = fourth (the
                                third's result contract; pixel tiles flow through an LDS-DMA ring: 4 = three stages, fragment reads two

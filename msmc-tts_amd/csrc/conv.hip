@@ -779,6 +779,7 @@ static int cv_geometry(const msmc_conv_desc* d, CvGeom* G, int elt_bytes, int XS
 
 #include "gather3.inc"
 #include "gather4.inc"
+#include "gemm1.inc"
 
 template <typename T, int NT, int MT>
 static int cv_try_pipe(const msmc_conv_desc* d, msmc_stream stream, bool* done) {
@@ -1280,6 +1281,10 @@ extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
         const int rc = cv4_launch(d, stream);
         return rc < 0 ? rc : rc == 1 ? 0 : MSMC_E_SHAPE;
     }
+    if (g1_is_variant(d->variant)) {            // 1-tap layers as a plain channel GEMM (bf16): E_SHAPE outside its scope
+        const int rc = g1_launch(d, stream);
+        return rc < 0 ? rc : rc == 1 ? 0 : MSMC_E_SHAPE;
+    }
     if (d->variant == 9) {                      // wave-split deep reduction (E_SHAPE when it does not apply)
         int rc = d->dtype == 0 ? cv_ks_launch<float>(d, stream)
                  : d->dtype == 1 ? cv_ks_launch<unsigned short>(d, stream) : MSMC_E_SHAPE;
@@ -1647,9 +1652,10 @@ static int cv_group_launch(const msmc_conv_desc* descs, int n, msmc_stream strea
         const msmc_conv_desc* d = &descs[i];
         if (cv3_is_variant(d->variant) || done4[i]) continue;
         int nt_unused;
-        int rc = (cv_takes_direct(d) || d->variant == 9 || cv4_is_variant(d->variant)) ? 0 : cv2_plan<T>(d, &plans[i], &nt_unused);
+        const bool own_grid = d->variant == 9 || cv4_is_variant(d->variant) || g1_is_variant(d->variant);
+        int rc = (cv_takes_direct(d) || own_grid) ? 0 : cv2_plan<T>(d, &plans[i], &nt_unused);
         if (rc) return rc;
-        if (d->variant == 9 || cv4_is_variant(d->variant)) {   // (one launch each: both fill the chip on their own)
+        if (own_grid) {                                         // (one launch each: they fill the chip on their own)
             rc = msmc_conv_gather(d, stream);
             if (rc) return rc;
         } else if (cv_takes_direct(d)) {

@@ -61,7 +61,13 @@ SMALL = [
 def csmsc_layers(B=16):
     """Every convolution layer shape of the CSMSC model's HifiGAN generator, period and resolution discriminators
     (40-frame window = 12000 samples), as CONVS-style cases keyed by family."""
-    out = {'gen': [], 'mpd': [], 'mrd': []}
+    out = {'gen': [], 'mpd': [], 'mrd': [], 'fft': []}
+    # kernel-size-1 layers of the FFT blocks / quantiser glue (T = 400 and T / 4): Q|K|V and output projections, 1x1 stacks
+    for T in (400, 100):
+        for ci, co in ((256, 384), (128, 256), (256, 256), (512, 256), (80, 256), (256, 80)):
+            out['fft'].append(('fft 1x1 T%d %d->%d' % (T, ci, co), B, ci, co, 1, T, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0))
+    out['fft'].append(('fft ffn k3 256->1024', B, 256, 1024, 1, 400, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0))
+    out['fft'].append(('fft ffn k3 1024->256 relu', B, 1024, 256, 1, 400, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.0))
     out['gen'].append(('gen conv_pre k7 256->512', B, 256, 512, 1, 40, (1, 7), (1, 1), (1, 1), (0, 3), False, 1.0))
     for C, L in ((256, 240), (128, 1200), (64, 6000), (32, 12000)):
         for k in (3, 7, 11):

@@ -313,7 +313,7 @@ def _forced(kind, variant_shift, data, parts, conv):
     return errs, ran
 
 
-@pytest.mark.parametrize('family', ['gen', 'mpd', 'mrd'])
+@pytest.mark.parametrize('family', ['gen', 'mpd', 'mrd', 'fft'])
 def test_every_gather_candidate_forced_on_every_csmsc_layer(family):
     """No forward / data-gradient kernel reaches hip/tuned_gfx950.json without a direct hardware test: every tuner
     candidate (msmc_conv_desc.variant, hip/conv.py _GATHER_CANDIDATES: generations 1-2, direct, wave-split, third
@@ -340,7 +340,7 @@ def test_every_gather_candidate_forced_on_every_csmsc_layer(family):
     assert not bad, bad[:20]
 
 
-@pytest.mark.parametrize('family', ['gen', 'mpd', 'mrd'])
+@pytest.mark.parametrize('family', ['gen', 'mpd', 'mrd', 'fft'])
 def test_every_wgrad_candidate_forced_on_every_csmsc_layer(family):
     """the same for the weight (+ bias) gradient candidates (_WGRAD_CANDIDATES: generations 1-4 with their pixel-split
     shifts and the general-lattice LDS-DMA generation, variant 7) -- in particular variant 7 on every stride-3

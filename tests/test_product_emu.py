@@ -648,3 +648,59 @@ def test_wgrad_deferred_second_stage_equals_the_immediate_one():
     finally:
         L.msmc_conv_set_wgrad_generation(2)
         L.msmc_conv_set_wgrad_split(0)
+
+
+def test_gather_one_tap_gemm_variant():
+    """variant 34 (gemm1.inc: kernel-size-1 layers as a plain channel GEMM, both operands by LDS-DMA in 64-channel chunks,
+    swapped operand roles with the epilogue in registers): forward and data gradient (mask operand) of the FFT-block
+    projection / quantiser 1x1 shapes against PyTorch -- ragged pixel and channel tiles, a channel count that is not a
+    multiple of the chunk, more pixel tiles than one XCD group, 2-D images -- every epilogue operand against the second
+    generation, layers outside its scope refused"""
+    from msmctts_amd.hip import conv, lib
+    cases = [('g1 qkv 256->384', 3, 256, 384, 1, 100, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+             ('g1 out 128->256 ragged', 2, 128, 256, 1, 77, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+             ('g1 in_linear 80->256', 2, 80, 256, 1, 70, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+             ('g1 mel 256->80 lrelu', 1, 256, 80, 1, 140, (1, 1), (1, 1), (1, 1), (0, 0), False, 0.1),
+             ('g1 many tiles 64->72', 1, 64, 72, 1, 1200, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+             ('g1 image 96->32', 2, 96, 32, 9, 7, (1, 1), (1, 1), (1, 1), (0, 0), False, 0.2)]
+    real = conv._build_desc
+    state = {'variant': 34}
+
+    def forced(*a, **k):
+        d = real(*a, **k)
+        if d.dtype == 1:
+            d.variant = state['variant']
+        return d
+    conv._build_desc = forced
+    try:
+        for case in cases:
+            for part in ('fwd', 'dgrad'):
+                conv._PLANS.clear()
+                _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=(part,))
+                assert b'conv_gemm1_kernel' in lib.get().msmc_conv_last_kernel(), (case[0], part)
+        torch.manual_seed(0)
+        B, Ci, Co, Lx = 2, 128, 96, 150
+        geom = conv.Geometry(1, Lx, (1, 1), (1, 1), (1, 1), (0, 0), False)
+        x = torch.randn(B, 1, Lx, Ci).bfloat16()
+        w = (torch.randn(1, Co, Ci) / Ci ** 0.5).bfloat16()
+        bias, res, res2 = torch.randn(Co), torch.randn(B, 1, Lx, Co).bfloat16(), torch.randn(B, 1, Lx, Co).bfloat16()
+        outs = []
+        for v in (34, 2):
+            state['variant'] = v
+            conv._PLANS.clear()
+            outs.append(conv.conv_forward(x, w, geom, bias=bias, in_slope=0.1, res=res, res2=res2, out_div=3.0, out_slope=0.2))
+        assert _convcases.rel(outs[0], outs[1]) < 1e-2
+        # grouped call with 1-tap members: each on a grid of its own, results of single launches
+        state['variant'] = 34
+        items = [dict(x=x, w=(torch.randn(1, Co, Ci) / Ci ** 0.5).bfloat16(), geom=geom, bias=bias, res=res) for _ in range(3)]
+        conv._PLANS.clear()
+        singles = [conv.conv_forward(**it) for it in items]
+        for a, b in zip(conv.conv_forward_group(items), singles):
+            assert torch.equal(a, b)
+        # outside the scope: a 3-tap layer -> MSMC_E_SHAPE surfaces as an error, nothing is mis-computed
+        conv._PLANS.clear()
+        with pytest.raises(RuntimeError, match='msmc_conv_gather'):
+            _convcases.check_conv_case(_convcases.SMALL[2], torch.bfloat16, 2e-2, 'cpu', parts=('fwd',))
+    finally:
+        conv._build_desc = real
+        conv._PLANS.clear()
