@@ -88,6 +88,7 @@ class KernelTimer(object):
 
     def __init__(self):
         self.calls = []
+        self.shapes = []                 # one description per entry of ``calls`` (layer shape: --calls-out)
         self.enabled = False
         self.lib = None
 
@@ -110,13 +111,12 @@ class KernelTimer(object):
             i0 = timer.lib.msmc_prof_count()
             out = inner(*args, **kw)
             timer.calls.append((i0, timer.lib.msmc_prof_count()) + tuple(work(*args, **kw)))
+            timer.shapes.append(fn_name + ' ' + describe_call(args, kw))
             return out
 
         setattr(module, fn_name, timed)
 
-    def summary(self):
-        if self.lib is None:
-            return {}
+    def records(self):
         import ctypes
         n = self.lib.msmc_prof_count()
         buf, ms = ctypes.create_string_buffer(128), ctypes.c_float()
@@ -125,6 +125,33 @@ class KernelTimer(object):
             if self.lib.msmc_prof_read(i, buf, 128, ctypes.byref(ms)) != 0:
                 raise RuntimeError('msmc_prof_read(%d) failed' % i)
             recs.append([buf.value.decode(), float(ms.value), 0.0, 0.0])
+        return recs
+
+    def by_call(self, steps):
+        """per (entry point, layer shape): calls per step, summed launch time per step, kernels, work -- the table the
+        per-symbol summary cannot give (which LAYERS a symbol's time belongs to)"""
+        if self.lib is None:
+            return []
+        recs = self.records()
+        out = {}
+        for (i0, i1, flops, byts), shape in zip(self.calls, self.shapes):
+            o = out.setdefault(shape, dict(call=shape, calls=0, ms=0.0, kernels={}, gflop=0.0, mbytes=0.0))
+            o['calls'] += 1
+            o['gflop'], o['mbytes'] = flops / 1e9, byts / 1e6
+            for name, t, _, _ in recs[i0:i1]:
+                o['ms'] += t
+                o['kernels'][name] = o['kernels'].get(name, 0) + 1
+        rows = sorted(out.values(), key=lambda o: -o['ms'])
+        for o in rows:
+            o['us_per_call'] = o['ms'] * 1e3 / o['calls']
+            o['ms_per_step'] = o.pop('ms') / steps
+            o['calls_per_step'] = o.pop('calls') / float(steps)
+        return rows
+
+    def summary(self):
+        if self.lib is None:
+            return {}
+        recs = self.records()
         for i0, i1, flops, byts in self.calls:
             main = [r for r in recs[i0:i1] if not r[0].startswith(self.HELPERS)]
             tot = sum(r[1] for r in main)
@@ -140,6 +167,26 @@ class KernelTimer(object):
             o['flops'] += f
             o['bytes'] += b
         return out
+
+
+def describe_call(args, kw):
+    """shapes of a convolution entry point's operands as one short string (tensors: shape, geometry objects: their
+    lattice, grouped calls: every member)"""
+    def one(v):
+        if torch.is_tensor(v):
+            return 'x'.join(str(int(n)) for n in v.shape)
+        if isinstance(v, (list, tuple)) and v and isinstance(v[0], dict):
+            return '[' + ' | '.join(describe_call((), it) for it in v) + ']'
+        if isinstance(v, (int, float, bool)) or v is None:
+            return str(v)
+        fields = [f for f in ('kh', 'kw', 'sy', 'sx', 'dy', 'dx', 'Hout', 'Wout') if hasattr(v, f)]
+        if fields:
+            return 'geom(' + ','.join('%s=%s' % (f, getattr(v, f)) for f in fields) + ')'
+        return type(v).__name__
+    parts = [one(v) for v in args]
+    parts += ['%s=%s' % (k, one(v)) for k, v in kw.items() if k in ('x', 'w', 'g', 'wb', 'geom', 'n_slices') or
+              isinstance(v, (int, float))]
+    return ' '.join(parts)
 
 
 def build(args, device, rank, world):
@@ -289,6 +336,9 @@ def main():
     ap.add_argument('--kernel-timing-steps', type=int, default=3, help='extra steps timed kernel by kernel (rank 0)')
     ap.add_argument('--kernels-out', default=os.path.join(ROOT, 'gpurun_out', 'bench_kernels.json'),
                     help='JSON side file for the per-kernel-symbol table (the printed line only names it)')
+    ap.add_argument('--calls-out', default=None,
+                    help='JSON side file: the instrumented steps per (entry point, layer shape) -- which layers a '
+                         "symbol's time belongs to")
     ap.add_argument('--fp32-steps', type=int, default=3,
                     help='eager fp32 steps (the parity configuration) timed after the headline, 0 = skip')
     args = ap.parse_args()
@@ -428,6 +478,9 @@ def main():
         torch.cuda.synchronize()
         ms_instr = (time.perf_counter() - t1) / args.kernel_timing_steps * 1e3
         timer.stop()
+        if args.calls_out:
+            with open(args.calls_out, 'w') as f:
+                json.dump(timer.by_call(args.kernel_timing_steps), f, indent=0)
         convnet.STREAMS_ENABLED = True
         trainer.use_graphs = graphs_were
     # warm-up phase (iteration < warmup_steps: autoencoder + frame decoder only), SURVEY.md 8d asks for it separately
