@@ -780,6 +780,7 @@ static int cv_geometry(const msmc_conv_desc* d, CvGeom* G, int elt_bytes, int XS
 #include "gather3.inc"
 #include "gather4.inc"
 #include "gemm1.inc"
+#include "gather5.inc"
 
 template <typename T, int NT, int MT>
 static int cv_try_pipe(const msmc_conv_desc* d, msmc_stream stream, bool* done) {
@@ -1285,6 +1286,10 @@ extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
         const int rc = g1_launch(d, stream);
         return rc < 0 ? rc : rc == 1 ? 0 : MSMC_E_SHAPE;
     }
+    if (cv5_is_variant(d->variant)) {           // fifth generation (bf16, sixteen waves, staged taps): E_SHAPE outside its scope
+        const int rc = cv5_launch(d, stream);
+        return rc < 0 ? rc : rc == 1 ? 0 : MSMC_E_SHAPE;
+    }
     if (d->variant == 9) {                      // wave-split deep reduction (E_SHAPE when it does not apply)
         int rc = d->dtype == 0 ? cv_ks_launch<float>(d, stream)
                  : d->dtype == 1 ? cv_ks_launch<unsigned short>(d, stream) : MSMC_E_SHAPE;
@@ -1646,6 +1651,12 @@ static int cv_group_launch(const msmc_conv_desc* descs, int n, msmc_stream strea
     {
         const int rc = cv4_group_launch(descs, n, stream, done4);
         if (rc) return rc;
+    }
+    {
+        bool done5[MSMC_GROUP_LIMIT];                           // fifth-generation members: one grid per configuration
+        const int rc = cv5_group_launch(descs, n, stream, done5);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) done4[i] = done4[i] || done5[i];
     }
     for (int i = 0; i < n; ++i) {
         pending[i] = direct[i] = false;

@@ -148,6 +148,13 @@ MSMC_DEV unsigned int wave_xor32_u(unsigned int v) {
     const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
     return (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 32u) ? r[0] : r[1];
 }
+// a of the upper half <-> b of the lower half (one v_permlane32_swap): lane l < 32 ends with (its a, lane l+32's a),
+// lane l + 32 with (lane l's b, its b)
+MSMC_DEV void wave_swap32(unsigned int& a, unsigned int& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
 MSMC_DEV float wave_xor16(float v) { return __uint_as_float(wave_xor16_u(__float_as_uint(v))); }
 MSMC_DEV float wave_xor32(float v) { return __uint_as_float(wave_xor32_u(__float_as_uint(v))); }
 MSMC_DEV int wave_xor16(int v) { return (int)wave_xor16_u((unsigned int)v); }

@@ -85,6 +85,11 @@ static inline T emu_exchange(T v, int src_lane) {
 static inline int wave_uniform(int v) { return v; }
 MSMC_DEV float wave_xor(float v, int mask) { return emu_exchange(v, emu::lane() ^ mask); }
 MSMC_DEV int wave_xor(int v, int mask) { return emu_exchange(v, emu::lane() ^ mask); }
+MSMC_DEV void wave_swap32(unsigned int& a, unsigned int& b) {
+    const unsigned int pa = emu_exchange(a, emu::lane() ^ 32), pb = emu_exchange(b, emu::lane() ^ 32);
+    if (emu::lane() < 32) b = pa;
+    else a = pb;
+}
 MSMC_DEV float wave_xor16(float v) { return emu_exchange(v, emu::lane() ^ 16); }
 MSMC_DEV float wave_xor32(float v) { return emu_exchange(v, emu::lane() ^ 32); }
 MSMC_DEV int wave_xor16(int v) { return emu_exchange(v, emu::lane() ^ 16); }

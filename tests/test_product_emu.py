@@ -704,3 +704,77 @@ def test_gather_one_tap_gemm_variant():
     finally:
         conv._build_desc = real
         conv._PLANS.clear()
+
+
+@pytest.mark.parametrize('variant', [40, 41, 42, 43, 44])
+def test_gather_fifth_generation_variants(variant):
+    """variants 40..44 (gather5.inc: sixteen waves, stages of (64-channel chunk, tap) with the weight slices in an LDS-DMA
+    ring and the halo tile of a chunk shared by its taps, swapped operand roles, epilogue in registers with 16-byte stores):
+    every tile shape where it applies, forward and data gradient -- ragged pixel and channel tiles, dilation, stride,
+    reflection, 2-D taps, two taps (ring of three stages), several chunks, more pixel tiles than one XCD group -- every
+    epilogue operand against the second generation, grouped calls equal to single launches, 1-tap layers refused"""
+    from msmctts_amd.hip import conv, lib
+    cases = [('g5 k3 64->128', 2, 64, 128, 1, 150, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
+             ('g5 k11 d5 128->136', 1, 128, 136, 1, 70, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
+             ('g5 k5x1 s3 64->256', 1, 64, 256, 40, 3, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
+             ('g5 3x3 reflect s2 64->72', 1, 64, 72, 13, 18, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
+             ('g5 k2 192->128', 1, 192, 128, 1, 45, (1, 2), (1, 1), (1, 1), (0, 1), False, 1.0),
+             ('g5 k3 many tiles 64->128', 1, 64, 128, 1, 1300, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
+             ('g5 ffn 256->512 relu', 2, 256, 512, 1, 100, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.0)]
+    real = conv._build_desc
+    state = {'variant': variant}
+
+    def forced(*a, **k):
+        d = real(*a, **k)
+        if d.dtype == 1:
+            d.variant = state['variant']
+        return d
+    conv._build_desc = forced
+    ran = 0
+    try:
+        for case in cases:
+            for part in ('fwd', 'dgrad'):
+                conv._PLANS.clear()
+                try:
+                    _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=(part,))
+                    assert b'conv_gather5_kernel' in lib.get().msmc_conv_last_kernel(), (case[0], part)
+                    ran += 1
+                except RuntimeError as e:             # MSMC_E_SHAPE: this configuration does not apply to the layer
+                    assert 'msmc_conv_gather' in str(e), e
+        assert ran >= 3, (variant, ran)
+        torch.manual_seed(0)
+        B, Ci, Co, Lx = 2, 128, 264, 150
+        geom = conv.Geometry(1, Lx, (1, 3), (1, 1), (1, 2), (0, 2), False)
+        x = torch.randn(B, 1, Lx, Ci).bfloat16()
+        w = (torch.randn(3, Co, Ci) / (3 * Ci) ** 0.5).bfloat16()
+        bias, res, res2 = torch.randn(Co), torch.randn(B, 1, Lx, Co).bfloat16(), torch.randn(B, 1, Lx, Co).bfloat16()
+        outs = []
+        for v in (variant, 2):
+            state['variant'] = v
+            conv._PLANS.clear()
+            fresh = conv.Geometry(1, Lx, (1, 3), (1, 1), (1, 2), (0, 2), False)         # (a geometry keeps its descriptors)
+            outs.append(conv.conv_forward(x, w, fresh, bias=bias, in_slope=0.1, res=res, res2=res2, out_div=3.0, out_slope=0.2))
+        assert b'conv_gather2' in lib.get().msmc_conv_last_kernel()
+        assert _convcases.rel(outs[0], outs[1]) < 1e-2
+        # grouped call: members of one configuration share a grid, results of single launches
+        state['variant'] = variant
+        geom7 = conv.Geometry(1, Lx, (1, 7), (1, 1), (1, 1), (0, 3), False)
+        items = [dict(x=x, w=w, geom=geom, bias=bias, res=res),
+                 dict(x=x, w=(torch.randn(7, Co, Ci) / (7 * Ci) ** 0.5).bfloat16(), geom=geom7, bias=bias, in_slope=0.1),
+                 dict(x=x[:1], w=w, geom=geom, res=res[:1])]
+        conv._PLANS.clear()
+        singles = [conv.conv_forward(**it) for it in items]
+        n0 = lib.get().msmc_conv_launch_count()
+        grouped = conv.conv_forward_group(items)
+        assert lib.get().msmc_conv_launch_count() - n0 == 1
+        assert b'conv_gather5_group_kernel' in lib.get().msmc_conv_last_kernel()
+        for a, b in zip(grouped, singles):
+            assert torch.equal(a, b)
+        # outside the scope: a 1-tap layer -> MSMC_E_SHAPE surfaces as an error
+        conv._PLANS.clear()
+        with pytest.raises(RuntimeError, match='msmc_conv_gather'):
+            _convcases.check_conv_case(('g5 k1', 1, 64, 128, 1, 40, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+                                       torch.bfloat16, 2e-2, 'cpu', parts=('fwd',))
+    finally:
+        conv._build_desc = real
+        conv._PLANS.clear()

@@ -99,7 +99,7 @@ for name, B, Cin, Cout, H, W, k, s_, dil, pad, reflect, slope in SHAPES:
     if os.environ.get('ABLATE'):
         v = int(os.environ['ABLATE'])
         row = []
-        for abl in (0, 1, 2, 4, 8, 1 | 8, 2 | 4, 1 | 2 | 4, 1 | 2 | 4 | 8):
+        for abl in [int(a) for a in os.environ.get('ABLS', '0 1 2 4 8 9 6 7 15').split()]:
             d3 = lib.ConvDesc.from_buffer_copy(desc)
             d3.variant, d3.split_shift = v, abl
             t3 = timed(d3, stream)

@@ -4,7 +4,7 @@ GPU test-suite's layer cases) and write the choices to msmctts_amd/hip/tuned_gfx
 RETUNE=wgrad4 keeps the committed table and re-times only the single-launch bf16 weight gradients the fourth-generation
 kernel can serve (one pass).  RETUNE=gather3x keeps it too and times only the LDS-DMA halo variants (24..31) of every bf16
 forward / data-gradient shape, merging them with the committed timings of the other candidates; RETUNE=gather4 does the
-same for the persistent thin-layer kernel (variant 32), RETUNE=gemm1 for the 1-tap GEMM kernel (variant 34) and RETUNE=wgrad5 for the general-lattice LDS-DMA weight gradient
+same for the persistent thin-layer kernel (variant 32), RETUNE=gemm1 for the 1-tap GEMM kernel (variant 34), RETUNE=gather5 for the sixteen-wave staged-tap kernel (variants 40..44) and RETUNE=wgrad5 for the general-lattice LDS-DMA weight gradient
 (variant 7; the grouped calls whose members change are re-timed by the run itself)."""
 import os, sys, random, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -60,6 +60,11 @@ if RETUNE == 'gemm1':                                     # 1-tap layers as a pl
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
             if k[0] == 'gather' and k[1] == 1 and k[15] == 1 and tuple(k[16]) == (0,) and tuple(k[17]) == (0,)}
     print('timing the 1-tap GEMM kernel on %d forward / data-gradient shapes' % len(kept))
+if RETUNE == 'gather5':                                   # sixteen-wave staged-tap kernel (variants 40..44): every bf16
+    conv._GATHER_CANDIDATES = tuple((v, 0) for v in range(40, 45))      # shape with 64-multiple input channels and >= 2 taps
+    kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
+            if k[0] == 'gather' and k[1] == 1 and k[5] % 64 == 0 and k[15] >= 2}
+    print('timing the fifth-generation forward / data-gradient kernel on %d shapes' % len(kept))
 if RETUNE == 'wgrad5':                                    # general-lattice LDS-DMA weight gradient (variant 7): time it on
     conv._WGRAD_CANDIDATES = ((7, 0), (7, -1))            # every bf16 shape with 64-multiple channels, merge with the table
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
