@@ -150,6 +150,9 @@ MSMC_DEV unsigned int wave_xor32_u(unsigned int v) {
 }
 // a of the upper half <-> b of the lower half (one v_permlane32_swap): lane l < 32 ends with (its a, lane l+32's a),
 // lane l + 32 with (lane l's b, its b)
+// value of lane `src_lane` (wave-uniform index) as a scalar: v_readlane_b32, no LDS round trip
+MSMC_DEV int wave_read_lane(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+MSMC_DEV unsigned int wave_read_lane(unsigned int v, int src_lane) { return (unsigned int)__builtin_amdgcn_readlane((int)v, src_lane); }
 MSMC_DEV void wave_swap32(unsigned int& a, unsigned int& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     a = r[0];
