@@ -317,8 +317,14 @@ def _tap_grad(g_tap, like):
 
 class _HipConv(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, res2, weight_token, bank, layer, in_slope, out_slope, out_div, tap=False):
+    def forward(ctx, x, res, res2, weight_token, bank, layer, in_slope, out_slope, out_div, tap=False, in_act=1.0,
+                out_masked=False):
+        # ``in_act`` != 1: x was activated by its producer's epilogue (that producer ran with out_slope = in_act and
+        # ``out_masked``); forward and weight gradient read it as it is, the data gradient applies the activation's
+        # derivative (sign of the activated value = sign of the pre-activation).  ``out_masked``: this convolution's ONLY
+        # consumer does that, so the backward pass here does not.
         m = layer.module
+        assert in_act == 1.0 or (in_slope == 1.0 and not layer.reflect)
         if layer.kind == 'conv':
             geom = layer.geom(x.shape[1], x.shape[2])
             out = K.conv_forward(x, layer.wf, geom, bias=m.bias, in_slope=in_slope, res=res, res2=res2,
@@ -329,9 +335,11 @@ class _HipConv(torch.autograd.Function):
                                              bias=m.bias, in_slope=in_slope)
         ctx.bank, ctx.layer = bank, layer
         ctx.in_slope, ctx.out_slope, ctx.out_div = in_slope, out_slope, out_div
+        ctx.mask_slope = in_act if in_act != 1.0 else in_slope
+        ctx.out_masked = bool(out_masked)
         ctx.has_res, ctx.has_res2 = res is not None, res2 is not None
         ctx.need_w = layer.weight.requires_grad
-        ctx.save_for_backward(x, out if out_slope != 1.0 else None)
+        ctx.save_for_backward(x, out if (out_slope != 1.0 and not out_masked) else None)
         ctx.set_materialize_grads(False)
         # ``tap``: also return an alias of x for x's OTHER consumer (a residual add, a feature-matching loss, a fused
         # LayerNorm's residual input).  Its gradient then arrives HERE and is added in the data-gradient launch's epilogue
@@ -343,16 +351,16 @@ class _HipConv(torch.autograd.Function):
         x, out = ctx.saved_tensors
         layer, bank = ctx.layer, ctx.bank
         if g is None:                                  # only the tap was used
-            return (g_tap,) + (None,) * 9
+            return (g_tap,) + (None,) * 11
         g = g.contiguous()
         g_tap = _tap_grad(g_tap, g)
-        if ctx.out_slope != 1.0:                       # y = lrelu(z): dz = dy * (y > 0 ? 1 : slope)
+        if ctx.out_slope != 1.0 and not ctx.out_masked:        # y = lrelu(z): dz = dy * (y > 0 ? 1 : slope)
             g = K.lrelu_bwd(g, out, ctx.out_slope)
         if ctx.out_div != 1.0:
             g = g / ctx.out_div
         gx = None
         if ctx.needs_input_grad[0]:
-            mask = x if ctx.in_slope != 1.0 else None
+            mask = x if ctx.mask_slope != 1.0 else None
             if layer.kind == 'conv':
                 geom = layer.geom(x.shape[1], x.shape[2])
                 if layer.reflect:
@@ -362,10 +370,10 @@ class _HipConv(torch.autograd.Function):
                     if g_tap is not None:
                         gx = gx + g_tap
                 else:
-                    gx = K.conv_dgrad(g, layer.wb, geom, mask_src=mask, mask_slope=ctx.in_slope, res=g_tap)
+                    gx = K.conv_dgrad(g, layer.wb, geom, mask_src=mask, mask_slope=ctx.mask_slope, res=g_tap)
             else:
                 gx = K.conv_transpose1d_dgrad(g, layer.wb, layer.kernel[1], layer.stride[1], layer.padding[1],
-                                              x.shape[2], mask_src=mask, mask_slope=ctx.in_slope, res=g_tap)
+                                              x.shape[2], mask_src=mask, mask_slope=ctx.mask_slope, res=g_tap)
             if g_tap is not None:
                 bank._hold.append(g_tap)               # (read by a launch that may replay on another stream)
                 bank._queue_finish()
@@ -391,19 +399,20 @@ class _HipConv(torch.autograd.Function):
             bank._queue_finish()
         # weight_token (the layer's weight_v) only ties the output to the parameters in the autograd graph;
         # parameter gradients are produced in kernel layout and delivered by ConvBank._finish_backward.
-        return gx, (g if ctx.has_res else None), (g if ctx.has_res2 else None), None, None, None, None, None, None, None
+        return (gx, (g if ctx.has_res else None), (g if ctx.has_res2 else None)) + (None,) * 9
 
 
 class _HipConvGroup(torch.autograd.Function):
     """Several independent convolutions of one bank as grouped launches (K.conv_forward_group / conv_dgrad_group /
     conv_wgrad_group): the parallel ResBlocks of a generator stage, one layer of all period / resolution
-    sub-discriminators.  ``specs[k] = (layer, in_slope, out_slope, out_div, has_res, has_res2)``; ``tensors`` is the
-    flattened list x_k, [res_k], [res2_k], weight_token_k."""
+    sub-discriminators.  ``specs[k] = (layer, in_slope, out_slope, out_div, has_res, has_res2, tap, in_act, out_masked)``
+    (the last two as in _HipConv.forward); ``tensors`` is the flattened list x_k, [res_k], [res2_k], weight_token_k."""
 
     @staticmethod
     def forward(ctx, bank, specs, *tensors):
         items, pos, members = [], 0, []
-        for layer, in_slope, out_slope, out_div, has_res, has_res2, tap in specs:
+        for layer, in_slope, out_slope, out_div, has_res, has_res2, tap, in_act, out_masked in specs:
+            assert in_act == 1.0 or (in_slope == 1.0 and not layer.reflect)
             x = tensors[pos]
             res = tensors[pos + 1] if has_res else None
             res2 = tensors[pos + 1 + has_res] if has_res2 else None
@@ -416,7 +425,7 @@ class _HipConvGroup(torch.autograd.Function):
         ctx.bank, ctx.specs, ctx.ntensors = bank, specs, len(tensors)
         ctx.need_w = [sp[0].weight.requires_grad for sp in specs]     # as of the forward (a frozen pass stays frozen)
         ctx.xpos = [m[0] for m in members]
-        saved = [m[1] for m in members] + [o if sp[2] != 1.0 else None for o, sp in zip(outs, specs)]
+        saved = [m[1] for m in members] + [o if (sp[2] != 1.0 and not sp[8]) else None for o, sp in zip(outs, specs)]
         ctx.save_for_backward(*saved)
         ctx.set_materialize_grads(False)
         # members with ``tap``: an alias of their input follows the outputs (see _HipConv.forward)
@@ -440,11 +449,12 @@ class _HipConvGroup(torch.autograd.Function):
             raise RuntimeError('grouped convolution: an output without gradient (not expected on the training path)')
         gs = [g.contiguous() for g in gs]
         # y = lrelu(z): dz = dy * (y > 0 ? 1 : slope) -- one multi-tensor launch per slope value
-        for slope in sorted(set(sp[2] for sp in ctx.specs if sp[2] != 1.0)):
-            ks = [k for k, sp in enumerate(ctx.specs) if sp[2] == slope]
+        for slope in sorted(set(sp[2] for sp in ctx.specs if sp[2] != 1.0 and not sp[8])):
+            ks = [k for k, sp in enumerate(ctx.specs) if sp[2] == slope and not sp[8]]
             for k, gm in zip(ks, K.lrelu_bwd_group([(gs[k], outs[k]) for k in ks], slope)):
                 gs[k] = gm
-        for k, (layer, in_slope, out_slope, out_div, has_res, has_res2, tap) in enumerate(ctx.specs):
+        for k, (layer, in_slope, out_slope, out_div, has_res, has_res2, tap, in_act, out_masked) in enumerate(ctx.specs):
+            mask_slope = in_act if in_act != 1.0 else in_slope
             g = gs[k]
             if out_div != 1.0:
                 g = g / out_div
@@ -453,12 +463,12 @@ class _HipConvGroup(torch.autograd.Function):
             geom = layer.geom(x.shape[1], x.shape[2])
             pos = ctx.xpos[k]
             if ctx.needs_input_grad[2 + pos]:
-                mask = x if in_slope != 1.0 else None
+                mask = x if mask_slope != 1.0 else None
                 g_tap = _tap_grad(g_taps.get(k), g)
                 if layer.reflect:
                     d_items.append(dict(g=g, wb=layer.wb, geom=geom))
                 else:
-                    d_items.append(dict(g=g, wb=layer.wb, geom=geom, mask_src=mask, mask_slope=in_slope, res=g_tap))
+                    d_items.append(dict(g=g, wb=layer.wb, geom=geom, mask_src=mask, mask_slope=mask_slope, res=g_tap))
                     if g_tap is not None:
                         bank._hold.append(g_tap)
                 d_members.append(k)
@@ -502,7 +512,8 @@ def hip_conv_group(bank, members):
     for m in members:
         res, res2 = m.get('res'), m.get('res2')
         specs.append((m['layer'], float(m.get('in_slope', 1.0)), float(m.get('out_slope', 1.0)),
-                      float(m.get('out_div', 1.0)), int(res is not None), int(res2 is not None), bool(m.get('tap', False))))
+                      float(m.get('out_div', 1.0)), int(res is not None), int(res2 is not None), bool(m.get('tap', False)),
+                      float(m.get('in_act', 1.0)), bool(m.get('out_masked', False))))
         tensors.append(m['x'])
         if res is not None:
             tensors.append(res)
@@ -521,8 +532,12 @@ def hip_conv_group(bank, members):
 GROUPED = os.environ.get('MSMC_GROUPED', '1') != '0'
 
 
-def hip_conv(bank, layer, x, res=None, res2=None, in_slope=1.0, out_slope=1.0, out_div=1.0, tap=False):
+def hip_conv(bank, layer, x, res=None, res2=None, in_slope=1.0, out_slope=1.0, out_div=1.0, tap=False, in_act=1.0,
+             out_masked=False):
     """``tap=True``: returns (out, x_tap) -- x_tap aliases x and is what x's other consumer should read, so that its
-    gradient is added inside this convolution's data-gradient launch (see _HipConv.forward)."""
+    gradient is added inside this convolution's data-gradient launch (see _HipConv.forward).
+    Activation in the PRODUCER's epilogue: ``a = hip_conv(.., out_slope=s, out_masked=True)`` followed by
+    ``hip_conv(.., a, in_act=s)`` computes conv(lrelu_s(conv(..))) with the activation applied once, where the value is
+    produced, instead of in every load of the consumer (a must have no other consumer)."""
     return _HipConv.apply(x, res, res2, layer.weight, bank, layer, float(in_slope), float(out_slope),
-                          float(out_div), bool(tap))
+                          float(out_div), bool(tap), float(in_act), bool(out_masked))

@@ -178,11 +178,12 @@ class PositionwiseFeedForward(nn.Module):
         """x [B, T, C] (already masked) in the compute dtype -> layer_norm(dropout(w_2(relu(w_1 x))) + x) * non_pad_mask"""
         bank, (l1, l2) = hip
         # [B, T, C] IS the channels-last layout of a 1-D convolution: no transposes; the ReLU between the two
-        # convolutions is the second one's input activation (leaky slope 0)
+        # convolutions is applied once, in the first one's epilogue (leaky slope 0), and its derivative in the second one's
+        # data-gradient epilogue
         # (tap: the residual input of the fused LayerNorm reads the alias the first convolution hands back, so the residual
         # gradient is added in that convolution's data-gradient epilogue)
-        h1, x_res = hip_conv(bank, l1, x.unsqueeze(1), tap=True)
-        h = hip_conv(bank, l2, h1, in_slope=0.0).squeeze(1)
+        h1, x_res = hip_conv(bank, l1, x.unsqueeze(1), tap=True, out_slope=0.0, out_masked=True)
+        h = hip_conv(bank, l2, h1, in_act=0.0).squeeze(1)
         x = x_res.squeeze(1)
         pd = self.dropout.p if self.training else 0.0
         return hipnorm.add_layer_norm(h, x, self.layer_norm.weight, self.layer_norm.bias, keep_row=keep_row, p_drop=pd,
@@ -193,10 +194,10 @@ class PositionwiseFeedForward(nn.Module):
             h = self.w_2(F.relu(self.w_1(x.transpose(1, 2)))).transpose(1, 2)
         else:
             # [B, T, C] IS the channels-last layout of a 1-D convolution: no transposes; the ReLU between the two
-            # convolutions is the second one's input activation (leaky slope 0)
+            # convolutions runs in the first one's epilogue (leaky slope 0)
             bank, (l1, l2), dtype = hip
             x4 = x.unsqueeze(1).to(dtype)
-            h = hip_conv(bank, l2, hip_conv(bank, l1, x4), in_slope=0.0).squeeze(1)
+            h = hip_conv(bank, l2, hip_conv(bank, l1, x4, out_slope=0.0, out_masked=True), in_act=0.0).squeeze(1)
         return self.layer_norm(self.dropout(h) + x)
 
 

@@ -30,7 +30,8 @@ class ResBlock1(nn.Module):
         self._bank = None
 
     def forward(self, x):
-        """x (B, C, L) -> (B, C, L): every leaky-ReLU fused into the consuming convolution's load, the residual add into
+        """x (B, C, L) -> (B, C, L): the leaky-ReLU in front of a unit fused into its first convolution's load, the one between its two convolutions
+        into the first one's epilogue (its derivative into the second one's data-gradient epilogue), the residual add into
         the second convolution's epilogue (and its gradient into the first one's data-gradient epilogue: tap)."""
         if self._bank is None:
             self._layers = ([c.hip_layer() for c in self.convs1], [c.hip_layer() for c in self.convs2])
@@ -38,6 +39,6 @@ class ResBlock1(nn.Module):
         self._bank.prepare(self.hip_dtype)
         y = x.transpose(1, 2).unsqueeze(1).contiguous().to(self.hip_dtype)            # channels-last [B, 1, L, C]
         for c1, c2 in zip(*self._layers):
-            t, y = hip_conv(self._bank, c1, y, in_slope=LRELU_SLOPE, tap=True)
-            y = hip_conv(self._bank, c2, t, res=y, in_slope=LRELU_SLOPE)
+            t, y = hip_conv(self._bank, c1, y, in_slope=LRELU_SLOPE, tap=True, out_slope=LRELU_SLOPE, out_masked=True)
+            y = hip_conv(self._bank, c2, t, res=y, in_act=LRELU_SLOPE)
         return y.squeeze(1).transpose(1, 2).to(x.dtype)

@@ -14,6 +14,11 @@ from ...hip.convnet import ConvBank, fork_join, hip_conv, hip_conv_group, make_s
 from ..layers import WNConv1d, WNConvTranspose1d
 from .common import LRELU_SLOPE, ResBlock1
 
+# the leaky-ReLU between the two convolutions of a ResBlock unit (reference vocoders/hifigan.py ResBlock1.forward) runs
+# once, in the first convolution's epilogue; the second reads the activated tensor (in_act) and applies the derivative in
+# its data-gradient epilogue
+ACT = dict(out_slope=LRELU_SLOPE, out_masked=True)
+
 
 class Generator(nn.Module):
     def __init__(self, resblock_kernel_sizes, resblock_dilation_sizes, upsample_rates, upsample_initial_channel,
@@ -63,9 +68,9 @@ class Generator(nn.Module):
                 c1s, c2s = L['rb'][i * nk + j]
                 y = x
                 for m in range(len(c1s) - 1):
-                    t, y = hip_conv(bank, c1s[m], y, in_slope=LRELU_SLOPE, tap=True)   # (the residual edge reads the tap)
-                    y = hip_conv(bank, c2s[m], t, res=y, in_slope=LRELU_SLOPE)
-                t, y = hip_conv(bank, c1s[-1], y, in_slope=LRELU_SLOPE, tap=True)
+                    t, y = hip_conv(bank, c1s[m], y, in_slope=LRELU_SLOPE, tap=True, **ACT)   # (the residual edge reads the tap)
+                    y = hip_conv(bank, c2s[m], t, res=y, in_act=LRELU_SLOPE)
+                t, y = hip_conv(bank, c1s[-1], y, in_slope=LRELU_SLOPE, tap=True, **ACT)
                 return y, t
 
             if convnet.GROUPED:
@@ -75,18 +80,18 @@ class Generator(nn.Module):
                 # tap=True: the residual edge of a unit reads an alias of the unit's input handed back by its first
                 # convolution, so the residual gradient is added in that convolution's data-gradient epilogue
                 for m in range(nu - 1):
-                    tt = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][0][m], x=ys[j], in_slope=LRELU_SLOPE, tap=True)
+                    tt = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][0][m], x=ys[j], in_slope=LRELU_SLOPE, tap=True, **ACT)
                                                for j in range(nk)])
                     ys = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][1][m], x=tt[j][0], res=tt[j][1],
-                                                    in_slope=LRELU_SLOPE) for j in range(nk)])
-                tt = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][0][nu - 1], x=ys[j], in_slope=LRELU_SLOPE, tap=True)
-                                           for j in range(nk)])
+                                                    in_act=LRELU_SLOPE) for j in range(nk)])
+                tt = hip_conv_group(bank, [dict(layer=L['rb'][i * nk + j][0][nu - 1], x=ys[j], in_slope=LRELU_SLOPE, tap=True,
+                                                **ACT) for j in range(nk)])
                 parts = [(t_[1], t_[0]) for t_ in tt]
             else:
                 parts = fork_join(self._streams, [lambda j=j: block_body(j) for j in range(nk)], inputs=(x,))
             xs = None
             for j, (y, t) in enumerate(parts):    # block outputs, running sum over blocks and the final mean
-                xs = hip_conv(bank, L['rb'][i * nk + j][1][-1], t, res=y, res2=xs, in_slope=LRELU_SLOPE,
+                xs = hip_conv(bank, L['rb'][i * nk + j][1][-1], t, res=y, res2=xs, in_act=LRELU_SLOPE,
                               out_div=float(nk) if j == nk - 1 else 1.0)
             x = xs
         x = hip_conv(bank, L['post'], x, in_slope=0.01)       # F.leaky_relu default slope (generator.py:52)
