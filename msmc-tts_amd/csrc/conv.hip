@@ -3238,26 +3238,55 @@ MSMC_DEV void wn_store(void* dst, int dtype, long off, float v) {
     else ((unsigned short*)dst)[off] = f32_to_bf16_bits(v);
 }
 
+// sum over the 256 work-items of a workgroup: wave reduction by lane exchange, then four partial sums through LDS
+MSMC_DEV float block_sum_fast(float v, float* red4) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + wave_xor(v, m);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();                                   // (red4 may still be read from a previous call)
+    if ((threadIdx.x & 63) == 0) red4[w] = v;
+    __syncthreads();
+    return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+
+// Row pass: one workgroup per normalised row a (n = Bc * T parameters, contiguous).  The row is read once in its own
+// order (sum of squares), then written to layout 1 TAP-OUTER: for a fixed tap the Bc elements of the row are consecutive
+// in layout 1 (s1[2] = 1 for every layer the banks build), so a wave stores 64 consecutive elements; the strided re-read
+// of the row hits L1.  No per-element integer division (the previous form spent ~60 instructions per parameter on it).
 __global__ __launch_bounds__(256) void wn_prepare_kernel(const msmc_wn_item* __restrict__ items, int nitems, int skip2) {
-    __shared__ float red[256];
+    __shared__ float red[4];
     const msmc_wn_item it = items[wn_find(items, nitems, blockIdx.x)];
     const int a = blockIdx.x - it.block0;
-    const int n = it.Bc * it.T;
+    const int n = it.Bc * it.T, T = it.T, Bc = it.Bc;
     const float* v = it.v + (size_t)a * n;
     float scale = 1.f;
     if (it.g) {                                        // weight norm; g == NULL: plain weight, layout conversion only
         float ss = 0.f;
-        for (int e = threadIdx.x; e < n; e += 256) ss = fmaf(v[e], v[e], ss);
-        ss = block_sum(ss, red);
+        if ((n & 3) == 0) {
+            const f32x4* v4 = (const f32x4*)v;         // (rows of 4k floats off a 16-byte aligned parameter)
+            for (int e = threadIdx.x; e < (n >> 2); e += 256) {
+                const f32x4 q = v4[e];
+                ss = fmaf(q[0], q[0], ss);
+                ss = fmaf(q[1], q[1], ss);
+                ss = fmaf(q[2], q[2], ss);
+                ss = fmaf(q[3], q[3], ss);
+            }
+        } else {
+            for (int e = threadIdx.x; e < n; e += 256) ss = fmaf(v[e], v[e], ss);
+        }
+        ss = block_sum_fast(ss, red);
         const float norm = sqrtf(ss);
         scale = it.g[a] / norm;
         if (threadIdx.x == 0) it.inv_norm[a] = 1.f / norm;
     }
-    for (int e = threadIdx.x; e < n; e += 256) {
-        const int b = e / it.T, t = e - b * it.T;
-        const float wv = v[e] * scale;
-        wn_store(it.dst1, it.dtype, t * it.s1[0] + a * it.s1[1] + b * it.s1[2], wv);
-        if (it.dst2 && !skip2) wn_store(it.dst2, it.dtype, t * it.s2[0] + a * it.s2[1] + b * it.s2[2], wv);
+    const bool two = it.dst2 && !skip2;
+    for (int t = 0; t < T; ++t) {
+        const long o1 = t * it.s1[0] + a * it.s1[1], o2 = t * it.s2[0] + a * it.s2[1];
+        for (int b = threadIdx.x; b < Bc; b += 256) {
+            const float wv = v[b * T + t] * scale;
+            wn_store(it.dst1, it.dtype, o1 + b * it.s1[2], wv);
+            if (two) wn_store(it.dst2, it.dtype, o2 + b * it.s2[2], wv);
+        }
     }
 }
 
@@ -3265,7 +3294,7 @@ __global__ __launch_bounds__(256) void wn_prepare_kernel(const msmc_wn_item* __r
 // wn_prepare_kernel it is one 2-byte store per cache line.  Here a workgroup owns a tile of 64 rows (a) x 16 columns (b),
 // all taps: the parameter is read in its own order (contiguous 16*T floats per row) into LDS and written out with a
 // fastest -- 64 consecutive elements per store.  Runs after wn_prepare_kernel (inv_norm); item i owns tile-blocks
-// [tblock0, tblock0 + ceil(A/64) * ceil(Bc/16)).
+// [tblock0, tblock0 + ceil(A/64) * ceil(Bc/16)).  Index walks are incremental (no per-element division).
 #define WN_TA 64
 #define WN_TB 16
 MSMC_DEV int wn_find_tile(const msmc_wn_item* items, int n, int blk) {
@@ -3277,67 +3306,121 @@ MSMC_DEV int wn_find_tile(const msmc_wn_item* items, int n, int blk) {
     return lo;
 }
 
+#define WN_TC 128                                      // columns (b, t) of a tile staged at once: 33 KB of LDS, four workgroups per CU
 __global__ __launch_bounds__(256) void wn_transpose_kernel(const msmc_wn_item* __restrict__ items, int nitems) {
-    MSMC_DYN_LDS(smem);
-    float* tile = (float*)smem;                         // [WN_TA][WN_TB * T + 1]
-    float* scl = tile + WN_TA * (WN_TB * MSMC_CONV_MAX_TAPS + 1);
+    __shared__ float tile[WN_TA * (WN_TC + 1)];
+    __shared__ float scl[WN_TA];
     const msmc_wn_item it = items[wn_find_tile(items, nitems, blockIdx.x)];
     const int tb = blockIdx.x - it.tblock0;
     const int nbt = (it.Bc + WN_TB - 1) / WN_TB;
     const int a0 = (tb / nbt) * WN_TA, b0 = (tb - (tb / nbt) * nbt) * WN_TB;
-    const int T = it.T, span = WN_TB * T, pitch = span + 1;
+    const int T = it.T, pitch = WN_TC + 1;
     const int nb = it.Bc - b0 < WN_TB ? it.Bc - b0 : WN_TB, na = it.A - a0 < WN_TA ? it.A - a0 : WN_TA;
-    for (int e = threadIdx.x; e < WN_TA * span; e += 256) {
-        const int r = e / span, c = e - r * span;
-        if (r < na && c < nb * T) tile[r * pitch + c] = it.v[((size_t)(a0 + r) * it.Bc + b0) * T + c];
-    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ncol = nb * T;
     if (threadIdx.x < WN_TA)
         scl[threadIdx.x] = (it.g && (int)threadIdx.x < na) ? it.g[a0 + threadIdx.x] * it.inv_norm[a0 + threadIdx.x] : 1.f;
-    __syncthreads();
-    for (int e = threadIdx.x; e < WN_TA * span; e += 256) {
-        const int r = e % WN_TA, c = e / WN_TA;          // c = b * T + t
-        const int b = c / T, t = c - b * T;
-        if (r < na && b < nb)
-            wn_store(it.dst2, it.dtype, t * it.s2[0] + (a0 + r) * it.s2[1] + (b0 + b) * it.s2[2], tile[r * pitch + c] * scl[r]);
+    int b = 0, t = w;                                  // column c = b * T + t of this wave's next store
+    while (t >= T) { t -= T; ++b; }
+    for (int c0 = 0; c0 < ncol; c0 += WN_TC) {
+        const int nc = ncol - c0 < WN_TC ? ncol - c0 : WN_TC;
+        __syncthreads();                               // (previous chunk's reads done; scl visible)
+        for (int r = w; r < na; r += 4) {              // a wave reads nc consecutive floats of one row
+            const float* src = it.v + ((size_t)(a0 + r) * it.Bc + b0) * T + c0;
+            for (int c = lane; c < nc; c += 64) tile[r * pitch + c] = src[c];
+        }
+        __syncthreads();
+        // lane = row: 64 consecutive a per store; wave w takes columns w, w + 4, .. of the chunk (WN_TC % 4 == 0, so
+        // the walk of (b, t) carries over from chunk to chunk)
+        const float sc = lane < na ? scl[lane] : 0.f;
+        for (int c = w; c < nc; c += 4) {
+            if (lane < na)
+                wn_store(it.dst2, it.dtype, t * it.s2[0] + (a0 + lane) * it.s2[1] + (b0 + b) * it.s2[2], tile[lane * pitch + c] * sc);
+            t += 4;
+            while (t >= T) { t -= T; ++b; }
+        }
     }
 }
 
+// Row pass of the backward: dW arrives in layout 1 (tap-major), v / gv live in the parameter's own order.  Rows of up
+// to WN_ROW_MAX parameters go through LDS: dW is read TAP-OUTER (64 consecutive floats per wave load, privatised copies
+// folded and zeroed on the way), then everything else runs in the parameter's order (coalesced v reads, coalesced gv
+// stores).  Longer rows keep the direct form.
+#define WN_ROW_MAX 6144
 __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __restrict__ items, int nitems,
                                                          int accumulate) {
-    __shared__ float red[256];
+    __shared__ float red[4];
+    __shared__ float row[WN_ROW_MAX];
     const msmc_wn_item it = items[wn_find(items, nitems, blockIdx.x)];
     const int a = blockIdx.x - it.block0;
-    const int n = it.Bc * it.T;
+    const int n = it.Bc * it.T, T = it.T, Bc = it.Bc;
     const float* v = it.v + (size_t)a * n;
     float* dw = (float*)it.dw;
     const int R = it.copies > 1 ? it.copies : 1;
+    const bool staged = n <= WN_ROW_MAX;
     float dot = 0.f;
-    for (int e = threadIdx.x; e < n; e += 256) {
-        const int b = e / it.T, t = e - b * it.T;
-        const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
-        float sum = dw[o];
-        for (int r = 1; r < R; ++r) {                 // privatised copies: fold into copy 0, leave the others zeroed
-            sum = sum + dw[o + r * it.dw_copy_stride];
-            dw[o + r * it.dw_copy_stride] = 0.f;
+    if (staged) {
+        for (int t = 0; t < T; ++t) {
+            const long o1 = t * it.s1[0] + a * it.s1[1];
+            for (int b = threadIdx.x; b < Bc; b += 256) {
+                const long o = o1 + b * it.s1[2];
+                float sum = dw[o];
+                dw[o] = 0.f;                           // each accumulator element has exactly this one reader
+                for (int r = 1; r < R; ++r) {          // privatised copies: fold, leave them zeroed
+                    sum = sum + dw[o + r * it.dw_copy_stride];
+                    dw[o + r * it.dw_copy_stride] = 0.f;
+                }
+                row[b * T + t] = sum;
+            }
         }
-        if (R > 1) dw[o] = sum;
-        dot = fmaf(sum, v[e], dot);
+        __syncthreads();
+        if (it.g)
+            for (int e = threadIdx.x; e < n; e += 256) dot = fmaf(row[e], v[e], dot);
+    } else {
+        int b = 0, t = threadIdx.x;
+        while (t >= T) { t -= T; ++b; }
+        const int db_ = 256 / T, dt_ = 256 - db_ * T;  // e += 256 as (b, t) += (db_, dt_) with carry
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
+            float sum = dw[o];
+            for (int r = 1; r < R; ++r) {
+                sum = sum + dw[o + r * it.dw_copy_stride];
+                dw[o + r * it.dw_copy_stride] = 0.f;
+            }
+            if (R > 1) dw[o] = sum;
+            dot = fmaf(sum, v[e], dot);
+            b += db_;
+            t += dt_;
+            if (t >= T) { t -= T; ++b; }
+        }
     }
     float k1 = 1.f, k2 = 0.f;                          // plain weight: gv = dW
     if (it.g) {
-        dot = block_sum(dot, red);
+        dot = block_sum_fast(dot, red);
         const float inv = it.inv_norm[a], gval = it.g[a];
         if (threadIdx.x == 0) it.gg[a] = accumulate ? it.gg[a] + dot * inv : dot * inv;
         k1 = gval * inv;
         k2 = dot * inv * inv;
     }
     float* gv = it.gv + (size_t)a * n;
-    for (int e = threadIdx.x; e < n; e += 256) {
-        const int b = e / it.T, t = e - b * it.T;
-        const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
-        const float gnew = k1 * (dw[o] - v[e] * k2);
-        gv[e] = accumulate ? gv[e] + gnew : gnew;
-        dw[o] = 0.f;                                  // each accumulator element has exactly this one reader
+    if (staged) {
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const float gnew = k1 * (row[e] - v[e] * k2);
+            gv[e] = accumulate ? gv[e] + gnew : gnew;
+        }
+    } else {
+        int b = 0, t = threadIdx.x;
+        while (t >= T) { t -= T; ++b; }
+        const int db_ = 256 / T, dt_ = 256 - db_ * T;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
+            const float gnew = k1 * (dw[o] - v[e] * k2);
+            gv[e] = accumulate ? gv[e] + gnew : gnew;
+            dw[o] = 0.f;
+            b += db_;
+            t += dt_;
+            if (t >= T) { t -= T; ++b; }
+        }
     }
     if (it.db && threadIdx.x == 0)
         for (int c = a; c < it.nbias; c += it.A) {
@@ -3556,10 +3639,7 @@ int msmc_wn_prepare_multi_tiled(const msmc_wn_item* items, int nitems, int total
     MSMC_LAUNCH(wn_prepare_kernel, dim3(total_blocks), dim3(256), 0, (msmc_stream_t)stream, items, nitems, 1);
     int rc = msmc_check_launch();
     if (rc || total_tile_blocks == 0) return rc;
-    const size_t lds = (size_t)(WN_TA * (WN_TB * MSMC_CONV_MAX_TAPS + 1) + WN_TA) * sizeof(float);
-    rc = msmc_allow_lds((const void*)wn_transpose_kernel, (int)lds);
-    if (rc) return rc;
-    MSMC_LAUNCH(wn_transpose_kernel, dim3(total_tile_blocks), dim3(256), lds, (msmc_stream_t)stream, items, nitems);
+    MSMC_LAUNCH(wn_transpose_kernel, dim3(total_tile_blocks), dim3(256), 0, (msmc_stream_t)stream, items, nitems);
     return msmc_check_launch();
 }
 
