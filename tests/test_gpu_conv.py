@@ -388,3 +388,32 @@ def test_every_candidate_ran_somewhere():
 def csmsc_layers_cached():
     from _convcases import csmsc_layers
     return csmsc_layers()
+
+
+@pytest.mark.parametrize('g1v', [34, 35])
+def test_one_tap_gemm_fp32_forced_on_the_spectral_shapes(g1v):
+    """variants 34 / 35 (128 x 128 / 64 x 128 tiles) on fp32 (gemm1.inc, exact fp32 matrix-core multiplies): forced on the framed-DFT / mel-basis GEMM shapes
+    of the spectral front-ends (STFT loss resolutions, resolution-discriminator spectrograms, mel projection), forward
+    and data gradient, against PyTorch fp32 at 1e-5 of the output scale"""
+    from msmctts_amd.hip import conv, lib
+    from _convcases import conv_case_data
+    cases = [('dft 1200->2052 T40', 16, 1200, 2052, 1, 40, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+             ('dft 960->964 T51', 32, 960, 964, 1, 51, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+             ('dft 480->484 T101', 16, 480, 484, 1, 101, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+             ('dft 200->204 T241', 16, 200, 204, 1, 241, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+             ('mel 1028->128 T40', 16, 1028, 128, 1, 40, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0)]
+    saved = (conv._GATHER_CANDIDATES, dict(conv.TUNED), conv.TUNE_BORROW)
+    conv.TUNE_BORROW = False
+    bad = []
+    try:
+        for case in cases:
+            data = conv_case_data(case, torch.float32, DEV)
+            for part in ('fwd', 'dgrad'):
+                errs, ran = _forced('gather', (g1v, 0), data, (part,), conv)
+                assert ran == 1 and b'conv_gemm1_kernel<float' in lib.get().msmc_conv_last_kernel(), (case[0], part, ran)
+                bad.extend((case[0], p_, e) for p_, e in errs.items() if not e < 1e-5)
+    finally:
+        conv._GATHER_CANDIDATES, conv.TUNE_BORROW = saved[0], saved[2]
+        conv.TUNED.clear()
+        conv.TUNED.update(saved[1])
+    assert not bad, bad

@@ -650,8 +650,9 @@ def test_wgrad_deferred_second_stage_equals_the_immediate_one():
         L.msmc_conv_set_wgrad_split(0)
 
 
-def test_gather_one_tap_gemm_variant():
-    """variant 34 (gemm1.inc: kernel-size-1 layers as a plain channel GEMM, both operands by LDS-DMA in 64-channel chunks,
+@pytest.mark.parametrize('g1v', [34, 35])
+def test_gather_one_tap_gemm_variant(g1v):
+    """variants 34 / 35 (128 x 128 and 64 x 128 tiles; gemm1.inc: kernel-size-1 layers as a plain channel GEMM, both operands by LDS-DMA in 64-channel chunks,
     swapped operand roles with the epilogue in registers): forward and data gradient (mask operand) of the FFT-block
     projection / quantiser 1x1 shapes against PyTorch -- ragged pixel and channel tiles, a channel count that is not a
     multiple of the chunk, more pixel tiles than one XCD group, 2-D images -- every epilogue operand against the second
@@ -664,7 +665,7 @@ def test_gather_one_tap_gemm_variant():
              ('g1 many tiles 64->72', 1, 64, 72, 1, 1200, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
              ('g1 image 96->32', 2, 96, 32, 9, 7, (1, 1), (1, 1), (1, 1), (0, 0), False, 0.2)]
     real = conv._build_desc
-    state = {'variant': 34}
+    state = {'variant': g1v}
 
     def forced(*a, **k):
         d = real(*a, **k)
@@ -685,13 +686,15 @@ def test_gather_one_tap_gemm_variant():
         w = (torch.randn(1, Co, Ci) / Ci ** 0.5).bfloat16()
         bias, res, res2 = torch.randn(Co), torch.randn(B, 1, Lx, Co).bfloat16(), torch.randn(B, 1, Lx, Co).bfloat16()
         outs = []
-        for v in (34, 2):
+        for v in (g1v, 2):
             state['variant'] = v
             conv._PLANS.clear()
+            geom = conv.Geometry(1, Lx, (1, 1), (1, 1), (1, 1), (0, 0), False)      # (a geometry keeps its descriptors)
             outs.append(conv.conv_forward(x, w, geom, bias=bias, in_slope=0.1, res=res, res2=res2, out_div=3.0, out_slope=0.2))
         assert _convcases.rel(outs[0], outs[1]) < 1e-2
         # grouped call with 1-tap members: each on a grid of its own, results of single launches
-        state['variant'] = 34
+        state['variant'] = g1v
+        geom = conv.Geometry(1, Lx, (1, 1), (1, 1), (1, 1), (0, 0), False)
         items = [dict(x=x, w=(torch.randn(1, Co, Ci) / Ci ** 0.5).bfloat16(), geom=geom, bias=bias, res=res) for _ in range(3)]
         conv._PLANS.clear()
         singles = [conv.conv_forward(**it) for it in items]
@@ -775,6 +778,48 @@ def test_gather_fifth_generation_variants(variant):
         with pytest.raises(RuntimeError, match='msmc_conv_gather'):
             _convcases.check_conv_case(('g5 k1', 1, 64, 128, 1, 40, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
                                        torch.bfloat16, 2e-2, 'cpu', parts=('fwd',))
+    finally:
+        conv._build_desc = real
+        conv._PLANS.clear()
+
+
+@pytest.mark.parametrize('g1v', [34, 35])
+def test_gather_one_tap_gemm_variant_fp32(g1v):
+    """variants 34 / 35 on fp32 operands (exact fp32 multiplies on v_mfma_f32_32x32x2_f32, fp32 output): the framed-DFT and
+    mel-basis GEMM shapes of the spectral front-ends -- channel counts that are multiples of four only, ragged pixel and
+    channel tiles, more than one round of four chunks -- forward and data gradient against PyTorch, every epilogue operand
+    against the second generation"""
+    from msmctts_amd.hip import conv, lib
+    cases = [('g1f dft 204->200', 2, 204, 200, 1, 70, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+             ('g1f dft 480->484 ragged', 1, 480, 484, 1, 45, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+             ('g1f mel 516->80', 2, 516, 80, 1, 140, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+             ('g1f lrelu 64->72', 1, 64, 72, 1, 300, (1, 1), (1, 1), (1, 1), (0, 0), False, 0.1)]
+    real = conv._build_desc
+    state = {'variant': g1v}
+
+    def forced(*a, **k):
+        d = real(*a, **k)
+        d.variant = state['variant']
+        return d
+    conv._build_desc = forced
+    try:
+        for case in cases:
+            for part in ('fwd', 'dgrad'):
+                conv._PLANS.clear()
+                _convcases.check_conv_case(case, torch.float32, 1e-5, 'cpu', parts=(part,))
+                assert b'conv_gemm1_kernel<float' in lib.get().msmc_conv_last_kernel(), (case[0], part)
+        torch.manual_seed(0)
+        B, Ci, Co, Lx = 2, 132, 96, 150
+        x = torch.randn(B, 1, Lx, Ci)
+        w = torch.randn(1, Co, Ci) / Ci ** 0.5
+        bias, res, res2 = torch.randn(Co), torch.randn(B, 1, Lx, Co), torch.randn(B, 1, Lx, Co)
+        outs = []
+        for v in (g1v, 2):
+            state['variant'] = v
+            conv._PLANS.clear()
+            geom = conv.Geometry(1, Lx, (1, 1), (1, 1), (1, 1), (0, 0), False)
+            outs.append(conv.conv_forward(x, w, geom, bias=bias, in_slope=0.1, res=res, res2=res2, out_div=3.0, out_slope=0.2))
+        assert _convcases.rel(outs[0], outs[1]) < 1e-5
     finally:
         conv._build_desc = real
         conv._PLANS.clear()

@@ -56,9 +56,9 @@ if RETUNE == 'gather4':                                   # the persistent thin-
             if k[0] == 'gather' and k[1] == 1 and k[5] in (32, 64) and k[8] in (32, 64)}
     print('timing the persistent thin-layer kernel on %d forward / data-gradient shapes' % len(kept))
 if RETUNE == 'gemm1':                                     # 1-tap layers as a plain channel GEMM (variant 34)
-    conv._GATHER_CANDIDATES = ((34, 0),)
+    conv._GATHER_CANDIDATES = ((34, 0), (35, 0))
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
-            if k[0] == 'gather' and k[1] == 1 and k[15] == 1 and tuple(k[16]) == (0,) and tuple(k[17]) == (0,)}
+            if k[0] == 'gather' and k[1] in (0, 1) and k[15] == 1 and tuple(k[16]) == (0,) and tuple(k[17]) == (0,)}
     print('timing the 1-tap GEMM kernel on %d forward / data-gradient shapes' % len(kept))
 if RETUNE == 'gather5':                                   # sixteen-wave staged-tap kernel (variants 40..44): every bf16
     conv._GATHER_CANDIDATES = tuple((v, 0) for v in range(40, 45))      # shape with 64-multiple input channels and >= 2 taps
