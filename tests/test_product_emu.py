@@ -655,7 +655,7 @@ def test_gather_one_tap_gemm_variant(g1v):
     """variants 34 / 35 (128 x 128 and 64 x 128 tiles; gemm1.inc: kernel-size-1 layers as a plain channel GEMM, both operands by LDS-DMA in 64-channel chunks,
     swapped operand roles with the epilogue in registers): forward and data gradient (mask operand) of the FFT-block
     projection / quantiser 1x1 shapes against PyTorch -- ragged pixel and channel tiles, a channel count that is not a
-    multiple of the chunk, more pixel tiles than one XCD group, 2-D images -- every epilogue operand against the second
+    multiple of the chunk, more pixel tiles than one XCD group, 2-D images, a contraction deeper than the four stages (ring) -- every epilogue operand against the second
     generation, layers outside its scope refused"""
     from msmctts_amd.hip import conv, lib
     cases = [('g1 qkv 256->384', 3, 256, 384, 1, 100, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
@@ -663,7 +663,8 @@ def test_gather_one_tap_gemm_variant(g1v):
              ('g1 in_linear 80->256', 2, 80, 256, 1, 70, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
              ('g1 mel 256->80 lrelu', 1, 256, 80, 1, 140, (1, 1), (1, 1), (1, 1), (0, 0), False, 0.1),
              ('g1 many tiles 64->72', 1, 64, 72, 1, 1200, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
-             ('g1 image 96->32', 2, 96, 32, 9, 7, (1, 1), (1, 1), (1, 1), (0, 0), False, 0.2)]
+             ('g1 image 96->32', 2, 96, 32, 9, 7, (1, 1), (1, 1), (1, 1), (0, 0), False, 0.2),
+             ('g1 ring of stages 456->136', 1, 456, 136, 1, 90, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0)]
     real = conv._build_desc
     state = {'variant': g1v}
 
@@ -793,7 +794,8 @@ def test_gather_one_tap_gemm_variant_fp32(g1v):
     cases = [('g1f dft 204->200', 2, 204, 200, 1, 70, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
              ('g1f dft 480->484 ragged', 1, 480, 484, 1, 45, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
              ('g1f mel 516->80', 2, 516, 80, 1, 140, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
-             ('g1f lrelu 64->72', 1, 64, 72, 1, 300, (1, 1), (1, 1), (1, 1), (0, 0), False, 0.1)]
+             ('g1f lrelu 64->72', 1, 64, 72, 1, 300, (1, 1), (1, 1), (1, 1), (0, 0), False, 0.1),
+             ('g1f wide basis 512->1100 (channel tiles share an XCD)', 1, 512, 1100, 1, 130, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0)]
     real = conv._build_desc
     state = {'variant': g1v}
 
