@@ -163,6 +163,22 @@ MSMC_DEV float wave_xor32(float v) { return __uint_as_float(wave_xor32_u(__float
 MSMC_DEV int wave_xor16(int v) { return (int)wave_xor16_u((unsigned int)v); }
 MSMC_DEV int wave_xor32(int v) { return (int)wave_xor32_u((unsigned int)v); }
 
+// sum over the 64 lanes, every lane ends with the total: four DPP steps inside each row of 16 (quad permutes, half-row and
+// row mirrors -- one VALU instruction each, the permute rides on the add), then the row and half swaps
+template <int CTRL>
+MSMC_DEV float wave_dpp_t(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+MSMC_DEV float wave_sum(float v) {
+    v = v + wave_dpp_t<0xB1>(v);                       // quad_perm [1,0,3,2]
+    v = v + wave_dpp_t<0x4E>(v);                       // quad_perm [2,3,0,1]
+    v = v + wave_dpp_t<0x141>(v);                      // row_half_mirror
+    v = v + wave_dpp_t<0x140>(v);                      // row_mirror
+    v = v + wave_xor16(v);
+    v = v + wave_xor32(v);
+    return v;
+}
+
 // Intra-wave LDS hand-off point: lanes of ONE wave exchange data through LDS (a wave executes its
 // LDS instructions in order, so no hardware barrier is needed); this only stops the compiler from
 // moving LDS accesses across the hand-off.

@@ -85,6 +85,10 @@ static inline T emu_exchange(T v, int src_lane) {
 static inline int wave_uniform(int v) { return v; }
 MSMC_DEV float wave_xor(float v, int mask) { return emu_exchange(v, emu::lane() ^ mask); }
 MSMC_DEV int wave_xor(int v, int mask) { return emu_exchange(v, emu::lane() ^ mask); }
+MSMC_DEV float wave_sum(float v) {
+    for (int m = 1; m < 64; m <<= 1) v = v + emu_exchange(v, emu::lane() ^ m);
+    return v;
+}
 MSMC_DEV int wave_read_lane(int v, int src_lane) { return emu_exchange(v, src_lane); }
 MSMC_DEV unsigned int wave_read_lane(unsigned int v, int src_lane) { return emu_exchange(v, src_lane); }
 MSMC_DEV void wave_swap32(unsigned int& a, unsigned int& b) {

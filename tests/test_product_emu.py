@@ -825,3 +825,54 @@ def test_gather_one_tap_gemm_variant_fp32(g1v):
     finally:
         conv._build_desc = real
         conv._PLANS.clear()
+
+
+def test_wgrad_direct_thin_layer_kernel():
+    """variant 8 of the bf16 weight gradient (wgrad6.inc: one lattice point per work-item, a block of taps x output x input
+    channels of dW in registers, DPP wave sums, one atomic per element and workgroup into the privatised copy): the thin
+    discriminator layers -- 2->4 and 4->8 3x3 (stride 1 and 2, reflection), 1->16 5x1 stride 3, 8->16, a 1-channel output
+    layer with 128 inputs, odd channel counts (blocks with dead lanes), several pixel splits -- weight and bias gradient
+    against PyTorch; privatised copies summed; layers with too many blocks refused"""
+    from msmctts_amd.hip import conv, lib
+    cases = [('w6 mrd 2->4', 2, 2, 4, 21, 40, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
+             ('w6 mrd 4->8 s2', 2, 4, 8, 21, 40, (3, 3), (2, 2), (1, 1), (1, 1), True, 0.2),
+             ('w6 mrd 8->16', 1, 8, 16, 9, 50, (3, 3), (1, 1), (1, 1), (1, 1), True, 0.2),
+             ('w6 mpd 1->16 s3', 2, 1, 16, 300, 3, (5, 1), (3, 1), (1, 1), (2, 0), False, 1.0),
+             ('w6 post 128->1', 2, 128, 1, 12, 5, (3, 1), (1, 1), (1, 1), (1, 0), False, 0.2),
+             ('w6 odd 3->5 k3', 1, 3, 5, 1, 700, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
+             ('w6 many points 2->4', 1, 2, 4, 1, 5000, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0)]
+    real = conv._build_desc
+    state = {'variant': 8}
+
+    def forced(*a, **k):
+        d = real(*a, **k)
+        if d.dtype == 1:
+            d.variant = state['variant']
+        return d
+    conv._build_desc = forced
+    try:
+        for case in cases:
+            conv._PLANS.clear()
+            _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=('wgrad',))
+            assert b'conv_wgrad6_kernel' in lib.get().msmc_conv_last_kernel(), case[0]
+        # privatised copies: the sum over the copies is the gradient
+        torch.manual_seed(0)
+        B, H, W, Ci, Co = 2, 11, 300, 2, 4
+        geom = conv.Geometry(H, W, (3, 3), (1, 1), (1, 1), (1, 1), False)
+        x, g = torch.randn(B, H, W, Ci).bfloat16(), torch.randn(B, H, W, Co).bfloat16()
+        dw1, db1 = torch.zeros(9, Co, Ci), torch.zeros(Co)
+        conv._PLANS.clear()
+        conv.conv_wgrad(x, g, geom, 9, in_slope=1.0, dw=dw1, db=db1)
+        dw8, db8 = torch.zeros(8, 9, Co, Ci), torch.zeros(8, Co)
+        conv._PLANS.clear()
+        conv.conv_wgrad(x, g, conv.Geometry(H, W, (3, 3), (1, 1), (1, 1), (1, 1), False), 9, in_slope=1.0, dw=dw8.view(-1),
+                        db=db8.view(-1), copies=8)
+        assert _convcases.rel(dw8.sum(0), dw1) < 1e-5 and _convcases.rel(db8.sum(0), db1) < 1e-5
+        # too many blocks of dW: MSMC_E_SHAPE surfaces as an error
+        conv._PLANS.clear()
+        with pytest.raises(RuntimeError, match='wgrad'):
+            _convcases.check_conv_case(('w6 big 128->128', 1, 128, 128, 1, 40, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
+                                       torch.bfloat16, 2e-2, 'cpu', parts=('wgrad',))
+    finally:
+        conv._build_desc = real
+        conv._PLANS.clear()

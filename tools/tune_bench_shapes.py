@@ -4,7 +4,7 @@ GPU test-suite's layer cases) and write the choices to msmctts_amd/hip/tuned_gfx
 RETUNE=wgrad4 keeps the committed table and re-times only the single-launch bf16 weight gradients the fourth-generation
 kernel can serve (one pass).  RETUNE=gather3x keeps it too and times only the LDS-DMA halo variants (24..31) of every bf16
 forward / data-gradient shape, merging them with the committed timings of the other candidates; RETUNE=gather4 does the
-same for the persistent thin-layer kernel (variant 32), RETUNE=gemm1 for the 1-tap GEMM kernel (variant 34), RETUNE=gather5 for the sixteen-wave staged-tap kernel (variants 40..44) and RETUNE=wgrad5 for the general-lattice LDS-DMA weight gradient
+same for the persistent thin-layer kernel (variant 32), RETUNE=gemm1 for the 1-tap GEMM kernel (variant 34), RETUNE=gather5 for the sixteen-wave staged-tap kernel (variants 40..44), RETUNE=wgrad6 for the direct thin-layer weight gradient (variant 8) and RETUNE=wgrad5 for the general-lattice LDS-DMA weight gradient
 (variant 7; the grouped calls whose members change are re-timed by the run itself)."""
 import os, sys, random, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -65,6 +65,11 @@ if RETUNE == 'gather5':                                   # sixteen-wave staged-
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
             if k[0] == 'gather' and k[1] == 1 and k[5] % 64 == 0 and k[15] >= 2}
     print('timing the fifth-generation forward / data-gradient kernel on %d shapes' % len(kept))
+if RETUNE == 'wgrad6':                                    # direct thin-layer weight gradient (variant 8): every bf16 shape with a
+    conv._WGRAD_CANDIDATES = ((8, 0),)                    # channel count of at most 16 on one side
+    kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
+            if k[0] == 'wgrad' and k[1] == 1 and min(k[5], k[8]) <= 16}
+    print('timing the direct thin-layer weight gradient on %d shapes' % len(kept))
 if RETUNE == 'wgrad5':                                    # general-lattice LDS-DMA weight gradient (variant 7): time it on
     conv._WGRAD_CANDIDATES = ((7, 0), (7, -1))            # every bf16 shape with 64-multiple channels, merge with the table
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
