@@ -85,6 +85,7 @@ static inline T emu_exchange(T v, int src_lane) {
 static inline int wave_uniform(int v) { return v; }
 MSMC_DEV float wave_xor(float v, int mask) { return emu_exchange(v, emu::lane() ^ mask); }
 MSMC_DEV int wave_xor(int v, int mask) { return emu_exchange(v, emu::lane() ^ mask); }
+static inline unsigned int __umulhi(unsigned int a, unsigned int b) { return (unsigned int)(((unsigned long long)a * b) >> 32); }
 MSMC_DEV float wave_sum(float v) {
     for (int m = 1; m < 64; m <<= 1) v = v + emu_exchange(v, emu::lane() ^ m);
     return v;
