@@ -10,7 +10,7 @@ cd /tmp
 TAG=${1:-r01}
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $REPO/bench.py < /dev/null > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.log
 cp $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_kernel_stats.csv
-SHORT="--steps 2 --warmup 2 --no-microbench --cpu-steps 0 --kernel-timing-steps 0"
+SHORT="--steps 2 --warmup 2 --no-microbench --cpu-steps 0 --kernel-timing-steps 0 --fp32-steps 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- python $REPO/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- python $REPO/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_write.log
 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d /tmp/prof_mfma -- python $REPO/bench.py $SHORT > /dev/null 2> $OUT/${TAG}_pmc_mfma.log
