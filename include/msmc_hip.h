@@ -157,8 +157,14 @@ typedef struct msmc_conv_desc {
                                registers; MSMC_E_SHAPE outside that scope), 33 = 32 with the epilogue of a tile deferred into the next
                                iteration (measured no faster: not a tuner candidate), 34 = 1-tap unit-stride layers as a plain channel GEMM
                                (csrc/gemm1.inc: 128 x 128 tiles, both operands by LDS-DMA in 64-channel chunks, epilogue in
-                               registers; MSMC_E_SHAPE for anything but a bf16 kernel-size-1 layer on the identity lattice with
-                               Cin % 8 == 0, Cout % 4 == 0), 9 = 32-point tiles with the channel
+                               registers; bf16 with Cin % 8 == 0, or exact fp32 -- v_mfma_f32_32x32x2_f32, fp32 output -- with Cin % 4 == 0;
+                               Cout % 4 == 0; MSMC_E_SHAPE for anything but a kernel-size-1 layer on the identity lattice), 35 = 34 with
+                               64 x 128 tiles on eight waves (GEMMs with few pixel rows), 40..46 = fifth generation (csrc/gather5.inc, bf16,
+                               >= 2 taps, Cin % 64 == 0, Cout % 8 == 0: sixteen waves, stages of (64-channel chunk, tap) with the weight
+                               slices in an LDS-DMA ring and the halo tile of a chunk shared by its taps, epilogue in registers with 16-byte
+                               stores; tiles 40: 128 x 128, 41: 256 x 128, 42 / 43: 128 x 256, 44: 64 x 256, 45: 64 x 128 with the
+                               contraction split over two groups of eight waves (Cin % 128 == 0), 46: 256 x 64; MSMC_E_SHAPE where a
+                               configuration does not apply), 9 = 32-point tiles with the channel
                                chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation (fp32 atomics), 3 = third (split partials + fixed-order reduce), 4 / 5 / 6 = fourth (the
                                third's result contract; pixel tiles flow through an LDS-DMA ring: 4 = three stages, fragment reads two
@@ -166,11 +172,12 @@ typedef struct msmc_conv_desc {
                                MSMC_E_SHAPE outside its scope: unit strides, zero padding, channel counts multiples of 64,
                                taps along one axis), 7 = the third generation's lattice tiles with both operands staged by LDS-DMA into
                                a two-stage ring (csrc/wgrad5.inc: strided, 2-D and reflection-padded layers with channel counts that
-                               are multiples of 64; interpreter-tested, first GPU timings 1.15-1.57 x ahead of generations 2 / 3 on the strided period- /
-                               resolution-discriminator layers, not a tuner candidate yet).  The host
+                               are multiples of 64; a tuner candidate since round 3), 8 = direct kernel for thin layers (csrc/wgrad6.inc:
+                               one lattice point per work-item, a block of <= 128 elements of dW in registers, atomics into the
+                               privatised copies as generations 1 / 2; MSMC_E_SHAPE when dW needs more than 96 such blocks).  The host
                                layer times the candidates once per layer shape.       */
     int split_shift;        /* msmc_conv_wgrad: pixel split = model << split_shift (>> when negative).  msmc_conv_gather
-                               variants 16..23 only: DIAGNOSTICS mask, 0 in production (1 skip the MFMAs, 2 the weight stream,
+                               variants 16..31 and 40..46 only: DIAGNOSTICS mask, 0 in production (1 skip the MFMAs, 2 the weight stream,
                                4 the halo loads, 8 the epilogue: tools/bench_gather3.py ABLATE=...; results are then garbage) */
     int dw_copies;          /* msmc_conv_wgrad: R > 1 = dw is [R][ntaps][Cout][Cin] and db [R][Cout]; workgroup i adds
                                into copy i % R (same-address atomics retire serially; R copies shorten the chain R
