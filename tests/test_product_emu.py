@@ -710,7 +710,7 @@ def test_gather_one_tap_gemm_variant(g1v):
         conv._PLANS.clear()
 
 
-@pytest.mark.parametrize('variant', [40, 41, 42, 43, 44, 45, 46])
+@pytest.mark.parametrize('variant', [40, 41, 42, 43, 44, 45, 46, 47])
 def test_gather_fifth_generation_variants(variant):
     """variants 40..44 (gather5.inc: sixteen waves, stages of (64-channel chunk, tap) with the weight slices in an LDS-DMA
     ring and the halo tile of a chunk shared by its taps, swapped operand roles, epilogue in registers with 16-byte stores):
@@ -726,6 +726,7 @@ def test_gather_fifth_generation_variants(variant):
              ('g5 k3 many tiles 64->128', 1, 64, 128, 1, 1300, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
              ('g5 ffn 256->512 relu', 2, 256, 512, 1, 100, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.0),
              ('g5 k7 d3 64->64 thin', 1, 64, 64, 1, 700, (1, 7), (1, 1), (1, 3), (0, 9), False, 0.1),
+             ('g5 mrd 64->128 s2 wide halo', 2, 64, 128, 21, 40, (3, 3), (2, 2), (1, 1), (1, 1), True, 0.2),
              ('g5 k5x1 512->128 two contraction groups', 1, 512, 128, 30, 5, (5, 1), (1, 1), (1, 1), (2, 0), False, 0.2)]
     real = conv._build_desc
     state = {'variant': variant}
@@ -747,7 +748,9 @@ def test_gather_fifth_generation_variants(variant):
                     ran += 1
                 except RuntimeError as e:             # MSMC_E_SHAPE: this configuration does not apply to the layer
                     assert 'msmc_conv_gather' in str(e), e
-        assert ran >= 3, (variant, ran)
+        assert ran >= (1 if variant == 47 else 3), (variant, ran)
+        if variant == 47:                  # (one-chunk wide-halo form: Cin = 64 only -- the cases above are its scope)
+            return
         torch.manual_seed(0)
         B, Ci, Co, Lx = 2, 128, 264, 150
         geom = conv.Geometry(1, Lx, (1, 3), (1, 1), (1, 2), (0, 2), False)

@@ -61,7 +61,7 @@ if RETUNE == 'gemm1':                                     # 1-tap layers as a pl
             if k[0] == 'gather' and k[1] in (0, 1) and k[15] == 1 and tuple(k[16]) == (0,) and tuple(k[17]) == (0,)}
     print('timing the 1-tap GEMM kernel on %d forward / data-gradient shapes' % len(kept))
 if RETUNE == 'gather5':                                   # sixteen-wave staged-tap kernel (variants 40..44): every bf16
-    conv._GATHER_CANDIDATES = tuple((v, 0) for v in range(40, 47))      # shape with 64-multiple input channels and >= 2 taps
+    conv._GATHER_CANDIDATES = tuple((v, 0) for v in range(40, 48))      # shape with 64-multiple input channels and >= 2 taps
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
             if k[0] == 'gather' and k[1] == 1 and k[5] % 64 == 0 and k[15] >= 2}
     print('timing the fifth-generation forward / data-gradient kernel on %d shapes' % len(kept))
