@@ -70,6 +70,11 @@ if RETUNE == 'wgrad6':                                    # direct thin-layer we
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
             if k[0] == 'wgrad' and k[1] == 1 and min(k[5], k[8]) <= 16}
     print('timing the direct thin-layer weight gradient on %d shapes' % len(kept))
+if RETUNE == 'groups':                                    # grouped-versus-single decisions only (every single shape stays cached)
+    dropped = [k for k in conv.TUNED if k[0].endswith('-group')]
+    for k in dropped:
+        del conv.TUNED[k]
+    print('re-timing %d grouped calls' % len(dropped))
 if RETUNE == 'wgrad5':                                    # general-lattice LDS-DMA weight gradient (variant 7): time it on
     conv._WGRAD_CANDIDATES = ((7, 0), (7, -1))            # every bf16 shape with 64-multiple channels, merge with the table
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
