@@ -20,16 +20,18 @@ SLOW_COUNT = None           # tests / bench: an int64 [2] device tensor counting
                             # two-candidate exact re-rank [0] / the full exact re-search [1]
 
 
-def vq_prepare(embed):
+def vq_prepare(embed, frames=None):
     """embed [H, d, K] -> (embed_t [H, K, d], enorm [H, K]); where the shortlist kernel takes the shape its codebook
-    image rides along as ``embed_t.shortlist_image``."""
+    image rides along as ``embed_t.shortlist_image``.  ``frames``: the number of frames the caller is about to search
+    (the modules pass it): below the cross-over the image would never be read and is not built (a launch per call)."""
     H, d, K = embed.shape
     embed_t = torch.empty((H, K, d), dtype=torch.float32, device=embed.device)
     enorm = torch.empty((H, K), dtype=torch.float32, device=embed.device)
     L = lib.get()
     lib.check(L.msmc_vq_prepare(lib.ptr(embed, torch.float32), lib.ptr(embed_t), lib.ptr(enorm), H, d, K,
                                 lib.stream(embed)), 'msmc_vq_prepare')
-    nbytes = int(L.msmc_vq_shortlist_bytes(H, d, K)) if SHORTLIST else 0
+    wanted = SHORTLIST and (frames is None or frames * K >= SHORTLIST_MIN_WORK)
+    nbytes = int(L.msmc_vq_shortlist_bytes(H, d, K)) if wanted else 0
     if nbytes:
         image = torch.empty(nbytes, dtype=torch.uint8, device=embed.device)
         lib.check(L.msmc_vq_prepare_shortlist(lib.ptr(embed_t), lib.ptr(enorm), lib.ptr(image), H, d, K,

@@ -60,7 +60,7 @@ class Quantize(nn.Module):
 
     def forward(self, input, input_length=None, update=True, sort=False):
         embed, cs, ea = self._packed()
-        embed_t, enorm = hipvq.vq_prepare(embed)
+        embed_t, enorm = hipvq.vq_prepare(embed, frames=input.numel() // max(1, input.shape[-1]))
         quant, diff, ind = hipvq.vq_search(input, embed_t, enorm)
         rank = _ranking(input, embed).squeeze(-2) if sort else None         # [..., K]
         if self.training and update and input.numel() > 0:          # (an empty batch has no statistics to add)
@@ -114,7 +114,7 @@ class MultiHeadQuantize(nn.Module):
 
     def forward(self, input, input_length=None, update=True, sort=False):
         embed, cs, ea = self._packed()
-        embed_t, enorm = hipvq.vq_prepare(embed)
+        embed_t, enorm = hipvq.vq_prepare(embed, frames=input.numel() // max(1, input.shape[-1]))
         quant, diff, ind = hipvq.vq_search(input, embed_t, enorm)
         rank = _ranking(input, embed).transpose(-1, -2) if sort else None   # [..., K, H], as the reference's stack
         if self.training and update and input.numel() > 0:          # (an empty batch has no statistics to add)
