@@ -1308,7 +1308,7 @@ extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
 // Four times the workgroups, a quarter of the chain.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NT, int CKM>
-__global__ __launch_bounds__(256) void conv_gather_ks_kernel(msmc_conv_desc d, CvGeom G, int region_bytes) {
+MSMC_DEV void cvks_body(const msmc_conv_desc& d, const CvGeom& G, const int region_bytes, const int block_x, const int block_y) {
     MSMC_DYN_LDS(smem);
     constexpr int VEC = Elt<T>::VEC, CK = Elt<T>::CK * CKM, CKV = CK / VEC, XS = CK + VEC, BN = 32 * NT, OS = BN + 4;
     constexpr int BNV = BN / VEC, SB = 8;
@@ -1320,12 +1320,12 @@ __global__ __launch_bounds__(256) void conv_gather_ks_kernel(msmc_conv_desc d, C
     const int tid = threadIdx.x, w = wave_uniform(tid >> 6), lane = tid & 63, i = lane & 31, g = lane >> 5;
     T* xt = (T*)(regions + (size_t)w * region_bytes);           // this wave's [npix][XS]
     T* wt = xt + (size_t)npix * XS;                             //             [ntaps][BN][XS]
-    int bt = blockIdx.x;
+    int bt = block_x;
     const int tx_ = bt % G.tilesX;
     bt /= G.tilesX;
     const int ty_ = bt % G.tilesY;
     const int b = bt / G.tilesY;
-    const int co0 = blockIdx.y * BN;
+    const int co0 = block_y * BN;
     const int qy0 = ty_ * G.TH, qx0 = tx_ * G.TW;
     const int iyBase = qy0 * d.isy + d.iy0 + G.dyMin, ixBase = qx0 * d.isx + d.ix0 + G.dxMin;
     for (int pi = tid; pi < npix; pi += 256) {
@@ -1467,16 +1467,39 @@ __global__ __launch_bounds__(256) void conv_gather_ks_kernel(msmc_conv_desc d, C
 }
 
 // returns 1 when launched, 0 when the kernel does not apply
+template <typename T, int NT, int CKM>
+__global__ __launch_bounds__(256) void conv_gather_ks_kernel(msmc_conv_desc d, CvGeom G, int region_bytes) {
+    cvks_body<T, NT, CKM>(d, G, region_bytes, blockIdx.x, blockIdx.y);
+}
+// the wave-split members of a grouped call on one grid (the phases of a transposed convolution, of a strided layer's data
+// gradient: five to thirteen launches of tens of workgroups each otherwise)
+struct CvKsGroupArgs {
+    CvGroupArgs a;
+    int reg[MSMC_GROUP_MAX];
+};
+template <typename T, int NT, int CKM>
+__global__ __launch_bounds__(256) void conv_gather_ks_group_kernel(CvKsGroupArgs ga) {
+    const int k = cv_group_member(ga.a.first, ga.a.n);
+    const int id = blockIdx.x - ga.a.first[k];
+    cvks_body<T, NT, CKM>(ga.a.d[k], ga.a.G[k], ga.reg[k], id % ga.a.nx[k], id / ga.a.nx[k]);
+}
+
+struct CvKsPlan {
+    int applies, nt, ckm;
+    CvGeom G;
+    size_t reg, lds;
+    unsigned gx, gy;
+};
 template <typename T>
-static int cv_ks_launch(const msmc_conv_desc* d, msmc_stream stream) {
+static int cv_ks_plan(const msmc_conv_desc* d, CvKsPlan* pl) {
     constexpr int VEC = Elt<T>::VEC;
+    pl->applies = 0;
     if ((d->Cin % VEC) != 0 || (d->Cout % VEC) != 0 || d->Cin < 8 * Elt<T>::CK) return 0;
     if ((long)d->Hin * d->Win * d->Cin >= (1L << 31) || (long)d->Hout * d->Wout >= (1L << 31)) return 0;
-    CvGeom G;
     size_t unused;
-    int rc = cv_geometry(d, &G, sizeof(T), 0, 0, &unused, 32);
+    int rc = cv_geometry(d, &pl->G, sizeof(T), 0, 0, &unused, 32);
     if (rc) return rc;
-    const long npix = (long)G.IH * G.IW;
+    const long npix = (long)pl->G.IH * pl->G.IW;
     const int nt = d->Cout > 32 ? 2 : 1;
     const size_t tables = (((size_t)(npix + 32 + 16) * sizeof(int)) + 15) & ~(size_t)15;
     auto region = [&](int ckm) {
@@ -1486,25 +1509,96 @@ static int cv_ks_launch(const msmc_conv_desc* d, msmc_stream stream) {
         if (r < part) r = part;
         return (r + 15) & ~(size_t)15;
     };
-    int ckm = (tables + 4 * region(2) <= 150 * 1024) ? 2 : 1;
-    const size_t reg = region(ckm), lds = tables + 4 * reg;
-    if (lds > 160 * 1024) return 0;
-    dim3 grid((unsigned)(G.tilesX * G.tilesY * d->B), (unsigned)((d->Cout + 32 * nt - 1) / (32 * nt)));
+    const int ckm = (tables + 4 * region(2) <= 150 * 1024) ? 2 : 1;
+    pl->reg = region(ckm);
+    pl->lds = tables + 4 * pl->reg;
+    if (pl->lds > 160 * 1024) return 0;
+    pl->nt = nt;
+    pl->ckm = ckm;
+    pl->gx = (unsigned)(pl->G.tilesX * pl->G.tilesY * d->B);
+    pl->gy = (unsigned)((d->Cout + 32 * nt - 1) / (32 * nt));
+    pl->applies = 1;
+    return 0;
+}
+// SINGLE (d, G) or GROUP launch of one wave-split configuration
+template <typename T>
+static int cv_ks_dispatch(const CvKsPlan& pl, dim3 grid, size_t lds, msmc_stream stream, const msmc_conv_desc* d,
+                          const CvKsGroupArgs* group) {
+    int rc;
 #define KS_GO(NT_, CKM_)                                                                                            \
     do {                                                                                                            \
-        rc = msmc_allow_lds((const void*)conv_gather_ks_kernel<T, NT_, CKM_>, (int)lds);                            \
-        if (rc) return rc;                                                                                          \
-        MSMC_LAUNCH((conv_gather_ks_kernel<T, NT_, CKM_>), grid, dim3(256), lds, (msmc_stream_t)stream, *d, G,      \
-                    (int)reg);                                                                                      \
+        if (group) {                                                                                                \
+            rc = msmc_allow_lds((const void*)conv_gather_ks_group_kernel<T, NT_, CKM_>, (int)lds);                  \
+            if (rc) return rc;                                                                                      \
+            MSMC_LAUNCH((conv_gather_ks_group_kernel<T, NT_, CKM_>), grid, dim3(256), lds, (msmc_stream_t)stream,   \
+                        *group);                                                                                    \
+        } else {                                                                                                    \
+            rc = msmc_allow_lds((const void*)conv_gather_ks_kernel<T, NT_, CKM_>, (int)lds);                        \
+            if (rc) return rc;                                                                                      \
+            MSMC_LAUNCH((conv_gather_ks_kernel<T, NT_, CKM_>), grid, dim3(256), lds, (msmc_stream_t)stream, *d,     \
+                        pl.G, (int)pl.reg);                                                                         \
+        }                                                                                                           \
     } while (0)
-    if (nt == 2 && ckm == 2) KS_GO(2, 2);
-    else if (nt == 2) KS_GO(2, 1);
-    else if (ckm == 2) KS_GO(1, 2);
+    if (pl.nt == 2 && pl.ckm == 2) KS_GO(2, 2);
+    else if (pl.nt == 2) KS_GO(2, 1);
+    else if (pl.ckm == 2) KS_GO(1, 2);
     else KS_GO(1, 1);
 #undef KS_GO
-    msmc_conv_last = msmc_prof_name(msmc_kname("conv_gather_ks_kernel", EltName<T>::v, nt, ckm));
-    rc = msmc_check_launch();
+    msmc_conv_last = msmc_prof_name(msmc_kname(group ? "conv_gather_ks_group_kernel" : "conv_gather_ks_kernel", EltName<T>::v,
+                                               pl.nt, pl.ckm));
+    return msmc_check_launch();
+}
+template <typename T>
+static int cv_ks_launch(const msmc_conv_desc* d, msmc_stream stream) {
+    CvKsPlan pl;
+    int rc = cv_ks_plan<T>(d, &pl);
+    if (rc) return rc;
+    if (!pl.applies) return 0;
+    rc = cv_ks_dispatch<T>(pl, dim3(pl.gx, pl.gy), pl.lds, stream, d, nullptr);
     return rc ? rc : 1;
+}
+// variant-9 members of a grouped call: one grid per (column tiles, chunk width) configuration.  done[i] = launched here.
+template <typename T>
+static int cv_ks_group_launch(const msmc_conv_desc* descs, int n, msmc_stream stream, bool* done) {
+    CvKsPlan pk[MSMC_GROUP_LIMIT];
+    bool todo[MSMC_GROUP_LIMIT];
+    int count = 0;
+    for (int i = 0; i < n; ++i) {
+        done[i] = todo[i] = false;
+        if (descs[i].variant != 9) continue;
+        int rc = cv_ks_plan<T>(&descs[i], &pk[i]);
+        if (rc) return rc;
+        if (!pk[i].applies) return MSMC_E_SHAPE;
+        todo[i] = true;
+        ++count;
+    }
+    if (count < 2) return 0;                                    // (a lone member: the single launch below)
+    for (int i = 0; i < n; ++i) {
+        if (!todo[i]) continue;
+        CvKsGroupArgs ga;
+        ga.a.n = 0;
+        int blocks = 0;
+        size_t lds = 0;
+        for (int j = i; j < n && ga.a.n < MSMC_GROUP_MAX; ++j) {
+            if (!todo[j] || pk[j].nt != pk[i].nt || pk[j].ckm != pk[i].ckm) continue;
+            ga.a.first[ga.a.n] = blocks;
+            ga.a.nx[ga.a.n] = (int)pk[j].gx;
+            ga.a.d[ga.a.n] = descs[j];
+            ga.a.G[ga.a.n] = pk[j].G;
+            ga.reg[ga.a.n] = (int)pk[j].reg;
+            blocks += (int)(pk[j].gx * pk[j].gy);
+            if (pk[j].lds > lds) lds = pk[j].lds;
+            todo[j] = false;
+            done[j] = true;
+            ++ga.a.n;
+        }
+        ga.a.first[ga.a.n] = blocks;
+        ++msmc_conv_launches;
+        int rc = ga.a.n == 1 ? cv_ks_dispatch<T>(pk[i], dim3(pk[i].gx, pk[i].gy), pk[i].lds, stream, &ga.a.d[0], nullptr)
+                             : cv_ks_dispatch<T>(pk[i], dim3((unsigned)blocks), lds, stream, nullptr, &ga);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 // which direct kernel would take this descriptor: 0 none, 1 small, 2 dot, 3 outer (mirrors cv_direct_launch)
@@ -1657,6 +1751,12 @@ static int cv_group_launch(const msmc_conv_desc* descs, int n, msmc_stream strea
         const int rc = cv5_group_launch(descs, n, stream, done5);
         if (rc) return rc;
         for (int i = 0; i < n; ++i) done4[i] = done4[i] || done5[i];
+    }
+    {
+        bool doneks[MSMC_GROUP_LIMIT];                          // wave-split members (variant 9): one grid per configuration
+        const int rc = cv_ks_group_launch<T>(descs, n, stream, doneks);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) done4[i] = done4[i] || doneks[i];
     }
     for (int i = 0; i < n; ++i) {
         pending[i] = direct[i] = false;

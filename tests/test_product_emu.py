@@ -162,6 +162,24 @@ def test_gather_wave_split_deep_reduction_variant():
                 del conv._PLANS[g]
             _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=('fwd', 'dgrad'))
             _convcases.check_conv_case(case, torch.float32, 2e-4, 'cpu', parts=('fwd', 'dgrad'))
+        # grouped call: the wave-split members share ONE grid per configuration (the phases of a transposed convolution,
+        # of a strided layer's data gradient), results of single launches bit for bit
+        from msmctts_amd.hip import lib
+        torch.manual_seed(0)
+        x = torch.randn(2, 1, 70, 512).bfloat16()
+        items = []
+        for k, Co in ((3, 64), (3, 72), (3, 96)):
+            geom = conv.Geometry(1, 70, (1, k), (1, 1), (1, 1), (0, k // 2), False)
+            items.append(dict(x=x, w=(torch.randn(k, Co, 512) / (512 * k) ** 0.5).bfloat16(), geom=geom, bias=torch.randn(Co),
+                              in_slope=0.1))
+        conv._PLANS.clear()
+        singles = [conv.conv_forward(**it) for it in items]
+        n0 = lib.get().msmc_conv_launch_count()
+        grouped = conv.conv_forward_group(items)
+        assert lib.get().msmc_conv_launch_count() - n0 == 1
+        assert b'conv_gather_ks_group_kernel' in lib.get().msmc_conv_last_kernel()
+        for a, b in zip(grouped, singles):
+            assert torch.equal(a, b)
     finally:
         conv._build_desc = real
         conv._GATHER_CANDIDATES = saved

@@ -70,11 +70,10 @@ if RETUNE == 'wgrad6':                                    # direct thin-layer we
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
             if k[0] == 'wgrad' and k[1] == 1 and min(k[5], k[8]) <= 16}
     print('timing the direct thin-layer weight gradient on %d shapes' % len(kept))
+old_groups = {}
 if RETUNE == 'groups':                                    # grouped-versus-single decisions only (every single shape stays cached)
-    dropped = [k for k in conv.TUNED if k[0].endswith('-group')]
-    for k in dropped:
-        del conv.TUNED[k]
-    print('re-timing %d grouped calls' % len(dropped))
+    old_groups = {k: conv.TUNED.pop(k) for k in list(conv.TUNED) if k[0].endswith('-group')}
+    print('re-timing the grouped calls the run meets (%d decisions on file)' % len(old_groups))
 if RETUNE == 'wgrad5':                                    # general-lattice LDS-DMA weight gradient (variant 7): time it on
     conv._WGRAD_CANDIDATES = ((7, 0), (7, -1))            # every bf16 shape with 64-multiple channels, merge with the table
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
@@ -109,6 +108,8 @@ for k, v in kept.items():                                 # committed candidates
         times[c] = min(t, times.get(c, t))
     best = min(times, key=times.get) if times else (v[0], v[1])
     conv.TUNED[k] = (best[0], best[1], times)
+for k, v in old_groups.items():                           # decisions of calls this run did not meet (other configurations, tests)
+    conv.TUNED.setdefault(k, v)
 out = os.path.join(ROOT, 'gpurun_out', 'tuned_gfx950.json')
 conv.save_tuned(out)
 print('shapes tuned:', len(conv.TUNED))
