@@ -422,24 +422,32 @@ def _snapshot(desc, stream):
     return lib.ConvDesc.from_buffer_copy(desc)
 
 
-_GROUP_CODES = {'single': 0, 'group': 1, 'group4': 2}
+_GROUP_CODES = {'single': 0, 'group': 1, 'group4': 2, 'uniform': 3}
+# grouped forward / data-gradient calls whose members chose different kernel families become several launches; the tuner
+# also times the call with ONE variant imposed on every member (where all of them accept it): a single grid
+_UNIFORM_CANDIDATES = tuple(int(v) for v in os.environ.get('MSMC_UNIFORM_VARIANTS', '2,3,24,25,28,29,40,44,45,46').split(',') if v)
 
 
-def _group_choice(kind, snaps, grouped_fn, single_fn, group4_fn=None):
+def _group_choice(kind, snaps, grouped_fn, single_fn, group4_fn=None, uniform_fn=None):
     """1: issue the members as one grouped call, 0: one by one, 2: grouped with the fourth-generation weight-gradient
-    members on grids of their own (``group4_fn``, weight gradients only).  Timed once per member-shape combination
-    (grouping fills the chip for small grids but imposes one kernel instantiation on all members)."""
+    members on grids of their own (``group4_fn``, weight gradients only), (3, v): grouped with variant v imposed on every
+    member (``uniform_fn(v)`` returns the launcher or None when a member refuses v; forward / data gradients only).
+    Timed once per member-shape combination (grouping fills the chip for small grids but imposes one kernel
+    instantiation on all members).  Returns (code, variant)."""
     if len(snaps) == 1:
-        return 0
+        return 0, 0
     if lib._host_pointers_ok:
-        return 1
+        return 1, 0
     sig = (kind,) + tuple(_signature(d) + (d.variant, d.split_shift) for d in snaps)
     hit = TUNED.get(sig)
     if hit is None and (not AUTOTUNE or torch.cuda.is_current_stream_capturing()):
-        return 1
+        return 1, 0
     if hit is None:
         times = {}
-        for name, fn in (('group', grouped_fn), ('single', single_fn), ('group4', group4_fn)):
+        options = [(('group', 0), grouped_fn), (('single', 0), single_fn), (('group4', 0), group4_fn)]
+        if uniform_fn is not None and len(set(d.variant for d in snaps)) > 1:
+            options += [(('uniform', v), uniform_fn(v)) for v in _UNIFORM_CANDIDATES]
+        for name, fn in options:
             if fn is None:
                 continue
             fn()
@@ -449,10 +457,10 @@ def _group_choice(kind, snaps, grouped_fn, single_fn, group4_fn=None):
                 fn()
             e.record()
             e.synchronize()
-            times[(name, 0)] = s.elapsed_time(e) / 3.0
+            times[name] = s.elapsed_time(e) / 3.0
         best = min(times, key=times.get)
-        hit = TUNED[sig] = (_GROUP_CODES[best[0]], 0, times)
-    return hit[0]
+        hit = TUNED[sig] = (_GROUP_CODES[best[0]], best[1], times)
+    return hit[0], hit[1]
 
 
 def _gather_group(snaps, stream, what):
@@ -470,7 +478,22 @@ def _gather_group(snaps, stream, what):
     def grouped():
         lib.check(L.msmc_conv_gather_group(arr, len(snaps), stream), what)
 
-    (grouped if _group_choice('gather-group', snaps, grouped, single) else single)()
+    def uniform(v):
+        """launcher of the call with variant v on every member, None when the library refuses it for one of them"""
+        forced = (lib.ConvDesc * len(snaps))(*[lib.ConvDesc.from_buffer_copy(d) for d in snaps])
+        for d in forced:
+            d.variant, d.split_shift = v, 0
+        if L.msmc_conv_gather_group(forced, len(snaps), stream) != 0:
+            return None
+        return lambda: lib.check(L.msmc_conv_gather_group(forced, len(snaps), stream), what)
+
+    code, v = _group_choice('gather-group', snaps, grouped, single, uniform_fn=uniform)
+    if code == 3:
+        fn = uniform(v)             # (validating launch included: the outputs are simply written twice)
+        if fn is not None:
+            return
+        code = 1
+    (grouped if code else single)()
 
 
 def conv_forward_group(items):
@@ -705,7 +728,7 @@ def conv_wgrad_group(items):
                 dwa, dba = vp(*[t.data_ptr() for t in scratch]), vp(*[t.data_ptr() for t in sb])
                 _group_choice('wgrad-group', part, grouped, single, g4)
                 dwa, dba = keep
-        deferred((single, grouped, g4 or grouped)[_group_choice('wgrad-group', part, grouped, single, g4)])
+        deferred((single, grouped, g4 or grouped)[_group_choice('wgrad-group', part, grouped, single, g4)[0]])
 
 
 def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None, copies=1):
