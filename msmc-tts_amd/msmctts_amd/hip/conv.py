@@ -425,7 +425,7 @@ def _snapshot(desc, stream):
 _GROUP_CODES = {'single': 0, 'group': 1, 'group4': 2, 'uniform': 3}
 # grouped forward / data-gradient calls whose members chose different kernel families become several launches; the tuner
 # also times the call with ONE variant imposed on every member (where all of them accept it): a single grid
-_UNIFORM_CANDIDATES = tuple(int(v) for v in os.environ.get('MSMC_UNIFORM_VARIANTS', '2,3,24,25,28,29,40,44,45,46').split(',') if v)
+_UNIFORM_CANDIDATES = tuple(int(v) for v in os.environ.get('MSMC_UNIFORM_VARIANTS', '2,3,4,5,8,9,16,17,20,21,24,25,26,27,28,29,30,31,40,41,42,44,45,46,47').split(',') if v)
 
 
 def _group_choice(kind, snaps, grouped_fn, single_fn, group4_fn=None, uniform_fn=None):
