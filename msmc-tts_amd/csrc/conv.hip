@@ -781,6 +781,7 @@ static int cv_geometry(const msmc_conv_desc* d, CvGeom* G, int elt_bytes, int XS
 #include "gather4.inc"
 #include "gemm1.inc"
 #include "gather5.inc"
+#include "gather6.inc"
 
 template <typename T, int NT, int MT>
 static int cv_try_pipe(const msmc_conv_desc* d, msmc_stream stream, bool* done) {
@@ -1290,6 +1291,10 @@ extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
         const int rc = cv5_launch(d, stream);
         return rc < 0 ? rc : rc == 1 ? 0 : MSMC_E_SHAPE;
     }
+    if (cv6_is_variant(d->variant)) {           // thin-channel kernel (bf16, Cin 8 / 16 / 32, fragments straight from global memory)
+        const int rc = cv6_launch(d, stream);
+        return rc < 0 ? rc : rc == 1 ? 0 : MSMC_E_SHAPE;
+    }
     if (d->variant == 9) {                      // wave-split deep reduction (E_SHAPE when it does not apply)
         int rc = d->dtype == 0 ? cv_ks_launch<float>(d, stream)
                  : d->dtype == 1 ? cv_ks_launch<unsigned short>(d, stream) : MSMC_E_SHAPE;
@@ -1751,6 +1756,12 @@ static int cv_group_launch(const msmc_conv_desc* descs, int n, msmc_stream strea
         const int rc = cv5_group_launch(descs, n, stream, done5);
         if (rc) return rc;
         for (int i = 0; i < n; ++i) done4[i] = done4[i] || done5[i];
+    }
+    {
+        bool done6[MSMC_GROUP_LIMIT];                           // thin-channel members (variant 50): one grid per channel count
+        const int rc = cv6_group_launch(descs, n, stream, done6);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) done4[i] = done4[i] || done6[i];
     }
     {
         bool doneks[MSMC_GROUP_LIMIT];                          // wave-split members (variant 9): one grid per configuration

@@ -899,3 +899,68 @@ def test_wgrad_direct_thin_layer_kernel():
     finally:
         conv._build_desc = real
         conv._PLANS.clear()
+
+
+def test_gather_thin_channel_variant():
+    """variant 50 (gather6.inc: Cin 8 / 16 / 32 -- the B fragment of the implicit GEMM is eight consecutive channels of one
+    tap, loaded straight from global memory; weights in LDS; a wave walks tiles of 32 lattice points alone): the thin
+    discriminator layers, forward and data gradient -- 3x3 stride 1 and 2 with reflection, 5x1 stride 3, a contraction that
+    is not a multiple of sixteen (Cin 8 x 9 taps), two output blocks (Cout 64), Cout 8 (data gradient of an 8 -> 16
+    layer), ragged last tile -- every epilogue operand against the second generation; grouped calls on one grid"""
+    from msmctts_amd.hip import conv, lib
+    cases = [('t6 mrd 8->16', 2, 8, 16, 21, 40, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
+             ('t6 mrd 16->32 s2', 2, 16, 32, 21, 40, (3, 3), (2, 2), (1, 1), (1, 1), True, 0.2),
+             ('t6 mrd 32->64', 1, 32, 64, 9, 50, (3, 3), (1, 1), (1, 1), (1, 1), True, 0.2),
+             ('t6 mpd 16->64 s3', 2, 16, 64, 100, 3, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
+             ('t6 k7 32->8', 1, 32, 8, 1, 333, (1, 7), (1, 1), (1, 1), (0, 3), False, 0.1),
+             ('t6 k3 8->8 ragged', 1, 8, 8, 1, 77, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0)]
+    real = conv._build_desc
+    state = {'variant': 50}
+
+    def forced(*a, **k):
+        d = real(*a, **k)
+        if d.dtype == 1:
+            d.variant = state['variant']
+        return d
+    conv._build_desc = forced
+    ran = 0
+    try:
+        for case in cases:
+            for part in ('fwd', 'dgrad'):
+                conv._PLANS.clear()
+                try:
+                    _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=(part,))
+                    assert b'conv_gather6_kernel' in lib.get().msmc_conv_last_kernel(), (case[0], part)
+                    ran += 1
+                except RuntimeError as e:             # MSMC_E_SHAPE: outside the scope (e.g. the 64-channel data gradient)
+                    assert 'msmc_conv_gather' in str(e), e
+        assert ran >= 9, ran
+        torch.manual_seed(0)
+        B, H, W, Ci, Co = 2, 11, 30, 16, 40
+        x = torch.randn(B, H, W, Ci).bfloat16()
+        w = (torch.randn(9, Co, Ci) / (9 * Ci) ** 0.5).bfloat16()
+        bias, res, res2 = torch.randn(Co), torch.randn(B, H, W, Co).bfloat16(), torch.randn(B, H, W, Co).bfloat16()
+        outs = []
+        for v in (50, 2):
+            state['variant'] = v
+            conv._PLANS.clear()
+            geom = conv.Geometry(H, W, (3, 3), (1, 1), (1, 1), (1, 1), False)
+            outs.append(conv.conv_forward(x, w, geom, bias=bias, in_slope=0.1, res=res, res2=res2, out_div=3.0, out_slope=0.2))
+        assert _convcases.rel(outs[0], outs[1]) < 1e-2
+        state['variant'] = 50
+        items = []
+        for Wd in (30, 17, 30):
+            geom = conv.Geometry(H, Wd, (3, 3), (1, 1), (1, 1), (1, 1), False)
+            items.append(dict(x=torch.randn(B, H, Wd, Ci).bfloat16(), w=(torch.randn(9, Co, Ci) / (9 * Ci) ** 0.5).bfloat16(),
+                              geom=geom, bias=bias, out_slope=0.2))
+        conv._PLANS.clear()
+        singles = [conv.conv_forward(**it) for it in items]
+        n0 = lib.get().msmc_conv_launch_count()
+        grouped = conv.conv_forward_group(items)
+        assert lib.get().msmc_conv_launch_count() - n0 == 1
+        assert b'conv_gather6_group_kernel' in lib.get().msmc_conv_last_kernel()
+        for a, b in zip(grouped, singles):
+            assert torch.equal(a, b)
+    finally:
+        conv._build_desc = real
+        conv._PLANS.clear()
