@@ -913,7 +913,10 @@ def test_gather_thin_channel_variant():
              ('t6 mrd 32->64', 1, 32, 64, 9, 50, (3, 3), (1, 1), (1, 1), (1, 1), True, 0.2),
              ('t6 mpd 16->64 s3', 2, 16, 64, 100, 3, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
              ('t6 k7 32->8', 1, 32, 8, 1, 333, (1, 7), (1, 1), (1, 1), (0, 3), False, 0.1),
-             ('t6 k3 8->8 ragged', 1, 8, 8, 1, 77, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0)]
+             ('t6 k3 8->8 ragged', 1, 8, 8, 1, 77, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
+             ('t6 mrd 4->8 s2', 2, 4, 8, 21, 40, (3, 3), (2, 2), (1, 1), (1, 1), True, 0.2),
+             ('t6 mrd 2->4', 2, 2, 4, 13, 50, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
+             ('t6 k5x1 s3 4->20', 1, 4, 20, 60, 3, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2)]
     real = conv._build_desc
     state = {'variant': 50}
 
@@ -934,7 +937,7 @@ def test_gather_thin_channel_variant():
                     ran += 1
                 except RuntimeError as e:             # MSMC_E_SHAPE: outside the scope (e.g. the 64-channel data gradient)
                     assert 'msmc_conv_gather' in str(e), e
-        assert ran >= 9, ran
+        assert ran >= 14, ran
         torch.manual_seed(0)
         B, H, W, Ci, Co = 2, 11, 30, 16, 40
         x = torch.randn(B, H, W, Ci).bfloat16()
@@ -949,9 +952,9 @@ def test_gather_thin_channel_variant():
         assert _convcases.rel(outs[0], outs[1]) < 1e-2
         state['variant'] = 50
         items = []
-        for Wd in (30, 17, 30):
+        for Wd, ci in ((30, 16), (17, 4), (30, 32)):            # (members of different channel counts share the grid)
             geom = conv.Geometry(H, Wd, (3, 3), (1, 1), (1, 1), (1, 1), False)
-            items.append(dict(x=torch.randn(B, H, Wd, Ci).bfloat16(), w=(torch.randn(9, Co, Ci) / (9 * Ci) ** 0.5).bfloat16(),
+            items.append(dict(x=torch.randn(B, H, Wd, ci).bfloat16(), w=(torch.randn(9, Co, ci) / (9 * ci) ** 0.5).bfloat16(),
                               geom=geom, bias=bias, out_slope=0.2))
         conv._PLANS.clear()
         singles = [conv.conv_forward(**it) for it in items]
