@@ -163,8 +163,10 @@ typedef struct msmc_conv_desc {
                                >= 2 taps, Cin % 64 == 0, Cout % 8 == 0: sixteen waves, stages of (64-channel chunk, tap) with the weight
                                slices in an LDS-DMA ring and the halo tile of a chunk shared by its taps, epilogue in registers with 16-byte
                                stores; tiles 40: 128 x 128, 41: 256 x 128, 42 / 43: 128 x 256, 44: 64 x 256, 45: 64 x 128 with the
-                               contraction split over two groups of eight waves (Cin % 128 == 0), 46: 256 x 64; MSMC_E_SHAPE where a
-                               configuration does not apply), 9 = 32-point tiles with the channel
+                               contraction split over two groups of eight waves (Cin % 128 == 0), 46: 256 x 64, 47: 128 x 128 for one-chunk layers
+                               with halo tiles of up to 640 pixels; MSMC_E_SHAPE where a configuration does not apply), 50 = thin-channel
+                               kernel (csrc/gather6.inc: Cin in {2, 4, 8, 16, 32, 64}, Cout <= 64, Cin * taps <= 704; B fragments loaded
+                               straight from global memory, weights in LDS, no workgroup barriers in the tile loop), 9 = 32-point tiles with the channel
                                chunks split over the four waves (deep reductions on small grids).  msmc_conv_wgrad (bf16): 1 = first,
                                2 = second generation (fp32 atomics), 3 = third (split partials + fixed-order reduce), 4 / 5 / 6 = fourth (the
                                third's result contract; pixel tiles flow through an LDS-DMA ring: 4 = three stages, fragment reads two

@@ -67,7 +67,7 @@ if RETUNE == 'gather5':                                   # sixteen-wave staged-
     print('timing the fifth-generation forward / data-gradient kernel on %d shapes' % len(kept))
 if RETUNE == 'gather6':                                   # thin-channel kernel (variant 50): bf16 shapes with 8 / 16 / 32 input channels
     conv._GATHER_CANDIDATES = ((50, 0),)
-    kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED) if k[0] == 'gather' and k[1] == 1 and k[5] in (2, 4, 8, 16, 32)}
+    kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED) if k[0] == 'gather' and k[1] == 1 and k[5] in (2, 4, 8, 16, 32, 64)}
     print('timing the thin-channel kernel on %d forward / data-gradient shapes' % len(kept))
 if RETUNE == 'wgrad6':                                    # direct thin-layer weight gradient (variant 8): every bf16 shape with a
     conv._WGRAD_CANDIDATES = ((8, 0),)                    # channel count of at most 16 on one side
