@@ -353,6 +353,13 @@ int msmc_reflect_fold_multi(const void* const* gp, const void* const* mask_src, 
 int msmc_reflect_fold_multi_res(const void* const* gp, const void* const* mask_src, const void* const* res, void* const* gx,
                                 const int* B, const int* H, const int* W, const int* C, int n, int p, float slope, int dtype,
                                 msmc_stream stream);
+/* as msmc_reflect_fold_multi_res with the third input added BEFORE the mask: gx = (fold(gp) + tap) * lrelu'(mask_src).
+ * For a padded layer whose input is an ACTIVATED map with a second reader (the resolution discriminators' feature
+ * maps, reference msmctts/networks/hifigan/discriminator.py DiscriminatorR.forward: the in-place leaky ReLU makes the
+ * stored map the activated one): the producer's leaky-ReLU backward happens here instead of in a launch of its own. */
+int msmc_reflect_fold_multi_tap(const void* const* gp, const void* const* mask_src, const void* const* tap, void* const* gx,
+                                const int* B, const int* H, const int* W, const int* C, int n, int p, float slope, int dtype,
+                                msmc_stream stream);
 int msmc_lrelu_bwd_multi(const void* const* g, const void* const* y, void* const* gx, const long* nelem, int n, float slope,
                          int dtype, msmc_stream stream);
 

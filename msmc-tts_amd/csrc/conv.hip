@@ -3619,6 +3619,7 @@ __global__ __launch_bounds__(256) void reflect_fold_kernel(const T* __restrict__
 struct FoldMultiArgs {
     int n, p;
     float slope;
+    int res_first;                      // 1: (fold + res) * mask -- res is the gradient of a second reader of the ACTIVATED map
     int first[MSMC_GROUP_MAX + 1];
     const void* gp[MSMC_GROUP_MAX];
     const void* mask[MSMC_GROUP_MAX];
@@ -3675,8 +3676,9 @@ __global__ __launch_bounds__(256) void reflect_fold_multi_kernel(FoldMultiArgs a
 #pragma unroll
         for (int q = 0; q < V; ++q) {
             float sv = sacc[q];
+            if (res && a.res_first) sv = sv + Elt<T>::ld(&rv[q]);
             if (mask) sv = sv * (Elt<T>::ld(&mv[q]) > 0.f ? 1.f : a.slope);
-            if (res) sv = sv + Elt<T>::ld(&rv[q]);
+            if (res && !a.res_first) sv = sv + Elt<T>::ld(&rv[q]);
             Elt<T>::st(&ov[q], sv);
         }
         if (V * sizeof(T) == 16) *(u32x4*)(gx + o) = *(const u32x4*)ov;
@@ -3802,9 +3804,27 @@ int msmc_reflect_fold_multi(const void* const* gp, const void* const* mask_src, 
     return msmc_reflect_fold_multi_res(gp, mask_src, nullptr, gx, B, H, W, C, n, p, slope, dtype, stream);
 }
 
+static int fold_multi_impl(const void* const* gp, const void* const* mask_src, const void* const* res, void* const* gx,
+                           const int* B, const int* H, const int* W, const int* C, int n, int p, float slope, int dtype,
+                           int res_first, msmc_stream stream);
+
 int msmc_reflect_fold_multi_res(const void* const* gp, const void* const* mask_src, const void* const* res, void* const* gx,
                                 const int* B, const int* H, const int* W, const int* C, int n, int p, float slope, int dtype,
                                 msmc_stream stream) {
+    return fold_multi_impl(gp, mask_src, res, gx, B, H, W, C, n, p, slope, dtype, 0, stream);
+}
+
+int msmc_reflect_fold_multi_tap(const void* const* gp, const void* const* mask_src, const void* const* tap, void* const* gx,
+                                const int* B, const int* H, const int* W, const int* C, int n, int p, float slope, int dtype,
+                                msmc_stream stream) {
+    return fold_multi_impl(gp, mask_src, tap, gx, B, H, W, C, n, p, slope, dtype, 1, stream);
+}
+
+}  // extern "C"
+
+static int fold_multi_impl(const void* const* gp, const void* const* mask_src, const void* const* res, void* const* gx,
+                           const int* B, const int* H, const int* W, const int* C, int n, int p, float slope, int dtype,
+                           int res_first, msmc_stream stream) {
     if (!gp || !gx || !B || !H || !W || !C || n <= 0 || n > MSMC_GROUP_MAX || p < 0 || dtype < 0 || dtype > 1)
         return MSMC_E_SHAPE;
     const int VEC = dtype == 0 ? 4 : 8;
@@ -3817,6 +3837,7 @@ int msmc_reflect_fold_multi_res(const void* const* gp, const void* const* mask_s
     a.n = n;
     a.p = p;
     a.slope = slope;
+    a.res_first = res_first;
     int blocks = 0;
     for (int k = 0; k < n; ++k) {
         a.gp[k] = gp[k];
@@ -3835,6 +3856,8 @@ int msmc_reflect_fold_multi_res(const void* const* gp, const void* const* mask_s
     a.first[n] = blocks;
     return dtype == 0 ? fold_multi_launch<float>(a, vec, blocks, stream) : fold_multi_launch<unsigned short>(a, vec, blocks, stream);
 }
+
+extern "C" {
 
 int msmc_lrelu_bwd_multi(const void* const* g, const void* const* y, void* const* gx, const long* nelem, int n, float slope,
                          int dtype, msmc_stream stream) {

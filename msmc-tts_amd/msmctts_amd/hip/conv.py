@@ -804,11 +804,12 @@ def lrelu_bwd_group(pairs, slope):
     return outs
 
 
-def reflect_fold_group(items, p=1, slope=1.0):
+def reflect_fold_group(items, p=1, slope=1.0, tap_first=False):
     """[(gp, H, W, mask_src or None[, res or None]), ...] -> folded gradients (* lrelu'(mask_src) + res), up to six tensors
-    per launch (msmc_reflect_fold_multi_res)."""
+    per launch (msmc_reflect_fold_multi_res).  ``tap_first``: (fold + res) * lrelu'(mask_src) instead -- the input is an
+    activated map and res the gradient of its other reader (msmc_reflect_fold_multi_tap)."""
     items = [tuple(it) + (None,) * (5 - len(it)) for it in items]
-    if not _G['FOLD']:
+    if not _G['FOLD'] and not tap_first:
         outs = []
         for gp, H, W, mask, res in items:
             gx = reflect_fold(gp, H, W, p, mask_src=mask, slope=slope)
@@ -832,11 +833,12 @@ def reflect_fold_group(items, p=1, slope=1.0):
             masks.append(mask.data_ptr() if mask is not None else None)
             ress.append(res.data_ptr() if res is not None else None)
         vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
-        lib.check(L.msmc_reflect_fold_multi_res(vp(*[t[0].data_ptr() for t in part]), vp(*masks), vp(*ress),
-                                                vp(*[t.data_ptr() for t in gxs]), ip(*[t[0].shape[0] for t in part]),
-                                                ip(*[t[1] for t in part]), ip(*[t[2] for t in part]),
-                                                ip(*[t[0].shape[3] for t in part]), n, p, float(slope), _DT[part[0][0].dtype],
-                                                lib.stream(part[0][0])), 'msmc_reflect_fold_multi_res')
+        entry = L.msmc_reflect_fold_multi_tap if tap_first else L.msmc_reflect_fold_multi_res
+        lib.check(entry(vp(*[t[0].data_ptr() for t in part]), vp(*masks), vp(*ress),
+                        vp(*[t.data_ptr() for t in gxs]), ip(*[t[0].shape[0] for t in part]),
+                        ip(*[t[1] for t in part]), ip(*[t[2] for t in part]),
+                        ip(*[t[0].shape[3] for t in part]), n, p, float(slope), _DT[part[0][0].dtype],
+                        lib.stream(part[0][0])), 'msmc_reflect_fold_multi_tap' if tap_first else 'msmc_reflect_fold_multi_res')
         outs.extend(gxs)
     return outs
 

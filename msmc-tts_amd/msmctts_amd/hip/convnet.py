@@ -322,9 +322,11 @@ class _HipConv(torch.autograd.Function):
         # ``in_act`` != 1: x was activated by its producer's epilogue (that producer ran with out_slope = in_act and
         # ``out_masked``); forward and weight gradient read it as it is, the data gradient applies the activation's
         # derivative (sign of the activated value = sign of the pre-activation).  ``out_masked``: this convolution's ONLY
-        # consumer does that, so the backward pass here does not.
+        # consumer does that, so the backward pass here does not.  With ``tap`` on such an input (reflect-padded layers
+        # only: the resolution discriminators' feature maps) the tap's gradient is that of another reader of the ACTIVATED
+        # map and goes through the derivative as well: (fold + tap) * lrelu'.
         m = layer.module
-        assert in_act == 1.0 or (in_slope == 1.0 and not layer.reflect)
+        assert in_act == 1.0 or (in_slope == 1.0 and (layer.reflect or not tap))
         if layer.kind == 'conv':
             geom = layer.geom(x.shape[1], x.shape[2])
             out = K.conv_forward(x, layer.wf, geom, bias=m.bias, in_slope=in_slope, res=res, res2=res2,
@@ -363,7 +365,11 @@ class _HipConv(torch.autograd.Function):
             mask = x if ctx.mask_slope != 1.0 else None
             if layer.kind == 'conv':
                 geom = layer.geom(x.shape[1], x.shape[2])
-                if layer.reflect:
+                if layer.reflect and ctx.mask_slope != ctx.in_slope:         # activated input: (fold + tap) * lrelu'
+                    gp = K.conv_dgrad(g, layer.wb, geom)
+                    gx = K.reflect_fold_group([(gp, x.shape[1], x.shape[2], mask, g_tap)], layer.padding[0],
+                                              ctx.mask_slope, tap_first=True)[0]
+                elif layer.reflect:
                     gp = K.conv_dgrad(g, layer.wb, geom)
                     gx = K.reflect_fold(gp, x.shape[1], x.shape[2], layer.padding[0], mask_src=mask,
                                         slope=ctx.in_slope)
@@ -412,7 +418,7 @@ class _HipConvGroup(torch.autograd.Function):
     def forward(ctx, bank, specs, *tensors):
         items, pos, members = [], 0, []
         for layer, in_slope, out_slope, out_div, has_res, has_res2, tap, in_act, out_masked in specs:
-            assert in_act == 1.0 or (in_slope == 1.0 and not layer.reflect)
+            assert in_act == 1.0 or (in_slope == 1.0 and (layer.reflect or not tap))
             x = tensors[pos]
             res = tensors[pos + 1] if has_res else None
             res2 = tensors[pos + 1 + has_res] if has_res2 else None
@@ -491,12 +497,15 @@ class _HipConvGroup(torch.autograd.Function):
                     g_tap = _tap_grad(g_taps.get(k), gx)
                     if g_tap is not None:
                         bank._hold.append(g_tap)
-                    folds.setdefault((layer.padding[0], in_slope), []).append(
-                        (k, (gx, x.shape[1], x.shape[2], x if in_slope != 1.0 else None, g_tap)))
+                    in_act = ctx.specs[k][7]
+                    slope = in_act if in_act != 1.0 else in_slope
+                    folds.setdefault((layer.padding[0], slope, in_act != 1.0), []).append(
+                        (k, (gx, x.shape[1], x.shape[2], x if slope != 1.0 else None, g_tap)))
                 else:
                     grads[ctx.xpos[k]] = gx
-            for (pad, in_slope), members in folds.items():
-                for (k, _), gx in zip(members, K.reflect_fold_group([m[1] for m in members], pad, in_slope)):
+            for (pad, slope, tap_first), members in folds.items():
+                for (k, _), gx in zip(members, K.reflect_fold_group([m[1] for m in members], pad, slope,
+                                                                     tap_first=tap_first)):
                     grads[ctx.xpos[k]] = gx
         if w_items:
             with bank.wgrad_side(*([it['x'] for it in w_items] + [it['g'] for it in w_items])):

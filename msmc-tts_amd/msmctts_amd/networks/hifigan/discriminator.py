@@ -21,6 +21,7 @@ from .common import get_padding
 # ReflectionPad2d into the load; feature maps are handed to the trainer as NCHW-shaped views.
 
 LRELU_SLOPE = 0.2
+ACT = dict(out_slope=LRELU_SLOPE, out_masked=True)      # activation in the producer's epilogue, its backward in the consumer
 
 
 class _Stage(nn.Module):
@@ -54,10 +55,12 @@ class DiscriminatorR(nn.Module):
         fmaps = []
         last = len(layers) - 1
         for i, layer in enumerate(layers):
+            # every map has exactly two readers, the next layer and (through that layer's tap) the feature-matching loss:
+            # the leaky ReLU's backward is applied to the SUM of their gradients in the next layer's fold (ACT / in_act)
             if i == 0:
-                x = hip_conv(bank, layer, x, out_slope=LRELU_SLOPE)
+                x = hip_conv(bank, layer, x, **ACT)
             else:               # (tap: the feature-matching loss reads the alias of the map the next layer hands back)
-                x, tap = hip_conv(bank, layer, x, out_slope=LRELU_SLOPE if i < last else 1.0, tap=True)
+                x, tap = hip_conv(bank, layer, x, tap=True, in_act=LRELU_SLOPE, **(ACT if i < last else {}))
                 fmaps.append(tap.permute(0, 3, 1, 2))    # aliased post-activation map, see module docstring
         return x.permute(0, 3, 1, 2), fmaps
 
@@ -166,11 +169,11 @@ class Discriminator(nn.Module):
         xs = [stft.image_cl(wav, dtype) for stft in self.mrd.stfts]      # (images written in the compute dtype: no cast launches)
         r_fmaps = [[] for _ in xs]
         last = len(mrd[0]) - 1
-        xs = hip_conv_group(bank, [dict(layer=mrd[j][0], x=xs[j], out_slope=LRELU_SLOPE) for j in range(len(xs))])
+        xs = hip_conv_group(bank, [dict(layer=mrd[j][0], x=xs[j], **ACT) for j in range(len(xs))])
         for i in range(1, last + 1):
             # (tap: the feature-matching loss reads the alias of map i-1 that layer i hands back, so its gradient is added
-            # in layer i's data-gradient fold instead of by a stock add_)
-            xt = hip_conv_group(bank, [dict(layer=mrd[j][i], x=xs[j], out_slope=LRELU_SLOPE if i < last else 1.0, tap=True)
+            # in layer i's data-gradient fold -- before the leaky ReLU's derivative, which that fold applies too: in_act)
+            xt = hip_conv_group(bank, [dict(layer=mrd[j][i], x=xs[j], tap=True, in_act=LRELU_SLOPE, **(ACT if i < last else {}))
                                        for j in range(len(xs))])
             for j, (x, tap) in enumerate(xt):
                 r_fmaps[j].append(tap.permute(0, 3, 1, 2))      # aliased post-activation map, see module docstring

@@ -132,6 +132,13 @@ def test_multi_tensor_fold_and_lrelu_equal_single_tensor_kernels():
                 refs.append(conv.reflect_fold(gp, H, W, 1, mask_src=m, slope=0.2))
             for o, r in zip(conv.reflect_fold_group(items, 1, 0.2), refs):
                 assert torch.equal(o, r)
+            # (fold + tap) * lrelu'(mask): the tap is the gradient of another reader of the ACTIVATED input
+            taps = [torch.randn_like(it[3]) for it in items]
+            plain = conv.reflect_fold_group([it[:3] for it in items], 1, 1.0)
+            got = conv.reflect_fold_group([it + (t,) for it, t in zip(items, taps)], 1, 0.2, tap_first=True)
+            for o, f, t, it in zip(got, plain, taps, items):
+                want = (f.float() + t.float()) * torch.where(it[3].float() > 0, 1.0, 0.2)
+                torch.testing.assert_close(o.float(), want, rtol=1e-2 if dt == torch.bfloat16 else 1e-6, atol=1e-2 if dt == torch.bfloat16 else 1e-6)
             pairs = [(torch.randn(3, 7, 5, C).to(dt), torch.randn(3, 7, 5, C).to(dt)) for _ in range(4)]
             for (g, y), o in zip(pairs, conv.lrelu_bwd_group(pairs, 0.2)):
                 assert torch.equal(o, conv.lrelu_bwd(g, y, 0.2))
