@@ -34,6 +34,12 @@ DW_COPIES_MAX_ELEMS = 256 * 1024
 # False: fork_join runs its branches back to back on the calling stream (bench.py's per-kernel timing pass)
 STREAMS_ENABLED = True
 
+# Weight gradients of convolutions that are NOT part of a grouped call (the FFT blocks' projections and feed-forward
+# layers, the pre- / post-nets): each alone is a grid of 24-100 workgroups on 256 CUs, and none of them has a consumer
+# before the end of the backward pass.  They wait in the bank until WGRAD_BATCH of them are pending (or the pass ends)
+# and go out as ONE grouped call (K.conv_wgrad_group; the tuner keeps separate launches where grouping does not pay).
+WGRAD_BATCH = int(os.environ.get('MSMC_WGRAD_BATCH', '8'))
+
 
 def fork_join(streams, thunks, inputs=()):
     """Run independent launch sequences on side HIP streams and join them back (hipGraph-capturable).
@@ -140,6 +146,32 @@ class ConvBank(object):
         self._side_used = []            # weight-gradient side streams to join at the end of the backward pass
         self._side_rr = 0
         self.deferred = K.DeferredReduce()     # partial-result arena + pending second stages of the running backward pass
+        self._pending_w = {}            # stream -> (Stream, weight gradients waiting for company), see WGRAD_BATCH
+
+    def queue_wgrad(self, item):
+        """Backward nodes replay on the stream of their forward (fork_join branches): a waiting list per stream, flushed
+        on that stream, so that a grouped launch only reads what its own stream produced."""
+        st = torch.cuda.current_stream(item['x'].device) if item['x'].is_cuda else None
+        key = st.cuda_stream if st is not None else 0
+        items = self._pending_w.setdefault(key, (st, []))[1]
+        if any(it['dw'].data_ptr() == item['dw'].data_ptr() for it in items):
+            self._flush_stream(key)     # a layer applied twice: its two accumulations must not share a launch
+            items = self._pending_w.setdefault(key, (st, []))[1]
+        items.append(item)
+        if len(items) >= WGRAD_BATCH:
+            self._flush_stream(key)
+
+    def _flush_stream(self, key):
+        st, items = self._pending_w.pop(key, (None, []))
+        if not items:
+            return
+        with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+            with self.wgrad_side(*([it['x'] for it in items] + [it['g'] for it in items])):
+                K.conv_wgrad_group(items)
+
+    def flush_wgrad(self):
+        for key in list(self._pending_w):
+            self._flush_stream(key)
 
     @contextlib.contextmanager
     def wgrad_side(self, *tensors):
@@ -261,6 +293,7 @@ class ConvBank(object):
 
     def _finish_backward(self):
         self._queued = False
+        self.flush_wgrad()
         if self._side_used:             # weight-gradient branches join here, before their inputs are released
             cur = torch.cuda.current_stream(self.w1.device)
             for st in self._side_used:
@@ -386,14 +419,18 @@ class _HipConv(torch.autograd.Function):
         elif g_tap is not None:
             gx = g_tap
         if ctx.need_w:
-            with bank.wgrad_side(x, g):
-                if layer.kind == 'conv':
-                    K.conv_wgrad(x, g, layer.geom(x.shape[1], x.shape[2]), layer.taps, in_slope=ctx.in_slope,
-                                 dw=layer.dw, db=layer.db, copies=layer.dw_copies)
-                else:
-                    K.conv_transpose1d_wgrad(x, g, layer.kernel[1], layer.stride[1], layer.padding[1],
-                                             in_slope=ctx.in_slope, dw=layer.dw, copies=layer.dw_copies)
-                    layer.db.add_(K.colsum(g.reshape(-1, g.shape[-1])))
+            if layer.kind == 'conv' and WGRAD_BATCH > 1:       # waits in the bank for company (see WGRAD_BATCH)
+                bank.queue_wgrad(dict(x=x, g=g, geom=layer.geom(x.shape[1], x.shape[2]), n_slices=layer.taps,
+                                      in_slope=ctx.in_slope, dw=layer.dw, db=layer.db, copies=layer.dw_copies))
+            else:
+                with bank.wgrad_side(x, g):
+                    if layer.kind == 'conv':
+                        K.conv_wgrad(x, g, layer.geom(x.shape[1], x.shape[2]), layer.taps, in_slope=ctx.in_slope,
+                                     dw=layer.dw, db=layer.db, copies=layer.dw_copies)
+                    else:
+                        K.conv_transpose1d_wgrad(x, g, layer.kernel[1], layer.stride[1], layer.padding[1],
+                                                 in_slope=ctx.in_slope, dw=layer.dw, copies=layer.dw_copies)
+                        layer.db.add_(K.colsum(g.reshape(-1, g.shape[-1])))
             bank._touched.add(layer.index)
             bank._queue_finish()
         if ctx.has_res or ctx.has_res2:

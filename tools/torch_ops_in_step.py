@@ -48,10 +48,23 @@ def main():
     import random
     trainer.rng = random.Random(1234)
 
+    # the operators of the step AS THE GRAPHS RECORD IT (window indices on the device, segments A / B / C back to
+    # back): what trainers/msmctts_trainer.py::_capture runs, eagerly
+    from msmctts_amd.hip import vq as hipvq
+    from msmctts_amd.trainers.msmctts_trainer import _StepState
+    st = _StepState()
+    st.phase = 2
+    st.mel, st.mel_length = batch['mel'].clone(), batch['mel_length'].clone()
+    g = {'state': st, 'wav': batch['wav'].reshape(args.batch, -1).clone(),
+         'starts': torch.zeros(args.batch, dtype=torch.int64, device=device)}
+
     def step(i):
-        trainer.model.zero_grad()
-        trainer.optimizer.zero_grad()
-        return trainer.train_step(batch, 10 + i)
+        trainer.model.zero_grad(set_to_none=True)
+        trainer._build_windows(g, st)
+        trainer._segment_a(st)
+        hipvq.flush_codebook_sync(local=True)
+        trainer._segment_b(st)
+        trainer._segment_c(st)
 
     for i in range(a.warmup):
         step(i)

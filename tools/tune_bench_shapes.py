@@ -5,7 +5,9 @@ RETUNE=wgrad4 keeps the committed table and re-times only the single-launch bf16
 kernel can serve (one pass).  RETUNE=gather3x keeps it too and times only the LDS-DMA halo variants (24..31) of every bf16
 forward / data-gradient shape, merging them with the committed timings of the other candidates; RETUNE=gather4 does the
 same for the persistent thin-layer kernel (variant 32), RETUNE=gemm1 for the 1-tap GEMM kernel (variant 34), RETUNE=gather5 for the sixteen-wave staged-tap kernel (variants 40..44), RETUNE=wgrad6 for the direct thin-layer weight gradient (variant 8) and RETUNE=wgrad5 for the general-lattice LDS-DMA weight gradient
-(variant 7; the grouped calls whose members change are re-timed by the run itself)."""
+(variant 7; the grouped calls whose members change are re-timed by the run itself).  RETUNE=new keeps every decision
+on file and only adds the shapes and grouped calls the run meets for the first time (after a change of how the step
+groups its launches, e.g. MSMC_WGRAD_BATCH)."""
 import os, sys, random, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd'), os.path.join(ROOT, 'tests')]
