@@ -39,6 +39,7 @@ STREAMS_ENABLED = True
 # before the end of the backward pass.  They wait in the bank until WGRAD_BATCH of them are pending (or the pass ends)
 # and go out as ONE grouped call (K.conv_wgrad_group; the tuner keeps separate launches where grouping does not pay).
 WGRAD_BATCH = int(os.environ.get('MSMC_WGRAD_BATCH', '8'))
+WGRAD_BATCH_GROUPS = os.environ.get('MSMC_WGRAD_BATCH_GROUPS', '1') == '1'    # grouped calls' members join the waiting list too
 
 
 def fork_join(streams, thunks, inputs=()):
@@ -544,7 +545,10 @@ class _HipConvGroup(torch.autograd.Function):
                 for (k, _), gx in zip(members, K.reflect_fold_group([m[1] for m in members], pad, slope,
                                                                      tap_first=tap_first)):
                     grads[ctx.xpos[k]] = gx
-        if w_items:
+        if w_items and WGRAD_BATCH_GROUPS and WGRAD_BATCH > 1:
+            for it in w_items:
+                bank.queue_wgrad(it)
+        elif w_items:
             with bank.wgrad_side(*([it['x'] for it in w_items] + [it['g'] for it in w_items])):
                 K.conv_wgrad_group(w_items)
         bank._queue_finish()
