@@ -975,3 +975,39 @@ def test_gather_thin_channel_variant():
     finally:
         conv._build_desc = real
         conv._PLANS.clear()
+
+
+@pytest.mark.parametrize('batch', [1, 2, 8])
+def test_weight_gradients_waiting_in_the_bank_equal_immediate_ones(batch):
+    """hip/convnet.py ConvBank.queue_wgrad: single-layer weight gradients go out as grouped calls of up to
+    MSMC_WGRAD_BATCH members; a layer applied TWICE in one pass (the second application is queued while the first still
+    waits) must flush first.  Compared with the stock operator chain and across batch sizes."""
+    import torch.nn.functional as F
+    from msmctts_amd.hip import convnet
+    from msmctts_amd.networks.hifigan.common import ResBlock1
+    keep = convnet.WGRAD_BATCH
+    convnet.WGRAD_BATCH = batch
+    try:
+        torch.manual_seed(11)
+        rb = ResBlock1(16, 3, (1, 3, 5))
+        x = torch.randn(2, 16, 53, requires_grad=True)
+        y = rb(rb(x))                                   # every layer twice
+        go = torch.randn_like(y)
+        (y * go).sum().backward()
+        got = {n: p.grad.clone() for n, p in rb.named_parameters()}
+        gx = x.grad.clone()
+        rb.zero_grad()
+        xr = x.detach().clone().requires_grad_(True)
+        h = xr
+        for _ in range(2):
+            for c1, c2 in zip(rb.convs1, rb.convs2):
+                t_ = F.conv1d(F.leaky_relu(h, 0.1), c1.weight(), c1.bias, 1, c1.padding, c1.dilation)
+                h = F.conv1d(F.leaky_relu(t_, 0.1), c2.weight(), c2.bias, 1, c2.padding, c2.dilation) + h
+        (h * go).sum().backward()
+        _parity.close(y, h, 2e-4, what='out')
+        _parity.close(gx, xr.grad, 2e-4, 1e-3, what='gx')
+        for n, p in rb.named_parameters():
+            _parity.close(got[n], p.grad, 2e-4, 2e-3, what=n)
+        assert not any(items for _, items in rb._bank._pending_w.values()) if hasattr(rb, '_bank') else True
+    finally:
+        convnet.WGRAD_BATCH = keep
