@@ -363,6 +363,14 @@ int msmc_reflect_fold_multi_tap(const void* const* gp, const void* const* mask_s
 int msmc_lrelu_bwd_multi(const void* const* g, const void* const* y, void* const* gx, const long* nelem, int n, float slope,
                          int dtype, msmc_stream stream);
 
+/* EXPERIMENTAL (measured by tools/bench_resunit.py, not on the train step's path): one ResBlock1 unit (reference
+ * msmctts/networks/hifigan/common.py:44-51, one (c1, c2) pair) as ONE launch, bf16, C = 32 / 64 channels, odd k <= 11:
+ *   a = lrelu(conv1d(lrelu(x), w1, dilation dil1) + b1);  y = conv1d(a, w2, dilation 1) + b2 + x
+ * x, a, y [B][L][C]; w1, w2 [k][C][C] in the forward layout (tap, output channel, input channel); b1, b2 fp32 [C];
+ * nt = tiles of 32 rows per wave step (2 or 3; anything else: chosen from the LDS footprint). */
+int msmc_resunit_forward(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* a, void* y,
+                         int B, int L, int C, int k, int dil1, float slope, int nt, msmc_stream stream);
+
 /* Column sums: out[c] = sum_rows g[row][c] (bias gradients); g dtype as above, out fp32 (overwritten). */
 int msmc_colsum(const void* g, float* out, long rows, int C, int dtype, msmc_stream stream);
 

@@ -760,6 +760,19 @@ def colsum(g2d):
     return out
 
 
+def resunit_forward(x, w1, b1, w2, b2, dilation, slope, nt=0):
+    """EXPERIMENTAL (tools/bench_resunit.py): one ResBlock1 unit in one launch (msmc_resunit_forward).  x [B, 1, L, C] bf16,
+    w1 / w2 [k, C, C] (forward layout), b1 / b2 fp32 [C] -> (a, y) = (lrelu(conv(lrelu(x), w1, dilation) + b1),
+    conv(a, w2) + b2 + x)."""
+    B, _, L, C = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and w1.shape == w2.shape == (w1.shape[0], C, C)
+    a, y = torch.empty_like(x), torch.empty_like(x)
+    lib.check(lib.get().msmc_resunit_forward(lib.ptr(x), lib.ptr(w1), lib.ptr(b1), lib.ptr(w2), lib.ptr(b2), lib.ptr(a),
+                                             lib.ptr(y), B, L, C, w1.shape[0], int(dilation), float(slope), int(nt),
+                                             lib.stream(x)), 'msmc_resunit_forward')
+    return a, y
+
+
 def reflect_fold(gp, H, W, p=1, mask_src=None, slope=1.0):
     """Backward of ReflectionPad2d(p) (+ leaky-ReLU' mask): gp [B,H+2p,W+2p,C] -> gx [B,H,W,C]."""
     B, C = gp.shape[0], gp.shape[3]
