@@ -276,6 +276,8 @@ class ConvBank(object):
         if sig != self._sig:
             self._build(dtype)
             self._sig = sig
+        if self._pending_w:             # a backward pass that raised before its end-of-pass callback: its waiting weight
+            self._pending_w.clear()     # gradients must not ride along with the next pass
         lib.check(lib.get().msmc_wn_prepare_multi_tiled(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
                                                         self.total_tile_blocks, lib.stream(self.w1)),
                   'msmc_wn_prepare_multi_tiled')
