@@ -457,6 +457,13 @@ int msmc_add_ln_bwd(const void* g, const void* v, const float* mean, const float
                     const unsigned char* keep_row, void* gx, void* gres, float* dgamma, float* dbeta, void* workspace,
                     size_t workspace_bytes, long N, int C, float p_drop, const long long* seed, long long salt, int accumulate,
                     int dtype, msmc_stream stream);
+/* Head of FFTBlocks.forward (reference msmctts/networks/acoustic_models/transformer.py:375-395) with the positions of
+ * vqgantts/msmc_vqgan.py:56-58 folded in: out[b][t][:] = seq[b][t][:] + table[t < len[b] ? t + 1 : 0][:] (seq / out
+ * [B][T][C] in in_dtype / out_dtype, table fp32 [table_rows][C], T + 1 <= table_rows), keep_row[b T + t] = t < len[b],
+ * key_bias (may be NULL) [B][Tp] = 0 on real frames, -inf on padding and on the tail T .. Tp - 1.  lengths: int32 or int64. */
+int msmc_fft_prologue(const void* seq, const void* lengths, int len_is_64, const float* table, int table_rows, void* out,
+                      unsigned char* keep_row, float* key_bias, int B, int T, int C, int Tp, int in_dtype, int out_dtype,
+                      msmc_stream stream);
 /* x [N][2C] -> y [N][C] = drop(tanh(x[:, :C]) * sigmoid(x[:, C:])); backward recomputes from x. */
 int msmc_gate_fwd(const void* x, void* y, long N, int C, float p_drop, const long long* seed, long long salt, int dtype,
                   msmc_stream stream);

@@ -302,6 +302,42 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const T* __restrict__ y, 
     }
 }
 
+// ---- FFT-stack prologue ---------------------------------------------------------------------------------------
+// The head of FFTBlocks.forward (reference acoustic_models/transformer.py:375-395) with the positions of
+// vqgantts/msmc_vqgan.py:56-58 (1 .. len per utterance, 0 on padding) folded in -- one launch instead of the chain
+// arange / repeat / compare / masked_fill / embedding gather / add / cast / ne / fill / masked_fill:
+//   out[b][t][:]   = seq[b][t][:] + table[t < len[b] ? t + 1 : 0][:]      (fp32 sum, rounded once to the output dtype)
+//   keep_row[b T + t] = t < len[b]                                        (the non-pad mask: rows of 0 / 1)
+//   key_bias[b][t']  = t' < len[b] ? 0 : -inf      for t' < Tp            (additive key-padding bias of csrc/attn.hip)
+// One wave per row, V-element vector accesses as the LayerNorm kernels.
+template <typename TI, typename TO, int V>
+__global__ __launch_bounds__(256) void fft_prologue_kernel(const TI* __restrict__ seq, const void* __restrict__ lengths,
+                                                           int len64, const float* __restrict__ table, TO* __restrict__ out,
+                                                           unsigned char* __restrict__ keep_row, float* __restrict__ key_bias,
+                                                           int B, int T, int C, int Tp) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * 4 + w;
+    if (row >= (long)B * T) return;
+    const int b = (int)(row / T), t = (int)(row - (long)b * T);
+    const long len = len64 ? (long)((const long long*)lengths)[b] : (long)((const int*)lengths)[b];
+    const bool live = t < len;
+    const float* trow = table + (size_t)(live ? t + 1 : 0) * C;
+    for (int c = lane * V; c < C; c += 64 * V) {
+        float a[V], e[V], o[V];
+        nm_ldv<V>(seq, row * C + c, a);
+        nm_ldv<V>(trow, c, e);
+#pragma unroll
+        for (int q = 0; q < V; ++q) o[q] = a[q] + e[q];
+        nm_stv<V>(out, row * C + c, o);
+    }
+    const float ninf = -__builtin_huge_valf();
+    if (lane == 0) {
+        keep_row[row] = live ? 1 : 0;
+        if (key_bias) key_bias[(size_t)b * Tp + t] = live ? 0.f : ninf;
+    }
+    if (key_bias && t == T - 1 && lane < Tp - T) key_bias[(size_t)b * Tp + T + lane] = ninf;      // (Tp - T < 32)
+}
+
 static int nm_grid(long n) {
     long b = (n + 255) / 256;
     const long cap = 8L * MSMC_NUM_CU;
@@ -357,6 +393,25 @@ int msmc_add_ln_bwd(const void* g, const void* v, const float* mean, const float
     }
     MSMC_LAUNCH(add_ln_param_kernel, dim3((unsigned)(2 * ((C + 15) / 16))), dim3(256), 0, (msmc_stream_t)stream,
                 (const float*)workspace, nblocks, C, dgamma, dbeta, accumulate);
+    return msmc_check_launch();
+}
+
+int msmc_fft_prologue(const void* seq, const void* lengths, int len_is_64, const float* table, int table_rows, void* out,
+                      unsigned char* keep_row, float* key_bias, int B, int T, int C, int Tp, int in_dtype, int out_dtype,
+                      msmc_stream stream) {
+    if (!seq || !lengths || !table || !out || !keep_row || B <= 0 || T <= 0 || C <= 0 || T + 1 > table_rows) return MSMC_E_SHAPE;
+    if (key_bias && (Tp < T || Tp - T >= 64)) return MSMC_E_SHAPE;
+    if (in_dtype < 0 || in_dtype > 1 || out_dtype < 0 || out_dtype > 1) return MSMC_E_SHAPE;
+    const dim3 grid((unsigned)(((long)B * T + 3) / 4));
+#define NM_PRO(TI_, TO_, V_)                                                                                           \
+    MSMC_LAUNCH((fft_prologue_kernel<TI_, TO_, V_>), grid, dim3(256), 0, (msmc_stream_t)stream, (const TI_*)seq, lengths, \
+                len_is_64, table, (TO_*)out, keep_row, key_bias, B, T, C, Tp)
+    const bool vec = (C % 4) == 0;
+    if (in_dtype == 0 && out_dtype == 0) { if (vec) NM_PRO(float, float, 4); else NM_PRO(float, float, 1); }
+    else if (in_dtype == 0) { if (vec) NM_PRO(float, unsigned short, 4); else NM_PRO(float, unsigned short, 1); }
+    else if (out_dtype == 0) { if (vec) NM_PRO(unsigned short, float, 4); else NM_PRO(unsigned short, float, 1); }
+    else { if (vec) NM_PRO(unsigned short, unsigned short, 4); else NM_PRO(unsigned short, unsigned short, 1); }
+#undef NM_PRO
     return msmc_check_launch();
 }
 

@@ -143,6 +143,7 @@ _SIGNATURES.update({
     'msmc_add_ln_bwd_workspace': (_sz, [ctypes.c_long, _i]),
     'msmc_add_ln_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, ctypes.c_long, _i, _f, _vp,
                         ctypes.c_longlong, _i, _i, _vp]),
+    'msmc_fft_prologue': (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'msmc_gate_fwd': (_i, [_vp, _vp, ctypes.c_long, _i, _f, _vp, ctypes.c_longlong, _i, _vp]),
     'msmc_gate_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _i, _f, _vp, ctypes.c_longlong, _i, _vp]),
     'msmc_tanh_fwd': (_i, [_vp, _vp, ctypes.c_long, _i, _vp]),

@@ -117,6 +117,38 @@ def gate(x, p_drop=0.0, salt=0):
     return _Gate.apply(x, p_drop, salt)
 
 
+class _FftPrologue(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seq, lengths, table, out_dtype, Tp):
+        assert seq.dtype in _DT and out_dtype in _DT and seq.is_contiguous() and table.dtype == torch.float32
+        assert lengths.dtype in (torch.int32, torch.int64) and lengths.is_contiguous() and table.is_contiguous()
+        B, T, C = seq.shape
+        out = torch.empty((B, T, C), dtype=out_dtype, device=seq.device)
+        keep_row = torch.empty(B * T, dtype=torch.uint8, device=seq.device)
+        bias = torch.empty((B, Tp), dtype=torch.float32, device=seq.device) if Tp else None
+        lib.check(lib.get().msmc_fft_prologue(lib.ptr(seq), lib.ptr(lengths, lengths.dtype), int(lengths.dtype == torch.int64),
+                                              lib.ptr(table), table.shape[0], lib.ptr(out), lib.ptr(keep_row, torch.uint8),
+                                              lib.ptr(bias), B, T, C, int(Tp), _DT[seq.dtype], _DT[out_dtype],
+                                              lib.stream(seq)), 'msmc_fft_prologue')
+        ctx.in_dtype = seq.dtype
+        ctx.mark_non_differentiable(keep_row)
+        if bias is None:
+            return out, keep_row
+        ctx.mark_non_differentiable(bias)
+        return out, keep_row, bias
+
+    @staticmethod
+    def backward(ctx, g, *_):
+        return (g if g.dtype == ctx.in_dtype else g.to(ctx.in_dtype)), None, None, None, None
+
+
+def fft_prologue(seq, lengths, table, out_dtype, key_bias_width=0):
+    """seq [B, T, C] + sinusoid-table rows of the positions 1 .. len (0 on padding), in ``out_dtype``; the row mask
+    (uint8 [B T]) and, with ``key_bias_width`` = Tp > 0, the additive key-padding bias [B, Tp] of hip/attn.py -- one launch
+    (msmc_fft_prologue) for the head of FFTBlocks.forward and the positions its callers build."""
+    return _FftPrologue.apply(seq.contiguous(), lengths.contiguous(), table, out_dtype, int(key_bias_width))
+
+
 class _Tanh(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -47,7 +47,9 @@ def get_non_pad_mask(seq):
 
 # fused scaled_dot_product_attention for the FFT blocks (stock PyTorch-ROCm operator); MSMC_SDPA=0 keeps the bmm chain
 USE_SDPA = os.environ.get('MSMC_SDPA', '1') != '0'
-USE_HIP_ATTENTION = os.environ.get('MSMC_HIP_ATTENTION', '1') != '0'     # 0: stock fused attention also in bf16 (A/B)
+USE_HIP_ATTENTION = os.environ.get('MSMC_HIP_ATTENTION', '1') != '0'
+# 1: the head of FFTBlocks.forward as one launch when the caller passes ``lengths`` (off until measured on the GPU)
+FFT_PROLOGUE = os.environ.get('MSMC_FFT_PROLOGUE', '0') == '1'     # 0: stock fused attention also in bf16 (A/B)
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -241,7 +243,25 @@ class FFTBlocks(nn.Module):
             self._bank = ConvBank([l for attn, ffn in self._layers for l in attn + ffn])
         return self._bank, self._layers
 
-    def forward(self, seq, pos, return_attns=False, acts=None):
+    def forward(self, seq, pos, return_attns=False, acts=None, lengths=None):
+        """``lengths`` (optional, per-utterance frame counts): with MSMC_FFT_PROLOGUE=1 the positions 1 .. len / 0, the
+        positional-embedding add, the cast, the row mask and the key-padding bias are ONE launch (hip/norm.py
+        fft_prologue) and ``pos`` may be None."""
+        if (FFT_PROLOGUE and lengths is not None and self.use_hip and (seq.is_cuda or _interpreter_bound())
+                and seq.dtype in (torch.float32, torch.bfloat16)):
+            att0 = self.layer_stack[0].slf_attn
+            if USE_HIP_ATTENTION and hipattn.supported(self.hip_dtype, att0.d_k, att0.d_v):
+                bank, layers = self._hip()
+                bank.prepare(self.hip_dtype)
+                B, T = seq.shape[0], seq.shape[1]
+                out, keep_row, bias = hipnorm.fft_prologue(seq, lengths.to(seq.device), self.position.weight, self.hip_dtype,
+                                                           (T + 31) // 32 * 32)
+                for layer, (attn, ffn) in zip(self.layer_stack, layers):
+                    out = layer.forward_hip(out, keep_row, (bias,), (bank, attn), (bank, ffn))
+                return out, keep_row.view(torch.bool).view(B, T, 1)
+        if pos is None:
+            steps = torch.arange(1, seq.shape[1] + 1, device=seq.device).unsqueeze(0)
+            pos = steps * (steps <= lengths.to(seq.device).unsqueeze(1))
         keep = get_non_pad_mask(pos)
         out = seq + self.position(pos)
         if self.use_hip and (out.is_cuda or _interpreter_bound()):

@@ -24,6 +24,13 @@ def _positions(lengths, device, width):
     return pos.masked_fill(get_mask_from_lengths(lengths.to(device), width), 0)
 
 
+def _fft_pos(lengths, feat):
+    """the positions an FFT stack is called with; None when the stack derives them from ``lengths`` itself
+    (MSMC_FFT_PROLOGUE=1: acoustic_models/transformer.py FFTBlocks.forward)"""
+    from ..acoustic_models import transformer
+    return None if transformer.FFT_PROLOGUE else _positions(lengths, feat.device, feat.shape[1])
+
+
 class MultiStageEncoder(nn.Module):
     def __init__(self, in_channels, downsample_scales=[1], max_seq_len=2400, n_layers=4, n_head=2, d_k=64, d_v=64,
                  d_inner=1024, fft_conv1d_kernel=3, fft_conv1d_padding=1, dropout=0.2, attn_dropout=0.1,
@@ -45,7 +52,7 @@ class MultiStageEncoder(nn.Module):
                 feat = F.avg_pool1d(feat.transpose(1, 2), kernel_size=scale, stride=scale,
                                     ceil_mode=True).transpose(1, 2)
                 flen = torch.ceil(flen / scale).int()
-            feat, _ = enc(feat, _positions(flen, feat.device, feat.shape[1]))
+            feat, _ = enc(feat, _fft_pos(flen, feat), lengths=flen)
             outputs.append((feat, flen))
         return outputs
 
@@ -282,7 +289,7 @@ class MSMCVQGAN(nn.Module):
 
     def _decode_frames(self, x, lengths):
         if hasattr(self, 'frame_decoder'):
-            x, _ = self.frame_decoder(x, _positions(lengths, x.device, x.shape[1]))
+            x, _ = self.frame_decoder(x, _fft_pos(lengths, x), lengths=lengths)
         return x
 
     def forward(self, mel, mel_length, warmup=False, window=None):

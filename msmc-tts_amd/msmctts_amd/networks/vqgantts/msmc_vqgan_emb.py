@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from ...hip import norm as hipnorm
 from ..acoustic_models.transformer import FFTBlocks
 from ..hifigan.generator import Generator as HifiGANGenerator
-from .msmc_vqgan import MultiStageQuantizer, PriorPredictor, _positions
+from .msmc_vqgan import MultiStageQuantizer, PriorPredictor, _fft_pos
 
 
 class AttrPredictor(PriorPredictor):
@@ -61,7 +61,7 @@ class MAMSEncoder(nn.Module):
                 if self.use_pitch:
                     side = F.avg_pool1d(side.transpose(1, 2), kernel_size=scale, stride=scale, ceil_mode=True).transpose(1, 2)
                 flen = torch.ceil(flen / scale).int()
-            feat, _ = enc(feat, _positions(flen, feat.device, feat.shape[1]))
+            feat, _ = enc(feat, _fft_pos(flen, feat), lengths=flen)
             if not outputs:
                 content = feat
             if self.use_pitch:
@@ -92,7 +92,7 @@ class MSMCVQGANEmb(nn.Module):
 
     def _decode_frames(self, x, lengths):
         if hasattr(self, 'frame_decoder'):
-            x, _ = self.frame_decoder(x, _positions(lengths, x.device, x.shape[1]))
+            x, _ = self.frame_decoder(x, _fft_pos(lengths, x), lengths=lengths)
         return x
 
     def forward(self, emb, emb_length, pitch=None, energy=None, mel=None, ref=None, window='full'):

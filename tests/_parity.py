@@ -695,3 +695,31 @@ def check_vq_edge_cases(device):
     assert qq.shape == (0, 7, D) and dd.shape == (0, 7, D // H) and ii.shape == (0, 7, H)
     for m, b in zip(q.quantizers, before):
         assert torch.equal(m.embed, b)
+
+
+def check_fft_prologue(dev, B=5, T=45, C=24):
+    """csrc/norm.hip fft_prologue_kernel (MSMC_FFT_PROLOGUE=1, off by default): positions from lengths, positional-embedding
+    add, cast, row mask and key-padding bias in one launch -- bit for bit the chain of stock operators it replaces
+    (reference acoustic_models/transformer.py FFTBlocks.forward head, vqgantts/msmc_vqgan.py:56-58)"""
+    from msmctts_amd.hip import attn as hipattn, norm as hipnorm
+    from msmctts_amd.networks.acoustic_models.transformer import get_sinusoid_encoding_table
+    torch.manual_seed(4)
+    table = get_sinusoid_encoding_table(T + 3, C, padding_idx=0).to(dev)
+    for len_dtype in (torch.int32, torch.int64):
+        lengths = torch.tensor(([T, 1, 17, T - 1, 30] * B)[:B], dtype=len_dtype).to(dev)
+        steps = torch.arange(1, T + 1, device=dev).unsqueeze(0)
+        pos = steps * (steps <= lengths.unsqueeze(1))
+        for in_dt, out_dt in ((torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)):
+            seq = torch.randn(B, T, C).to(dev, in_dt).requires_grad_(True)
+            out, keep_row, bias = hipnorm.fft_prologue(seq, lengths, table, out_dt, (T + 31) // 32 * 32)
+            want = (seq.detach() + table[pos]).to(out_dt)
+            assert torch.equal(out, want), (in_dt, out_dt)
+            assert torch.equal(keep_row.view(B, T), pos.ne(0).to(torch.uint8))
+            assert torch.equal(bias, hipattn.pad_key_bias(pos))
+            g = torch.randn(B, T, C).to(dev, out_dt)
+            out.backward(g)
+            assert seq.grad.dtype == in_dt and torch.equal(seq.grad, g.to(in_dt))
+    seq = torch.randn(2, 7, 6).to(dev)                      # channel count without vector accesses, no bias
+    out, keep_row = hipnorm.fft_prologue(seq, torch.tensor([7, 3]).to(dev), table[:, :6].contiguous(), torch.float32)
+    pos = torch.tensor([[1, 2, 3, 4, 5, 6, 7], [1, 2, 3, 0, 0, 0, 0]]).to(dev)
+    assert torch.equal(out, seq + table[:, :6][pos]) and torch.equal(keep_row.view(2, 7), pos.ne(0).to(torch.uint8))

@@ -297,6 +297,13 @@ def test_fused_add_layernorm_gate_tanh_match_torch(dtype, tol):
     _parity.check_norm_kernels(DEV, dtype, tol)
 
 
+def test_fft_stack_prologue_is_bit_identical_to_the_operator_chain():
+    """csrc/norm.hip fft_prologue_kernel (MSMC_FFT_PROLOGUE=1, off by default) on the device, small and at the bench
+    configuration's size"""
+    _parity.check_fft_prologue(DEV)
+    _parity.check_fft_prologue(DEV, B=16, T=400, C=256)
+
+
 def test_hip_adamw_matches_torch_adamw_with_clipping():
     _parity.check_hip_adamw(DEV)
 

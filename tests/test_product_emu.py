@@ -1034,3 +1034,54 @@ def test_resblock_unit_in_one_launch(C, k, dil, L, nt):
     y_ref = F.conv1d(a_q, wt(w2), b2, 1, (k - 1) // 2, 1) + xc
     _parity.close(a.float().squeeze(1).transpose(1, 2), a_ref, 1e-2, 1e-2, what='a')
     _parity.close(y.float().squeeze(1).transpose(1, 2), y_ref, 2e-2, 2e-2, what='y')
+
+
+def test_fft_stack_prologue_equals_the_operator_chain():
+    _parity.check_fft_prologue('cpu')
+
+
+def test_fft_stack_with_the_fused_prologue_equals_the_stack_called_with_positions():
+    """FFTBlocks in bf16 on the HIP attention path: forward(seq, None, lengths=...) with MSMC_FFT_PROLOGUE on against
+    forward(seq, positions) -- same bits out, same gradient in"""
+    from msmctts_amd.networks.acoustic_models import transformer
+    torch.manual_seed(9)
+    stack = transformer.FFTBlocks(max_seq_len=100, n_layers=2, n_head=2, d_k=64, d_v=64, d_model=128, d_inner=256,
+                                  fft_conv1d_kernel=3, fft_conv1d_padding=1, dropout=0.0, name='t', attn_dropout=0.0)
+    stack.hip_dtype = torch.bfloat16
+    stack.train()
+    lengths = torch.tensor([37, 12, 1], dtype=torch.int32)
+    T = 37
+    steps = torch.arange(1, T + 1).unsqueeze(0)
+    pos = steps * (steps <= lengths.unsqueeze(1))
+    seq = torch.randn(3, T, 128)
+    go = torch.randn(3, T, 128).to(torch.bfloat16)
+    calls = []
+    real = transformer.hipnorm.fft_prologue
+    outs = []
+    keep_flag = transformer.FFT_PROLOGUE
+    try:
+        for fused in (False, True):
+            transformer.FFT_PROLOGUE = fused
+            transformer.hipnorm.fft_prologue = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+            x = seq.clone().requires_grad_(True)
+            out, keep = stack(x, None if fused else pos, lengths=lengths)
+            (out * go).sum().backward()
+            outs.append((out.detach(), keep, x.grad.clone()))
+            stack.zero_grad()
+    finally:
+        transformer.FFT_PROLOGUE = keep_flag
+        transformer.hipnorm.fft_prologue = real
+    assert calls == [1]                                   # only the fused run took the one-launch path
+    assert outs[0][0].dtype == torch.bfloat16 and torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_train_steps_match_reference_with_the_fused_fft_prologue():
+    """the same reference fixture with MSMC_FFT_PROLOGUE on (FFT stacks called with lengths instead of positions)"""
+    from msmctts_amd.networks.acoustic_models import transformer
+    keep = transformer.FFT_PROLOGUE
+    transformer.FFT_PROLOGUE = True
+    try:
+        _parity.check_train_steps('cpu')
+    finally:
+        transformer.FFT_PROLOGUE = keep
