@@ -70,13 +70,6 @@ int msmc_vq_search_shortlist(const float* x, const float* embed_t, const float* 
                              float* diff, int64_t* ind, unsigned long long* slow_count, int N, int D, int H, int K,
                              msmc_stream stream);
 
-/* DIAGNOSTICS (tools/bench_vq.py ABLATE=...), 0 in production (any other value selects a separate diagnostics build of the
- * kernel; results are garbage for bits 0-4): bit 0 one codeword tile instead of K/16, 1 no exact paths, 2 no codeword-row
- * gather, 3 no stores, 4 no frame loads, 5 phase timers: shader cycles per phase of a step of every wave of workgroup 0 into
- * slow_count[2 + 8 w ..] (slow_count then holds 2 + 8 * 8 words). */
-void msmc_vq_set_shortlist_ablate(int mask);
-/* Perf-experiment switch: 0 selects the LDS-tile search kernel for every shape; default 1. */
-void msmc_vq_set_variant(int v);
 /* Symbol of the search kernel the calling thread's most recent msmc_vq_search launched (profiling aid). */
 const char* msmc_vq_last_kernel(void);
 
@@ -186,23 +179,6 @@ typedef struct msmc_conv_desc {
                                times); the consumer sums the copies (msmc_wn_backward_multi does)                      */
 } msmc_conv_desc;
 
-/* Tests / sweeps: workgroups of the persistent grid of msmc_conv_gather variant 32 (0 = one or two per CU). */
-void msmc_conv_set_gather4_grid(int n);
-/* 1: the variant-32 members of msmc_conv_gather_group share ONE persistent grid (interpreter-tested, not yet timed on the
- * GPU); default 0: one launch per member. */
-void msmc_conv_set_gather4_grouping(int on);
-/* Perf-experiment switch: 0 selects the simple (un-pipelined) gather kernel everywhere; default 1. */
-void msmc_conv_set_pipeline(int on);
-/* Perf-sweep switches: force the weight-gradient pixel split (0 = model), allow 32-channel N tiles for small grids. */
-void msmc_conv_set_wgrad_split(int n);
-/* Perf-sweep switch: accumulators (32x32 output blocks) per wave of the second-generation weight gradient, 1..5 (default 5:
- * fewest re-reads of the staged tiles; fewer = more workgroups per CU). */
-void msmc_conv_set_wgrad_tpw(int n);
-/* 2 (default) = second-generation bf16 weight-gradient kernel, 1 = first generation (A/B tests) */
-void msmc_conv_set_wgrad_generation(int n);
-/* 2 (default) = second-generation forward / data-gradient gather kernel, 1 = first generation (A/B tests) */
-void msmc_conv_set_gather_generation(int n);
-void msmc_conv_set_narrow(int on);
 /* ---------------------------------------------------------------------------------------------
  * Attention core of the FFT blocks (bf16, head size 64): softmax(q k^T * scale + bias) (dropout) v per (batch, head),
  * q / k / v read in place from the fused projection, heads merged on the way out.  Replaces
@@ -242,8 +218,6 @@ int msmc_conv_gather(const msmc_conv_desc* desc, msmc_stream stream);
  * parallel ResBlocks of a generator stage; one layer of the five period / six resolution sub-discriminators).  Each
  * alone is a grid of tens to a few hundred workgroups; together they fill the 256 CUs. */
 int msmc_conv_gather_group(const msmc_conv_desc* descs, int n, msmc_stream stream);
-/* 0: grouped entry points launch their members one by one (A/B tests); default 1. */
-void msmc_conv_set_grouping(int on);
 
 /* dw[tap_w[t]][co][ci] += sum_{b,q} g[b][out(q)][co] * act(x[b][in(q, t)][ci])   (fp32 atomics; caller zeroes dw).
  * Geometry fields as for the forward convolution it differentiates; desc->x = x, desc->out unused,
@@ -262,10 +236,7 @@ int msmc_conv_wgrad_group(const msmc_conv_desc* descs, const void* const* g, flo
  * Fourth generation (desc->variant 4 / 5 / 6, msmc-tts_amd/csrc/wgrad4.inc): same contract and second stage; the
  * workgroup's pixel tiles (output gradient rows + the x rows all its taps touch) stream global -> LDS through a ring
  * filled by global_load_lds_dwordx4 while the matrix cores work on the previous tile.  Inside msmc_conv_wgrad_group_ws
- * such members join the shared grid as third-generation members.
- * msmc_conv_set_wgrad4_ablate: DIAGNOSTICS (tools/bench_wgrad_splits.py ABLATE=...), 0 in production: 1 skips the MFMA
- * steps, 2 the LDS-DMA stream; results are then garbage. */
-void msmc_conv_set_wgrad4_ablate(int mask);
+ * such members join the shared grid as third-generation members. */
 size_t msmc_conv_wgrad_workspace(const msmc_conv_desc* desc, const void* g);
 int msmc_conv_wgrad_ws(const msmc_conv_desc* desc, const void* g, float* dw, float* db, void* workspace,
                        size_t workspace_bytes, msmc_stream stream);
@@ -363,13 +334,6 @@ int msmc_reflect_fold_multi_tap(const void* const* gp, const void* const* mask_s
 int msmc_lrelu_bwd_multi(const void* const* g, const void* const* y, void* const* gx, const long* nelem, int n, float slope,
                          int dtype, msmc_stream stream);
 
-/* EXPERIMENTAL (measured by tools/bench_resunit.py, not on the train step's path): one ResBlock1 unit (reference
- * msmctts/networks/hifigan/common.py:44-51, one (c1, c2) pair) as ONE launch, bf16, C = 32 / 64 channels, odd k <= 11:
- *   a = lrelu(conv1d(lrelu(x), w1, dilation dil1) + b1);  y = conv1d(a, w2, dilation 1) + b2 + x
- * x, a, y [B][L][C]; w1, w2 [k][C][C] in the forward layout (tap, output channel, input channel); b1, b2 fp32 [C];
- * nt = tiles of 32 rows per wave step (2 or 3; anything else: chosen from the LDS footprint). */
-int msmc_resunit_forward(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* a, void* y,
-                         int B, int L, int C, int k, int dil1, float slope, int nt, msmc_stream stream);
 
 /* Column sums: out[c] = sum_rows g[row][c] (bias gradients); g dtype as above, out fp32 (overwritten). */
 int msmc_colsum(const void* g, float* out, long rows, int C, int dtype, msmc_stream stream);

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <msmc_rt.hpp>
 #include <msmc_hip.h>
+#include <msmc_hip_debug.h>
 
 #define CV_BM 128
 
@@ -2807,6 +2808,15 @@ extern "C" int msmc_conv_wgrad_reduce_pending(const msmc_wg_pending* items, int 
             int blocks = 0;
             for (; i < n && a.n < MSMC_GROUP_MAX; ++i) {
                 const msmc_wg_pending& p = items[i];
+                if (level == 1) {
+                    // a layer applied twice in one backward pass (D(real) and D(fake) as separate calls, rb(rb(x))) has two
+                    // records with the same accumulator: their `dw += sum` are plain read-modify-writes, so they must not
+                    // share a launch -- close this one, the next is ordered after it on the stream
+                    bool clash = false;
+                    for (int j = 0; j < a.n && !clash; ++j)
+                        clash = (a.dw[j] && a.dw[j] == p.dw) || (a.db[j] && a.db[j] == p.db);
+                    if (clash) break;
+                }
                 wg3_reduce_add(a, &blocks, p.ws, p.stride, p.n_dw, p.n_db, p.nsplit, p.mid, p.dw, p.db, level);
             }
             if (!a.n) continue;

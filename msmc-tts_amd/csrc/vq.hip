@@ -17,6 +17,7 @@
 // smoothing / renormalisation of the three buffers in place.
 #include <msmc_rt.hpp>
 #include <msmc_hip.h>
+#include <msmc_hip_debug.h>
 
 #define VQ_TILE 16
 #define VQ_LDS_LIMIT (160 * 1024)

@@ -249,6 +249,10 @@ class DeferredReduce(object):
         after the launches that wrote the partial results); the arena is free again afterwards"""
         if self.n:
             lib.check(lib.get().msmc_conv_wgrad_reduce_pending(self.records, self.n, stream), 'msmc_conv_wgrad_reduce_pending')
+        self.reset()
+
+    def reset(self):
+        """forget the recorded second stages and hand the arena back (also the way out of a backward pass that raised)"""
         self.n = 0
         for c in self.chunks:
             c[1] = 0

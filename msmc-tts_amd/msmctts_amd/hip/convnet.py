@@ -276,8 +276,15 @@ class ConvBank(object):
         if sig != self._sig:
             self._build(dtype)
             self._sig = sig
-        if self._pending_w:             # a backward pass that raised before its end-of-pass callback: its waiting weight
-            self._pending_w.clear()     # gradients must not ride along with the next pass
+        if self._pending_w or self.deferred.n:
+            # a backward pass that raised before its end-of-pass callback (no forward of a bank starts while its backward
+            # runs): its waiting weight gradients and the recorded second stages of its partial sums must not ride along
+            # with the next pass
+            self._pending_w.clear()
+            self.deferred.reset()
+            self._queued = False
+            self._touched = set()
+            del self._hold[:]
         lib.check(lib.get().msmc_wn_prepare_multi_tiled(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
                                                         self.total_tile_blocks, lib.stream(self.w1)),
                   'msmc_wn_prepare_multi_tiled')
@@ -389,6 +396,10 @@ class _HipConv(torch.autograd.Function):
         x, out = ctx.saved_tensors
         layer, bank = ctx.layer, ctx.bank
         if g is None:                                  # only the tap was used
+            if g_tap is not None and ctx.mask_slope != ctx.in_slope:
+                # the tap's gradient is that of a reader of the ACTIVATED map (the producer ran with out_masked and leaves
+                # the derivative to this node): the grouped form refuses the case, so does this one
+                raise RuntimeError('hip_conv: output unused but its tap carries a gradient through an activated input')
             return (g_tap,) + (None,) * 11
         g = g.contiguous()
         g_tap = _tap_grad(g_tap, g)

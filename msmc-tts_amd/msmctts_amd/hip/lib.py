@@ -26,8 +26,6 @@ _SIGNATURES = {
     'msmc_vq_shortlist_bytes': (_sz, [_i, _i, _i]),
     'msmc_vq_prepare_shortlist': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'msmc_vq_search_shortlist': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'msmc_vq_set_shortlist_ablate': (None, [_i]),
-    'msmc_vq_set_variant': (None, [_i]),
     'msmc_vq_last_kernel': (ctypes.c_char_p, []),
     'msmc_vq_ema_workspace': (_sz, [_i, _i, _i, _i]),
     'msmc_vq_ema_update': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _f, _f, _vp]),
@@ -96,17 +94,8 @@ _SIGNATURES.update({
     'msmc_mse_const_multi_bwd': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp]),
     'msmc_conv_gather': (_i, [ctypes.POINTER(ConvDesc), _vp]),
     'msmc_conv_gather_group': (_i, [ctypes.POINTER(ConvDesc), _i, _vp]),
-    'msmc_conv_set_grouping': (None, [_i]),
-    'msmc_conv_set_pipeline': (None, [_i]),
-    'msmc_conv_set_wgrad_split': (None, [_i]),
-    'msmc_conv_set_wgrad_generation': (None, [_i]),
-    'msmc_conv_set_wgrad4_ablate': (None, [_i]),
-    'msmc_conv_set_gather4_grid': (None, [_i]),
-    'msmc_conv_set_gather4_grouping': (None, [_i]),
-    'msmc_conv_set_gather_generation': (None, [_i]),
     'msmc_conv_last_kernel': (ctypes.c_char_p, []),
     'msmc_conv_launch_count': (ctypes.c_long, []),
-    'msmc_conv_set_narrow': (None, [_i]),
     'msmc_conv_wgrad': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     'msmc_conv_wgrad_group': (_i, [ctypes.POINTER(ConvDesc), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                               _i, _vp]),
@@ -116,7 +105,6 @@ _SIGNATURES.update({
                                  _i, _vp, _sz, _vp]),
     'msmc_conv_wgrad_group_ws4': (_i, [ctypes.POINTER(ConvDesc), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                   _i, _vp, _sz, _vp, _i]),
-    'msmc_conv_set_wgrad_tpw': (None, [_i]),
     'msmc_conv_wgrad_defer_begin': (None, [ctypes.POINTER(WgPending), _i]),
     'msmc_conv_wgrad_defer_end': (_i, []),
     'msmc_conv_wgrad_reduce_pending': (_i, [ctypes.POINTER(WgPending), _i, _vp]),
@@ -137,7 +125,6 @@ _SIGNATURES.update({
                                     ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), _i, _i, _f, _i, _vp]),
     'msmc_lrelu_bwd_multi': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_long), _i, _f, _i, _vp]),
     'msmc_colsum': (_i, [_vp, _vp, ctypes.c_long, _i, _i, _vp]),
-    'msmc_resunit_forward': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     'msmc_add_ln_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _i, _f, _f, _vp, ctypes.c_longlong,
                         _i, _vp]),
     'msmc_add_ln_bwd_workspace': (_sz, [ctypes.c_long, _i]),
@@ -154,14 +141,37 @@ _SIGNATURES.update({
     'msmc_reflect_fold': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
 })
 
+# include/msmc_hip_debug.h: process-global A/B switches, ablation masks and the experimental fused ResBlock unit -- exported by
+# the library for tools/ and tests/, not part of the product ABI
+_DEBUG_SIGNATURES = {
+    'msmc_vq_set_shortlist_ablate': (None, [_i]),
+    'msmc_vq_set_variant': (None, [_i]),
+    'msmc_conv_set_grouping': (None, [_i]),
+    'msmc_conv_set_pipeline': (None, [_i]),
+    'msmc_conv_set_wgrad_split': (None, [_i]),
+    'msmc_conv_set_wgrad_generation': (None, [_i]),
+    'msmc_conv_set_wgrad4_ablate': (None, [_i]),
+    'msmc_conv_set_gather4_grid': (None, [_i]),
+    'msmc_conv_set_gather4_grouping': (None, [_i]),
+    'msmc_conv_set_gather_generation': (None, [_i]),
+    'msmc_conv_set_narrow': (None, [_i]),
+    'msmc_conv_set_wgrad_tpw': (None, [_i]),
+    'msmc_resunit_forward': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+}
+
 
 def exported_symbols():
-    """Names every build of the library must export (checked by the CPU test-suite)."""
+    """Names of the product ABI (include/msmc_hip.h) every build of the library must export (checked by the CPU test-suite)."""
     return sorted(_SIGNATURES)
 
 
+def debug_symbols():
+    """Names of include/msmc_hip_debug.h (switches for tools/ and tests/)."""
+    return sorted(_DEBUG_SIGNATURES)
+
+
 def _bind(handle):
-    for name, (res, args) in _SIGNATURES.items():
+    for name, (res, args) in list(_SIGNATURES.items()) + list(_DEBUG_SIGNATURES.items()):
         fn = getattr(handle, name)
         fn.restype = res
         fn.argtypes = args

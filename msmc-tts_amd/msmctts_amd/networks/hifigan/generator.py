@@ -14,7 +14,7 @@ from ...hip.convnet import ConvBank, fork_join, hip_conv, hip_conv_group, make_s
 from ..layers import WNConv1d, WNConvTranspose1d
 from .common import LRELU_SLOPE, ResBlock1
 
-# the leaky-ReLU between the two convolutions of a ResBlock unit (reference vocoders/hifigan.py ResBlock1.forward) runs
+# the leaky-ReLU between the two convolutions of a ResBlock unit (reference msmctts/networks/hifigan/common.py:44-51 ResBlock1.forward) runs
 # once, in the first convolution's epilogue; the second reads the activated tensor (in_act) and applies the derivative in
 # its data-gradient epilogue
 ACT = dict(out_slope=LRELU_SLOPE, out_masked=True)

@@ -12,7 +12,7 @@ from torch.optim.optimizer import Optimizer
 
 
 class RAdam(Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0):
+    def __init__(self, params, lr=1e-3, betas=(0.5, 0.9), eps=1e-8, weight_decay=0):      # (the reference class defaults, radam.py:11)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
     @torch.no_grad()

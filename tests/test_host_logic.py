@@ -21,8 +21,12 @@ def test_c_abi_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, 'include', 'msmc_hip.h')).read()
     declared = set(re.findall(r'\b(msmc_[a-z0-9_]+)\s*\(', header))
     assert declared == set(lib.exported_symbols())
+    # the product ABI carries no process-global switch ("no hidden global state"): those live in the debug header
+    assert not [n for n in declared if '_set_' in n], sorted(n for n in declared if '_set_' in n)
+    debug = set(re.findall(r'\b(msmc_[a-z0-9_]+)\s*\(', open(os.path.join(ROOT, 'include', 'msmc_hip_debug.h')).read()))
+    assert debug == set(lib.debug_symbols()) and not (debug & declared)
     handle = ctypes.CDLL(lib.DEFAULT_PATH)
-    for name in declared:
+    for name in declared | debug:
         assert hasattr(handle, name), name
     assert lib.load().msmc_backend() == b'gfx950'
 
@@ -211,3 +215,73 @@ def test_conv_descriptor_is_the_same_in_header_binding_and_integration_doc():
     # the other by-value structs of the ABI, binding against header
     for cname, cls in (('msmc_opt_tensor', lib.OptTensor), ('msmc_wn_item', lib.WnItem)):
         assert [n for n, _ in cls._fields_] == [n for n, _ in _header_struct_fields(cname)], cname
+
+
+@pytest.mark.parametrize('case', ['csmsc', 'decay', 'default'])
+def test_radam_matches_the_reference_optimizer(case):
+    """``optimizer._name: RAdam`` (reference trainers/optimizers/__init__.py:8-21, radam.py:8-85) against parameters and
+    moments the reference's own class produced (tests/golden/make_golden_radam.py): eight steps through both branches of
+    the variance rectification, with and without weight decay, and with the class defaults."""
+    import numpy as np
+    from msmctts_amd.trainers.optimizers.radam import RAdam
+    kw = {'csmsc': dict(lr=2e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.0),
+          'decay': dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01), 'default': {}}[case]
+    z = np.load(os.path.join(GOLDEN, 'radam_cases.npz'))
+    n = len([k for k in z.files if k.startswith(case + '/p0/')])
+    params = [torch.nn.Parameter(torch.from_numpy(z['%s/p0/%d' % (case, i)].copy())) for i in range(n)]
+    opt = RAdam(params, **kw)
+    for t in range(8):
+        for i, p in enumerate(params):
+            p.grad = torch.from_numpy(z['%s/g%d/%d' % (case, t, i)].copy())
+        opt.step()
+        for i, p in enumerate(params):
+            want = z['%s/p%d/%d' % (case, t + 1, i)]
+            assert np.allclose(p.detach().numpy(), want, rtol=0, atol=1e-6), (case, t, i, np.abs(p.detach().numpy() - want).max())
+    for i, p in enumerate(params):
+        st = opt.state[p]
+        assert int(st['step']) == int(z['%s/step/%d' % (case, i)])
+        assert np.allclose(st['exp_avg'].numpy(), z['%s/exp_avg/%d' % (case, i)], rtol=0, atol=1e-6)
+        assert np.allclose(st['exp_avg_sq'].numpy(), z['%s/exp_avg_sq/%d' % (case, i)], rtol=0, atol=1e-6)
+
+
+def test_radam_is_selectable_from_the_optimizer_section():
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    from msmctts_amd.trainers.optimizers.radam import RAdam
+    from msmctts_amd.utils.config import Config
+    model = torch.nn.Module()
+    model.add_module('autoencoder', torch.nn.Linear(3, 2))
+    cfg = Config({'optimizer': {'_default': dict(_name='RAdam', learning_rate=1e-3, betas=[0.5, 0.9], eps=1e-8, weight_decay=0.0)}})
+    bundle = build_optimizer(model, cfg.optimizer)
+    assert isinstance(bundle.optimizers['autoencoder'], RAdam)
+    model.autoencoder.weight.grad = torch.ones(2, 3)
+    model.autoencoder.bias.grad = torch.ones(2)
+    before = model.autoencoder.weight.detach().clone()
+    bundle.step(['autoencoder'])
+    assert not torch.equal(before, model.autoencoder.weight)
+
+
+REF_CONFIGS = '/root/reference/examples/csmsc/configs'
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason='build-container test: needs the reference tree (never on the GPU box)')
+@pytest.mark.parametrize('name,mode,children', [('msmc_vq_gan.yaml', 'train', {'autoencoder': 0, 'discriminator': 0}),
+                                                ('msmc_vq_gan_am.yaml', 'train', {'predictor': 0})])
+def test_the_reference_yaml_files_load_unchanged(name, mode, children):
+    """The reference's own configuration files (examples/csmsc/configs/*.yaml) through Config -> build_task ->
+    build_trainer -> build_optimizer of this package: the plug-in names resolve, the constructors take the YAML's
+    keywords, and the checkpoint surface is the reference's (636 keys for the autoencoder + discriminator task,
+    tests/golden/schedule.json)."""
+    from msmctts_amd.tasks import build_task
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    from msmctts_amd.utils.config import Config
+    cfg = Config(os.path.join(REF_CONFIGS, name))
+    task = build_task(cfg, mode=mode)
+    assert set(n for n, _ in task.named_children()) >= set(children)
+    trainer = build_trainer(cfg, task, num_gpus=0, rank=0)
+    trainer.optimizer = build_optimizer(task, cfg.optimizer)
+    assert type(trainer).__name__ == cfg.trainer._name
+    sd = task.state_dict()
+    if name == 'msmc_vq_gan.yaml':
+        want = json.load(open(os.path.join(GOLDEN, 'schedule.json')))['csmsc_state_dict']
+        assert want == [[k, list(v.shape)] for k, v in sd.items()]
