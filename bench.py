@@ -58,7 +58,7 @@ def emit_line(out, kernels_path=None):
             except OSError as e:
                 sys.stderr.write('bench.py: could not write %s: %s\n' % (kernels_path, e))
     line = json.dumps(out)
-    for drop in (('roofline', 'note'), ('runtime', 'note'), ('step_flop_model',), ('warmup_phase', 'note'),
+    for drop in (('roofline', 'note'), ('roofline_step', 'note'), ('runtime', 'note'), ('step_flop_model',), ('warmup_phase', 'note'),
                  ('cpu_baseline', 'sample'), ('runtime',), ('losses',), ('vq_microbench',), ('warmup_phase',)):
         if len(line) <= LINE_LIMIT:
             break
@@ -110,11 +110,34 @@ class KernelTimer(object):
                 return inner(*args, **kw)
             i0 = timer.lib.msmc_prof_count()
             out = inner(*args, **kw)
-            timer.calls.append((i0, timer.lib.msmc_prof_count()) + tuple(work(*args, **kw)))
+            timer.calls.append((i0, timer.lib.msmc_prof_count()) + tuple(work(*args, **kw)) + (True,))
             timer.shapes.append(fn_name + ' ' + describe_call(args, kw))
             return out
 
         setattr(module, fn_name, timed)
+
+    def wrap_abi(self, L, name, work):
+        """wrap one C-ABI entry point of the loaded library (the helper families: normalisation, attention, losses,
+        spectral glue, VQ statistics ...): ``work(*args) -> (flops, bytes)`` from the call's own size arguments"""
+        inner = getattr(L, name)
+        timer = self
+
+        def timed(*args):
+            if not timer.enabled:
+                return inner(*args)
+            i0 = L.msmc_prof_count()
+            rc = inner(*args)
+            timer.calls.append((i0, L.msmc_prof_count()) + tuple(work(*args)) + (False,))
+            timer.shapes.append(name)
+            return rc
+
+        setattr(L, name, timed)
+
+    def note(self, name, i0, flops, byts):
+        """work of the launches issued since record ``i0`` by a host-level call (bank / optimizer passes)"""
+        if self.enabled:
+            self.calls.append((i0, self.lib.msmc_prof_count(), flops, byts, False))
+            self.shapes.append(name)
 
     def records(self):
         import ctypes
@@ -134,7 +157,7 @@ class KernelTimer(object):
             return []
         recs = self.records()
         out = {}
-        for (i0, i1, flops, byts), shape in zip(self.calls, self.shapes):
+        for (i0, i1, flops, byts, _), shape in zip(self.calls, self.shapes):
             o = out.setdefault(shape, dict(call=shape, calls=0, ms=0.0, kernels={}, gflop=0.0, mbytes=0.0))
             o['calls'] += 1
             o['gflop'], o['mbytes'] = flops / 1e9, byts / 1e6
@@ -152,8 +175,10 @@ class KernelTimer(object):
         if self.lib is None:
             return {}
         recs = self.records()
-        for i0, i1, flops, byts in self.calls:
-            main = [r for r in recs[i0:i1] if not r[0].startswith(self.HELPERS)]
+        for i0, i1, flops, byts, conv_call in self.calls:
+            # (inside a convolution entry point, helper launches -- partial-sum reduce, bias column sums -- take none of the
+            # convolution's work; a helper family's own call shares its work among all of its launches)
+            main = [r for r in recs[i0:i1] if not (conv_call and r[0].startswith(self.HELPERS))] or recs[i0:i1]
             tot = sum(r[1] for r in main)
             for r in main:
                 share = r[1] / tot if tot > 0 else 1.0 / len(main)
@@ -167,6 +192,90 @@ class KernelTimer(object):
             o['flops'] += f
             o['bytes'] += b
         return out
+
+
+def _val(v):
+    return getattr(v, 'value', v)
+
+
+def abi_work_models():
+    """{C-ABI entry point: work(*args) -> (algorithmic flops, algorithmic bytes)} for the helper families of the step, from
+    each call's own size arguments (include/msmc_hip.h gives the positions).  Bytes = every operand read or written once;
+    element sizes from the call's dtype code (0 fp32, 1 bf16)."""
+    E = lambda code: 4 if int(_val(code)) == 0 else 2
+    HEAD = 64
+
+    def table_bytes(tab_ref, passes):
+        tab = tab_ref._obj
+        e = E(tab.dtype)
+        return sum(int(tab.n[i]) for i in range(tab.count)) * e * passes
+
+    def fold(gp, mask, res, gx, B, H, W, C, n, p, slope, dt, st):
+        e, tot = E(dt), 0
+        for k in range(int(n)):
+            b, h, w, c = int(B[k]), int(H[k]), int(W[k]), int(C[k])
+            tot += b * c * ((h + 2 * p) * (w + 2 * p) + h * w * (1 + (1 if mask[k] else 0) + (1 if res is not None and res[k] else 0))) * e
+        return 0.0, float(tot)
+
+    def pending(items, n, st):          # second stage of the no-atomics weight gradients: 4 (splits + 1) |dW| bytes per record
+        tot = 0
+        for i in range(int(n)):
+            r = items[i]
+            tot += 4 * (int(r.nsplit) + 2) * (int(r.n_dw) + int(r.n_db))       # partials in, dW in and out
+        return 0.0, float(tot)
+
+    return {
+        'msmc_add_ln_fwd': lambda x, res, g, b, keep, y, v, mean, rstd, N, C, eps, p, seed, salt, dt, st:
+            (0.0, float(N * C * E(dt) * (3 + (1 if res else 0)) + 8 * N)),
+        'msmc_add_ln_bwd': lambda g, v, mean, rstd, gamma, keep, gx, gres, dga, dbe, ws, wsb, N, C, p, seed, salt, acc, dt, st:
+            (0.0, float(N * C * E(dt) * (3 + (1 if gres else 0)) + 8 * N)),
+        'msmc_attn_fwd': lambda qkv, bias, out, lse, B, T, H, Tp, *a:
+            (4.0 * T * T * HEAD * B * H, float(B * T * H * (3 * HEAD + HEAD) * 2)),
+        'msmc_attn_bwd': lambda qkv, bias, out, lse, dout, dqkv, dsum, B, T, H, Tp, *a:
+            (10.0 * T * T * HEAD * B * H, float(B * T * H * (3 * HEAD + HEAD) * 2 * 2)),
+        'msmc_fft_prologue': lambda seq, ln, l64, table, rows, out, keep, bias, B, T, C, Tp, idt, odt, st:
+            (0.0, float(B * T * C * (E(idt) + E(odt) + 4))),
+        'msmc_gate_fwd': lambda x, y, N, C, p, seed, salt, dt, st: (0.0, float(N * C * 3 * E(dt))),
+        'msmc_gate_bwd': lambda x, g, gx, N, C, p, seed, salt, dt, st: (0.0, float(N * C * 5 * E(dt))),
+        'msmc_tanh_fwd': lambda x, y, n, dt, st: (0.0, float(n * 2 * E(dt))),
+        'msmc_tanh_bwd': lambda y, g, gx, n, dt, st: (0.0, float(n * 3 * E(dt))),
+        'msmc_lrelu_bwd': lambda g, y, gx, n, slope, dt, st: (0.0, float(n * 3 * E(dt))),
+        'msmc_lrelu_bwd_multi': lambda g, y, gx, nelem, n, slope, dt, st:
+            (0.0, float(sum(int(nelem[k]) for k in range(int(n))) * 3 * E(dt))),
+        'msmc_reflect_fold_multi_res': fold,
+        'msmc_reflect_fold_multi_tap': fold,
+        'msmc_reflect_fold': lambda gp, mask, gx, B, H, W, C, p, slope, dt, st:
+            (0.0, float(B * C * ((H + 2 * p) * (W + 2 * p) + H * W * (2 if mask else 1)) * E(dt))),
+        'msmc_colsum': lambda g, out, rows, C, dt, st: (0.0, float(rows * C * E(dt) + 4 * C)),
+        'msmc_colsum_ws': lambda g, out, rows, C, dt, acc, ws, wsb, st: (0.0, float(rows * C * E(dt) + 4 * C)),
+        'msmc_masked_mean_fwd': lambda a, b, ln, l64, B, T, C, adt, bdt, mode, part, out, st:
+            (0.0, float(B * T * C * (E(adt) + (E(bdt) if mode else 0)))),
+        'msmc_masked_mean_bwd': lambda a, b, ln, l64, B, T, C, adt, bdt, mode, out, gout, ga, gb, st:
+            (0.0, float(B * T * C * ((E(adt) + E(bdt)) * (1 if mode else 0) + (E(adt) if ga else 0) + (E(bdt) if gb else 0)))),
+        'msmc_conv_wgrad_reduce_pending': pending,
+        'msmc_stft_frames_fwd': lambda x, fr, B, L, T, n_fft, NP, hop, pad, st: (0.0, 4.0 * B * (L + T * NP)),
+        'msmc_stft_frames_bwd': lambda gf, gx, B, L, T, n_fft, NP, hop, pad, st: (0.0, 4.0 * B * (L + T * NP)),
+        'msmc_spec_mag_fwd': lambda spec, mag, R, F, CP, FP, lo, mode, st: (0.0, 4.0 * R * (2 * F + F)),
+        'msmc_spec_mag_bwd': lambda spec, mag, gmag, gspec, R, F, CP, FP, lo, mode, st: (0.0, 4.0 * R * (2 * F + F + F + 2 * F)),
+        'msmc_mrd_image_fwd_dt': lambda mel, img, B, T, F, FP, dt, st: (0.0, float(B * T * F * (4 + 2 * E(dt)))),
+        'msmc_mrd_image_bwd_dt': lambda mel, gimg, gmel, B, T, F, FP, dt, st: (0.0, float(B * T * F * (8 + 2 * E(dt)))),
+        'msmc_mrd_image_fwd': lambda mel, img, B, T, F, FP, st: (0.0, 12.0 * B * T * F),
+        'msmc_mrd_image_bwd': lambda mel, gimg, gmel, B, T, F, FP, st: (0.0, 16.0 * B * T * F),
+        'msmc_log_clamp_fwd': lambda x, y, n, lo, st: (0.0, 8.0 * n),
+        'msmc_log_clamp_bwd': lambda x, g, gx, n, lo, st: (0.0, 12.0 * n),
+        'msmc_l1_multi_fwd': lambda tab, out, st: (0.0, float(table_bytes(tab, 2))),
+        'msmc_l1_multi_bwd': lambda tab, gout, st: (0.0, float(table_bytes(tab, 3))),
+        'msmc_mse_const_multi_fwd': lambda tab, target, out, st: (0.0, float(table_bytes(tab, 1))),
+        'msmc_mse_const_multi_bwd': lambda tab, target, gout, st: (0.0, float(table_bytes(tab, 2))),
+        'msmc_vq_prepare': lambda e, et, en, H, d, K, st: (0.0, 4.0 * H * d * K * 2 + 4.0 * H * K),
+        'msmc_vq_prepare_shortlist': lambda et, en, img, H, d, K, st: (0.0, 4.0 * H * d * K + 4.0 * H * d * K),
+        'msmc_vq_ema_update': lambda x, ind, ln, emb, cs, ea, ws, wsb, B, T, D, H, K, decay, eps, st:
+            (2.0 * B * T * D, float(B * T * (4 * D + 8 * H) + 4 * D * K * 4)),
+        'msmc_vq_ema_stats': lambda x, ind, ln, stats, ws, wsb, B, T, D, H, K, st:
+            (2.0 * B * T * D, float(B * T * (4 * D + 8 * H) + 4 * D * K)),
+        'msmc_vq_ema_apply': lambda stats, emb, cs, ea, D, H, K, decay, eps, st: (0.0, 4.0 * D * K * 4),
+        'msmc_vq_backward': lambda gq, gd, x, q, gx, N, D, H, st: (0.0, 16.0 * N * D + (4.0 * N * D / H if gd else 0.0)),
+    }
 
 
 def describe_call(args, kw):
@@ -195,8 +304,7 @@ def build(args, device, rank, world):
     from msmctts_amd.trainers import build_trainer
     from msmctts_amd.trainers.optimizers import build_optimizer
     from msmctts_amd.utils.config import Config
-    cfg = Config(csmsc_config(embedding_sizes=args.codewords, n_heads=args.heads, batch_size=args.batch,
-                              warmup_steps=0))
+    cfg = Config(csmsc_config(batch_size=args.batch, warmup_steps=0, **args.model_kw))
     torch.manual_seed(cfg.seed)
     task = build_task(cfg, mode='train')
     trainer = build_trainer(cfg, task, num_gpus=world, rank=rank)      # moves to GPU; arms RCCL reducer if world>1
@@ -312,10 +420,14 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--config', type=int, default=2, choices=[1, 2, 3, 5],
+                    help='BASELINE.json configuration (msmctts_amd/configs.py BASELINE_CONFIGS): 2 = the headline (CSMSC, 2 stages, '
+                         '4 heads x 256, B=16, one GPU); 1 = 1 stage, 1 head x 64, B=4; 3 = the LJSpeech-named copy of #2 meant for '
+                         '--gpus 8; 5 = 1024-wide input, 8 heads x 512, meant for --gpus 8.  --batch/--heads/--codewords override.')
+    ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--frames', type=int, default=400)
-    ap.add_argument('--heads', type=int, default=4)
-    ap.add_argument('--codewords', type=int, default=256)
+    ap.add_argument('--heads', type=int, default=None)
+    ap.add_argument('--codewords', type=int, default=None)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--cpu-steps', type=int, default=5, help='timed oracle steps per phase for cpu_baseline (0 = skip)')
     ap.add_argument('--cpu-warmup', type=int, default=2, help='untimed oracle steps per phase')
@@ -342,6 +454,16 @@ def main():
     ap.add_argument('--fp32-steps', type=int, default=3,
                     help='eager fp32 steps (the parity configuration) timed after the headline, 0 = skip')
     args = ap.parse_args()
+    from msmctts_amd.configs import BASELINE_CONFIGS
+    preset = BASELINE_CONFIGS[args.config]
+    args.model_kw = dict(preset['model'])
+    if args.heads is not None:
+        args.model_kw['n_heads'] = args.heads
+    if args.codewords is not None:
+        args.model_kw['embedding_sizes'] = args.codewords
+    args.heads, args.codewords = args.model_kw['n_heads'], args.model_kw['embedding_sizes']
+    args.batch = args.batch if args.batch is not None else preset['per_gpu_batch']
+    args.in_dim = args.model_kw.get('in_dim', 80)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     args.graph = args.graph or args.exec_mode in ('graph', 'auto')
@@ -364,7 +486,7 @@ def main():
         return
     cfg, trainer = build(args, device, rank, world)
     state0 = {k: v.detach().clone() for k, v in trainer.model.state_dict().items()} if rank == 0 and world == 1 else None
-    batch = make_batch(args.batch, args.frames, 80, 300, seed=1234, rank=rank, device='cpu')
+    batch = make_batch(args.batch, args.frames, args.in_dim, 300, seed=1234, rank=rank, device='cpu')
     lengths_host = batch['mel_length'].tolist()
     batch = {k: v.to(device) for k, v in batch.items()}
     batch['mel_length_host'] = lengths_host
@@ -435,6 +557,32 @@ def main():
     for fn, one in (('conv_forward_group', conv_work), ('conv_dgrad_group', dgrad_work), ('conv_wgrad_group', wgrad_work)):
         timer.wrap(hipconv, fn, last_kernel, group_work(one))
 
+    # every other hand-written kernel: C-ABI level (sizes are the call's own arguments)
+    L0 = lib.get()
+    for name, work in abi_work_models().items():
+        timer.wrap_abi(L0, name, work)
+    # weight-norm passes and the fused optimizer take device tables: their sizes come from the objects that own the tables
+    wn_elems, chunk = {}, L0.msmc_opt_chunk()
+
+    def wn_bytes(per_elem_of):
+        def work(items, nitems, *rest):
+            n, e = wn_elems.get(_val(items), (0, 2))
+            return 0.0, float(n * per_elem_of(e))
+        return work
+    # prepare: v read once, both kernel layouts written (+ the transposing pass's second read); backward: dW read and
+    # re-zeroed, v read, gradient written
+    timer.wrap_abi(L0, 'msmc_wn_prepare_multi_tiled', wn_bytes(lambda e: 8 + 2 * e))
+    timer.wrap_abi(L0, 'msmc_wn_backward_multi_acc', wn_bytes(lambda e: 16))
+    timer.wrap_abi(L0, 'msmc_opt_clip_adamw', lambda table, nt, nblocks, max_norm, *rest:
+                   (0.0, float(nblocks) * chunk * (28 + (4 if max_norm > 0 else 0))))
+
+    def register_banks():
+        import gc
+        from msmctts_amd.hip.convnet import ConvBank
+        for o in gc.get_objects():
+            if isinstance(o, ConvBank) and getattr(o, 'items_dev', None) is not None:
+                wn_elems[o.items_dev.data_ptr()] = (o.w1.numel(), o.w1.element_size())
+
     def step(i):
         if not trainer.use_graphs:
             trainer.model.zero_grad()
@@ -450,14 +598,21 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # per-step durations from events recorded on the step's stream between the steps (no host synchronisation inside the
+    # timed region: the headline stays the wall clock over all K steps; the events give the median SURVEY 8d asks for)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         log = step(args.warmup + i)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     # second pass over the same steps with HIP events around every hand-written launch (the events cost a
     # few percent of host time, so the headline value above is taken without them)
     ms_instr = None
@@ -467,6 +622,8 @@ def main():
         from msmctts_amd.hip import convnet
         convnet.STREAMS_ENABLED = False          # ... and one stream, so that an event pair brackets exactly one kernel
         trainer.model.zero_grad()
+        step(args.warmup + args.steps)           # (untimed: the eager banks / tables of this mode exist afterwards)
+        register_banks()
         timer.start(lib.get())
         t1 = time.perf_counter()
         for i in range(args.kernel_timing_steps):
@@ -474,7 +631,7 @@ def main():
             # execution only (an eager step is host-paced; without this the pairs would also time the GPU waiting
             # for the next launch packet and disagree with rocprofv3's per-kernel durations)
             torch.cuda._sleep(int(2.0e8))
-            step(args.warmup + args.steps + i)
+            step(args.warmup + args.steps + 1 + i)
         torch.cuda.synchronize()
         ms_instr = (time.perf_counter() - t1) / args.kernel_timing_steps * 1e3
         timer.stop()
@@ -549,8 +706,18 @@ def main():
                               mfma_peak_tflops=peak, frac_mfma=t_mfma / sec, frac_hbm=t_hbm / sec,
                               bytes_per_launch=rec['bytes'] / rec['launches'],
                               flops_per_launch=rec['flops'] / rec['launches'])
+    step_roof = None
     if kernels:
-        # (helper kernels carry no algorithmic work of their own: the roofline object is about a kernel that does)
+        # step-level figure: the time the step's launches would take at their rooflines / the time they took
+        t_roof = sum(max(rec['flops'] / ((MFMA_PEAK_TFLOPS['fp32'] if ('float' in label or label.startswith('vq_')) else mfma_peak) * 1e12),
+                         rec['bytes'] / (HBM_PEAK_GBS * 1e9)) for label, rec in ks.items()) / nst * 1e3
+        t_all = sum(rec['total_ms'] for rec in ks.values()) / nst
+        t_attr = sum(rec['total_ms'] for rec in ks.values() if rec['flops'] > 0 or rec['bytes'] > 0) / nst
+        step_roof = dict(roofline_ms_per_step=t_roof, kernel_ms_per_step=t_all, frac=t_roof / max(t_all, 1e-9),
+                         attributed_time_frac=t_attr / max(t_all, 1e-9),
+                         launches_per_step=sum(rec['launches'] for rec in ks.values()) / float(nst),
+                         note='sum over every hand-written launch of max(flops / dense MFMA peak of its dtype, bytes / 8 TB/s) '
+                              'divided by the summed launch durations (HIP events, instrumented single-stream steps)')
         label = max((k for k in kernels if kernels[k]['flops_per_launch'] > 0), key=lambda k: kernels[k]['ms_per_step'])
         k = kernels[label]
         traffic = mfma_util = None
@@ -577,17 +744,20 @@ def main():
     out = {
         'metric': 'mel-frames/sec MSMC-VQ-GAN train step (GAN phase)', 'value': value, 'unit': 'mel-frames/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'ms_per_step_median': ms_median, 'ms_per_step_min': per_step[0], 'ms_per_step_max': per_step[-1],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': 'CSMSC msmc_vq_gan 2-stage %d-head x %d-codeword VQ + HifiGAN + MPD/MRD, GAN phase'
-                               % (args.heads, args.codewords),
+        'config': {'workload': '%s: %d-stage %d-head x %d-codeword VQ + HifiGAN + MPD/MRD, GAN phase'
+                               % (preset['name'], len(args.model_kw.get('downsample_scales', (1, 4))), args.heads, args.codewords),
+                   'baseline_config': args.config, 'in_dim': args.in_dim,
                    'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'frames': args.frames,
                    'mel_frames_per_step': frames_per_step, 'parallelism': 'dp%d' % world,
                    'vq_search': 'fp32 (bit-exact indices)',
                    'execution': 'hipGraph replay (3 segments/step)' if args.graph else 'eager, multi-stream'},
-        'step_tflops': FLOP_PER_STEP_ELIDED * (args.batch / 16.0) * world / (elapsed / args.steps) / 1e12,
+        'step_tflops': (FLOP_PER_STEP_ELIDED * (args.batch / 16.0) * world / (elapsed / args.steps) / 1e12) if args.config in (2, 3) else None,
         'step_flop_model': 'SURVEY 8d: 3.006 TFLOP/step at B=16,T=400 minus the elided D weight-grads of the G step '
                            '= 2.65 TFLOP',
         'roofline': roof,
+        'roofline_step': step_roof,
         'kernels': kernels,
         'ms_per_step_instrumented': ms_instr,
         'fp32_ms_per_step': fp32_ms if fp32_err is None else fp32_err,

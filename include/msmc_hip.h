@@ -337,6 +337,11 @@ int msmc_lrelu_bwd_multi(const void* const* g, const void* const* y, void* const
 
 /* Column sums: out[c] = sum_rows g[row][c] (bias gradients); g dtype as above, out fp32 (overwritten). */
 int msmc_colsum(const void* g, float* out, long rows, int C, int dtype, msmc_stream stream);
+/* The same without atomics (bit-reproducible): per-block partial sums into ``workspace`` (msmc_colsum_workspace bytes), then a
+ * fixed-order sum; accumulate != 0: out += (the bias-gradient accumulators of a bank).  Two launches. */
+size_t msmc_colsum_workspace(long rows, int C);
+int msmc_colsum_ws(const void* g, float* out, long rows, int C, int dtype, int accumulate, void* workspace,
+                   size_t workspace_bytes, msmc_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * D3/L1  spectral front-ends as framed-DFT GEMMs on the matrix cores (exact-fp32 MFMA through
@@ -399,6 +404,21 @@ int msmc_l1_multi_bwd(const msmc_tensor_table* t, const float* gout, msmc_stream
 /* out[0] = sum_i mean_e (a_i[e] - target)^2 ;  ga_i[e] = gout[0] * 2 (a_i[e] - target) / n_i */
 int msmc_mse_const_multi_fwd(const msmc_tensor_table* t, float target, float* out, msmc_stream stream);
 int msmc_mse_const_multi_bwd(const msmc_tensor_table* t, float target, const float* gout, msmc_stream stream);
+
+/* Length-masked means over [B][T][C] tensors (rows t >= lengths[b] are padding): the scalar terms
+ *   QuantizerLoss                      reference msmctts/trainers/msmctts_trainer.py:52-62
+ *   frame loss                         reference msmctts/trainers/msmctts_trainer.py:129-133
+ *   'mse' embedding loss               reference msmctts/networks/vqgantts/msmc_vqgan.py:228-247
+ * as two launches forward (partial sums over the valid rows, then a fixed-order sum: bit-reproducible) and one backward,
+ * instead of ~10 stock kernels per term.  mode 0: out[0] = sum_valid a / sum_b lengths[b] / C; mode 1: the same over
+ * (a - b)^2.  a / b dtype codes 0 fp32, 1 bf16 (mode 0 ignores b); lengths int64 (len_is_64) or int32.  partial: fp32
+ * scratch of msmc_masked_mean_parts(B) floats; out: fp32[2] ([1] = 1 / (sum lengths * C), read by the backward pass).
+ * Backward: ga = gout[0] * d out[0] / d a (zeros on padding rows), gb = -ga; either may be NULL. */
+int msmc_masked_mean_parts(int B);
+int msmc_masked_mean_fwd(const void* a, const void* b, const void* lengths, int len_is_64, int B, int T, int C, int a_dtype,
+                         int b_dtype, int mode, float* partial, float* out, msmc_stream stream);
+int msmc_masked_mean_bwd(const void* a, const void* b, const void* lengths, int len_is_64, int B, int T, int C, int a_dtype,
+                         int b_dtype, int mode, const float* out, const float* gout, void* ga, void* gb, msmc_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * E1/V3  fused element-wise / row-normalisation kernels of the FFT blocks and the quantiser glue (csrc/norm.hip).

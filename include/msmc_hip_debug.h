@@ -1,7 +1,7 @@
 /* msmc_hip_debug.h -- NOT part of the product ABI (include/msmc_hip.h).
  *
  * Process-global A/B switches, ablation masks and one experimental entry point that libmsmc_hip.so also exports for the
- * perf tools (tools/*.py), the CPU kernel-interpreter tests and the forced-variant GPU tests.  A production caller never
+ * perf tools (tools/), the CPU kernel-interpreter tests and the forced-variant GPU tests.  A production caller never
  * includes this header: every kernel choice that matters to a caller is per call (msmc_conv_desc.variant / split_shift),
  * and the product package (msmc-tts_amd/msmctts_amd) touches none of these except the two environment-driven sweeps read
  * once in hip/lib.py (MSMC_WGRAD_TPW, MSMC_GATHER4_GROUPING).  All switches are plain ints read at launch time.

@@ -3597,6 +3597,60 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, fl
     if (tid < C) atomicAdd(out + tid, red[tid]);
 }
 
+// Column sums without atomics (the bias gradients of the transposed convolutions: 10^4 - 10^5 rows of 32-256 channels; the
+// atomic form above serialises several hundred same-address atomics per column: 38 us for 12 MB): a block sums a contiguous
+// range of rows into part[block][C]; colsum_final_kernel adds the blocks in order (bit-reproducible) into out (+=).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ g, float* __restrict__ part, long rows, int C,
+                                                         int rows_per_block) {
+    __shared__ float red[256];
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    const int tid = threadIdx.x;
+    float* dst = part + (size_t)blockIdx.x * C;
+    if (C >= 256 || (256 % C) != 0) {               // one or more whole columns per work-item
+        for (int c = tid; c < C; c += 256) {
+            float s = 0.f;
+            for (long r = r0; r < r1; ++r) s = s + Elt<T>::ld(g + r * C + c);
+            dst[c] = s;
+        }
+        return;
+    }
+    const long n = (r1 - r0) * C;                   // C divides 256: the flat index tid + 256 k stays on column tid % C
+    const T* base = g + r0 * C;
+    float s = 0.f;
+    for (long e = tid; e < n; e += 256) s = s + Elt<T>::ld(base + e);
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 128; st >= C; st >>= 1) {
+        if (tid < st) red[tid] = red[tid] + red[tid + st];
+        __syncthreads();
+    }
+    if (tid < C) dst[tid] = red[tid];
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nblocks, int C,
+                                                           float* __restrict__ out, int accumulate) {
+    __shared__ float red[256];
+    // 256 / CG slices of blocks per column group of CG = min(C, 256) columns, each summed in order, then added in order
+    const int CG = C < 256 ? C : 256, slices = 256 / CG;
+    for (int c0 = blockIdx.x * CG; c0 < C; c0 += gridDim.x * CG) {
+        const int c = c0 + (int)(threadIdx.x % CG), sl = threadIdx.x / CG;
+        const int per = (nblocks + slices - 1) / slices, b0 = sl * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+        float s = 0.f;
+        if (sl < slices && c < C)
+            for (int b = b0; b < b1; ++b) s = s + part[(size_t)b * C + c];
+        __syncthreads();
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (sl == 0 && c < C) {
+            float t = red[threadIdx.x];
+            for (int q = 1; q < slices; ++q) t = t + red[q * CG + threadIdx.x];
+            out[c] = accumulate ? out[c] + t : t;
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void reflect_fold_kernel(const T* __restrict__ gp, const T* __restrict__ mask,
                                                           T* __restrict__ gx, int B, int H, int W, int C, int p,
@@ -3829,6 +3883,30 @@ int msmc_reflect_fold_multi_tap(const void* const* gp, const void* const* mask_s
                                 const int* B, const int* H, const int* W, const int* C, int n, int p, float slope, int dtype,
                                 msmc_stream stream) {
     return fold_multi_impl(gp, mask_src, tap, gx, B, H, W, C, n, p, slope, dtype, 1, stream);
+}
+
+static int colsum_blocks(long rows) {
+    long nb = (rows + 63) / 64;                      // >= 64 rows per block, at most two blocks per CU
+    if (nb > 512) nb = 512;
+    return (int)(nb < 1 ? 1 : nb);
+}
+size_t msmc_colsum_workspace(long rows, int C) { return rows > 0 && C > 0 ? (size_t)colsum_blocks(rows) * C * sizeof(float) : 0; }
+int msmc_colsum_ws(const void* g, float* out, long rows, int C, int dtype, int accumulate, void* workspace,
+                   size_t workspace_bytes, msmc_stream stream) {
+    if (!g || !out || rows <= 0 || C <= 0) return MSMC_E_SHAPE;
+    if (!workspace || workspace_bytes < msmc_colsum_workspace(rows, C)) return MSMC_E_WORKSPACE;
+    const int nb = colsum_blocks(rows);
+    const int rpb = (int)((rows + nb - 1) / nb);
+    float* part = (float*)workspace;
+    if (dtype == 0) MSMC_LAUNCH(colsum_part_kernel<float>, dim3(nb), dim3(256), 0, (msmc_stream_t)stream, (const float*)g, part, rows, C, rpb);
+    else if (dtype == 1) MSMC_LAUNCH(colsum_part_kernel<unsigned short>, dim3(nb), dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)g, part, rows, C, rpb);
+    else return MSMC_E_SHAPE;
+    int rc = msmc_check_launch();
+    if (rc) return rc;
+    const int used = (int)((rows + rpb - 1) / rpb);  // (blocks that own rows)
+    MSMC_LAUNCH(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, (msmc_stream_t)stream, (const float*)part, used, C, out,
+                accumulate);
+    return msmc_check_launch();
 }
 
 }  // extern "C"

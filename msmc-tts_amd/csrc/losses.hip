@@ -75,6 +75,75 @@ __global__ __launch_bounds__(256) void loss_multi_bwd_kernel(msmc_tensor_table t
 
 __global__ void loss_zero_kernel(float* p) { p[0] = 0.f; }
 
+// ---- masked means over [B][T][C] tensors with per-utterance lengths ------------------------------------------------------
+// The length-masked scalar terms of the step -- QuantizerLoss (reference msmctts_trainer.py:52-62: diff.masked_fill(pad, 0)
+// .sum() / length.sum() / C), the frame loss (:129-133: the same over mse(mel, mel_outputs)) and the 'mse' embedding loss of
+// the prior predictor (vqgantts/msmc_vqgan.py:228-247) -- were chains of ~10 stock kernels each (arange, compare,
+// masked_fill, sum, sum of lengths, two divisions ...).  Here: partial sums per (block, utterance) over the VALID rows only,
+// one single-workgroup launch that adds them in a fixed order (bit-reproducible) and divides, and one backward launch.
+// MODE 0: sum a;  MODE 1: sum (a - b)^2.
+MSMC_DEV long loss_len(const void* len, int is64, int b) {
+    return is64 ? (long)((const long long*)len)[b] : (long)((const int*)len)[b];
+}
+#define MM_BX 32
+template <typename TA, typename TB, int MODE>
+__global__ __launch_bounds__(256) void masked_mean_partial_kernel(const TA* __restrict__ a, const TB* __restrict__ b,
+                                                                  const void* __restrict__ len, int is64, int T, int C,
+                                                                  float* __restrict__ part) {
+    __shared__ float red[256];
+    const int bi = blockIdx.y;
+    long L = loss_len(len, is64, bi);
+    if (L > T) L = T;
+    if (L < 0) L = 0;
+    const long n = L * C, base = (long)bi * T * C;
+    float s = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)MM_BX * 256) {
+        const float av = LEl<TA>::ld(a + base + e);
+        if (MODE == 0) {
+            s = s + av;
+        } else {
+            const float dlt = av - LEl<TB>::ld(b + base + e);
+            s = fmaf(dlt, dlt, s);
+        }
+    }
+    s = loss_block_sum(s, red);
+    if (threadIdx.x == 0) part[bi * MM_BX + blockIdx.x] = s;
+}
+// out[0] = (sum of the partials in index order) / sum_b len_b / C;  out[1] = 1 / (sum_b len_b * C) for the backward pass
+__global__ __launch_bounds__(256) void masked_mean_final_kernel(const float* __restrict__ part, int nparts,
+                                                                const void* __restrict__ len, int is64, int B, int T, int C,
+                                                                float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int k = threadIdx.x; k < nparts; k += 256) s = s + part[k];
+    s = loss_block_sum(s, red);
+    if (threadIdx.x == 0) {
+        float tot = 0.f;                                   // (the reference sums the lengths as they are: no clamp to T)
+        for (int b = 0; b < B; ++b) tot = tot + (float)loss_len(len, is64, b);
+        out[0] = s / tot / (float)C;
+        out[1] = 1.f / tot / (float)C;
+    }
+}
+// ga = gout * out[1] * (MODE 0: 1, MODE 1: 2 (a - b)) on valid rows, 0 on padding; gb = -ga (when asked for)
+template <typename TA, typename TB, int MODE>
+__global__ __launch_bounds__(256) void masked_mean_bwd_kernel(const TA* __restrict__ a, const TB* __restrict__ b,
+                                                              const void* __restrict__ len, int is64, int T, int C,
+                                                              const float* __restrict__ out, const float* __restrict__ gout,
+                                                              TA* __restrict__ ga, TB* __restrict__ gb) {
+    const int bi = blockIdx.y;
+    long L = loss_len(len, is64, bi);
+    if (L > T) L = T;
+    if (L < 0) L = 0;
+    const long n = (long)T * C, nv = L * C, base = (long)bi * T * C;
+    const float k = gout[0] * out[1];
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        float g = 0.f;
+        if (e < nv) g = MODE == 0 ? k : 2.f * (LEl<TA>::ld(a + base + e) - LEl<TB>::ld(b + base + e)) * k;
+        if (ga) LEl<TA>::st(ga + base + e, g);
+        if (gb) LEl<TB>::st(gb + base + e, -g);
+    }
+}
+
 template <int MODE>
 static int loss_launch(const msmc_tensor_table* t, float target, float* out, const float* gout, bool bwd,
                        msmc_stream stream) {
@@ -100,7 +169,52 @@ static int loss_launch(const msmc_tensor_table* t, float target, float* out, con
     return msmc_check_launch();
 }
 
+template <typename TA, typename TB>
+static int masked_mean_go(const void* a, const void* b, const void* len, int is64, int B, int T, int C, int mode, float* part,
+                          float* out, const float* gout, void* ga, void* gb, bool bwd, msmc_stream stream) {
+    const dim3 grid(MM_BX, (unsigned)B);
+    if (!bwd) {
+        if (mode == 0) MSMC_LAUNCH((masked_mean_partial_kernel<TA, TB, 0>), grid, dim3(256), 0, (msmc_stream_t)stream, (const TA*)a, (const TB*)b, len, is64, T, C, part);
+        else MSMC_LAUNCH((masked_mean_partial_kernel<TA, TB, 1>), grid, dim3(256), 0, (msmc_stream_t)stream, (const TA*)a, (const TB*)b, len, is64, T, C, part);
+        int rc = msmc_check_launch();
+        if (rc) return rc;
+        MSMC_LAUNCH(masked_mean_final_kernel, dim3(1), dim3(256), 0, (msmc_stream_t)stream, (const float*)part, B * MM_BX, len, is64, B, T, C, out);
+    } else {
+        long bx = ((long)T * C + 2047) / 2048;
+        if (bx > 64) bx = 64;
+        if (bx < 1) bx = 1;
+        const dim3 g2((unsigned)bx, (unsigned)B);
+        if (mode == 0) MSMC_LAUNCH((masked_mean_bwd_kernel<TA, TB, 0>), g2, dim3(256), 0, (msmc_stream_t)stream, (const TA*)a, (const TB*)b, len, is64, T, C, (const float*)out, gout, (TA*)ga, (TB*)gb);
+        else MSMC_LAUNCH((masked_mean_bwd_kernel<TA, TB, 1>), g2, dim3(256), 0, (msmc_stream_t)stream, (const TA*)a, (const TB*)b, len, is64, T, C, (const float*)out, gout, (TA*)ga, (TB*)gb);
+    }
+    return msmc_check_launch();
+}
+static int masked_mean_dispatch(const void* a, const void* b, const void* len, int is64, int B, int T, int C, int a_dtype,
+                                int b_dtype, int mode, float* part, float* out, const float* gout, void* ga, void* gb, bool bwd,
+                                msmc_stream stream) {
+    if (!a || !len || !out || B <= 0 || T <= 0 || C <= 0 || (mode != 0 && mode != 1) || (mode == 1 && !b)) return MSMC_E_SHAPE;
+    if (!bwd && !part) return MSMC_E_WORKSPACE;
+    if (bwd && !gout) return MSMC_E_SHAPE;
+    if (mode == 0) b_dtype = a_dtype;
+    if (a_dtype == 0 && b_dtype == 0) return masked_mean_go<float, float>(a, b, len, is64, B, T, C, mode, part, out, gout, ga, gb, bwd, stream);
+    if (a_dtype == 0 && b_dtype == 1) return masked_mean_go<float, unsigned short>(a, b, len, is64, B, T, C, mode, part, out, gout, ga, gb, bwd, stream);
+    if (a_dtype == 1 && b_dtype == 0) return masked_mean_go<unsigned short, float>(a, b, len, is64, B, T, C, mode, part, out, gout, ga, gb, bwd, stream);
+    if (a_dtype == 1 && b_dtype == 1) return masked_mean_go<unsigned short, unsigned short>(a, b, len, is64, B, T, C, mode, part, out, gout, ga, gb, bwd, stream);
+    return MSMC_E_SHAPE;
+}
+
 extern "C" {
+int msmc_masked_mean_parts(int B) { return B * MM_BX; }
+int msmc_masked_mean_fwd(const void* a, const void* b, const void* lengths, int len_is_64, int B, int T, int C, int a_dtype,
+                         int b_dtype, int mode, float* partial, float* out, msmc_stream stream) {
+    return masked_mean_dispatch(a, b, lengths, len_is_64, B, T, C, a_dtype, b_dtype, mode, partial, out, nullptr, nullptr, nullptr,
+                                false, stream);
+}
+int msmc_masked_mean_bwd(const void* a, const void* b, const void* lengths, int len_is_64, int B, int T, int C, int a_dtype,
+                         int b_dtype, int mode, const float* out, const float* gout, void* ga, void* gb, msmc_stream stream) {
+    return masked_mean_dispatch(a, b, lengths, len_is_64, B, T, C, a_dtype, b_dtype, mode, nullptr, (float*)out, gout, ga, gb, true,
+                                stream);
+}
 int msmc_l1_multi_fwd(const msmc_tensor_table* t, float* out, msmc_stream stream) {
     return loss_launch<0>(t, 0.f, out, nullptr, false, stream);
 }

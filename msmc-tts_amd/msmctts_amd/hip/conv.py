@@ -755,12 +755,18 @@ def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None, copi
     return dw
 
 
-def colsum(g2d):
-    """g [rows, C] (fp32 / bf16) -> fp32 [C] column sums (bias gradient)."""
+def colsum(g2d, out=None):
+    """g [rows, C] (fp32 / bf16) -> fp32 [C] column sums (bias gradient), added to ``out`` when given (no atomics: per-block
+    partial sums + a fixed-order second stage, msmc_colsum_ws)."""
     rows, C = g2d.shape
-    out = torch.empty(C, dtype=torch.float32, device=g2d.device)
-    lib.check(lib.get().msmc_colsum(lib.ptr(g2d), lib.ptr(out), rows, C, _DT[g2d.dtype], lib.stream(g2d)),
-              'msmc_colsum')
+    L = lib.get()
+    acc = out is not None
+    if out is None:
+        out = torch.empty(C, dtype=torch.float32, device=g2d.device)
+    need = int(L.msmc_colsum_workspace(rows, C))
+    ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=g2d.device)
+    lib.check(L.msmc_colsum_ws(lib.ptr(g2d), lib.ptr(out, torch.float32), rows, C, _DT[g2d.dtype], int(acc), lib.ptr(ws), need,
+                               lib.stream(g2d)), 'msmc_colsum_ws')
     return out
 
 

@@ -16,6 +16,7 @@ import contextlib
 import ctypes
 
 import os
+import weakref
 
 import torch
 from torch.autograd import Variable
@@ -134,9 +135,45 @@ class ConvLayer(object):
         return g
 
 
+# The kernel-layout weight images of a bank only change when its parameters do.  A step runs the discriminator three times
+# (D step, then twice against the updated D) and the next step's first pass still sees the weights of the previous step's
+# last two: ``prepare`` launches nothing while the bank is CLEAN -- no optimizer step of its parameters since the last
+# refresh (``params_updated``, called by HipAdamW, whose raw-pointer update torch's version counters cannot see) and no
+# in-place torch operation on them either (their ``_version`` counters: load_state_dict, init, the capture roll-back).
+# MSMC_SKIP_CLEAN_PREPARE=0 refreshes on every forward pass (A/B).
+SKIP_CLEAN_PREPARE = os.environ.get('MSMC_SKIP_CLEAN_PREPARE', '1') != '0'
+_BANKS = weakref.WeakSet()
+
+
+def params_updated(owner, params):
+    """an optimizer wrote ``params`` through raw pointers: the banks holding any of them must refresh their weight images"""
+    ptrs = getattr(owner, '_msmc_ptrs', None)
+    if ptrs is None or ptrs[0] != len(params):
+        ptrs = owner._msmc_ptrs = (len(params), frozenset(p.data_ptr() for p in params))
+    for bank in list(_BANKS):
+        hit = bank._owner_hits.get(id(owner))
+        if hit is None or hit[0] is not ptrs:
+            hit = bank._owner_hits[id(owner)] = (ptrs, bool(bank.param_ptrs() & ptrs[1]))
+        if hit[1]:
+            bank.dirty = True
+
+
+def refresh_stale_banks():
+    """eager refresh of every bank whose parameters changed behind a captured step's back (checkpoint load between replays,
+    the roll-back of the capture warm-up): the replayed graphs only refresh a bank where the capture saw it dirty"""
+    for bank in list(_BANKS):
+        if bank._sig is not None and (bank.dirty or bank._clean_versions != bank._versions()):
+            bank.prepare(bank.dtype)
+
+
 class ConvBank(object):
     def __init__(self, layers):
         self.layers = list(layers)
+        self.dirty = True               # kernel-layout weights older than the parameters (see SKIP_CLEAN_PREPARE)
+        self._clean_versions = None
+        self._owner_hits = {}
+        self._ptrs = None
+        _BANKS.add(self)
         for i, l in enumerate(self.layers):
             l.index = i
         self._sig = None
@@ -270,12 +307,28 @@ class ConvBank(object):
         self.items_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.dtype = dtype
 
-    def prepare(self, dtype):
-        """Refresh kernel-layout weights from (weight_v, weight_g): one launch for the whole network."""
+    def _weight_params(self):
+        for l in self.layers:
+            yield l.weight
+            if not l.plain:
+                yield l.module.weight_g
+
+    def _versions(self):
+        return tuple(p._version for p in self._weight_params())
+
+    def param_ptrs(self):
+        if self._ptrs is None or self._ptrs[0] != self._sig:
+            self._ptrs = (self._sig, frozenset(p.data_ptr() for p in self._weight_params()))
+        return self._ptrs[1]
+
+    def prepare(self, dtype, force=False):
+        """Refresh kernel-layout weights from (weight_v, weight_g): one call (two launches) for the whole network -- skipped
+        while the bank is clean (see SKIP_CLEAN_PREPARE)."""
         sig = self._signature(dtype)
         if sig != self._sig:
             self._build(dtype)
             self._sig = sig
+            self.dirty = True
         if self._pending_w or self.deferred.n:
             # a backward pass that raised before its end-of-pass callback (no forward of a bank starts while its backward
             # runs): its waiting weight gradients and the recorded second stages of its partial sums must not ride along
@@ -285,9 +338,13 @@ class ConvBank(object):
             self._queued = False
             self._touched = set()
             del self._hold[:]
+        versions = self._versions()
+        if SKIP_CLEAN_PREPARE and not force and not self.dirty and versions == self._clean_versions:
+            return
         lib.check(lib.get().msmc_wn_prepare_multi_tiled(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
                                                         self.total_tile_blocks, lib.stream(self.w1)),
                   'msmc_wn_prepare_multi_tiled')
+        self.dirty, self._clean_versions = False, versions
 
     # -- end-of-backward: kernel-layout dW -> parameter gradients --------------------------------------
     def _queue_finish(self):
@@ -444,7 +501,7 @@ class _HipConv(torch.autograd.Function):
                     else:
                         K.conv_transpose1d_wgrad(x, g, layer.kernel[1], layer.stride[1], layer.padding[1],
                                                  in_slope=ctx.in_slope, dw=layer.dw, copies=layer.dw_copies)
-                        layer.db.add_(K.colsum(g.reshape(-1, g.shape[-1])))
+                        K.colsum(g.reshape(-1, g.shape[-1]), out=layer.db)
             bank._touched.add(layer.index)
             bank._queue_finish()
         if ctx.has_res or ctx.has_res2:

@@ -92,6 +92,9 @@ _SIGNATURES.update({
     'msmc_l1_multi_bwd': (_i, [ctypes.POINTER(TensorTable), _vp, _vp]),
     'msmc_mse_const_multi_fwd': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp]),
     'msmc_mse_const_multi_bwd': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp]),
+    'msmc_masked_mean_parts': (_i, [_i]),
+    'msmc_masked_mean_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'msmc_masked_mean_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'msmc_conv_gather': (_i, [ctypes.POINTER(ConvDesc), _vp]),
     'msmc_conv_gather_group': (_i, [ctypes.POINTER(ConvDesc), _i, _vp]),
     'msmc_conv_last_kernel': (ctypes.c_char_p, []),
@@ -125,6 +128,8 @@ _SIGNATURES.update({
                                     ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i), _i, _i, _f, _i, _vp]),
     'msmc_lrelu_bwd_multi': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(ctypes.c_long), _i, _f, _i, _vp]),
     'msmc_colsum': (_i, [_vp, _vp, ctypes.c_long, _i, _i, _vp]),
+    'msmc_colsum_workspace': (_sz, [ctypes.c_long, _i]),
+    'msmc_colsum_ws': (_i, [_vp, _vp, ctypes.c_long, _i, _i, _i, _vp, _sz, _vp]),
     'msmc_add_ln_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _i, _f, _f, _vp, ctypes.c_longlong,
                         _i, _vp]),
     'msmc_add_ln_bwd_workspace': (_sz, [ctypes.c_long, _i]),

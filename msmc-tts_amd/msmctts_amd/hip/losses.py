@@ -97,3 +97,44 @@ def l1_sum(fake, real):
 def mse_const_sum(tensors, target):
     """sum_i mean((t_i - target)^2)  -- the LSGAN terms of the D and G steps."""
     return _MseConstSum.apply(float(target), *tensors)
+
+
+class _MaskedMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, lengths, mode):
+        assert a.dim() == 3 and a.dtype in _DT and a.is_contiguous(), 'masked_mean takes contiguous [B, T, C] tensors'
+        assert b is None or (b.shape == a.shape and b.dtype in _DT and b.is_contiguous())
+        assert lengths.dtype in (torch.int32, torch.int64) and lengths.is_contiguous() and lengths.numel() == a.shape[0]
+        B, T, C = a.shape
+        L = lib.get()
+        part = torch.empty(L.msmc_masked_mean_parts(B), dtype=torch.float32, device=a.device)
+        out = torch.empty(2, dtype=torch.float32, device=a.device)
+        lib.check(L.msmc_masked_mean_fwd(lib.ptr(a), lib.ptr(b), lib.ptr(lengths), int(lengths.dtype == torch.int64), B, T, C,
+                                         _DT[a.dtype], _DT[b.dtype] if b is not None else 0, mode, lib.ptr(part), lib.ptr(out),
+                                         lib.stream(a)), 'msmc_masked_mean_fwd')
+        ctx.save_for_backward(a, b, lengths, out)
+        ctx.mode = mode
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b, lengths, out = ctx.saved_tensors
+        B, T, C = a.shape
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if (b is not None and ctx.needs_input_grad[1]) else None
+        g = gout.reshape(1).float().contiguous()
+        lib.check(lib.get().msmc_masked_mean_bwd(lib.ptr(a), lib.ptr(b), lib.ptr(lengths), int(lengths.dtype == torch.int64), B, T,
+                                                 C, _DT[a.dtype], _DT[b.dtype] if b is not None else 0, ctx.mode, lib.ptr(out),
+                                                 lib.ptr(g), lib.ptr(ga), lib.ptr(gb), lib.stream(a)), 'msmc_masked_mean_bwd')
+        return ga, gb, None, None
+
+
+def masked_mean(a, lengths, b=None):
+    """sum over the valid rows (t < lengths[b]) of ``a`` -- or of ``(a - b)^2`` -- divided by ``lengths.sum() * C``:
+    the length-masked scalar terms of the step (QuantizerLoss, frame loss, 'mse' embedding loss) in two launches."""
+    return _MaskedMean.apply(a.contiguous(), None if b is None else b.contiguous(), lengths.contiguous(), 0 if b is None else 1)
+
+
+def usable(*tensors):
+    """the fused loss ops run on the GPU (or on the kernel interpreter in the CPU tests)"""
+    return all(t is None or t.is_cuda or lib._host_pointers_ok for t in tensors)

@@ -155,19 +155,127 @@ def projection(mat, device):
     return W.unsqueeze(0).contiguous().to(device), W.t().unsqueeze(0).contiguous().to(device)
 
 
+_GEOMS = {}
+
+
+def _geom1(T):
+    """geometry of a one-tap GEMM over [B, 1, T, C] rows (cached: its descriptors and tuner choices live on it)"""
+    g = _GEOMS.get(T)
+    if g is None:
+        K._bounded(_GEOMS, 256)
+        g = _GEOMS[T] = K.Geometry(1, T, (1, 1))
+    return g
+
+
+class MrdFront(object):
+    """Every tensor of one ``mrd_image`` evaluation (frames -> spectrum -> magnitude -> mel-scaled magnitude -> image),
+    kept so that (a) the backward pass of the chain is five launches on the saved tensors and (b) a LATER consumer of some
+    rows of the same waveforms -- the generator step, which shows the discriminator the batch the D step already framed and
+    transformed: the front-end has no parameters -- reuses the image and back-propagates through its rows only
+    (``image_rows``) instead of recomputing 25 launches per pass."""
+
+    def __init__(self, x, n_fft, hop, dft, fb, dtype):
+        B, L = x.shape
+        self.B, self.L, self.n_fft, self.hop, self.dft, self.fb, self.dtype = B, L, n_fft, hop, dft, fb, dtype
+        F = self.F = n_fft // 2 + 1
+        T = self.T = L // hop + 1
+        lo, n_eff = dft[2], dft[3]
+        self.frame_args = (T, n_eff, _pad4(n_eff), hop, n_fft // 2 - lo)
+        Lb = lib.get()
+        xc = x.detach().contiguous().float()
+        fr = torch.empty((B, 1, T, _pad4(n_eff)), dtype=torch.float32, device=x.device)
+        lib.check(Lb.msmc_stft_frames_fwd(lib.ptr(xc), lib.ptr(fr), B, L, T, n_eff, _pad4(n_eff), hop, n_fft // 2 - lo,
+                                          lib.stream(xc)), 'msmc_stft_frames_fwd')
+        geom = _geom1(T)
+        self.spec = K.conv_forward(fr, dft[0], geom)
+        CP, FP = self.spec.shape[-1], _pad4(F)
+        self.mag = torch.empty((B, 1, T, FP), dtype=torch.float32, device=x.device)
+        lib.check(Lb.msmc_spec_mag_fwd(lib.ptr(self.spec), lib.ptr(self.mag), B * T, F, CP, FP, 1e-7, 1, lib.stream(xc)),
+                  'msmc_spec_mag_fwd')
+        self.mel = K.conv_forward(self.mag, fb[0], geom) if fb is not None else self.mag
+        self.img = torch.empty((B, F, T, 2), dtype=dtype, device=x.device)
+        lib.check(Lb.msmc_mrd_image_fwd_dt(lib.ptr(self.mel), lib.ptr(self.img), B, T, F, FP, _IMG_DT[dtype], lib.stream(xc)),
+                  'msmc_mrd_image_fwd_dt')
+
+    def image(self, r0, r1):
+        """rows r0 .. r1-1 of the image: a view where the kernels can take it (16-byte aligned -- any row offset that is a
+        multiple of 8: the training batches), a copy otherwise"""
+        v = self.img[r0:r1]
+        return v if v.data_ptr() % 16 == 0 else v.clone()
+
+    def backward_rows(self, g, r0, r1):
+        """gradient of the waveform rows r0 .. r1-1 from the gradient ``g`` of their image rows"""
+        b, T, F = r1 - r0, self.T, self.F
+        FP, CP = self.mag.shape[-1], self.spec.shape[-1]
+        Lb = lib.get()
+        g = g.contiguous()
+        if g.dtype != self.dtype:
+            g = g.to(self.dtype)
+        mel, mag, spec = self.mel[r0:r1], self.mag[r0:r1], self.spec[r0:r1]
+        gm = torch.empty_like(mel)
+        lib.check(Lb.msmc_mrd_image_bwd_dt(lib.ptr(mel), lib.ptr(g), lib.ptr(gm), b, T, F, FP, _IMG_DT[self.dtype],
+                                           lib.stream(g)), 'msmc_mrd_image_bwd_dt')
+        geom = _geom1(T)
+        if self.fb is not None:
+            gm = K.conv_dgrad(gm, self.fb[1], geom)
+        gs = torch.empty_like(spec)
+        lib.check(Lb.msmc_spec_mag_bwd(lib.ptr(spec), lib.ptr(mag), lib.ptr(gm), lib.ptr(gs), b * T, F, CP, FP, 1e-7, 1,
+                                       lib.stream(g)), 'msmc_spec_mag_bwd')
+        gfr = K.conv_dgrad(gs, self.dft[1], geom)
+        T_, n_eff, NP, hop, pad = self.frame_args
+        gx = torch.empty((b, self.L), dtype=torch.float32, device=g.device)
+        lib.check(Lb.msmc_stft_frames_bwd(lib.ptr(gfr), lib.ptr(gx), b, self.L, T_, n_eff, NP, hop, pad, lib.stream(g)),
+                  'msmc_stft_frames_bwd')
+        return gx
+
+
+class _MrdImage2(torch.autograd.Function):
+    """the whole chain as ONE autograd node: forward = MrdFront(x), backward = MrdFront.backward_rows over all rows"""
+
+    @staticmethod
+    def forward(ctx, x, n_fft, hop, dft, fb, dtype):
+        ctx.front = MrdFront(x, n_fft, hop, dft, fb, dtype)
+        img, ctx.front.img = ctx.front.img, None         # (the node must not hold its own output: a reference cycle)
+        return img
+
+    @staticmethod
+    def backward(ctx, g):
+        f = ctx.front
+        return f.backward_rows(g, 0, f.B), None, None, None, None, None
+
+
+class _MrdImageRows(torch.autograd.Function):
+    """rows r0 .. r1-1 of an image an earlier ``MrdFront`` computed from the same waveform rows; ``x`` (those rows of the
+    waveform, possibly with a gradient history the earlier evaluation did not have) only ties the node into the graph"""
+
+    @staticmethod
+    def forward(ctx, x, front, r0, r1):
+        assert x.shape == (r1 - r0, front.L), (x.shape, r0, r1, front.L)
+        ctx.front, ctx.rows = front, (r0, r1)
+        return front.image(r0, r1)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.front.backward_rows(g, *ctx.rows), None, None, None
+
+
 def mrd_image(x, n_fft, hop, dft, fb, dtype=torch.float32):
     """x (B, L) -> MRD input image, channels-last [B, F, T', 2] (ch0 mel-scaled magnitude, ch1 normalised log), written
     in ``dtype`` (the discriminator stack's compute dtype: the spectra themselves stay fp32)."""
-    B, L = x.shape
-    F = n_fft // 2 + 1
-    T = L // hop + 1
-    lo, n_eff = dft[2], dft[3]
-    fr = _Frames.apply(x, T, n_eff, _pad4(n_eff), hop, n_fft // 2 - lo)
-    spec = _ConstGemm.apply(fr, dft[0], dft[1])
-    mag = _SpecMag.apply(spec, F, _pad4(F), 1e-7, 1)
-    if fb is not None:
-        mag = _ConstGemm.apply(mag, fb[0], fb[1])
-    return _MrdImage.apply(mag, F, dtype)
+    return _MrdImage2.apply(x, n_fft, hop, dft, fb, dtype)
+
+
+def mrd_front(x, n_fft, hop, dft, fb, dtype=torch.float32):
+    """the same evaluation as an object whose image (``.img``) and intermediates outlive the call (no autograd: for
+    waveforms without gradient history -- the D step's detached batch)"""
+    return MrdFront(x, n_fft, hop, dft, fb, dtype)
+
+
+def mrd_image_rows(x, front, r0, r1):
+    """image rows r0 .. r1-1 of ``front`` as a function of ``x`` (= the waveform rows they were computed from)"""
+    if not x.requires_grad:
+        return front.image(r0, r1)
+    return _MrdImageRows.apply(x.contiguous(), front, r0, r1)
 
 
 def stft_magnitude(x, n_fft, hop, dft, lo):

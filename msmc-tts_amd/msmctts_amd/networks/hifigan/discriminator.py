@@ -130,6 +130,28 @@ class MultiPeriodDiscriminator(nn.Module):
         return [lambda d=d, ls=ls: d.forward_hip(bank, ls, y, dtype) for d, ls in zip(self.discriminators, layers)]
 
 
+class SpectralFronts(object):
+    """The resolution discriminators' input images of one batch of waveforms (one hip/spectral.py MrdFront per hop length),
+    computed once and shown to the discriminator again later: the framed-DFT front-end has no parameters, so the generator
+    step's two passes (fake with gradient, real without) read rows of the images the D step already built from the very
+    same waveforms -- 50 launches per step less (``VQGANTrainer._segment_a / _segment_b``)."""
+
+    def __init__(self, fronts, r0, r1, wav=None):
+        self.fronts, self.r0, self.r1, self.wav = fronts, r0, r1, wav
+
+    def rows(self, r0, r1, wav=None):
+        """the sub-batch r0 .. r1-1; ``wav``: those rows of the waveform WITH their gradient history (the generator's
+        output), so that the images' gradient flows back through the saved front-end tensors"""
+        return SpectralFronts(self.fronts, self.r0 + r0, self.r0 + r1, wav)
+
+    def images(self):
+        from ...hip import spectral
+        if self.wav is None:
+            return [f.image(self.r0, self.r1) for f in self.fronts]
+        wav = self.wav.squeeze(1) if self.wav.dim() == 3 else self.wav
+        return [spectral.mrd_image_rows(wav.float(), f, self.r0, self.r1) for f in self.fronts]
+
+
 class Discriminator(nn.Module):
     def __init__(self, mrd_config, mpd_config):
         super().__init__()
@@ -148,25 +170,36 @@ class Discriminator(nn.Module):
             self._bank.streams = self._streams
         return self._bank, self._layers
 
-    def forward(self, y):
+    def spectral_fronts(self, y):
+        """the resolution discriminators' images of waveforms ``y`` (B, L) / (B, 1, L) WITHOUT gradient history, as an
+        object later passes can take rows from (``forward(.., fronts=...)``)"""
+        wav = y.squeeze(1) if y.dim() == 3 else y
+        return SpectralFronts([stft.front(wav.detach(), self.hip_dtype) for stft in self.mrd.stfts], 0, wav.shape[0])
+
+    def forward(self, y, fronts=None):
+        """``fronts`` (optional): SpectralFronts for exactly these waveforms -- the resolution discriminators then read its
+        images instead of framing and transforming ``y`` again (grouped execution only)"""
         if y.dim() == 2:
             y = y.unsqueeze(1)
         bank, (mrd, mpd) = self._hip()
         bank.prepare(self.hip_dtype)
         if convnet.GROUPED:
-            return self._forward_grouped(bank, mrd, mpd, y)
+            return self._forward_grouped(bank, mrd, mpd, y, fronts)
         # the ten sub-discriminators are independent chains of small launches: one HIP stream each
         outs = fork_join(self._streams, self.mrd.thunks(bank, mrd, y, self.hip_dtype) +
                          self.mpd.thunks(bank, mpd, y, self.hip_dtype), inputs=(y,))
         return [o[0] for o in outs], [o[1] for o in outs]
 
-    def _forward_grouped(self, bank, mrd, mpd, y):
+    def _forward_grouped(self, bank, mrd, mpd, y, fronts=None):
         """The sub-discriminators advance layer by layer: layer i of all six resolution (all five period) stacks is ONE
         grouped launch (hip_conv_group) -- each of them alone is a grid of tens to hundreds of workgroups."""
         dtype = self.hip_dtype
         assert self.mrd.domain == 'double', 'every shipped config uses the two-channel (mag, log-mag) image'
         wav = y.squeeze(1)
-        xs = [stft.image_cl(wav, dtype) for stft in self.mrd.stfts]      # (images written in the compute dtype: no cast launches)
+        if fronts is not None and fronts.fronts[0].dtype == dtype and fronts.r1 - fronts.r0 == wav.shape[0]:
+            xs = fronts.images()
+        else:
+            xs = [stft.image_cl(wav, dtype) for stft in self.mrd.stfts]      # (images written in the compute dtype: no cast launches)
         r_fmaps = [[] for _ in xs]
         last = len(mrd[0]) - 1
         xs = hip_conv_group(bank, [dict(layer=mrd[j][0], x=xs[j], **ACT) for j in range(len(xs))])

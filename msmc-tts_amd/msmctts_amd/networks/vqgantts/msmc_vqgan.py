@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...hip import losses as hiploss
 from ...hip import norm as hipnorm
 from ...hip.convnet import ConvBank, ConvLayer, hip_conv
 from ...utils.utils import get_mask_from_lengths
@@ -231,6 +232,15 @@ class MultiStageQuantizer(nn.Module):
                 continue
             weights = loss_weights[i] if isinstance(loss_weights[0], (list, tuple)) else loss_weights
             for method, weight in zip(methods, weights):
+                lengths = st['target_lengths']
+                if (method == 'mse' and p.dim() == 3 and hiploss.usable(p) and p.dtype in (torch.float32, torch.bfloat16)
+                        and st['target_outputs'].dtype in (torch.float32, torch.bfloat16) and torch.is_tensor(lengths)
+                        and lengths.device == p.device and lengths.dtype in (torch.int32, torch.int64)):
+                    # mean over channels, masked sum over frames, / sum of lengths: one fused masked mean (two launches)
+                    loss = hiploss.masked_mean(p, lengths, b=st['target_outputs'].detach())
+                    losses['embed_loss_%s_%d' % (method, i)] = loss
+                    losses['total_loss'] = losses['total_loss'] + loss * weight
+                    continue
                 if method == 'mse':
                     loss = F.mse_loss(p, st['target_outputs'].detach(), reduction='none').mean(-1)
                 elif method == 'softmax':
@@ -243,7 +253,6 @@ class MultiStageQuantizer(nn.Module):
                     loss = self.quantizer[i].compute_triple_loss(p, st['target_indices'], reduction='sum')
                 else:
                     raise NotImplementedError('embedding loss %r' % method)
-                lengths = st['target_lengths']
                 loss = loss.masked_fill(get_mask_from_lengths(lengths.to(loss.device), loss.shape[1]), 0)
                 loss = loss.sum() / lengths.sum()
                 losses['embed_loss_%s_%d' % (method, i)] = loss

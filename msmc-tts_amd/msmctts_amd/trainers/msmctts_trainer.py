@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..hip import convnet as hipconvnet
 from ..hip import losses as hiploss
 from ..hip import vq as hipvq
 from ..utils.utils import get_mask_from_lengths
@@ -41,8 +42,11 @@ class QuantizerLoss(nn.Module):
             length = outputs['encoder_lengths'][i]
             terms = terms if isinstance(terms, (tuple, list)) else [terms]
             for j, term in enumerate(terms):
-                pad = get_mask_from_lengths(length.to(term.device), term.shape[1]).unsqueeze(-1)
-                term = term.masked_fill(pad, 0).sum() / length.sum() / term.shape[2]
+                if _fused_masked(term, length):
+                    term = hiploss.masked_mean(term, length)       # sum over valid rows / (sum of lengths * channels), two launches
+                else:
+                    pad = get_mask_from_lengths(length.to(term.device), term.shape[1]).unsqueeze(-1)
+                    term = term.masked_fill(pad, 0).sum() / length.sum() / term.shape[2]
                 loss['latent_loss_{}_{}'.format(i, j)] = term
                 loss['vq_loss'] = loss['vq_loss'] + self.lambda_vq * term
         dd = outputs.get('decoder_diffs')
@@ -51,6 +55,12 @@ class QuantizerLoss(nn.Module):
             loss['vq_loss'] = loss['vq_loss'] + self.lambda_pr * dd.pop('total_loss')
             loss.update(dd)
         return loss
+
+
+def _fused_masked(x, lengths):
+    """the length-masked mean runs as csrc/losses.hip's masked_mean (GPU, or the interpreter in the CPU tests)"""
+    return (torch.is_tensor(x) and x.dim() == 3 and x.dtype in (torch.float32, torch.bfloat16) and hiploss.usable(x)
+            and torch.is_tensor(lengths) and lengths.device == x.device and lengths.dtype in (torch.int32, torch.int64))
 
 
 @contextlib.contextmanager
@@ -96,6 +106,8 @@ class VQGANTrainer(BaseTrainer):
         self.rng = random              # python global RNG, like the reference (:214); tests inject their own
         self._amp_applied = None
         self.batch_g_step = os.environ.get('MSMC_BATCH_G_STEP', '0') != '0'
+        # the generator step reads the spectral front-end images the D step built from the same waveforms (A/B: 0)
+        self.reuse_fronts = os.environ.get('MSMC_REUSE_FRONTS', '1') != '0'
         self.use_graphs = False        # replay the GAN-phase step as three hipGraphs (static shapes)
         self._graphs = None
         self.amp_autocast = True       # False: only the HIP conv stacks compute in amp_dtype, stock operators stay fp32
@@ -140,9 +152,13 @@ class VQGANTrainer(BaseTrainer):
         losses.update(vq)
         g_loss = vq['vq_loss']
         if 'mel_outputs' in out:
-            ml = F.mse_loss(mel, out['mel_outputs'].float(), reduction='none')
-            ml = ml.masked_fill(get_mask_from_lengths(mel_length, ml.shape[1]).unsqueeze(-1), 0)
-            ml = ml.sum() / mel_length.sum() / ml.shape[2]
+            if _fused_masked(out['mel_outputs'], mel_length) and mel.dtype == torch.float32 and mel.is_contiguous():
+                # masked mean of (mel - mel_outputs)^2, the prediction read in its own dtype (no cast pass)
+                ml = hiploss.masked_mean(out['mel_outputs'], mel_length, b=mel)
+            else:
+                ml = F.mse_loss(mel, out['mel_outputs'].float(), reduction='none')
+                ml = ml.masked_fill(get_mask_from_lengths(mel_length, ml.shape[1]).unsqueeze(-1), 0)
+                ml = ml.sum() / mel_length.sum() / ml.shape[2]
             losses['frame_loss'] = ml
             g_loss = g_loss + self.lambda_frame * ml
         st.g_loss = g_loss
@@ -160,8 +176,12 @@ class VQGANTrainer(BaseTrainer):
         # D(fake.detach()) and D(real) as ONE pass over the concatenated batch (every layer is per-sample, so
         # the scores are those of two separate passes): half the launches, twice the work per launch
         B = predict.shape[0]
+        both = torch.cat((predict.detach(), target), dim=0)
+        # the resolution discriminators' framed-DFT images of [fake; real], kept for the generator step (same waveforms,
+        # no parameters in the front-end): computed here once per step
+        st.fronts = disc.spectral_fronts(both) if (self.reuse_fronts and hasattr(disc, 'spectral_fronts')) else None
         with self._amp():
-            both_scores, _ = disc(torch.cat((predict.detach(), target), dim=0))
+            both_scores, _ = disc(both, fronts=st.fronts) if st.fronts is not None else disc(both)
         halves = [_SplitBatch.apply(s_, B) for s_ in both_scores]
         d_fake = hiploss.mse_const_sum([h[0] for h in halves], 0.0)   # LSGAN, summed over the 10 sub-discriminators
         d_real = hiploss.mse_const_sum([h[1] for h in halves], 1.0)
@@ -183,6 +203,13 @@ class VQGANTrainer(BaseTrainer):
                 fake_scores = [s_[:B] for s_ in scores]
                 fake_feats = [[f_[:B] for f_ in fl] for fl in feats]
                 real_feats = [[f_[B:].detach() for f_ in fl] for fl in feats]
+            elif getattr(st, 'fronts', None) is not None:
+                B = st.predict.shape[0]
+                with _frozen(disc), self._amp():
+                    fake_scores, fake_feats = disc(st.predict, fronts=st.fronts.rows(0, B, wav=st.predict))
+                    with torch.no_grad():
+                        _, real_feats = disc(st.target, fronts=st.fronts.rows(B, 2 * B))
+                st.fronts = None
             else:
                 with _frozen(disc), self._amp():
                     fake_scores, fake_feats = disc(st.predict)
@@ -255,6 +282,7 @@ class VQGANTrainer(BaseTrainer):
             st.mel.copy_(batch['mel'], non_blocking=True)
             st.mel_length.copy_(batch['mel_length'], non_blocking=True)
             g['wav'].copy_(batch['wav'].reshape(g['wav'].shape), non_blocking=True)
+        hipconvnet.refresh_stale_banks()               # (parameters changed behind the graphs' back: checkpoint load ...)
         g['a'].replay()
         self._sync_codebooks(g['codebooks'])
         self._sync_grads_static('discriminator', g)
@@ -349,7 +377,7 @@ class VQGANTrainer(BaseTrainer):
         # Drop every reference to the warm-up autograd graphs (their AccumulateGrad nodes are bound to a
         # stream) and capture on the SAME side stream the warm-up ran on, so that gradient accumulation is
         # recorded into the graphs instead of running on another stream.
-        for name in ('losses', 'g_loss', 'predict', 'target', 'frame_window'):
+        for name in ('losses', 'g_loss', 'predict', 'target', 'frame_window', 'fronts'):
             setattr(st, name, None)
         self.grad_norm = None
         import gc as _gc
@@ -382,6 +410,9 @@ class VQGANTrainer(BaseTrainer):
                  for name in ('discriminator', 'autoencoder') if hasattr(self.model, name)}
         g.update(a=ga, b=gb, c=gc, loss_vec=loss_vec, loss_keys=keys, grads=grads)
         self._restore_state(snap)
+        # the graphs refresh a bank's kernel-layout weights only where the capture saw it dirty (the discriminator's: after
+        # its optimizer step, not at the head of the step): bring every bank in line with the restored parameters now
+        hipconvnet.refresh_stale_banks()
         torch.cuda.synchronize()
         return g
 

@@ -13,7 +13,11 @@ import ctypes
 import torch
 from torch.optim.optimizer import Optimizer
 
-from ...hip import lib
+from ...hip import convnet, lib
+
+
+class _Owner(object):
+    """identity of one parameter group towards hip/convnet.params_updated (caches which banks hold its tensors)"""
 
 
 class HipAdamW(Optimizer):
@@ -23,6 +27,7 @@ class HipAdamW(Optimizer):
         lr_t = lr if torch.is_tensor(lr) else torch.tensor(float(lr), dtype=torch.float32, device=dev)
         super().__init__(params, dict(lr=lr_t, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self._built = None          # (signature of gradient pointers, tables) per group
+        self._owners = {}
         self.grad_norm = None
 
     # -- flat state ---------------------------------------------------------------------------
@@ -105,6 +110,7 @@ class HipAdamW(Optimizer):
                                                     float(b1), float(b2), float(group['eps']), float(group['weight_decay']), 1,
                                                     lib.stream(partial)), 'msmc_opt_clip_adamw')
             self.grad_norm = flat['norm_coef'][0]
+            convnet.params_updated(self._owners.setdefault(id(group), _Owner()), ps)    # (raw-pointer update: no version counter moves)
         return loss
 
     def load_state_dict(self, state_dict):

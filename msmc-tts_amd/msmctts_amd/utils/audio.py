@@ -91,6 +91,14 @@ class TorchSTFT(nn.Module):
         with torch.autocast(device_type=x.device.type, enabled=False):
             return spectral.mrd_image(x.float(), self.fft_size, self.hop_size, dft, fb, dtype)
 
+    def front(self, x, dtype=torch.float32):
+        """the same evaluation kept as an object (hip/spectral.py MrdFront): its image and intermediates can serve a later
+        pass over some of the same waveform rows (``image_rows``)"""
+        from ..hip import spectral
+        dft, fb = self.consts(x.device)
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            return spectral.mrd_front(x.float(), self.fft_size, self.hop_size, dft, fb, dtype)
+
     def transform(self, x):
         img = self.image_cl(x)                       # [B, F, T, 2]
         B, F, T, _ = img.shape

@@ -723,3 +723,48 @@ def check_fft_prologue(dev, B=5, T=45, C=24):
     out, keep_row = hipnorm.fft_prologue(seq, torch.tensor([7, 3]).to(dev), table[:, :6].contiguous(), torch.float32)
     pos = torch.tensor([[1, 2, 3, 4, 5, 6, 7], [1, 2, 3, 0, 0, 0, 0]]).to(dev)
     assert torch.equal(out, seq + table[:, :6][pos]) and torch.equal(keep_row.view(2, 7), pos.ne(0).to(torch.uint8))
+
+
+def check_masked_mean_and_colsum(dev):
+    """csrc/losses.hip masked_mean (QuantizerLoss / frame loss / 'mse' embedding loss) and the non-atomic column sums against
+    the stock operator chains they replace: values, gradients, int32 / int64 lengths, bf16 operands, zero-length rows"""
+    import torch.nn.functional as F
+    from msmctts_amd.hip import conv as K
+    from msmctts_amd.hip import losses
+    from msmctts_amd.utils.utils import get_mask_from_lengths
+    torch.manual_seed(2)
+    for (B, T, C, ldt) in ((3, 24, 8, torch.int64), (5, 100, 64, torch.int32), (2, 7, 80, torch.int64), (16, 400, 80, torch.int64)):
+        lengths = torch.randint(1, T + 1, (B,), device=dev).to(ldt)
+        lengths[0] = T
+        if B > 2:
+            lengths[B - 1] = 0
+        x = torch.randn(B, T, C, device=dev, requires_grad=True)
+        y = torch.randn(B, T, C, device=dev)
+        pad = get_mask_from_lengths(lengths, T).unsqueeze(-1)
+        # mode 0: QuantizerLoss term
+        want = x.masked_fill(pad, 0).sum() / lengths.sum() / C
+        gw, = torch.autograd.grad(want * 3.0, x)
+        got = losses.masked_mean(x, lengths)
+        gg, = torch.autograd.grad(got * 3.0, x)
+        close(got, want, 1e-5, what='masked mean')
+        close(gg, gw, 1e-6, what='masked mean grad')
+        # mode 1: frame loss (fp32 target, prediction in fp32 or bf16)
+        for adt in (torch.float32, torch.bfloat16):
+            a = x.detach().to(adt).requires_grad_(True)
+            ml = F.mse_loss(y, a.float(), reduction='none').masked_fill(pad, 0)
+            want = ml.sum() / lengths.sum() / C
+            gw, = torch.autograd.grad(want, a)
+            got = losses.masked_mean(a, lengths, b=y)
+            gg, = torch.autograd.grad(got, a)
+            close(got, want, 1e-5, what='masked mse')
+            close(gg, gw, 1e-6 if adt == torch.float32 else 2e-3 * float(gw.float().abs().max()), what='masked mse grad')
+            assert float(gg.float()[0, T - 1].abs().sum()) > 0 and (B <= 2 or float(gg.float()[B - 1].abs().sum()) == 0.0)
+    for rows, C, dt in ((3840, 256, torch.float32), (19200, 128, torch.bfloat16), (5000, 64, torch.float32), (777, 32, torch.bfloat16),
+                        (100, 24, torch.float32), (3, 512, torch.float32)):
+        g = torch.randn(rows, C, device=dev).to(dt)
+        want = g.float().sum(0)
+        close(K.colsum(g), want, 1e-4 * max(1.0, float(want.abs().max())), what='colsum')
+        acc = torch.ones(C, device=dev)
+        K.colsum(g, out=acc)
+        close(acc, want + 1.0, 1e-4 * max(1.0, float(want.abs().max())), what='colsum accumulate')
+        assert torch.equal(K.colsum(g), K.colsum(g))                  # fixed summation order

@@ -64,8 +64,26 @@ void run_grid(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void
 template <class F>
 static void emu_trampoline(void* p) { (*(F*)p)(); }
 
+// launch log of the interpreter build (msmc_prof_*): names only -- every record reads back as 1 ms -- so that the host-side
+// attribution of bench.py (which launches belong to which call) can be tested without a GPU
+struct MsmcProfRec { char name[120]; };
+#define MSMC_PROF_MAX 16384
+struct MsmcProfLog { int on = 0, n = 0; MsmcProfRec* rec = nullptr; };
+inline MsmcProfLog msmc_prof_log;
+inline int msmc_prof_mine = -1;
+static inline void msmc_prof_note(const char* text) {
+    MsmcProfLog& L = msmc_prof_log;
+    msmc_prof_mine = L.n < MSMC_PROF_MAX ? L.n++ : -1;
+    if (msmc_prof_mine < 0) return;
+    MsmcProfRec& r = L.rec[msmc_prof_mine];
+    int j = 0;
+    for (const char* c = text; *c && *c != '<' && j < (int)sizeof(r.name) - 1; ++c)
+        if (*c != '(' && *c != ' ') r.name[j++] = *c;
+    r.name[j] = 0;
+}
 #define MSMC_LAUNCH(kernel, grid, block, lds, stream, ...)                                   \
     do {                                                                                       \
+        if (msmc_prof_log.on) msmc_prof_note(#kernel);                                         \
         auto emu_body = [&]() { kernel(__VA_ARGS__); };                                        \
         emu::run_grid(grid, block, lds, &emu_trampoline<decltype(emu_body)>, (void*)&emu_body); \
     } while (0)
@@ -296,13 +314,24 @@ MSMC_DEV float fast_exp(float x) { return expf(x); }
 MSMC_DEV long long msmc_clock() { return 0; }
 MSMC_DEV float fast_sqrt(float x) { return sqrtf(x); }
 static inline int msmc_check_launch() { return 0; }
-// (the per-launch profiling log of the device build: nothing to time on the interpreter)
-struct MsmcProfRec { char name[120]; };
-struct MsmcProfLog { int on = 0, n = 0; MsmcProfRec* rec = nullptr; };
-inline MsmcProfLog msmc_prof_log;
-static inline int msmc_prof_used() { return 0; }
-static inline const char* msmc_prof_name(const char* name) { return name; }
-#define MSMC_PROF_MAX 1
-static inline void msmc_prof_reset_impl() {}
-static inline int msmc_prof_read_impl(int, char*, int, float*) { return -1; }
+static inline int msmc_prof_used() { return msmc_prof_log.n < MSMC_PROF_MAX ? msmc_prof_log.n : MSMC_PROF_MAX; }
+static inline const char* msmc_prof_name(const char* name) {
+    if (msmc_prof_log.on && msmc_prof_mine >= 0) {
+        MsmcProfRec& r = msmc_prof_log.rec[msmc_prof_mine];
+        int j = 0;
+        for (; name[j] && j < (int)sizeof(r.name) - 1; ++j) r.name[j] = name[j];
+        r.name[j] = 0;
+    }
+    return name;
+}
+static inline void msmc_prof_reset_impl() { msmc_prof_log.n = 0; msmc_prof_mine = -1; }
+static inline int msmc_prof_read_impl(int i, char* name, int cap, float* ms) {
+    if (i < 0 || i >= msmc_prof_used() || !name || cap <= 0 || !ms) return -1;
+    const MsmcProfRec& r = msmc_prof_log.rec[i];
+    int j = 0;
+    for (; r.name[j] && j < cap - 1; ++j) name[j] = r.name[j];
+    name[j] = 0;
+    *ms = 1.0f;
+    return 0;
+}
 static inline int msmc_allow_lds(const void*, int) { return 0; }

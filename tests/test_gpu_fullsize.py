@@ -175,6 +175,54 @@ def test_fp32_step_matches_oracle(name, B):
             assert err <= 1e-5 * scale, '%s buffer %s: %.3e (scale %.3g)' % (name, k, err, scale)
 
 
+@pytest.mark.parametrize('prologue', [False, True])
+def test_fft_block_stack_on_the_attention_kernels_matches_the_oracle(prologue):
+    """csrc/attn.hip INSIDE a model (the fp32 parity runs route around it to the stock fused operator): the CSMSC FFT-block
+    stack (4 blocks, 2 heads of 64, d_model 256, FFN 1024; reference acoustic_models/transformer.py:71-385) in bf16 with the
+    attention core forced onto the kernels, ragged lengths, against oracle/model.py's fp32 restatement of the same stack
+    (pinned by small_modules.npz) on the same weights: output and input gradient at a bf16 bound.  ``prologue``: the same
+    with the stack's head (positions, positional add, masks) as the one-launch prologue."""
+    from msmctts_amd.hip import attn as hipattn
+    from msmctts_amd.networks.acoustic_models import transformer as tfm
+    from oracle import model as omodel
+    cfg = dict(max_seq_len=2400, n_layers=4, n_head=2, d_k=64, d_v=64, d_model=256, d_inner=1024, fft_conv1d_kernel=3,
+               fft_conv1d_padding=1, dropout=0.0, attn_dropout=0.0)
+    torch.manual_seed(3)
+    net = tfm.FFTBlocks(name='enc', **cfg).to(DEV)
+    net.hip_dtype = torch.bfloat16
+    net.train()
+    B, T = 4, 400
+    lengths = torch.tensor([400, 333, 250, 201])
+    pos = omodel.position_ids(lengths, T)
+    x_cpu = torch.randn(B, T, 256) * pos.ne(0).unsqueeze(-1)
+    calls = []
+    real = hipattn.attention
+    keep_flag = tfm.FFT_PROLOGUE
+    try:
+        hipattn.attention = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        tfm.FFT_PROLOGUE = prologue
+        x = x_cpu.to(DEV).requires_grad_(True)
+        out, _ = net(x, None if prologue else pos.to(DEV), lengths=lengths.to(DEV))
+        go = torch.randn(B, T, 256)
+        (out.float() * go.to(DEV)).sum().backward()
+    finally:
+        hipattn.attention = real
+        tfm.FFT_PROLOGUE = keep_flag
+    assert len(calls) == cfg['n_layers'], 'the attention core did not run on csrc/attn.hip'
+    P = {'enc.' + k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    xo = x_cpu.clone().requires_grad_(True)
+    want = omodel.fft_blocks(P, 'enc', xo, pos, cfg, training=False)
+    (want * go).sum().backward()
+    got = out.float().cpu()
+    err = (got - want).abs().max().item()
+    assert err <= 6e-2 * max(1.0, want.abs().max().item()), 'FFT stack output: max abs err %.3e (scale %.3g)' % (err, want.abs().max())
+    rel = ((got - want).norm() / want.norm()).item()
+    assert rel <= 1.5e-2, 'FFT stack output: relative L2 error %.3e' % rel
+    grel = ((x.grad.float().cpu() - xo.grad).norm() / xo.grad.norm()).item()
+    assert grel <= 3e-2, 'FFT stack input gradient: relative L2 error %.3e' % grel
+    assert float(got[1, 333:].abs().max()) == 0.0            # padded rows stay masked
+
+
 def test_graph_memset_nodes_are_ordered():
     """the graph path's precondition (msmctts_amd/__init__.py): fails on ROCm 7.2's AQL packet-capture graphs"""
     from msmctts_amd.hip import graphs

@@ -356,3 +356,7 @@ def test_wave_exchange_primitives():
     q, df, i = vq.vq_search(torch.from_numpy(x).to(DEV), et, en, shortlist=True)
     assert np.array_equal(i.cpu().numpy(), want['ind']) and np.array_equal(q.cpu().numpy(), want['quant'])
     assert len(np.unique((want['ind'] >> 2) & 3)) == 4
+
+
+def test_masked_mean_and_non_atomic_colsum_match_stock_operators():
+    _parity.check_masked_mean_and_colsum(DEV)
