@@ -304,7 +304,8 @@ def build(args, device, rank, world):
     from msmctts_amd.trainers import build_trainer
     from msmctts_amd.trainers.optimizers import build_optimizer
     from msmctts_amd.utils.config import Config
-    cfg = Config(csmsc_config(batch_size=args.batch, warmup_steps=0, **args.model_kw))
+    model_kw = getattr(args, 'model_kw', None) or dict(n_heads=args.heads, embedding_sizes=args.codewords)    # (tools/ pass bare namespaces)
+    cfg = Config(csmsc_config(batch_size=args.batch, warmup_steps=0, **model_kw))
     torch.manual_seed(cfg.seed)
     task = build_task(cfg, mode='train')
     trainer = build_trainer(cfg, task, num_gpus=world, rank=rank)      # moves to GPU; arms RCCL reducer if world>1

@@ -38,7 +38,33 @@ __global__ __launch_bounds__(256) void loss_multi_fwd_kernel(msmc_tensor_table t
     const T* a = (const T*)t.a[i];
     const T* b = (const T*)t.b[i];
     float s = 0.f;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    // 16-byte vectors where the operands allow (the feature maps: 424 MB per step went through 2-byte loads at 2 TB/s)
+    constexpr int VE = 16 / (int)sizeof(T);
+    const bool vec = ((((size_t)a) | ((size_t)b)) & 15) == 0;
+    const long nv = vec ? n / VE : 0;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += (long)gridDim.x * 256) {
+        const u32x4 av4 = *(const u32x4*)(a + v * VE);
+        u32x4 bv4 = {0u, 0u, 0u, 0u};
+        if (MODE == 0) bv4 = *(const u32x4*)(b + v * VE);
+#pragma unroll
+        for (int q = 0; q < VE; ++q) {
+            float av, bv;
+            if (sizeof(T) == 4) {
+                av = __uint_as_float(av4[q & 3]);
+                bv = __uint_as_float(bv4[q & 3]);
+            } else {
+                av = bf16_bits_to_f32((unsigned short)(av4[(q >> 1) & 3] >> (16 * (q & 1))));
+                bv = bf16_bits_to_f32((unsigned short)(bv4[(q >> 1) & 3] >> (16 * (q & 1))));
+            }
+            if (MODE == 0) {
+                s = s + fabsf(av - bv);
+            } else {
+                const float dlt = av - target;
+                s = fmaf(dlt, dlt, s);
+            }
+        }
+    }
+    for (long e = nv * VE + (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         const float av = LEl<T>::ld(a + e);
         if (MODE == 0) {
             s = s + fabsf(av - LEl<T>::ld(b + e));
@@ -60,7 +86,43 @@ __global__ __launch_bounds__(256) void loss_multi_bwd_kernel(msmc_tensor_table t
     const T* b = (const T*)t.b[i];
     T* ga = (T*)t.ga[i];
     const float scale = gout[0] / (float)n;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    constexpr int VE = 16 / (int)sizeof(T);
+    const bool vec = ((((size_t)a) | ((size_t)b) | ((size_t)ga)) & 15) == 0;
+    const long nv = vec ? n / VE : 0;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += (long)gridDim.x * 256) {
+        const u32x4 av4 = *(const u32x4*)(a + v * VE);
+        u32x4 bv4 = {0u, 0u, 0u, 0u};
+        if (MODE == 0) bv4 = *(const u32x4*)(b + v * VE);
+        float gq[VE];
+#pragma unroll
+        for (int q = 0; q < VE; ++q) {
+            float av, bv;
+            if (sizeof(T) == 4) {
+                av = __uint_as_float(av4[q & 3]);
+                bv = __uint_as_float(bv4[q & 3]);
+            } else {
+                av = bf16_bits_to_f32((unsigned short)(av4[(q >> 1) & 3] >> (16 * (q & 1))));
+                bv = bf16_bits_to_f32((unsigned short)(bv4[(q >> 1) & 3] >> (16 * (q & 1))));
+            }
+            if (MODE == 0) {
+                const float dlt = av - bv;
+                gq[q] = dlt > 0.f ? scale : (dlt < 0.f ? -scale : 0.f);
+            } else {
+                gq[q] = 2.f * (av - target) * scale;
+            }
+        }
+        u32x4 o;
+        if (sizeof(T) == 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = __float_as_uint(gq[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                o[q] = (unsigned int)f32_to_bf16_bits(gq[(2 * q) % VE]) | ((unsigned int)f32_to_bf16_bits(gq[(2 * q + 1) % VE]) << 16);
+        }
+        *(u32x4*)(ga + v * VE) = o;
+    }
+    for (long e = nv * VE + (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         const float av = LEl<T>::ld(a + e);
         float g;
         if (MODE == 0) {
@@ -153,7 +215,7 @@ static int loss_launch(const msmc_tensor_table* t, float target, float* out, con
         if (t->n[i] <= 0) return MSMC_E_SHAPE;
         if (t->n[i] > nmax) nmax = t->n[i];
     }
-    long bx = (nmax + 2047) / 2048;
+    long bx = (nmax + 4095) / 4096;
     if (bx > 256) bx = 256;
     dim3 grid((unsigned)bx, (unsigned)t->count);
     if (!bwd) {

@@ -14,6 +14,13 @@ back.  Here, for one process per GPU on a fully connected xGMI node:
   values back.  Parameters that received no gradient (frozen tables, the vocoder during warm-up, the
   discriminator during the G step) are simply not communicated -- the reference reduces the stale D
   gradients on every G backward.
+* hipGraph mode has two exchanges: ``serial`` (default) -- the hooks are off and ONE flat all-reduce per child runs between
+  the replayed segments (``allreduce_child``) -- and ``overlap`` (``VQGANTrainer.graph_exchange`` / MSMC_GRAPH_EXCHANGE=overlap)
+  -- the hooks stay on DURING CAPTURE, so the bucketed all-reduces are recorded into the segment's graph on RCCL's stream as a
+  forked branch and ``finish()`` is recorded at the segment's end; together with the banks' early gradient delivery
+  (hip/convnet.py ``ConvBank._open_nodes``) the generator's buckets travel under the frame decoder's / quantiser's /
+  encoders' backward.  ``overlap`` has only ever run on ONE GPU (world-1 RCCL capture, tests/test_gpu_parity.py): no
+  multi-GPU node was reachable, which is why it is not the default.
 * VQ codebook statistics are, like the reference, NOT synchronised by default (each rank EMA-updates
   from its local batch; rank 0's codebook is checkpointed).
 """
@@ -156,13 +163,10 @@ class GradReducer(object):
             if b.ready:
                 self._launch(b)
         for work, flat, ps in self._inflight:
-            work.wait()
-            off = 0
-            for p in ps:
-                n = p.numel()
-                p.grad.copy_(flat[off:off + n].view_as(p.grad))
-                p.grad.div_(self.world)
-                off += n
+            work.wait()             # (the calling stream waits for RCCL's: also what a hipGraph capture records)
+            grads = [p.grad for p in ps]
+            torch._foreach_copy_(grads, self._views(flat, grads))        # two multi-tensor launches per bucket, not two
+            torch._foreach_div_(grads, float(self.world))                # per parameter (636 parameters per step)
         self._inflight = []
 
 

@@ -418,6 +418,36 @@ def conv_forward(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, out_d
     return out
 
 
+_SPLIT_CANDIDATES = ((36, 0), (37, 0))
+
+
+def const_gemm_split(x, wimg, cout):
+    """x [B, 1, T, Cin] fp32 times a CONSTANT matrix given as its pre-split bf16 image (hip/spectral.py split_image:
+    [cout][chunks of 32 values][hi 32 | lo 32]) -> [B, 1, T, cout] fp32: three bf16 matrix-core products with fp32
+    accumulation (csrc/gemm1.inc conv_gemm1s_kernel, variants 36 / 37 -- 128- or 64-row tiles, timed once per shape)."""
+    B, _, T, Cin = x.shape
+    assert x.dtype == torch.float32 and wimg.dtype == torch.bfloat16 and wimg.shape[0] == cout and wimg.is_contiguous()
+    assert wimg.shape[1] * 32 >= Cin and wimg.shape[2] == 64, (tuple(wimg.shape), Cin)
+    key = ('g1s', B, T, Cin, cout)
+    desc = _PLANS.get(key)
+    if desc is None:
+        _bounded(_PLANS)
+        desc = _PLANS[key] = _build_desc(torch.float32, B, 1, T, Cin, 1, T, cout, (1, T, 0, 1, 0, 1, 1, 1, 0, 0), ((0, 0, 0),), 0,
+                                         1.0, 1.0, 1.0, 1.0)
+        desc.variant = 37 if ((B * T + 127) // 128) * ((cout + 127) // 128) < 192 else 36
+    _dev_ok(x)
+    _dev_ok(wimg)
+    out = torch.empty((B, 1, T, cout), dtype=torch.float32, device=x.device)
+    desc.x, desc.w, desc.out = x.data_ptr(), wimg.data_ptr(), out.data_ptr()
+    desc.bias = desc.res = desc.res2 = desc.mask_src = None
+    stream = lib.stream(x)
+    fn = lib.get().msmc_conv_gather
+    if not getattr(desc, '_tuned', False):
+        _tune('gather-split', desc, lambda: fn(ctypes.byref(desc), stream), _SPLIT_CANDIDATES)
+    lib.check(fn(ctypes.byref(desc), stream), 'msmc_conv_gather(split constant GEMM)')
+    return out
+
+
 def _snapshot(desc, stream):
     """by-value copy of a (tuned) descriptor: grouped calls may meet the same cached descriptor twice"""
     if not getattr(desc, '_tuned', False):

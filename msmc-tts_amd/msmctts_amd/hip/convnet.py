@@ -41,6 +41,8 @@ STREAMS_ENABLED = True
 # and go out as ONE grouped call (K.conv_wgrad_group; the tuner keeps separate launches where grouping does not pay).
 WGRAD_BATCH = int(os.environ.get('MSMC_WGRAD_BATCH', '8'))
 WGRAD_BATCH_GROUPS = os.environ.get('MSMC_WGRAD_BATCH_GROUPS', '1') == '1'    # grouped calls' members join the waiting list too
+# 1: a bank delivers its parameter gradients as soon as its last backward node has run (see ConvBank._open_nodes)
+EARLY_FINISH = os.environ.get('MSMC_EARLY_FINISH', '1') != '0'
 
 
 def fork_join(streams, thunks, inputs=()):
@@ -169,6 +171,12 @@ def refresh_stale_banks():
 class ConvBank(object):
     def __init__(self, layers):
         self.layers = list(layers)
+        # autograd nodes of this bank whose backward (with a weight gradient) is still to come in the running pass: when the
+        # count returns to zero the bank's gradients are complete and ``_finish_backward`` runs AT ONCE -- not at the end of
+        # the whole backward pass -- so that the data-parallel reducer can send the generator's gradients while the frame
+        # decoder / quantiser / encoders are still back-propagating (EARLY_FINISH; the end-of-pass callback stays as the
+        # net for passes the count cannot see through: outputs nobody used, exceptions)
+        self._open_nodes = 0
         self.dirty = True               # kernel-layout weights older than the parameters (see SKIP_CLEAN_PREPARE)
         self._clean_versions = None
         self._owner_hits = {}
@@ -358,15 +366,28 @@ class ConvBank(object):
         return (((m.bias, l.gb_view), (m.weight, l.gv_view)) if l.plain else
                 ((m.bias, l.gb_view), (m.weight_g, l.gg_view), (m.weight_v, l.gv_view)))
 
-    def _finish_backward(self):
-        self._queued = False
+    def node_opened(self):
+        self._open_nodes += 1
+
+    def node_closed(self):
+        """a backward node with a weight gradient has issued it; the last one of the pass completes the bank"""
+        if self._open_nodes > 0:
+            self._open_nodes -= 1
+            if self._open_nodes == 0 and EARLY_FINISH and self._touched:
+                self._finish_backward(early=True)
+
+    def _finish_backward(self, early=False):
+        if not early:
+            self._queued = False
+            self._open_nodes = 0        # (whatever the count missed -- unused outputs -- ends with the pass)
         self.flush_wgrad()
         if self._side_used:             # weight-gradient branches join here, before their inputs are released
             cur = torch.cuda.current_stream(self.w1.device)
             for st in self._side_used:
                 cur.wait_stream(st)
             self._side_used = []
-        del self._hold[:]
+        if not early:                   # (held gradients may still be read by other banks' nodes: released with the pass)
+            del self._hold[:]
         touched, self._touched = self._touched, set()
         if not touched:                 # a pass that only propagated through this network (frozen D in the G step)
             self.deferred.flush(lib.stream(self.w1))
@@ -441,6 +462,9 @@ class _HipConv(torch.autograd.Function):
         ctx.out_masked = bool(out_masked)
         ctx.has_res, ctx.has_res2 = res is not None, res2 is not None
         ctx.need_w = layer.weight.requires_grad
+        ctx.counted = bool(ctx.need_w and ctx.needs_input_grad[3])      # (a graph is being recorded and the weight is in it)
+        if ctx.counted:
+            bank.node_opened()
         ctx.save_for_backward(x, out if (out_slope != 1.0 and not out_masked) else None)
         ctx.set_materialize_grads(False)
         # ``tap``: also return an alias of x for x's OTHER consumer (a residual add, a feature-matching loss, a fused
@@ -457,6 +481,9 @@ class _HipConv(torch.autograd.Function):
                 # the tap's gradient is that of a reader of the ACTIVATED map (the producer ran with out_masked and leaves
                 # the derivative to this node): the grouped form refuses the case, so does this one
                 raise RuntimeError('hip_conv: output unused but its tap carries a gradient through an activated input')
+            if ctx.counted:
+                ctx.counted = False
+                bank.node_closed()
             return (g_tap,) + (None,) * 11
         g = g.contiguous()
         g_tap = _tap_grad(g_tap, g)
@@ -511,6 +538,9 @@ class _HipConv(torch.autograd.Function):
             # reference until the end of the backward pass rules the in-place path out for this tensor.
             bank._hold.append(g)
             bank._queue_finish()
+        if ctx.counted:
+            ctx.counted = False
+            bank.node_closed()
         # weight_token (the layer's weight_v) only ties the output to the parameters in the autograd graph;
         # parameter gradients are produced in kernel layout and delivered by ConvBank._finish_backward.
         return (gx, (g if ctx.has_res else None), (g if ctx.has_res2 else None)) + (None,) * 9
@@ -539,6 +569,11 @@ class _HipConvGroup(torch.autograd.Function):
         ctx.bank, ctx.specs, ctx.ntensors = bank, specs, len(tensors)
         ctx.need_w = [sp[0].weight.requires_grad for sp in specs]     # as of the forward (a frozen pass stays frozen)
         ctx.xpos = [m[0] for m in members]
+        # (weight token of member k: the last of its tensors) -- counted when a graph is being recorded with a weight in it
+        wpos = [m[0] + 1 + sp[4] + sp[5] for m, sp in zip(members, specs)]
+        ctx.counted = any(nw and ctx.needs_input_grad[2 + wp] for nw, wp in zip(ctx.need_w, wpos))
+        if ctx.counted:
+            bank.node_opened()
         saved = [m[1] for m in members] + [o if (sp[2] != 1.0 and not sp[8]) else None for o, sp in zip(outs, specs)]
         ctx.save_for_backward(*saved)
         ctx.set_materialize_grads(False)
@@ -622,6 +657,9 @@ class _HipConvGroup(torch.autograd.Function):
             with bank.wgrad_side(*([it['x'] for it in w_items] + [it['g'] for it in w_items])):
                 K.conv_wgrad_group(w_items)
         bank._queue_finish()
+        if ctx.counted:
+            ctx.counted = False
+            bank.node_closed()
         return (None, None) + tuple(grads)
 
 

@@ -17,6 +17,12 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+# the constant-matrix GEMMs (framed DFT, mel / filter-bank projections) of the bf16 training configuration run as three
+# bf16 matrix-core products from two-piece splits (csrc/gemm1.inc conv_gemm1s_kernel); MSMC_SPECTRAL_SPLIT=0: exact fp32 (A/B)
+import os as _os
+SPLIT_BF16 = _os.environ.get('MSMC_SPECTRAL_SPLIT', '1') != '0'
+
+
 class _Frames(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, T, n_fft, NP, hop, pad):
@@ -42,16 +48,15 @@ class _ConstGemm(torch.autograd.Function):
     """y[b,1,t,:] = W x[b,1,t,:] with a constant matrix (DFT basis / filter bank): one-tap conv on the fp32 MFMA."""
 
     @staticmethod
-    def forward(ctx, x, wf, wb):
-        geom = K.Geometry(1, x.shape[2], (1, 1))
-        ctx.save_for_backward(wb)
-        ctx.geom = geom
-        return K.conv_forward(x, wf, geom)
+    def forward(ctx, x, wf, wb, split=False):
+        geom = _geom1(x.shape[2])
+        ctx.wb = wb                       # (a constant, not a graph tensor)
+        ctx.geom, ctx.split = geom, bool(split)
+        return _const_gemm(x, wf, geom, ctx.split)
 
     @staticmethod
     def backward(ctx, g):
-        (wb,) = ctx.saved_tensors
-        return K.conv_dgrad(g.contiguous(), wb, ctx.geom), None, None
+        return _const_gemm(g.contiguous(), ctx.wb, ctx.geom, ctx.split, dgrad=True), None, None, None
 
 
 class _SpecMag(torch.autograd.Function):
@@ -155,6 +160,36 @@ def projection(mat, device):
     return W.unsqueeze(0).contiguous().to(device), W.t().unsqueeze(0).contiguous().to(device)
 
 
+_SPLIT_IMAGES = {}
+
+
+def split_image(w):
+    """[1, N, K] fp32 constant one-tap slices -> their split-bf16 image [N][ceil(K / 32)][hi 32 | lo 32] (hi = bf16(w), lo =
+    bf16(w - hi)), built once per matrix (csrc/gemm1.inc conv_gemm1s_kernel)"""
+    hit = _SPLIT_IMAGES.get(w.data_ptr())
+    if hit is not None and hit[0] is w:
+        return hit[1]
+    K._bounded(_SPLIT_IMAGES, 256)
+    W = w[0]
+    N, Kc = W.shape
+    nch = (Kc + 31) // 32
+    Wp = torch.zeros((N, nch * 32), dtype=torch.float32, device=W.device)
+    Wp[:, :Kc] = W
+    hi = Wp.to(torch.bfloat16)
+    lo = (Wp - hi.float()).to(torch.bfloat16)
+    img = torch.cat((hi.view(N, nch, 32), lo.view(N, nch, 32)), dim=2).contiguous()
+    _SPLIT_IMAGES[w.data_ptr()] = (w, img)
+    return img
+
+
+def _const_gemm(x, w, geom, split, dgrad=False):
+    """x @ constant matrix ``w`` ([1, N, K] forward slices; ``dgrad``: w is the transposed slice set) -- exact fp32 on the
+    matrix cores, or (``split``: the bf16 training configuration) three bf16 products from two-piece splits"""
+    if split:
+        return K.const_gemm_split(x, split_image(w), w.shape[1])
+    return K.conv_dgrad(x, w, geom) if dgrad else K.conv_forward(x, w, geom)
+
+
 _GEOMS = {}
 
 
@@ -174,9 +209,11 @@ class MrdFront(object):
     transformed: the front-end has no parameters -- reuses the image and back-propagates through its rows only
     (``image_rows``) instead of recomputing 25 launches per pass."""
 
-    def __init__(self, x, n_fft, hop, dft, fb, dtype):
+    def __init__(self, x, n_fft, hop, dft, fb, dtype, split=None):
         B, L = x.shape
         self.B, self.L, self.n_fft, self.hop, self.dft, self.fb, self.dtype = B, L, n_fft, hop, dft, fb, dtype
+        # constant-matrix GEMMs in split bf16 (2^-16 relative) when the stack computes in bf16, exact fp32 otherwise
+        self.split = split = (dtype == torch.bfloat16 and SPLIT_BF16) if split is None else bool(split)
         F = self.F = n_fft // 2 + 1
         T = self.T = L // hop + 1
         lo, n_eff = dft[2], dft[3]
@@ -187,12 +224,12 @@ class MrdFront(object):
         lib.check(Lb.msmc_stft_frames_fwd(lib.ptr(xc), lib.ptr(fr), B, L, T, n_eff, _pad4(n_eff), hop, n_fft // 2 - lo,
                                           lib.stream(xc)), 'msmc_stft_frames_fwd')
         geom = _geom1(T)
-        self.spec = K.conv_forward(fr, dft[0], geom)
+        self.spec = _const_gemm(fr, dft[0], geom, split)
         CP, FP = self.spec.shape[-1], _pad4(F)
         self.mag = torch.empty((B, 1, T, FP), dtype=torch.float32, device=x.device)
         lib.check(Lb.msmc_spec_mag_fwd(lib.ptr(self.spec), lib.ptr(self.mag), B * T, F, CP, FP, 1e-7, 1, lib.stream(xc)),
                   'msmc_spec_mag_fwd')
-        self.mel = K.conv_forward(self.mag, fb[0], geom) if fb is not None else self.mag
+        self.mel = _const_gemm(self.mag, fb[0], geom, split) if fb is not None else self.mag
         self.img = torch.empty((B, F, T, 2), dtype=dtype, device=x.device)
         lib.check(Lb.msmc_mrd_image_fwd_dt(lib.ptr(self.mel), lib.ptr(self.img), B, T, F, FP, _IMG_DT[dtype], lib.stream(xc)),
                   'msmc_mrd_image_fwd_dt')
@@ -217,11 +254,11 @@ class MrdFront(object):
                                            lib.stream(g)), 'msmc_mrd_image_bwd_dt')
         geom = _geom1(T)
         if self.fb is not None:
-            gm = K.conv_dgrad(gm, self.fb[1], geom)
+            gm = _const_gemm(gm, self.fb[1], geom, self.split, dgrad=True)
         gs = torch.empty_like(spec)
         lib.check(Lb.msmc_spec_mag_bwd(lib.ptr(spec), lib.ptr(mag), lib.ptr(gm), lib.ptr(gs), b * T, F, CP, FP, 1e-7, 1,
                                        lib.stream(g)), 'msmc_spec_mag_bwd')
-        gfr = K.conv_dgrad(gs, self.dft[1], geom)
+        gfr = _const_gemm(gs, self.dft[1], geom, self.split, dgrad=True)
         T_, n_eff, NP, hop, pad = self.frame_args
         gx = torch.empty((b, self.L), dtype=torch.float32, device=g.device)
         lib.check(Lb.msmc_stft_frames_bwd(lib.ptr(gfr), lib.ptr(gx), b, self.L, T_, n_eff, NP, hop, pad, lib.stream(g)),
@@ -278,7 +315,7 @@ def mrd_image_rows(x, front, r0, r1):
     return _MrdImageRows.apply(x.contiguous(), front, r0, r1)
 
 
-def stft_magnitude(x, n_fft, hop, dft, lo):
+def stft_magnitude(x, n_fft, hop, dft, lo, split=False):
     """x (B, L) -> (B, T', F) magnitude sqrt(clamp(re^2 + im^2, lo)) of the centred STFT (torch.stft defaults:
     reflect padding n_fft // 2, window already folded into ``dft``)."""
     B, L = x.shape
@@ -286,12 +323,12 @@ def stft_magnitude(x, n_fft, hop, dft, lo):
     T = L // hop + 1
     lo_, n_eff = dft[2], dft[3]
     fr = _Frames.apply(x, T, n_eff, _pad4(n_eff), hop, n_fft // 2 - lo_)
-    spec = _ConstGemm.apply(fr, dft[0], dft[1])
+    spec = _ConstGemm.apply(fr, dft[0], dft[1], split)
     mag = _SpecMag.apply(spec, F, _pad4(F), lo, 1)
     return mag[:, 0, :, :F]
 
 
-def log_mel(y, n_fft, hop, dft, mel, num_mels):
+def log_mel(y, n_fft, hop, dft, mel, num_mels, split=False):
     """y (B, L) -> log-mel [B, 1, T', pad4(num_mels)] per MelLoss.mel_spectrogram (manual reflect pad, no centring)."""
     B, L = y.shape
     F = n_fft // 2 + 1
@@ -299,7 +336,7 @@ def log_mel(y, n_fft, hop, dft, mel, num_mels):
     T = (L + 2 * pad - n_fft) // hop + 1
     lo, n_eff = dft[2], dft[3]
     fr = _Frames.apply(y, T, n_eff, _pad4(n_eff), hop, pad - lo)
-    spec = _ConstGemm.apply(fr, dft[0], dft[1])
+    spec = _ConstGemm.apply(fr, dft[0], dft[1], split)
     mag = _SpecMag.apply(spec, F, _pad4(F), 1e-9, 0)
-    m = _ConstGemm.apply(mag, mel[0], mel[1])
+    m = _ConstGemm.apply(mag, mel[0], mel[1], split)
     return _LogClamp.apply(m, 1e-5)[..., :num_mels]

@@ -65,7 +65,8 @@ class MelLoss(nn.Module):
         from ...hip import spectral
         assert not center
         dft, mel = self._consts(y.device)
-        lm = spectral.log_mel(y.float(), self.fft_size, self.hop_size, dft, mel, self.num_mels)   # [B, 1, T', M]
+        split = getattr(self, 'hip_dtype', torch.float32) == torch.bfloat16 and spectral.SPLIT_BF16
+        lm = spectral.log_mel(y.float(), self.fft_size, self.hop_size, dft, mel, self.num_mels, split=split)   # [B, 1, T', M]
         return lm.squeeze(1).transpose(1, 2)
 
     def forward(self, predicts, targets):

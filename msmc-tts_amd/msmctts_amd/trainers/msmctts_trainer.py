@@ -108,6 +108,9 @@ class VQGANTrainer(BaseTrainer):
         self.batch_g_step = os.environ.get('MSMC_BATCH_G_STEP', '0') != '0'
         # the generator step reads the spectral front-end images the D step built from the same waveforms (A/B: 0)
         self.reuse_fronts = os.environ.get('MSMC_REUSE_FRONTS', '1') != '0'
+        # hipGraph mode under data parallelism: 'serial' = one flat all-reduce per child between the replayed segments;
+        # 'overlap' = the reducer's bucketed all-reduces captured INTO the segments (distributed/distributed.py docstring)
+        self.graph_exchange = os.environ.get('MSMC_GRAPH_EXCHANGE', 'serial')
         self.use_graphs = False        # replay the GAN-phase step as three hipGraphs (static shapes)
         self._graphs = None
         self.amp_autocast = True       # False: only the HIP conv stacks compute in amp_dtype, stock operators stay fp32
@@ -128,6 +131,8 @@ class VQGANTrainer(BaseTrainer):
             for m in self.model.modules():
                 if hasattr(m, 'hip_dtype'):
                     m.hip_dtype = self.amp_dtype or torch.float32
+            if hasattr(self, 'stft_criterion'):      # (bf16 runs: its constant-matrix GEMMs as split-bf16 products)
+                self.stft_criterion.hip_dtype = self.amp_dtype or torch.float32
             self._amp_applied = self.amp_dtype
         if self.amp_dtype is None or not self.amp_autocast:
             return contextlib.nullcontext()
@@ -268,7 +273,7 @@ class VQGANTrainer(BaseTrainer):
         g = self._graphs
         reducer = getattr(self.model, 'grad_reducer', None)
         if reducer is not None:
-            reducer.hooks_enabled = False        # no collectives inside capture; allreduce_child runs between segments
+            reducer.hooks_enabled = False        # (serial exchange: no collectives inside capture; overlap: _capture arms them)
         if g is None:
             g = self._graphs = self._capture(batch)
         st = g['state']
@@ -285,9 +290,11 @@ class VQGANTrainer(BaseTrainer):
         hipconvnet.refresh_stale_banks()               # (parameters changed behind the graphs' back: checkpoint load ...)
         g['a'].replay()
         self._sync_codebooks(g['codebooks'])
-        self._sync_grads_static('discriminator', g)
+        if not g['overlap']:
+            self._sync_grads_static('discriminator', g)
         g['b'].replay()
-        self._sync_grads_static('autoencoder', g)
+        if not g['overlap']:
+            self._sync_grads_static('autoencoder', g)
         g['c'].replay()
         vec = g['loss_vec'].clone()                  # the graph's outputs are static buffers: hand out a snapshot
         return {'loss': {k: vec[i] for i, k in enumerate(g['loss_keys'])}}
@@ -388,16 +395,31 @@ class VQGANTrainer(BaseTrainer):
         # may invalidate the capture
         import torch.distributed as dist
         mode = 'thread_local' if dist.is_available() and dist.is_initialized() else 'global'
+        reducer = getattr(self.model, 'grad_reducer', None)
+        overlap = g['overlap'] = reducer is not None and self.graph_exchange == 'overlap'
+
+        def exchange_in_graph():
+            """overlap mode: the bucketed all-reduces the hooks issued during this segment's backward are part of the capture
+            (a branch on RCCL's stream); join them and write the averages back, still inside the capture"""
+            if overlap:
+                reducer.finish()
+                reducer.hooks_enabled = False
         with torch.cuda.graph(ga, stream=side, capture_error_mode=mode):
             self._build_windows(g, st)
+            if overlap:
+                reducer.hooks_enabled = True
             self._segment_a(st)
+            exchange_in_graph()
         g['codebooks'] = list(hipvq.PENDING)    # (sync_codebook_stats: the stages whose statistics segment A refills)
         del hipvq.PENDING[:]
         torch.cuda.synchronize()
         prepare = getattr(self.optimizer, 'prepare', lambda names=None: None)
         prepare(['discriminator'])              # (tensor tables over the static gradients segment A just allocated)
         with torch.cuda.graph(gb, pool=ga.pool(), stream=side, capture_error_mode=mode):
+            if overlap:
+                reducer.hooks_enabled = True
             self._segment_b(st)
+            exchange_in_graph()
         keys = [k for k, v in st.losses.items() if torch.is_tensor(v)]
         torch.cuda.synchronize()
         prepare(['autoencoder'])

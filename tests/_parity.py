@@ -768,3 +768,85 @@ def check_masked_mean_and_colsum(dev):
         K.colsum(g, out=acc)
         close(acc, want + 1.0, 1e-4 * max(1.0, float(want.abs().max())), what='colsum accumulate')
         assert torch.equal(K.colsum(g), K.colsum(g))                  # fixed summation order
+
+
+def check_gan_loss_kernels(dev):
+    """csrc/losses.hip multi-tensor L1 (feature matching) and MSE-to-constant (LSGAN) sums against the per-tensor stock
+    operators of reference msmctts_trainer.py:165-171,187-193: values and gradients, fp32 / bf16, sizes that are not
+    multiples of the 16-byte vectors, permuted (dense) views and operands at unaligned addresses (scalar path)"""
+    import torch.nn.functional as F
+    from msmctts_amd.hip import losses
+    torch.manual_seed(4)
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        shapes = [(3, 5, 7, 2), (2, 16, 33, 4), (4, 1, 1000), (1, 9), (2, 8, 64, 8)]
+        fake = [torch.randn(s, device=dev).to(dt).requires_grad_(True) for s in shapes]
+        real = [torch.randn(s, device=dev).to(dt) for s in shapes]
+        fake_v = [fake[0].permute(0, 3, 1, 2), fake[1].permute(0, 3, 1, 2), fake[2], fake[3], fake[4].permute(0, 3, 1, 2)]
+        real_v = [real[0].permute(0, 3, 1, 2), real[1].permute(0, 3, 1, 2), real[2], real[3], real[4].permute(0, 3, 1, 2)]
+        got = losses.l1_sum(fake_v, real_v)
+        want = sum(F.l1_loss(a.float(), b.float()) for a, b in zip(fake_v, real_v))
+        close(got, want, tol, what='l1 sum')
+        gg = torch.autograd.grad(got * 2.0, fake)
+        gw = torch.autograd.grad(want * 2.0, fake)
+        for a, b in zip(gg, gw):
+            close(a, b, tol * max(1e-3, float(b.float().abs().max())) if dt == torch.bfloat16 else 1e-7, what='l1 grad')
+        for target in (0.0, 1.0):
+            got = losses.mse_const_sum(fake_v, target)
+            want = sum(((a.float() - target) ** 2).mean() for a in fake_v)
+            close(got, want, tol, what='mse const sum')
+            gg = torch.autograd.grad(got, fake)
+            gw = torch.autograd.grad(want, fake)
+            for a, b in zip(gg, gw):
+                close(a, b, tol * max(1e-3, float(b.float().abs().max())) if dt == torch.bfloat16 else 1e-6, what='mse grad')
+        # operands at unaligned addresses: halves of a batch whose row size is not a multiple of 16 bytes
+        base = torch.randn(4, 3, 5, device=dev).to(dt).requires_grad_(True)
+        other = torch.randn(4, 3, 5, device=dev).to(dt)
+        got = losses.l1_sum([base[1:3]], [other[1:3]])
+        want = F.l1_loss(base[1:3].float(), other[1:3].float())
+        close(got, want, tol, what='l1 sum (offset view)')
+        (ga,), (gb,) = torch.autograd.grad(got, base), torch.autograd.grad(want, base)
+        close(ga, gb, tol * max(1e-3, float(gb.float().abs().max())) if dt == torch.bfloat16 else 1e-7, what='l1 grad (offset view)')
+
+
+def check_split_constant_gemm(dev):
+    """csrc/gemm1.inc conv_gemm1s_kernel (variants 36 / 37: fp32 data times a pre-split constant matrix, three bf16
+    products with fp32 accumulation) against the fp64 product: relative error of the two-piece split (~2^-16 of |w||x| per
+    product), both tile shapes, ragged row counts, contractions that are not whole chunks, ring and all-in-flight paths; and
+    the spectral chain built on it (image + gradient) against the exact-fp32 chain."""
+    import ctypes
+    from msmctts_amd.hip import conv as K
+    from msmctts_amd.hip import lib, spectral
+    torch.manual_seed(6)
+    for (B, T, Cin, Cout) in ((2, 51, 960, 964), (3, 17, 60, 64), (1, 130, 484, 484), (2, 40, 1200, 2052), (1, 5, 128, 40)):
+        x = torch.randn(B, 1, T, Cin, device=dev)
+        w = torch.randn(1, Cout, Cin, device=dev) / Cin ** 0.5
+        want = (x.double().reshape(-1, Cin) @ w[0].double().t()).reshape(B, 1, T, Cout)
+        img = spectral.split_image(w)
+        for variant in (36, 37):
+            key = ('g1s', B, T, Cin, Cout)
+            K._PLANS.pop(key, None)
+            out = K.const_gemm_split(x, img, Cout)                      # (builds the descriptor)
+            d = K._PLANS[key]
+            d.variant, d._tuned = variant, True
+            out = K.const_gemm_split(x, img, Cout)
+            assert b'conv_gemm1s_kernel' in lib.get().msmc_conv_last_kernel()
+            err = (out.double() - want).abs().max().item()
+            scale = float((x.double().reshape(-1, Cin).abs() @ w[0].double().abs().t()).max())
+            assert err <= 3.0e-5 * scale, (B, T, Cin, Cout, variant, err, scale)
+    # the MRD image chain in split mode against exact fp32: values and waveform gradient
+    n_fft, hop = 240, 60
+    win = torch.hann_window(n_fft, device=dev)
+    dft = spectral.dft_basis(n_fft, win, True, dev)
+    F = n_fft // 2 + 1
+    fb = spectral.projection(torch.rand(F, F).clamp(1e-6, 1.0) * (torch.rand(F, F) < 0.05), dev)
+    wav = (torch.rand(3, 2400, device=dev) * 2 - 1)
+    outs = []
+    for split in (False, True):
+        x = wav.clone().requires_grad_(True)
+        front = spectral.MrdFront(x, n_fft, hop, dft, fb, torch.float32, split=split)
+        g = torch.randn(front.img.shape, generator=torch.Generator().manual_seed(1)).to(dev)
+        outs.append((front.img.clone(), front.backward_rows(g, 0, 3)))
+    (img0, gx0), (img1, gx1) = outs
+    close(img1, img0, 2e-4, what='split-bf16 MRD image')
+    rel = ((gx1 - gx0).norm() / gx0.norm()).item()
+    assert rel <= 2e-4, 'split-bf16 MRD waveform gradient: relative L2 error %.3e' % rel

@@ -215,7 +215,7 @@ def test_graphed_step_matches_eager():
     graphed_vs_eager()
 
 
-def graphed_vs_eager(arm_reducer=False):
+def graphed_vs_eager(arm_reducer=False, exchange='serial'):
     import random
     from msmctts_amd.synthetic import make_batch
     from msmctts_amd.trainers import build_trainer
@@ -232,6 +232,7 @@ def graphed_vs_eager(arm_reducer=False):
             apply_gradient_allreduce(task)
         tr.optimizer = build_optimizer(task, cfg.optimizer, capturable=True)
         tr.use_graphs = graphed
+        tr.graph_exchange = exchange
         tr.rng = random.Random(3)
         if graphed:
             log = tr.train_step(batch, 6)        # capture (its eager warm-up is rolled back) + first replay
@@ -259,7 +260,9 @@ def test_rccl_gradient_reducer_single_rank_matches_reference():
     (autograd hooks + the HIP conv banks' hand-delivered gradients, collectives on RCCL's stream next to the
     multi-stream backward).  Averaging over one rank is the identity, so the golden step must still match; then
     the hipGraph step (capture with the process group alive, flat all-reduce between the replayed segments)
-    against the eager step."""
+    against the eager step; then the same with the OVERLAPPED graph-mode exchange (the reducer's bucketed all-reduces
+    captured into the segments on RCCL's stream, joined at the segment's end).  The subprocess has a hard timeout: a
+    collective that wedges inside a capture fails the test instead of hanging the suite."""
     import subprocess, sys, os, socket
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -275,6 +278,7 @@ def test_rccl_gradient_reducer_single_rank_matches_reference():
         "_parity.check_train_steps('cuda:0', arm_reducer=True)\n"
         "import test_gpu_parity\n"
         "test_gpu_parity.graphed_vs_eager(arm_reducer=True)\n"
+        "test_gpu_parity.graphed_vs_eager(arm_reducer=True, exchange='overlap')\n"
         "dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()\n"
         "print('REDUCER-OK')\n" % (root, os.path.join(root, 'msmc-tts_amd'), os.path.join(root, 'tests'), port))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -360,3 +364,11 @@ def test_wave_exchange_primitives():
 
 def test_masked_mean_and_non_atomic_colsum_match_stock_operators():
     _parity.check_masked_mean_and_colsum(DEV)
+
+
+def test_multi_tensor_gan_loss_kernels_match_stock_operators():
+    _parity.check_gan_loss_kernels(DEV)
+
+
+def test_split_bf16_constant_matrix_gemm_and_spectral_chain():
+    _parity.check_split_constant_gemm(DEV)

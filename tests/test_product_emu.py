@@ -1136,3 +1136,11 @@ def test_bench_attributes_work_to_every_kernel_family_of_a_step():
 
 def test_masked_mean_and_non_atomic_colsum_match_stock_operators():
     _parity.check_masked_mean_and_colsum('cpu')
+
+
+def test_multi_tensor_gan_loss_kernels_match_stock_operators():
+    _parity.check_gan_loss_kernels('cpu')
+
+
+def test_split_bf16_constant_matrix_gemm_and_spectral_chain():
+    _parity.check_split_constant_gemm('cpu')

@@ -36,7 +36,8 @@ def main():
     ap.add_argument('--top', type=int, default=80)
     a = ap.parse_args()
     import bench
-    args = argparse.Namespace(codewords=256, heads=4, batch=16, frames=400, graph=False, dtype='bf16', no_autocast=False)
+    args = argparse.Namespace(codewords=256, heads=4, batch=16, frames=400, graph=False, dtype='bf16', no_autocast=False,
+                              model_kw=dict(n_heads=4, embedding_sizes=256))
     device = torch.device('cuda', 0)
     torch.cuda.set_device(device)
     cfg, trainer = bench.build(args, device, 0, 1)
