@@ -261,10 +261,19 @@ def abi_work_models():
         'msmc_mrd_image_bwd_dt': lambda mel, gimg, gmel, B, T, F, FP, dt, st: (0.0, float(B * T * F * (8 + 2 * E(dt)))),
         'msmc_mrd_image_fwd': lambda mel, img, B, T, F, FP, st: (0.0, 12.0 * B * T * F),
         'msmc_mrd_image_bwd': lambda mel, gimg, gmel, B, T, F, FP, st: (0.0, 16.0 * B * T * F),
+        'msmc_wave_fan_fwd': lambda y, copies, plen, n, B, L, dt, st:
+            (0.0, float(B * (4 * L + E(dt) * sum(int(plen[k]) for k in range(int(n)))))),
+        'msmc_wave_fan_bwd': lambda g32, n32, gc, plen, n, gy, B, L, dt, st:
+            (0.0, float(B * (4 * L * (1 + sum(1 for k in range(int(n32)) if g32[k])) +
+                             E(dt) * sum(int(plen[k]) for k in range(int(n)) if gc[k])))),
+        'msmc_scalar_wsum_fwd': lambda terms, w, n, out, st: (0.0, 4.0 * (n + 1)),
+        'msmc_scalar_wsum_bwd': lambda gout, w, n, gvec, st: (0.0, 4.0 * (n + 1)),
         'msmc_log_clamp_fwd': lambda x, y, n, lo, st: (0.0, 8.0 * n),
         'msmc_log_clamp_bwd': lambda x, g, gx, n, lo, st: (0.0, 12.0 * n),
         'msmc_l1_multi_fwd': lambda tab, out, st: (0.0, float(table_bytes(tab, 2))),
         'msmc_l1_multi_bwd': lambda tab, gout, st: (0.0, float(table_bytes(tab, 3))),
+        'msmc_l1_multi_fwd_ws': lambda tab, part, out, st: (0.0, float(table_bytes(tab, 2))),
+        'msmc_mse_const_multi_fwd_ws': lambda tab, target, part, out, st: (0.0, float(table_bytes(tab, 1))),
         'msmc_mse_const_multi_fwd': lambda tab, target, out, st: (0.0, float(table_bytes(tab, 1))),
         'msmc_mse_const_multi_bwd': lambda tab, target, gout, st: (0.0, float(table_bytes(tab, 2))),
         'msmc_vq_prepare': lambda e, et, en, H, d, K, st: (0.0, 4.0 * H * d * K * 2 + 4.0 * H * K),
@@ -550,6 +559,11 @@ def main():
             return f, b
         return work
 
+    def split_gemm_work(x, wimg, cout):                   # the THREE bf16 products it executes (priced against the bf16 peak);
+        m = x.numel() // x.shape[-1]                      # x, out and the matrix image once
+        return 6.0 * m * x.shape[-1] * cout, 4.0 * (x.numel() + m * cout) + 2.0 * wimg.numel()
+
+    timer.wrap(hipconv, 'const_gemm_split', last_kernel, split_gemm_work)
     for fn, work in (('conv_forward', conv_work), ('conv_dgrad', dgrad_work), ('conv_wgrad', wgrad_work),
                      ('conv_transpose1d_forward', convt_work), ('conv_transpose1d_dgrad', convt_dgrad_work),
                      ('conv_transpose1d_wgrad', convt_wgrad_work)):

@@ -378,6 +378,17 @@ int msmc_mrd_image_bwd_dt(const float* mel, const void* gimg, float* gmel, int B
 int msmc_mrd_image_bwd(const float* mel, const float* gimg, float* gmel, int B, int T, int F, int FP,
                        msmc_stream stream);
 
+/* Waveform fan-out of the discriminator (reference msmctts/networks/hifigan/discriminator.py:102-116,135-145,180-190): the period
+ * sub-discriminators read the waveform cast to the stack's dtype and reflection-padded on the right to a multiple of their
+ * period; the resolution sub-discriminators read it in fp32.  Forward: copies[k] [B][padded_len[k]] (dtype 0 fp32 / 1 bf16),
+ * L <= padded_len[k] <= 2L - 1, all n (<= 8) copies in one launch.  Backward: gy [B][L] fp32 = sum of the n32 (<= 8) fp32
+ * gradients g32[j] [B][L] and of the copies' gradients folded at the reflected tail (entries may be NULL: no gradient) -- one
+ * launch instead of two pad gradients, a cast gradient and ~20 accumulations by the autograd engine. */
+int msmc_wave_fan_fwd(const float* y, void* const* copies, const int* padded_len, int n, int B, int L, int dtype,
+                      msmc_stream stream);
+int msmc_wave_fan_bwd(const float* const* g32, int n32, const void* const* gcopies, const int* padded_len, int n, float* gy,
+                      int B, int L, int dtype, msmc_stream stream);
+
 /* y = log(max(x, lo)) and its backward gx = g * (x > lo ? 1/x : 0) over n elements (stft_loss.py:110-114). */
 int msmc_log_clamp_fwd(const float* x, float* y, long n, float lo, msmc_stream stream);
 int msmc_log_clamp_bwd(const float* x, const float* g, float* gx, long n, float lo, msmc_stream stream);
@@ -400,10 +411,21 @@ typedef struct msmc_tensor_table {
 /* out[0] = sum_i mean_e |a_i[e] - b_i[e]| */
 int msmc_l1_multi_fwd(const msmc_tensor_table* t, float* out, msmc_stream stream);
 /* ga_i[e] = gout[0] * sign(a_i[e] - b_i[e]) / n_i */
+/* the same forward sums without atomics: per-block partial sums into ``partial`` (msmc_loss_multi_parts() floats), added by one
+ * workgroup in a fixed order (tensor by tensor, block by block): bit-reproducible, and no thousands of same-address atomics */
+int msmc_loss_multi_parts(void);
+int msmc_l1_multi_fwd_ws(const msmc_tensor_table* t, float* partial, float* out, msmc_stream stream);
+int msmc_mse_const_multi_fwd_ws(const msmc_tensor_table* t, float target, float* partial, float* out, msmc_stream stream);
 int msmc_l1_multi_bwd(const msmc_tensor_table* t, const float* gout, msmc_stream stream);
 /* out[0] = sum_i mean_e (a_i[e] - target)^2 ;  ga_i[e] = gout[0] * 2 (a_i[e] - target) / n_i */
 int msmc_mse_const_multi_fwd(const msmc_tensor_table* t, float target, float* out, msmc_stream stream);
 int msmc_mse_const_multi_bwd(const msmc_tensor_table* t, float target, const float* gout, msmc_stream stream);
+
+/* Weighted sums of loss scalars: out[0] = sum_i weights[i] * terms[i][0] (terms: n <= 64 device pointers to fp32 scalars; weights:
+ * n HOST floats, copied into the launch), in term order; backward gvec[i] = gout[0] * weights[i].  Replaces the multiply-and-add
+ * chains of 0-dim tensors of reference msmctts_trainer.py:52-62,129-133,160-195 (one launch per sum instead of two per term). */
+int msmc_scalar_wsum_fwd(const float* const* terms, const float* weights, int n, float* out, msmc_stream stream);
+int msmc_scalar_wsum_bwd(const float* gout, const float* weights, int n, float* gvec, msmc_stream stream);
 
 /* Length-masked means over [B][T][C] tensors (rows t >= lengths[b] are padding): the scalar terms
  *   QuantizerLoss                      reference msmctts/trainers/msmctts_trainer.py:52-62

@@ -3603,12 +3603,42 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ g, fl
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_part_kernel(const T* __restrict__ g, float* __restrict__ part, long rows, int C,
                                                          int rows_per_block) {
-    __shared__ float red[256];
+    __shared__ float red[256 * 8];
     const long r0 = (long)blockIdx.x * rows_per_block;
     long r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
     const int tid = threadIdx.x;
     float* dst = part + (size_t)blockIdx.x * C;
+    constexpr int VE = 16 / (int)sizeof(T);          // elements per 16-byte vector
+    if (C % VE == 0 && (256 * VE) % C == 0 && ((size_t)g & 15) == 0) {
+        // vector v = tid + 256 k of the block's flat element range always covers the VE columns (tid * VE) % C ..: one
+        // 16-byte load per step, VE running sums per work-item, then the work-items of a column group are added in order
+        const long nvec = (r1 > r0 ? (r1 - r0) : 0) * C / VE;
+        const T* base = g + r0 * C;
+        float acc[VE];
+#pragma unroll
+        for (int q = 0; q < VE; ++q) acc[q] = 0.f;
+        for (long v = tid; v < nvec; v += 256) {
+            const u32x4 w = *(const u32x4*)(base + v * VE);
+#pragma unroll
+            for (int q = 0; q < VE; ++q) {
+                float x;
+                if (sizeof(T) == 4) x = __uint_as_float(w[q & 3]);
+                else x = bf16_bits_to_f32((unsigned short)(w[(q >> 1) & 3] >> (16 * (q & 1))));
+                acc[q] = acc[q] + x;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < VE; ++q) red[tid * VE + q] = acc[q];
+        __syncthreads();
+        const int groups = C / VE;                    // work-items t with t % groups == c / VE hold column c at slot c % VE
+        for (int c = tid; c < C; c += 256) {
+            float s = 0.f;
+            for (int t = c / VE; t < 256; t += groups) s = s + red[t * VE + (c % VE)];
+            dst[c] = s;
+        }
+        return;
+    }
     if (C >= 256 || (256 % C) != 0) {               // one or more whole columns per work-item
         for (int c = tid; c < C; c += 256) {
             float s = 0.f;
@@ -3897,8 +3927,8 @@ int msmc_reflect_fold_multi_tap(const void* const* gp, const void* const* mask_s
 }
 
 static int colsum_blocks(long rows) {
-    long nb = (rows + 127) / 128;                    // >= 128 rows per block, at most 128 blocks (the second stage is ONE
-    if (nb > 128) nb = 128;                          // workgroup per 256 columns: it reads nb rows of partial sums)
+    long nb = (rows + 127) / 128;                    // >= 128 rows per block, at most one block per CU (the second stage is ONE
+    if (nb > 256) nb = 256;                          // workgroup per 256 columns: it reads nb rows of partial sums)
     return (int)(nb < 1 ? 1 : nb);
 }
 size_t msmc_colsum_workspace(long rows, int C) { return rows > 0 && C > 0 ? (size_t)colsum_blocks(rows) * C * sizeof(float) : 0; }

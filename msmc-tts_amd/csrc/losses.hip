@@ -30,8 +30,11 @@ MSMC_DEV float loss_block_sum(float v, float* red) {
 }
 
 // MODE 0: L1(a, b)   MODE 1: (a - target)^2
+// part != NULL: the block's sum goes to part[tensor * gridDim.x + block] (loss_multi_final_kernel adds them in a fixed order:
+// bit-reproducible, and no 14 000 same-address atomics per launch); part == NULL: atomicAdd of the block's share into out
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void loss_multi_fwd_kernel(msmc_tensor_table t, float target, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void loss_multi_fwd_kernel(msmc_tensor_table t, float target, float* __restrict__ out,
+                                                            float* __restrict__ part) {
     __shared__ float red[256];
     const int i = blockIdx.y;
     const long n = t.n[i];
@@ -74,7 +77,25 @@ __global__ __launch_bounds__(256) void loss_multi_fwd_kernel(msmc_tensor_table t
         }
     }
     s = loss_block_sum(s, red);
+    if (part) {
+        if (threadIdx.x == 0) part[(size_t)i * gridDim.x + blockIdx.x] = s;
+        return;
+    }
     if (threadIdx.x == 0 && (long)blockIdx.x * 256 < n) atomicAdd(out, s / (float)n);
+}
+
+// out[0] = sum_i (sum_x part[i][x]) / n_i, tensors in table order, blocks in index order (one workgroup)
+__global__ __launch_bounds__(256) void loss_multi_final_kernel(msmc_tensor_table t, const float* __restrict__ part, int bx,
+                                                               float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < t.count; i += 256) {
+        float ti = 0.f;
+        for (int x = 0; x < bx; ++x) ti = ti + part[(size_t)i * bx + x];
+        s = s + ti / (float)t.n[i];
+    }
+    s = loss_block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s;
 }
 
 template <typename T, int MODE>
@@ -207,8 +228,9 @@ __global__ __launch_bounds__(256) void masked_mean_bwd_kernel(const TA* __restri
 }
 
 template <int MODE>
+#define LOSS_WS_BX 64
 static int loss_launch(const msmc_tensor_table* t, float target, float* out, const float* gout, bool bwd,
-                       msmc_stream stream) {
+                       msmc_stream stream, float* part = nullptr) {
     if (!t || t->count <= 0 || t->count > MSMC_MAX_TENSORS) return MSMC_E_SHAPE;
     long nmax = 0;
     for (int i = 0; i < t->count; ++i) {
@@ -218,10 +240,18 @@ static int loss_launch(const msmc_tensor_table* t, float target, float* out, con
     long bx = (nmax + 4095) / 4096;
     if (bx > 256) bx = 256;
     dim3 grid((unsigned)bx, (unsigned)t->count);
-    if (!bwd) {
+    if (!bwd && part) {
+        const dim3 g2(LOSS_WS_BX, (unsigned)t->count);
+        if (t->dtype == 0) MSMC_LAUNCH((loss_multi_fwd_kernel<float, MODE>), g2, dim3(256), 0, (msmc_stream_t)stream, *t, target, out, part);
+        else if (t->dtype == 1) MSMC_LAUNCH((loss_multi_fwd_kernel<unsigned short, MODE>), g2, dim3(256), 0, (msmc_stream_t)stream, *t, target, out, part);
+        else return MSMC_E_SHAPE;
+        int rc = msmc_check_launch();
+        if (rc) return rc;
+        MSMC_LAUNCH(loss_multi_final_kernel, dim3(1), dim3(256), 0, (msmc_stream_t)stream, *t, (const float*)part, LOSS_WS_BX, out);
+    } else if (!bwd) {
         MSMC_LAUNCH(loss_zero_kernel, dim3(1), dim3(64), 0, (msmc_stream_t)stream, out);
-        if (t->dtype == 0) MSMC_LAUNCH((loss_multi_fwd_kernel<float, MODE>), grid, dim3(256), 0, (msmc_stream_t)stream, *t, target, out);
-        else if (t->dtype == 1) MSMC_LAUNCH((loss_multi_fwd_kernel<unsigned short, MODE>), grid, dim3(256), 0, (msmc_stream_t)stream, *t, target, out);
+        if (t->dtype == 0) MSMC_LAUNCH((loss_multi_fwd_kernel<float, MODE>), grid, dim3(256), 0, (msmc_stream_t)stream, *t, target, out, (float*)nullptr);
+        else if (t->dtype == 1) MSMC_LAUNCH((loss_multi_fwd_kernel<unsigned short, MODE>), grid, dim3(256), 0, (msmc_stream_t)stream, *t, target, out, (float*)nullptr);
         else return MSMC_E_SHAPE;
     } else {
         if (t->dtype == 0) MSMC_LAUNCH((loss_multi_bwd_kernel<float, MODE>), grid, dim3(256), 0, (msmc_stream_t)stream, *t, target, gout);
@@ -229,6 +259,27 @@ static int loss_launch(const msmc_tensor_table* t, float target, float* out, con
         else return MSMC_E_SHAPE;
     }
     return msmc_check_launch();
+}
+
+// ---- weighted sums of loss scalars ------------------------------------------------------------------------------------------
+// vq_loss = sum_i lambda_i term_i, g_loss = vq_loss + lambda_frame frame + lambda_stft stft (+ adv + lambda_fm fm), d_loss =
+// d_real + d_fake (reference msmctts_trainer.py:52-62,129-133,160-195) were a multiply and an add of 0-dim tensors per term: ~25
+// one-thread launches per step.  One launch per sum here (and one for all the terms' gradients).
+struct ScalarSumArgs {
+    int n;
+    const float* x[MSMC_MAX_TENSORS];
+    float w[MSMC_MAX_TENSORS];
+};
+__global__ void scalar_wsum_fwd_kernel(ScalarSumArgs a, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < a.n; ++i) s = fmaf(a.w[i], a.x[i][0], s);      // (in term order)
+        out[0] = s;
+    }
+}
+__global__ void scalar_wsum_bwd_kernel(ScalarSumArgs a, const float* __restrict__ gout, float* __restrict__ gvec) {
+    const int i = threadIdx.x;
+    if (i < a.n) gvec[i] = gout[0] * a.w[i];
 }
 
 template <typename TA, typename TB>
@@ -279,6 +330,38 @@ int msmc_masked_mean_bwd(const void* a, const void* b, const void* lengths, int 
 }
 int msmc_l1_multi_fwd(const msmc_tensor_table* t, float* out, msmc_stream stream) {
     return loss_launch<0>(t, 0.f, out, nullptr, false, stream);
+}
+int msmc_scalar_wsum_fwd(const float* const* terms, const float* weights, int n, float* out, msmc_stream stream) {
+    if (!terms || !weights || !out || n <= 0 || n > MSMC_MAX_TENSORS) return MSMC_E_SHAPE;
+    ScalarSumArgs a;
+    a.n = n;
+    for (int i = 0; i < n; ++i) {
+        if (!terms[i]) return MSMC_E_SHAPE;
+        a.x[i] = terms[i];
+        a.w[i] = weights[i];
+    }
+    MSMC_LAUNCH(scalar_wsum_fwd_kernel, dim3(1), dim3(64), 0, (msmc_stream_t)stream, a, out);
+    return msmc_check_launch();
+}
+int msmc_scalar_wsum_bwd(const float* gout, const float* weights, int n, float* gvec, msmc_stream stream) {
+    if (!gout || !weights || !gvec || n <= 0 || n > MSMC_MAX_TENSORS) return MSMC_E_SHAPE;
+    ScalarSumArgs a;
+    a.n = n;
+    for (int i = 0; i < n; ++i) {
+        a.x[i] = nullptr;
+        a.w[i] = weights[i];
+    }
+    MSMC_LAUNCH(scalar_wsum_bwd_kernel, dim3(1), dim3(64), 0, (msmc_stream_t)stream, a, gout, gvec);
+    return msmc_check_launch();
+}
+int msmc_loss_multi_parts(void) { return MSMC_MAX_TENSORS * LOSS_WS_BX; }
+int msmc_l1_multi_fwd_ws(const msmc_tensor_table* t, float* partial, float* out, msmc_stream stream) {
+    if (!partial) return MSMC_E_WORKSPACE;
+    return loss_launch<0>(t, 0.f, out, nullptr, false, stream, partial);
+}
+int msmc_mse_const_multi_fwd_ws(const msmc_tensor_table* t, float target, float* partial, float* out, msmc_stream stream) {
+    if (!partial) return MSMC_E_WORKSPACE;
+    return loss_launch<1>(t, target, out, nullptr, false, stream, partial);
 }
 int msmc_l1_multi_bwd(const msmc_tensor_table* t, const float* gout, msmc_stream stream) {
     return loss_launch<0>(t, 0.f, nullptr, gout, true, stream);

@@ -161,6 +161,62 @@ static inline dim3 sp_grid(long total) {
     return dim3((unsigned)b);
 }
 
+// ---- waveform fan-out of the discriminator (reference hifigan/discriminator.py:102-116,135-145,180-190) ------------------
+// One generated waveform feeds five resolution sub-discriminators (fp32 spectral front-ends) and five period sub-discriminators
+// (a cast to the stack's dtype, a reflection pad to a multiple of the period for two of them, a fold).  As stock operators that
+// is a cast + two pads forward and, backward, two pad gradients, a cast gradient and ~20 accumulations of [B][L] gradients by
+// the autograd engine.  Forward here: every period's padded copy in ONE launch; backward: the sum of all consumers' gradients
+// (fp32 front-end gradients + padded period gradients folded at the reflected tail) in ONE launch.
+#define WF_MAX 8
+struct WaveFanArgs {
+    int n16, n32;                       // period copies / fp32 gradient tensors
+    int Lp[WF_MAX];                     // padded length of copy k
+    void* p16[WF_MAX];                  // copies [B][Lp[k]] (forward: written; backward: their gradients, NULL = none)
+    const float* p32[WF_MAX];           // backward only: fp32 gradients [B][L] (NULL = none)
+};
+template <typename T>
+__global__ __launch_bounds__(256) void wave_fan_fwd_kernel(const float* __restrict__ y, WaveFanArgs a, int L, int Lmax,
+                                                          long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int t = (int)(e % Lmax);
+        const long b = e / Lmax;
+        const float v = y[b * L + sp_reflect(t, L)];
+#pragma unroll
+        for (int k = 0; k < WF_MAX; ++k)
+            if (k < a.n16 && t < a.Lp[k]) {
+                if (sizeof(T) == 4) ((float*)a.p16[k])[b * a.Lp[k] + t] = v;
+                else ((unsigned short*)a.p16[k])[b * a.Lp[k] + t] = f32_to_bf16_bits(v);
+            }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void wave_fan_bwd_kernel(WaveFanArgs a, float* __restrict__ gy, int L, long total) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int l = (int)(e % L);
+        const long b = e / L;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < WF_MAX; ++k)
+            if (k < a.n32 && a.p32[k]) s = s + a.p32[k][e];
+        const int tr = 2 * (L - 1) - l;                  // padded position that reflects onto l (tail only: tr >= L)
+#pragma unroll
+        for (int k = 0; k < WF_MAX; ++k)
+            if (k < a.n16 && a.p16[k]) {
+                const long base = b * a.Lp[k];
+                if (sizeof(T) == 4) {
+                    const float* g = (const float*)a.p16[k];
+                    s = s + g[base + l];
+                    if (tr >= L && tr < a.Lp[k]) s = s + g[base + tr];
+                } else {
+                    const unsigned short* g = (const unsigned short*)a.p16[k];
+                    s = s + bf16_bits_to_f32(g[base + l]);
+                    if (tr >= L && tr < a.Lp[k]) s = s + bf16_bits_to_f32(g[base + tr]);
+                }
+            }
+        gy[e] = s;
+    }
+}
+
 extern "C" {
 
 int msmc_stft_frames_fwd(const float* x, float* frames, int B, int L, int T, int n_fft, int NP, int hop, int pad,
@@ -236,4 +292,41 @@ int msmc_log_clamp_bwd(const float* x, const float* g, float* gx, long n, float 
     return msmc_check_launch();
 }
 
+
+int msmc_wave_fan_fwd(const float* y, void* const* copies, const int* padded_len, int n, int B, int L, int dtype,
+                      msmc_stream stream) {
+    if (!y || !copies || !padded_len || n <= 0 || n > WF_MAX || B <= 0 || L <= 1 || dtype < 0 || dtype > 1) return MSMC_E_SHAPE;
+    WaveFanArgs a;
+    a.n16 = n;
+    a.n32 = 0;
+    int Lmax = 0;
+    for (int k = 0; k < n; ++k) {
+        if (!copies[k] || padded_len[k] < L || padded_len[k] > 2 * L - 1) return MSMC_E_SHAPE;   // (one reflection at most)
+        a.p16[k] = copies[k];
+        a.Lp[k] = padded_len[k];
+        if (padded_len[k] > Lmax) Lmax = padded_len[k];
+    }
+    const long total = (long)B * Lmax;
+    if (dtype == 0) MSMC_LAUNCH(wave_fan_fwd_kernel<float>, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, y, a, L, Lmax, total);
+    else MSMC_LAUNCH(wave_fan_fwd_kernel<unsigned short>, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, y, a, L, Lmax, total);
+    return msmc_check_launch();
+}
+int msmc_wave_fan_bwd(const float* const* g32, int n32, const void* const* gcopies, const int* padded_len, int n, float* gy,
+                      int B, int L, int dtype, msmc_stream stream) {
+    if (!gy || n < 0 || n > WF_MAX || n32 < 0 || n32 > WF_MAX || B <= 0 || L <= 1 || dtype < 0 || dtype > 1) return MSMC_E_SHAPE;
+    if ((n && (!gcopies || !padded_len)) || (n32 && !g32)) return MSMC_E_SHAPE;
+    WaveFanArgs a;
+    a.n16 = n;
+    a.n32 = n32;
+    for (int k = 0; k < n; ++k) {
+        if (padded_len[k] < L || padded_len[k] > 2 * L - 1) return MSMC_E_SHAPE;
+        a.p16[k] = (void*)gcopies[k];
+        a.Lp[k] = padded_len[k];
+    }
+    for (int k = 0; k < n32; ++k) a.p32[k] = g32[k];
+    const long total = (long)B * L;
+    if (dtype == 0) MSMC_LAUNCH(wave_fan_bwd_kernel<float>, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, a, gy, L, total);
+    else MSMC_LAUNCH(wave_fan_bwd_kernel<unsigned short>, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, a, gy, L, total);
+    return msmc_check_launch();
+}
 }  // extern "C"

@@ -86,9 +86,16 @@ _SIGNATURES.update({
     'msmc_mrd_image_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'msmc_mrd_image_fwd_dt': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'msmc_mrd_image_bwd_dt': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'msmc_wave_fan_fwd': (_i, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _i, _i, _i, _vp]),
+    'msmc_wave_fan_bwd': (_i, [ctypes.POINTER(_vp), _i, ctypes.POINTER(_vp), ctypes.POINTER(_i), _i, _vp, _i, _i, _i, _vp]),
     'msmc_log_clamp_fwd': (_i, [_vp, _vp, ctypes.c_long, _f, _vp]),
     'msmc_log_clamp_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _f, _vp]),
     'msmc_l1_multi_fwd': (_i, [ctypes.POINTER(TensorTable), _vp, _vp]),
+    'msmc_scalar_wsum_fwd': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_f), _i, _vp, _vp]),
+    'msmc_scalar_wsum_bwd': (_i, [_vp, ctypes.POINTER(_f), _i, _vp, _vp]),
+    'msmc_loss_multi_parts': (_i, []),
+    'msmc_l1_multi_fwd_ws': (_i, [ctypes.POINTER(TensorTable), _vp, _vp, _vp]),
+    'msmc_mse_const_multi_fwd_ws': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp, _vp]),
     'msmc_l1_multi_bwd': (_i, [ctypes.POINTER(TensorTable), _vp, _vp]),
     'msmc_mse_const_multi_fwd': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp]),
     'msmc_mse_const_multi_bwd': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp]),

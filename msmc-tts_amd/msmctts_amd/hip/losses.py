@@ -49,7 +49,9 @@ class _L1Sum(torch.autograd.Function):
         a, b = list(tensors[:k]), list(tensors[k:])
         out = torch.empty(1, dtype=torch.float32, device=a[0].device)
         tab = _table(a, b)
-        lib.check(lib.get().msmc_l1_multi_fwd(ctypes.byref(tab), lib.ptr(out), lib.stream(out)), 'msmc_l1_multi_fwd')
+        part = torch.empty(lib.get().msmc_loss_multi_parts(), dtype=torch.float32, device=a[0].device)
+        lib.check(lib.get().msmc_l1_multi_fwd_ws(ctypes.byref(tab), lib.ptr(part), lib.ptr(out), lib.stream(out)),
+                  'msmc_l1_multi_fwd_ws')
         ctx.k = k
         ctx.save_for_backward(*tensors)
         return out.reshape(())
@@ -72,8 +74,9 @@ class _MseConstSum(torch.autograd.Function):
         a = list(tensors)
         out = torch.empty(1, dtype=torch.float32, device=a[0].device)
         tab = _table(a)
-        lib.check(lib.get().msmc_mse_const_multi_fwd(ctypes.byref(tab), float(target), lib.ptr(out), lib.stream(out)),
-                  'msmc_mse_const_multi_fwd')
+        part = torch.empty(lib.get().msmc_loss_multi_parts(), dtype=torch.float32, device=a[0].device)
+        lib.check(lib.get().msmc_mse_const_multi_fwd_ws(ctypes.byref(tab), float(target), lib.ptr(part), lib.ptr(out),
+                                                        lib.stream(out)), 'msmc_mse_const_multi_fwd_ws')
         ctx.target = float(target)
         ctx.save_for_backward(*tensors)
         return out.reshape(())
@@ -87,6 +90,51 @@ class _MseConstSum(torch.autograd.Function):
         lib.check(lib.get().msmc_mse_const_multi_bwd(ctypes.byref(tab), ctx.target, lib.ptr(g), lib.stream(g)),
                   'msmc_mse_const_multi_bwd')
         return (None,) + tuple(ga)
+
+
+class _MseConstHalves(torch.autograd.Function):
+    """LSGAN terms of a discriminator pass over a concatenated batch [first; second]: (sum_i mean((t_i[:B] - c0)^2),
+    sum_i mean((t_i[B:] - c1)^2)) straight from the full tensors -- the halves are contiguous row ranges, so the tensor tables
+    point into them and the backward pass writes both halves of ONE full-size gradient per tensor (slicing each score tensor
+    first cost a concatenation per tensor in the backward pass: 10 launches per step)."""
+
+    @staticmethod
+    def forward(ctx, B, c0, c1, *tensors):
+        outs = []
+        L = lib.get()
+        for half, target in ((0, c0), (1, c1)):
+            part = [t[:B] if half == 0 else t[B:] for t in tensors]
+            out = torch.empty(1, dtype=torch.float32, device=tensors[0].device)
+            ws = torch.empty(L.msmc_loss_multi_parts(), dtype=torch.float32, device=tensors[0].device)
+            tab = _table(part)
+            lib.check(L.msmc_mse_const_multi_fwd_ws(ctypes.byref(tab), float(target), lib.ptr(ws), lib.ptr(out), lib.stream(out)),
+                      'msmc_mse_const_multi_fwd_ws')
+            outs.append(out.reshape(()))
+        ctx.args = (B, float(c0), float(c1))
+        ctx.save_for_backward(*tensors)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        B, c0, c1 = ctx.args
+        tensors = ctx.saved_tensors
+        ga = [torch.empty_like(t) for t in tensors]
+        L = lib.get()
+        for half, target, g in ((0, c0, g0), (1, c1, g1)):
+            rows = (lambda t: t[:B]) if half == 0 else (lambda t: t[B:])
+            if g is None:
+                for t in ga:
+                    rows(t).zero_()
+                continue
+            tab = _table([rows(t) for t in tensors], None, [rows(t) for t in ga])
+            gs = g.reshape(1).float().contiguous()
+            lib.check(L.msmc_mse_const_multi_bwd(ctypes.byref(tab), target, lib.ptr(gs), lib.stream(gs)), 'msmc_mse_const_multi_bwd')
+        return (None, None, None) + tuple(ga)
+
+
+def mse_const_halves(tensors, B, c0, c1):
+    """(sum_i mean((t_i[:B] - c0)^2), sum_i mean((t_i[B:] - c1)^2)) for score tensors of a [2B, ...] batch"""
+    return _MseConstHalves.apply(int(B), float(c0), float(c1), *tensors)
 
 
 def l1_sum(fake, real):
@@ -138,3 +186,39 @@ def masked_mean(a, lengths, b=None):
 def usable(*tensors):
     """the fused loss ops run on the GPU (or on the kernel interpreter in the CPU tests)"""
     return all(t is None or t.is_cuda or lib._host_pointers_ok for t in tensors)
+
+
+class _WeightedSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        n = len(terms)
+        ts = [t.reshape(1) if t.dtype == torch.float32 else t.float().reshape(1) for t in terms]
+        out = torch.empty(1, dtype=torch.float32, device=ts[0].device)
+        vp, fp = ctypes.c_void_p * n, ctypes.c_float * n
+        lib.check(lib.get().msmc_scalar_wsum_fwd(vp(*[lib.ptr(t, torch.float32).value for t in ts]), fp(*weights), n, lib.ptr(out),
+                                                 lib.stream(out)), 'msmc_scalar_wsum_fwd')
+        ctx.weights = tuple(weights)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        n = len(ctx.weights)
+        g = gout.reshape(1).float().contiguous()
+        gvec = torch.empty(n, dtype=torch.float32, device=g.device)
+        lib.check(lib.get().msmc_scalar_wsum_bwd(lib.ptr(g), (ctypes.c_float * n)(*ctx.weights), n, lib.ptr(gvec), lib.stream(g)),
+                  'msmc_scalar_wsum_bwd')
+        return (None,) + tuple(gvec[i] for i in range(n))
+
+
+def weighted_sum(terms, weights=None):
+    """sum_i weights[i] * terms[i] for 0-dim loss tensors (weights: python floats, default 1) -- one launch (msmc_scalar_wsum_fwd)
+    where the tensors live on the GPU / the interpreter is bound, the stock multiply-and-add chain otherwise"""
+    terms = list(terms)
+    weights = [1.0] * len(terms) if weights is None else [float(w) for w in weights]
+    if (0 < len(terms) <= lib.MAX_TENSORS and all(torch.is_tensor(t) and t.numel() == 1 and t.dtype.is_floating_point for t in terms)
+            and usable(*terms) and len(set(t.device for t in terms)) == 1):
+        return _WeightedSum.apply(tuple(weights), *terms)
+    out = 0
+    for t, w in zip(terms, weights):
+        out = out + (t if w == 1.0 else w * t)
+    return out

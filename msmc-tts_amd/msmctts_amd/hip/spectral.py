@@ -340,3 +340,45 @@ def log_mel(y, n_fft, hop, dft, mel, num_mels, split=False):
     mag = _SpecMag.apply(spec, F, _pad4(F), 1e-9, 0)
     m = _ConstGemm.apply(mag, mel[0], mel[1], split)
     return _LogClamp.apply(m, 1e-5)[..., :num_mels]
+
+
+class _WaveFan(torch.autograd.Function):
+    """y (B, L) fp32 -> ``n_alias`` aliases of y (for consumers that read it in fp32: the resolution sub-discriminators'
+    front-ends) followed by one copy per entry of ``padded`` in ``dtype``, reflection-padded on the right to that length (the
+    period sub-discriminators' inputs).  The backward pass is ONE launch summing every consumer's gradient (msmc_wave_fan_bwd)."""
+
+    @staticmethod
+    def forward(ctx, y, n_alias, padded, dtype):
+        import ctypes
+        B, L = y.shape
+        yc = y.contiguous().float()
+        copies = [torch.empty((B, lp), dtype=dtype, device=y.device) for lp in padded]
+        n = len(copies)
+        if n:
+            vp, ip = ctypes.c_void_p * n, ctypes.c_int * n
+            lib.check(lib.get().msmc_wave_fan_fwd(lib.ptr(yc), vp(*[lib.ptr(c).value for c in copies]), ip(*padded), n, B, L,
+                                                  _IMG_DT[dtype], lib.stream(yc)), 'msmc_wave_fan_fwd')
+        ctx.args = (B, L, int(n_alias), tuple(padded), dtype)
+        return tuple(yc.view_as(yc) for _ in range(n_alias)) + tuple(copies)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        B, L, n_alias, padded, dtype = ctx.args
+        g32 = [None if g is None else g.contiguous().float() for g in grads[:n_alias]]
+        g16 = [None if g is None else (g if g.dtype == dtype else g.to(dtype)).contiguous() for g in grads[n_alias:]]
+        dev = next(g.device for g in list(g32) + list(g16) if g is not None)
+        gy = torch.empty((B, L), dtype=torch.float32, device=dev)
+        n32, n = len(g32), len(g16)
+        vp32, vp16, ip = ctypes.c_void_p * max(1, n32), ctypes.c_void_p * max(1, n), ctypes.c_int * max(1, n)
+        p32 = vp32(*([None if g is None else lib.ptr(g).value for g in g32] or [None]))
+        p16 = vp16(*([None if g is None else lib.ptr(g).value for g in g16] or [None]))
+        lib.check(lib.get().msmc_wave_fan_bwd(p32, n32, p16, ip(*(list(padded) or [L])), n, lib.ptr(gy), B, L, _IMG_DT[dtype],
+                                              lib.stream(gy)), 'msmc_wave_fan_bwd')
+        return gy, None, None, None
+
+
+def wave_fan(y, n_alias, padded, dtype):
+    """-> (aliases of y for fp32 readers, reflection-padded copies of y in ``dtype``): see _WaveFan"""
+    outs = _WaveFan.apply(y, int(n_alias), tuple(int(v) for v in padded), dtype)
+    return list(outs[:n_alias]), list(outs[n_alias:])

@@ -144,12 +144,16 @@ class SpectralFronts(object):
         output), so that the images' gradient flows back through the saved front-end tensors"""
         return SpectralFronts(self.fronts, self.r0 + r0, self.r0 + r1, wav)
 
-    def images(self):
+    def images(self, wavs=None):
+        """``wavs``: one alias of the waveform per front (hip/spectral.py wave_fan), so that the fronts' gradients are
+        summed by the fan's backward launch instead of by the autograd engine"""
         from ...hip import spectral
         if self.wav is None:
             return [f.image(self.r0, self.r1) for f in self.fronts]
-        wav = self.wav.squeeze(1) if self.wav.dim() == 3 else self.wav
-        return [spectral.mrd_image_rows(wav.float(), f, self.r0, self.r1) for f in self.fronts]
+        if wavs is None:
+            wav = self.wav.squeeze(1) if self.wav.dim() == 3 else self.wav
+            wavs = [wav] * len(self.fronts)
+        return [spectral.mrd_image_rows(w.float(), f, self.r0, self.r1) for w, f in zip(wavs, self.fronts)]
 
 
 class Discriminator(nn.Module):
@@ -196,10 +200,23 @@ class Discriminator(nn.Module):
         dtype = self.hip_dtype
         assert self.mrd.domain == 'double', 'every shipped config uses the two-channel (mag, log-mag) image'
         wav = y.squeeze(1)
-        if fronts is not None and fronts.fronts[0].dtype == dtype and fronts.r1 - fronts.r0 == wav.shape[0]:
-            xs = fronts.images()
+        # ONE launch makes the period stacks' inputs (cast + reflection pad to a multiple of the period) and hands the
+        # resolution stacks' front-ends aliases of the waveform; its backward launch sums all ten consumers' gradients
+        from ...hip import spectral
+        L = wav.shape[1]
+        padded = [(L + d.period - 1) // d.period * d.period for d in self.mpd.discriminators]
+        fan = (len(padded) <= 8 and len(self.mrd.stfts) <= 8 and all(p <= 2 * L - 1 for p in padded)
+               and wav.dtype == torch.float32 and (wav.is_cuda or spectral.lib._host_pointers_ok))
+        if fan:
+            wavs, copies = spectral.wave_fan(wav, len(self.mrd.stfts) if wav.requires_grad else 0, padded, dtype)
+            if not wav.requires_grad:
+                wavs = [wav] * len(self.mrd.stfts)
         else:
-            xs = [stft.image_cl(wav, dtype) for stft in self.mrd.stfts]      # (images written in the compute dtype: no cast launches)
+            wavs, copies = [wav] * len(self.mrd.stfts), None
+        if fronts is not None and fronts.fronts[0].dtype == dtype and fronts.r1 - fronts.r0 == wav.shape[0]:
+            xs = fronts.images(wavs if (fan and wav.requires_grad) else None)
+        else:
+            xs = [stft.image_cl(w, dtype) for w, stft in zip(wavs, self.mrd.stfts)]      # (images written in the compute dtype: no cast launches)
         r_fmaps = [[] for _ in xs]
         last = len(mrd[0]) - 1
         xs = hip_conv_group(bank, [dict(layer=mrd[j][0], x=xs[j], **ACT) for j in range(len(xs))])
@@ -213,14 +230,18 @@ class Discriminator(nn.Module):
             xs = [x for x, _ in xt]
         r_scores = [x.permute(0, 3, 1, 2) for x in xs]
         ps = []
-        yc = y.to(dtype)                                  # ONE cast of the waveform; padding and folding in the compute dtype
-        for d in self.mpd.discriminators:
-            b, c, t = yc.shape
-            x = yc
-            if t % d.period != 0:
-                x = F.pad(x, (0, d.period - (t % d.period)), 'reflect')
-                t = x.shape[2]
-            ps.append(x.reshape(b, t // d.period, d.period, 1))                # C == 1: NCHW and NHWC coincide
+        if copies is not None:
+            for d, x in zip(self.mpd.discriminators, copies):
+                ps.append(x.reshape(x.shape[0], x.shape[1] // d.period, d.period, 1))      # C == 1: NCHW and NHWC coincide
+        else:
+            yc = y.to(dtype)                              # ONE cast of the waveform; padding and folding in the compute dtype
+            for d in self.mpd.discriminators:
+                b, c, t = yc.shape
+                x = yc
+                if t % d.period != 0:
+                    x = F.pad(x, (0, d.period - (t % d.period)), 'reflect')
+                    t = x.shape[2]
+                ps.append(x.reshape(b, t // d.period, d.period, 1))            # C == 1: NCHW and NHWC coincide
         p_fmaps = [[] for _ in ps]
         nl = len(mpd[0]) - 1
         # every feature map has two consumers (the next layer and the feature-matching loss): the loss reads the alias the

@@ -225,7 +225,8 @@ class MultiStageQuantizer(nn.Module):
         return out
 
     def compute_embedding_loss(self, pred_states, methods=['mse'], loss_weights=[1.0]):
-        losses = {'total_loss': 0}
+        losses = {}
+        parts, pweights = [], []                # total_loss = sum of weights * terms: one launch (hiploss.weighted_sum)
         for i, st in enumerate(pred_states):
             p = st['predictor_outputs']
             if p is None:
@@ -239,7 +240,8 @@ class MultiStageQuantizer(nn.Module):
                     # mean over channels, masked sum over frames, / sum of lengths: one fused masked mean (two launches)
                     loss = hiploss.masked_mean(p, lengths, b=st['target_outputs'].detach())
                     losses['embed_loss_%s_%d' % (method, i)] = loss
-                    losses['total_loss'] = losses['total_loss'] + loss * weight
+                    parts.append(loss)
+                    pweights.append(weight)
                     continue
                 if method == 'mse':
                     loss = F.mse_loss(p, st['target_outputs'].detach(), reduction='none').mean(-1)
@@ -256,7 +258,9 @@ class MultiStageQuantizer(nn.Module):
                 loss = loss.masked_fill(get_mask_from_lengths(lengths.to(loss.device), loss.shape[1]), 0)
                 loss = loss.sum() / lengths.sum()
                 losses['embed_loss_%s_%d' % (method, i)] = loss
-                losses['total_loss'] = losses['total_loss'] + loss * weight
+                parts.append(loss)
+                pweights.append(weight)
+        losses['total_loss'] = hiploss.weighted_sum(parts, pweights) if parts else 0
         return losses
 
 

@@ -34,7 +34,8 @@ class QuantizerLoss(nn.Module):
         self.lambda_vq, self.lambda_pr = lambda_vq, lambda_pr
 
     def forward(self, outputs):
-        loss = {'vq_loss': 0}
+        loss = {}
+        parts, weights = [], []                 # vq_loss = sum of weights[i] * parts[i]: ONE launch (hiploss.weighted_sum)
         diffs = outputs['encoder_diffs']
         if not isinstance(diffs, (tuple, list)):
             diffs = [diffs]
@@ -48,12 +49,15 @@ class QuantizerLoss(nn.Module):
                     pad = get_mask_from_lengths(length.to(term.device), term.shape[1]).unsqueeze(-1)
                     term = term.masked_fill(pad, 0).sum() / length.sum() / term.shape[2]
                 loss['latent_loss_{}_{}'.format(i, j)] = term
-                loss['vq_loss'] = loss['vq_loss'] + self.lambda_vq * term
+                parts.append(term)
+                weights.append(self.lambda_vq)
         dd = outputs.get('decoder_diffs')
         if isinstance(dd, dict):
             dd = dict(dd)
-            loss['vq_loss'] = loss['vq_loss'] + self.lambda_pr * dd.pop('total_loss')
+            parts.append(dd.pop('total_loss'))
+            weights.append(self.lambda_pr)
             loss.update(dd)
+        loss['vq_loss'] = hiploss.weighted_sum(parts, weights) if parts else 0
         return loss
 
 
@@ -165,9 +169,11 @@ class VQGANTrainer(BaseTrainer):
                 ml = ml.masked_fill(get_mask_from_lengths(mel_length, ml.shape[1]).unsqueeze(-1), 0)
                 ml = ml.sum() / mel_length.sum() / ml.shape[2]
             losses['frame_loss'] = ml
-            g_loss = g_loss + self.lambda_frame * ml
-        st.g_loss = g_loss
+            g_terms, g_weights = [g_loss, ml], [1.0, self.lambda_frame]
+        else:
+            g_terms, g_weights = [g_loss], [1.0]
         if st.phase < 2:
+            st.g_loss = hiploss.weighted_sum(g_terms, g_weights) if len(g_terms) > 1 else g_loss
             return
         st.predict = predict = out['decoder_outputs'].squeeze(-1).float()
         target = st.target
@@ -177,7 +183,7 @@ class VQGANTrainer(BaseTrainer):
                 losses[name] = term
             stl = sum(stl.values())
         losses['stft_loss'] = stl
-        st.g_loss = g_loss + self.lambda_stft * stl
+        st.g_loss = hiploss.weighted_sum(g_terms + [stl], g_weights + [self.lambda_stft])     # vq + frame + stft in one launch
         # D(fake.detach()) and D(real) as ONE pass over the concatenated batch (every layer is per-sample, so
         # the scores are those of two separate passes): half the launches, twice the work per launch
         B = predict.shape[0]
@@ -187,10 +193,9 @@ class VQGANTrainer(BaseTrainer):
         st.fronts = disc.spectral_fronts(both) if (self.reuse_fronts and hasattr(disc, 'spectral_fronts')) else None
         with self._amp():
             both_scores, _ = disc(both, fronts=st.fronts) if st.fronts is not None else disc(both)
-        halves = [_SplitBatch.apply(s_, B) for s_ in both_scores]
-        d_fake = hiploss.mse_const_sum([h[0] for h in halves], 0.0)   # LSGAN, summed over the 10 sub-discriminators
-        d_real = hiploss.mse_const_sum([h[1] for h in halves], 1.0)
-        d_loss = d_real + d_fake
+        # LSGAN terms of the two halves, summed over the 10 sub-discriminators, straight from the [2B] score tensors
+        d_fake, d_real = hiploss.mse_const_halves(both_scores, B, 0.0, 1.0)
+        d_loss = hiploss.weighted_sum([d_real, d_fake])
         losses['d_loss_real'], losses['d_loss_fake'], losses['d_loss'] = d_real, d_fake, d_loss
         self.optimizer.zero_grad(['discriminator'])
         d_loss.backward()
@@ -222,9 +227,11 @@ class VQGANTrainer(BaseTrainer):
                         _, real_feats = disc(st.target)
             adv = hiploss.mse_const_sum(fake_scores, 1.0)
             fm = hiploss.l1_sum([a for fa in fake_feats for a in fa], [b for fb in real_feats for b in fb])
-            lam = self.lambda_fm if self.lambda_fm != 'auto' else (st.g_loss / fm).detach()
-            adv = adv + fm * lam
-            st.g_loss = st.g_loss + adv
+            if self.lambda_fm != 'auto':
+                adv = hiploss.weighted_sum([adv, fm], [1.0, self.lambda_fm])
+            else:
+                adv = adv + fm * (st.g_loss / fm).detach()
+            st.g_loss = hiploss.weighted_sum([st.g_loss, adv])
             losses['fm_loss'], losses['adv_loss'], losses['g_loss'] = fm, adv, st.g_loss
         self.optimizer.zero_grad(['autoencoder'])
         st.g_loss.backward()

@@ -850,3 +850,35 @@ def check_split_constant_gemm(dev):
     close(img1, img0, 2e-4, what='split-bf16 MRD image')
     rel = ((gx1 - gx0).norm() / gx0.norm()).item()
     assert rel <= 2e-4, 'split-bf16 MRD waveform gradient: relative L2 error %.3e' % rel
+
+
+def check_wave_fan(dev):
+    """hip/spectral.py wave_fan (msmc_wave_fan_fwd / _bwd) against the stock chain it replaces in the discriminator: cast,
+    F.pad(.., 'reflect') to a multiple of each period, and the autograd engine's sum of all consumers' gradients"""
+    import torch.nn.functional as F
+    from msmctts_amd.hip import spectral
+    torch.manual_seed(8)
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-2)):
+        for (B, L, periods, n_alias) in ((3, 2400, (2, 3, 5, 7, 11), 5), (2, 37, (2, 3, 5), 0), (1, 100, (7,), 2)):
+            y = (torch.rand(B, L, device=dev) * 2 - 1).requires_grad_(True)
+            padded = [(L + p - 1) // p * p for p in periods]
+            wavs, copies = spectral.wave_fan(y, n_alias, padded, dtype)
+            yr = y.detach().clone().requires_grad_(True)
+            ref = []
+            for p, lp in zip(periods, padded):
+                x = yr.unsqueeze(1).to(dtype)
+                if lp != L:
+                    x = F.pad(x, (0, lp - L), 'reflect')
+                ref.append(x.squeeze(1))
+            for a, b in zip(copies, ref):
+                assert a.shape == b.shape and torch.equal(a, b), 'padded copy differs'
+            for w in wavs:
+                assert torch.equal(w, y)
+            gen = torch.Generator().manual_seed(3)
+            gc = [torch.randn(c.shape, generator=gen).to(dev).to(dtype) for c in copies]
+            gw = [torch.randn(B, L, generator=gen).to(dev) for _ in wavs]
+            loss = sum((c.float() * g.float()).sum() for c, g in zip(copies[:-1], gc[:-1])) + sum((w * g).sum() for w, g in zip(wavs, gw))
+            lref = sum((c.float() * g.float()).sum() for c, g in zip(ref[:-1], gc[:-1])) + sum((yr * g).sum() for g in gw)
+            loss.backward()                      # (the last copy has no consumer: its gradient arrives as None)
+            lref.backward()
+            close(y.grad, yr.grad, tol * max(1.0, float(yr.grad.abs().max())), what='wave fan gradient')

@@ -372,3 +372,7 @@ def test_multi_tensor_gan_loss_kernels_match_stock_operators():
 
 def test_split_bf16_constant_matrix_gemm_and_spectral_chain():
     _parity.check_split_constant_gemm(DEV)
+
+
+def test_wave_fan_out_matches_cast_pad_and_gradient_accumulation():
+    _parity.check_wave_fan(DEV)

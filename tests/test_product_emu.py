@@ -1124,7 +1124,7 @@ def test_bench_attributes_work_to_every_kernel_family_of_a_step():
             setattr(L, name, fn)
     assert set(seen) == {'msmc_wn_prepare_multi_tiled', 'msmc_wn_backward_multi_acc', 'msmc_opt_clip_adamw'}
     called = set(timer.shapes)
-    for family in ('msmc_add_ln_fwd', 'msmc_add_ln_bwd', 'msmc_l1_multi_fwd', 'msmc_mse_const_multi_bwd', 'msmc_stft_frames_fwd',
+    for family in ('msmc_add_ln_fwd', 'msmc_add_ln_bwd', 'msmc_l1_multi_fwd_ws', 'msmc_mse_const_multi_bwd', 'msmc_stft_frames_fwd',
                    'msmc_spec_mag_bwd', 'msmc_vq_backward', 'msmc_vq_prepare', 'msmc_tanh_fwd', 'msmc_gate_bwd'):
         assert family in called, (family, sorted(called))
     assert summary, 'the interpreter build logs its launches too'
@@ -1144,3 +1144,7 @@ def test_multi_tensor_gan_loss_kernels_match_stock_operators():
 
 def test_split_bf16_constant_matrix_gemm_and_spectral_chain():
     _parity.check_split_constant_gemm('cpu')
+
+
+def test_wave_fan_out_matches_cast_pad_and_gradient_accumulation():
+    _parity.check_wave_fan('cpu')
