@@ -4,10 +4,11 @@
  * (reference msmctts/networks/__init__.py:6-11).  This library sits *below* it:
  * every entry point takes plain device pointers, sizes and a HIP stream, allocates nothing, is
  * stream-ordered and re-entrant per stream, and returns 0 (hipSuccess) or a hipError_t / negative MSMC_E*
- * code.  Process-global state, all of it: the msmc_*_set_* switches below (plain ints read at launch time;
- * perf experiments and tests only -- a production caller never touches them, kernel choices that matter
- * are per call: msmc_conv_desc.variant / split_shift), the per-thread msmc_conv_last_kernel /
- * msmc_conv_launch_count / msmc_vq_last_kernel tags and the opt-in msmc_prof_* launch log.  The Python host side (msmc-tts_amd/msmctts_amd) binds these with
+ * code.  No entry point of this header changes process-global behaviour: kernel choices are per call
+ * (msmc_conv_desc.variant / split_shift); what remains global is observational -- the per-thread msmc_conv_last_kernel /
+ * msmc_conv_launch_count / msmc_vq_last_kernel tags, the opt-in msmc_prof_* launch log and the per-thread sink of
+ * msmc_conv_wgrad_defer_begin / _end.  The A/B switches, ablation masks and the experimental fused ResBlock unit that the perf
+ * tools and the tests use live in include/msmc_hip_debug.h, outside the product ABI.  The Python host side (msmc-tts_amd/msmctts_amd) binds these with
  * ctypes from modules that carry the reference's class names; INTEGRATION.md shows the stub a
  * reference maintainer would add.
  *
@@ -152,7 +153,10 @@ typedef struct msmc_conv_desc {
                                (csrc/gemm1.inc: 128 x 128 tiles, both operands by LDS-DMA in 64-channel chunks, epilogue in
                                registers; bf16 with Cin % 8 == 0, or exact fp32 -- v_mfma_f32_32x32x2_f32, fp32 output -- with Cin % 4 == 0;
                                Cout % 4 == 0; MSMC_E_SHAPE for anything but a kernel-size-1 layer on the identity lattice), 35 = 34 with
-                               64 x 128 tiles on eight waves (GEMMs with few pixel rows), 40..46 = fifth generation (csrc/gather5.inc, bf16,
+                               64 x 128 tiles on eight waves (GEMMs with few pixel rows), 36 / 37 = 34 / 35 for fp32 data times a CONSTANT matrix
+                               given as its pre-split bf16 image (w: [Cout][ceil(Cin / 32)][hi 32 | lo 32] bf16, hi = bf16(w), lo = bf16(w - hi);
+                               three products w_hi x_hi + w_lo x_hi + w_hi x_lo on v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32
+                               output, ~2^-16 relative; no epilogue operands: the framed-DFT / mel GEMMs of the bf16 configuration), 40..46 = fifth generation (csrc/gather5.inc, bf16,
                                >= 2 taps, Cin % 64 == 0, Cout % 8 == 0: sixteen waves, stages of (64-channel chunk, tap) with the weight
                                slices in an LDS-DMA ring and the halo tile of a chunk shared by its taps, epilogue in registers with 16-byte
                                stores; tiles 40: 128 x 128, 41: 256 x 128, 42 / 43: 128 x 256, 44: 64 x 256, 45: 64 x 128 with the

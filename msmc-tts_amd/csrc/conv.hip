@@ -3483,23 +3483,56 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     const int R = it.copies > 1 ? it.copies : 1;
     const bool staged = n <= WN_ROW_MAX;
     float dot = 0.f;
+    constexpr int NV = WN_ROW_MAX / 256;               // values of a staged row per work-item
+    float vreg[NV];                                    // this work-item's elements of v (parameter order), kept for the second pass
     if (staged) {
-        for (int t = 0; t < T; ++t) {
-            const long o1 = t * it.s1[0] + a * it.s1[1];
-            for (int b = threadIdx.x; b < Bc; b += 256) {
-                const long o = o1 + b * it.s1[2];
-                float sum = dw[o];
-                dw[o] = 0.f;                           // each accumulator element has exactly this one reader
-                for (int r = 1; r < R; ++r) {          // privatised copies: fold, leave them zeroed
-                    sum = sum + dw[o + r * it.dw_copy_stride];
-                    dw[o + r * it.dw_copy_stride] = 0.f;
+        // Memory-level parallelism first: ALL of a work-item's dW loads are issued before the first use (the row is walked
+        // tap-outer, i = tid + 256 k -> (t, b) = (i / Bc, i % Bc): 64 consecutive floats per wave load), then the accumulators are
+        // zeroed and the sums go to the LDS row in the parameter's order.  The previous form interleaved load / zero-store /
+        // LDS-store per element: with the store to the same array between two loads the compiler kept one load in flight
+        // (18 % of the HBM roofline on 45 M parameters per step).
+        float dreg[NV];
+        int ti = (int)threadIdx.x / Bc, bi = (int)threadIdx.x - ti * Bc;       // (t, b) of element i = tid; += 256 per step
+        const int dtq = 256 / Bc, dbq = 256 - dtq * Bc;
+        {
+            int t = ti, b = bi;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                float sum = 0.f;
+                if (threadIdx.x + 256 * k < n) {
+                    const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
+                    sum = dw[o];
+                    for (int r = 1; r < R; ++r) sum = sum + dw[o + r * it.dw_copy_stride];
                 }
-                row[b * T + t] = sum;
+                dreg[k] = sum;
+                t += dtq;
+                b += dbq;
+                if (b >= Bc) { b -= Bc; ++t; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) vreg[k] = threadIdx.x + 256 * k < n ? v[threadIdx.x + 256 * k] : 0.f;
+        {
+            int t = ti, b = bi;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (threadIdx.x + 256 * k < n) {
+                    const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
+                    dw[o] = 0.f;                       // each accumulator element has exactly this one reader
+                    for (int r = 1; r < R; ++r) dw[o + r * it.dw_copy_stride] = 0.f;      // privatised copies: left zeroed
+                    row[b * T + t] = dreg[k];
+                }
+                t += dtq;
+                b += dbq;
+                if (b >= Bc) { b -= Bc; ++t; }
             }
         }
         __syncthreads();
-        if (it.g)
-            for (int e = threadIdx.x; e < n; e += 256) dot = fmaf(row[e], v[e], dot);
+        if (it.g) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                if (threadIdx.x + 256 * k < n) dot = fmaf(row[threadIdx.x + 256 * k], vreg[k], dot);
+        }
     } else {
         int b = 0, t = threadIdx.x;
         while (t >= T) { t -= T; ++b; }
@@ -3528,9 +3561,18 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     }
     float* gv = it.gv + (size_t)a * n;
     if (staged) {
-        for (int e = threadIdx.x; e < n; e += 256) {
-            const float gnew = k1 * (row[e] - v[e] * k2);
-            gv[e] = accumulate ? gv[e] + gnew : gnew;
+        float greg[NV];
+        if (accumulate) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) greg[k] = threadIdx.x + 256 * k < n ? gv[threadIdx.x + 256 * k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int e = threadIdx.x + 256 * k;
+            if (e < n) {
+                const float gnew = k1 * (row[e] - vreg[k] * k2);
+                gv[e] = accumulate ? greg[k] + gnew : gnew;
+            }
         }
     } else {
         int b = 0, t = threadIdx.x;
@@ -3734,22 +3776,37 @@ struct FoldMultiArgs {
     int H[MSMC_GROUP_MAX], W[MSMC_GROUP_MAX], C[MSMC_GROUP_MAX];
     long items[MSMC_GROUP_MAX];         // B * H * W * (C / V)
 };
+// V consecutive channels per work-item (V * sizeof(T) = 16, 8, 4 or sizeof(T) bytes: the widest vector every member's channel
+// count allows -- the first layers of the resolution stacks have 4 channels, which kept the whole call on 2-byte accesses);
+// 32-bit index arithmetic (items < 2^31 is checked by the launcher: the 64-bit divisions cost more than the memory accesses)
+template <typename T, int V>
+MSMC_DEV void fold_ld(const T* src, float* out) {
+    alignas(16) T v[V];
+    if (V * sizeof(T) == 16) *(u32x4*)v = *(const u32x4*)src;
+    else if (V * sizeof(T) == 8) *(u32x2*)v = *(const u32x2*)src;
+    else if (V * sizeof(T) == 4) *(unsigned int*)v = *(const unsigned int*)src;
+    else v[0] = src[0];
+#pragma unroll
+    for (int q = 0; q < V; ++q) out[q] = Elt<T>::ld(&v[q]);
+}
 template <typename T, int V>
 __global__ __launch_bounds__(256) void reflect_fold_multi_kernel(FoldMultiArgs a) {
     const int k = cv_group_member(a.first, a.n);
-    const int nb = a.first[k + 1] - a.first[k], p = a.p;
-    const int H = a.H[k], W = a.W[k], C = a.C[k], CV = C / V, Hp = H + 2 * p, Wp = W + 2 * p;
+    const unsigned nb = (unsigned)(a.first[k + 1] - a.first[k]);
+    const int p = a.p;
+    const int H = a.H[k], W = a.W[k], C = a.C[k], Hp = H + 2 * p, Wp = W + 2 * p;
+    const unsigned CV = (unsigned)(C / V), items = (unsigned)a.items[k];
     const T* gp = (const T*)a.gp[k];
     const T* mask = (const T*)a.mask[k];
     const T* res = (const T*)a.res[k];
     T* gx = (T*)a.gx[k];
-    for (long e = (long)(blockIdx.x - a.first[k]) * 256 + threadIdx.x; e < a.items[k]; e += (long)nb * 256) {
-        const int c = (int)(e % CV) * V;
-        long r = e / CV;
-        const int x = (int)(r % W);
-        r /= W;
-        const int y = (int)(r % H);
-        const int b = (int)(r / H);
+    for (unsigned e = (unsigned)(blockIdx.x - a.first[k]) * 256u + threadIdx.x; e < items; e += nb * 256u) {
+        const unsigned pix = e / CV;
+        const int c = (int)(e - pix * CV) * V;
+        const unsigned row = pix / (unsigned)W;
+        const int x = (int)(pix - row * (unsigned)W);
+        const unsigned b = row / (unsigned)H;
+        const int y = (int)(row - b * (unsigned)H);
         int ys[3], xs[3], ny = 0, nx = 0;
         ys[ny++] = y + p;
         if (y >= 1 && y <= p) ys[ny++] = p - y;
@@ -3762,32 +3819,27 @@ __global__ __launch_bounds__(256) void reflect_fold_multi_kernel(FoldMultiArgs a
         for (int q = 0; q < V; ++q) sacc[q] = 0.f;
         for (int i = 0; i < ny; ++i)
             for (int j = 0; j < nx; ++j) {
-                const T* src = gp + (((size_t)b * Hp + ys[i]) * Wp + xs[j]) * C + c;
-                alignas(16) T v[V];
-                if (V * sizeof(T) == 16) *(u32x4*)v = *(const u32x4*)src;
-                else v[0] = src[0];
+                float v[V];
+                fold_ld<T, V>(gp + (((size_t)b * Hp + ys[i]) * Wp + xs[j]) * C + c, v);
 #pragma unroll
-                for (int q = 0; q < V; ++q) sacc[q] = sacc[q] + Elt<T>::ld(&v[q]);
+                for (int q = 0; q < V; ++q) sacc[q] = sacc[q] + v[q];
             }
-        const size_t o = (((size_t)b * H + y) * W + x) * C + c;
-        alignas(16) T mv[V], rv[V], ov[V];
-        if (mask) {
-            if (V * sizeof(T) == 16) *(u32x4*)mv = *(const u32x4*)(mask + o);
-            else mv[0] = mask[o];
-        }
-        if (res) {
-            if (V * sizeof(T) == 16) *(u32x4*)rv = *(const u32x4*)(res + o);
-            else rv[0] = res[o];
-        }
+        const size_t o = (size_t)pix * C + c;
+        float mv[V], rv[V];
+        if (mask) fold_ld<T, V>(mask + o, mv);
+        if (res) fold_ld<T, V>(res + o, rv);
+        alignas(16) T ov[V];
 #pragma unroll
         for (int q = 0; q < V; ++q) {
             float sv = sacc[q];
-            if (res && a.res_first) sv = sv + Elt<T>::ld(&rv[q]);
-            if (mask) sv = sv * (Elt<T>::ld(&mv[q]) > 0.f ? 1.f : a.slope);
-            if (res && !a.res_first) sv = sv + Elt<T>::ld(&rv[q]);
+            if (res && a.res_first) sv = sv + rv[q];
+            if (mask) sv = sv * (mv[q] > 0.f ? 1.f : a.slope);
+            if (res && !a.res_first) sv = sv + rv[q];
             Elt<T>::st(&ov[q], sv);
         }
         if (V * sizeof(T) == 16) *(u32x4*)(gx + o) = *(const u32x4*)ov;
+        else if (V * sizeof(T) == 8) *(u32x2*)(gx + o) = *(const u32x2*)ov;
+        else if (V * sizeof(T) == 4) *(unsigned int*)(gx + o) = *(const unsigned int*)ov;
         else gx[o] = ov[0];
     }
 }
@@ -3833,8 +3885,11 @@ __global__ void zero_kernel(float* p, int n) {
 }
 
 template <typename T>
-static int fold_multi_launch(FoldMultiArgs& a, bool vec, int blocks, msmc_stream stream) {
-    if (vec) MSMC_LAUNCH((reflect_fold_multi_kernel<T, Elt<T>::VEC>), dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
+static int fold_multi_launch(FoldMultiArgs& a, int v, int blocks, msmc_stream stream) {
+    constexpr int VMAX = Elt<T>::VEC;           // 16-byte vectors: 4 fp32 / 8 bf16
+    if (v == VMAX) MSMC_LAUNCH((reflect_fold_multi_kernel<T, VMAX>), dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
+    else if (v == VMAX / 2) MSMC_LAUNCH((reflect_fold_multi_kernel<T, VMAX / 2>), dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
+    else if (v == 2 && VMAX == 8) MSMC_LAUNCH((reflect_fold_multi_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
     else MSMC_LAUNCH((reflect_fold_multi_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
     return msmc_check_launch();
 }
@@ -3957,12 +4012,15 @@ static int fold_multi_impl(const void* const* gp, const void* const* mask_src, c
                            int res_first, msmc_stream stream) {
     if (!gp || !gx || !B || !H || !W || !C || n <= 0 || n > MSMC_GROUP_MAX || p < 0 || dtype < 0 || dtype > 1)
         return MSMC_E_SHAPE;
-    const int VEC = dtype == 0 ? 4 : 8;
-    bool vec = true;
+    int v = dtype == 0 ? 4 : 8;                 // widest vector (in elements) every member's channel count is a multiple of
     for (int k = 0; k < n; ++k) {
         if (!gp[k] || !gx[k] || B[k] <= 0 || C[k] <= 0 || H[k] <= p || W[k] <= p) return MSMC_E_SHAPE;
-        vec = vec && (C[k] % VEC) == 0;
+        while (v > 1 && (C[k] % v) != 0) v >>= 1;
     }
+    for (int k = 0; k < n; ++k)                 // (16 / 8 / 4-byte accesses need that alignment of every operand)
+        while (v > 1 && (((size_t)gp[k] | (size_t)gx[k] | (size_t)(mask_src && mask_src[k] ? mask_src[k] : nullptr) |
+                          (size_t)(res && res[k] ? res[k] : nullptr)) & (size_t)(v * (dtype == 0 ? 4 : 2) - 1)))
+            v >>= 1;
     FoldMultiArgs a;
     a.n = n;
     a.p = p;
@@ -3977,14 +4035,15 @@ static int fold_multi_impl(const void* const* gp, const void* const* mask_src, c
         a.H[k] = H[k];
         a.W[k] = W[k];
         a.C[k] = C[k];
-        a.items[k] = (long)B[k] * H[k] * W[k] * (C[k] / (vec ? VEC : 1));
+        a.items[k] = (long)B[k] * H[k] * W[k] * (C[k] / v);
+        if (a.items[k] >= (1L << 31)) return MSMC_E_SHAPE;
         long nb = (a.items[k] + 255) / 256;
         if (nb > 4L * MSMC_NUM_CU) nb = 4L * MSMC_NUM_CU;
         a.first[k] = blocks;
         blocks += (int)(nb < 1 ? 1 : nb);
     }
     a.first[n] = blocks;
-    return dtype == 0 ? fold_multi_launch<float>(a, vec, blocks, stream) : fold_multi_launch<unsigned short>(a, vec, blocks, stream);
+    return dtype == 0 ? fold_multi_launch<float>(a, v, blocks, stream) : fold_multi_launch<unsigned short>(a, v, blocks, stream);
 }
 
 extern "C" {
