@@ -3470,6 +3470,9 @@ __global__ __launch_bounds__(256) void wn_transpose_kernel(const msmc_wn_item* _
 // to WN_ROW_MAX parameters go through LDS: dW is read TAP-OUTER (64 consecutive floats per wave load, privatised copies
 // folded and zeroed on the way), then everything else runs in the parameter's order (coalesced v reads, coalesced gv
 // stores).  Longer rows keep the direct form.
+// (Round 4, measured and reverted: all of a row's dW / v loads issued up front from fully unrolled 24-step register arrays
+//  -- 77 -> 120 us per call: the predicated steps of short rows and the register footprint cost more than the loads in flight
+//  gain; profiles/README.md.)
 #define WN_ROW_MAX 6144
 __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __restrict__ items, int nitems,
                                                          int accumulate) {
@@ -3483,56 +3486,23 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     const int R = it.copies > 1 ? it.copies : 1;
     const bool staged = n <= WN_ROW_MAX;
     float dot = 0.f;
-    constexpr int NV = WN_ROW_MAX / 256;               // values of a staged row per work-item
-    float vreg[NV];                                    // this work-item's elements of v (parameter order), kept for the second pass
     if (staged) {
-        // Memory-level parallelism first: ALL of a work-item's dW loads are issued before the first use (the row is walked
-        // tap-outer, i = tid + 256 k -> (t, b) = (i / Bc, i % Bc): 64 consecutive floats per wave load), then the accumulators are
-        // zeroed and the sums go to the LDS row in the parameter's order.  The previous form interleaved load / zero-store /
-        // LDS-store per element: with the store to the same array between two loads the compiler kept one load in flight
-        // (18 % of the HBM roofline on 45 M parameters per step).
-        float dreg[NV];
-        int ti = (int)threadIdx.x / Bc, bi = (int)threadIdx.x - ti * Bc;       // (t, b) of element i = tid; += 256 per step
-        const int dtq = 256 / Bc, dbq = 256 - dtq * Bc;
-        {
-            int t = ti, b = bi;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                float sum = 0.f;
-                if (threadIdx.x + 256 * k < n) {
-                    const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
-                    sum = dw[o];
-                    for (int r = 1; r < R; ++r) sum = sum + dw[o + r * it.dw_copy_stride];
+        for (int t = 0; t < T; ++t) {
+            const long o1 = t * it.s1[0] + a * it.s1[1];
+            for (int b = threadIdx.x; b < Bc; b += 256) {
+                const long o = o1 + b * it.s1[2];
+                float sum = dw[o];
+                dw[o] = 0.f;                           // each accumulator element has exactly this one reader
+                for (int r = 1; r < R; ++r) {          // privatised copies: fold, leave them zeroed
+                    sum = sum + dw[o + r * it.dw_copy_stride];
+                    dw[o + r * it.dw_copy_stride] = 0.f;
                 }
-                dreg[k] = sum;
-                t += dtq;
-                b += dbq;
-                if (b >= Bc) { b -= Bc; ++t; }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < NV; ++k) vreg[k] = threadIdx.x + 256 * k < n ? v[threadIdx.x + 256 * k] : 0.f;
-        {
-            int t = ti, b = bi;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                if (threadIdx.x + 256 * k < n) {
-                    const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
-                    dw[o] = 0.f;                       // each accumulator element has exactly this one reader
-                    for (int r = 1; r < R; ++r) dw[o + r * it.dw_copy_stride] = 0.f;      // privatised copies: left zeroed
-                    row[b * T + t] = dreg[k];
-                }
-                t += dtq;
-                b += dbq;
-                if (b >= Bc) { b -= Bc; ++t; }
+                row[b * T + t] = sum;
             }
         }
         __syncthreads();
-        if (it.g) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k)
-                if (threadIdx.x + 256 * k < n) dot = fmaf(row[threadIdx.x + 256 * k], vreg[k], dot);
-        }
+        if (it.g)
+            for (int e = threadIdx.x; e < n; e += 256) dot = fmaf(row[e], v[e], dot);
     } else {
         int b = 0, t = threadIdx.x;
         while (t >= T) { t -= T; ++b; }
@@ -3561,18 +3531,9 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     }
     float* gv = it.gv + (size_t)a * n;
     if (staged) {
-        float greg[NV];
-        if (accumulate) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k) greg[k] = threadIdx.x + 256 * k < n ? gv[threadIdx.x + 256 * k] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int e = threadIdx.x + 256 * k;
-            if (e < n) {
-                const float gnew = k1 * (row[e] - vreg[k] * k2);
-                gv[e] = accumulate ? greg[k] + gnew : gnew;
-            }
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const float gnew = k1 * (row[e] - v[e] * k2);
+            gv[e] = accumulate ? gv[e] + gnew : gnew;
         }
     } else {
         int b = 0, t = threadIdx.x;
