@@ -320,6 +320,7 @@ def build(args, device, rank, world):
     trainer = build_trainer(cfg, task, num_gpus=world, rank=rank)      # moves to GPU; arms RCCL reducer if world>1
     trainer.optimizer = build_optimizer(trainer.model, cfg.optimizer, capturable=args.graph)
     trainer.use_graphs = args.graph
+    trainer.graph_exchange = getattr(args, 'exchange', 'serial')
     trainer.amp_dtype = torch.bfloat16 if args.dtype == 'bf16' else None
     trainer.amp_autocast = not args.no_autocast
     trainer.model.train()
@@ -455,6 +456,10 @@ def main():
                          'segments (no host launch cost: the eager step is paced by the host); eager: multi-stream eager '
                          'step with bucketed all-reduce overlapped with backward')
     ap.add_argument('--graph', action='store_true', help='same as --exec graph')
+    ap.add_argument('--exchange', default=os.environ.get('MSMC_GRAPH_EXCHANGE', 'serial'), choices=['serial', 'overlap'],
+                    help='graph mode, N > 1: serial = one flat all-reduce per child between the replayed segments (default); '
+                         'overlap = bucketed all-reduces captured into the segments on the RCCL stream (DESIGN.md section 6: '
+                         'only ever run on one GPU)')
     ap.add_argument('--kernel-timing-steps', type=int, default=3, help='extra steps timed kernel by kernel (rank 0)')
     ap.add_argument('--kernels-out', default=os.path.join(ROOT, 'gpurun_out', 'bench_kernels.json'),
                     help='JSON side file for the per-kernel-symbol table (the printed line only names it)')
@@ -767,7 +772,8 @@ def main():
                    'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'frames': args.frames,
                    'mel_frames_per_step': frames_per_step, 'parallelism': 'dp%d' % world,
                    'vq_search': 'fp32 (bit-exact indices)',
-                   'execution': 'hipGraph replay (3 segments/step)' if args.graph else 'eager, multi-stream'},
+                   'execution': 'hipGraph replay (3 segments/step)' if args.graph else 'eager, multi-stream',
+                   'gradient_exchange': None if world == 1 else (args.exchange if args.graph else 'bucketed from hooks')},
         'step_tflops': (FLOP_PER_STEP_ELIDED * (args.batch / 16.0) * world / (elapsed / args.steps) / 1e12) if args.config in (2, 3) else None,
         'step_flop_model': 'SURVEY 8d: 3.006 TFLOP/step at B=16,T=400 minus the elided D weight-grads of the G step '
                            '= 2.65 TFLOP',

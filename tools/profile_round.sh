@@ -24,6 +24,6 @@ fi
 python $REPO/tools/pmc_summary.py $OUT/${TAG}_pmc_traffic.json FETCH=/tmp/prof_fetch WRITE=/tmp/prof_write MFMA=/tmp/prof_mfma > $OUT/${TAG}_pmc_summary.txt 2>&1
 cd $REPO
 cp $OUT/${TAG}_pmc_traffic.json $REPO/profiles/pmc_traffic.json      # the line below reports roofline.traffic from this run's passes
-python bench.py --calls-out $OUT/${TAG}_layer_table.json > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.log
+python bench.py --calls-out $OUT/${TAG}_layer_table.json --kernels-out $OUT/${TAG}_bench_kernels.json --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.log
 tail -c 1500 $OUT/${TAG}_bench.json
 head -12 $OUT/${TAG}_pmc_summary.txt
