@@ -217,7 +217,8 @@ DEFER_TO = None             # the DeferredReduce the running weight-gradient cal
 
 class DeferredReduce(object):
     CAPACITY = 1024                       # records per backward pass
-    CHUNK = 256 << 20                     # arena growth step (bytes); chunks persist and are reused every pass
+    CHUNK = 256 << 20                     # largest arena growth step (bytes); chunks persist and are reused every pass
+    FIRST = 16 << 20                      # first chunk of a bank (small banks -- an FFT stack, the quantiser -- never need more)
 
     def __init__(self):
         self.records = (lib.WgPending * self.CAPACITY)()
@@ -232,7 +233,10 @@ class DeferredReduce(object):
                 p = c[0].data_ptr() + c[1]
                 c[1] += nbytes
                 return p
-        t = torch.empty(max(nbytes, self.CHUNK) // 4, dtype=torch.float32, device=device)
+        # grow geometrically from FIRST to CHUNK: a bank pins what its passes need, not 256 MiB each (round-3 advice)
+        have = sum(c[0].numel() * 4 for c in self.chunks)
+        step = min(self.CHUNK, max(self.FIRST, have))
+        t = torch.empty(max(nbytes, step) // 4, dtype=torch.float32, device=device)
         self.chunks.append([t, nbytes])
         return t.data_ptr()
 

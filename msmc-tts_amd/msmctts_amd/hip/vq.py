@@ -169,7 +169,8 @@ def flush_codebook_sync(pending=None, group=None, local=False):
         key = (views[0].device, total)
         flat = _FLAT.get(key)
         if flat is None:
-            _FLAT.clear()
+            # (buffers of other pending sets stay: a captured graph may still hold one -- round-3 advice; a handful of
+            #  stage combinations exist per process)
             flat = _FLAT[key] = torch.empty(total, dtype=torch.float32, device=views[0].device)
         parts = list(flat.split([v.numel() for v in views]))
         torch._foreach_copy_(parts, views)

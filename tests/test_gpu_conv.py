@@ -444,3 +444,39 @@ def test_resblock_unit_in_one_launch_equals_the_two_launch_chain(C, L, k, dil, n
     y_ref = F.conv1d(a_ref.to(torch.bfloat16).float(), wt(w2), b2, 1, (k - 1) // 2, 1) + xc
     assert rel(a.float().squeeze(1).transpose(1, 2), a_ref) <= 1e-2
     assert rel(y.float().squeeze(1).transpose(1, 2), y_ref) <= 1e-2
+
+
+def test_layer_applied_twice_keeps_its_two_weight_gradient_reductions_apart():
+    """A layer applied TWICE in one backward pass (rb(rb(x)); D(real) and D(fake) as separate calls) has two recorded second
+    stages with the same accumulator: msmc_conv_wgrad_reduce_pending must not put them into one launch (plain `dw += sum`
+    read-modify-writes; round-3 advice).  A bf16 ResBlock at a size where the split-partials generations run, every layer
+    twice: the weight gradients match the fp32 chain on the same (bf16-rounded) weights and are bit-identical run to run."""
+    from msmctts_amd.networks.hifigan.common import ResBlock1
+    torch.manual_seed(12)
+    rb = ResBlock1(64, 3, (1, 3, 5)).to(DEV)
+    rb.hip_dtype = torch.bfloat16
+    x = torch.randn(8, 64, 3000, device=DEV)
+    go = torch.randn(8, 64, 3000, device=DEV)
+    runs = []
+    for _ in range(3):
+        rb.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        y = rb(rb(xi))
+        (y.float() * go).sum().backward()
+        torch.cuda.synchronize()
+        runs.append({n: p.grad.detach().clone() for n, p in rb.named_parameters()})
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]) and torch.equal(runs[0][n], runs[2][n]), 'gradient of %s differs run to run' % n
+    # fp32 chain on the same weights
+    rb.zero_grad()
+    xr = x.clone().requires_grad_(True)
+    h = xr
+    for _ in range(2):
+        for c1, c2 in zip(rb.convs1, rb.convs2):
+            t_ = F.conv1d(F.leaky_relu(h, 0.1), c1.weight(), c1.bias, 1, c1.padding, c1.dilation)
+            h = F.conv1d(F.leaky_relu(t_, 0.1), c2.weight(), c2.bias, 1, c2.padding, c2.dilation) + h
+    (h * go).sum().backward()
+    for n, p in rb.named_parameters():
+        want, got = p.grad.float(), runs[0][n].float()
+        err = ((got - want).norm() / want.norm()).item()
+        assert err <= 3e-2, 'gradient of %s: relative L2 error %.3e against the fp32 chain' % (n, err)

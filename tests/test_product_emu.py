@@ -1148,3 +1148,56 @@ def test_split_bf16_constant_matrix_gemm_and_spectral_chain():
 
 def test_wave_fan_out_matches_cast_pad_and_gradient_accumulation():
     _parity.check_wave_fan('cpu')
+
+
+def test_clean_weight_banks_skip_their_refresh_and_notice_every_kind_of_update():
+    """ConvBank.prepare launches nothing while the bank is clean (hip/convnet.py SKIP_CLEAN_PREPARE) and refreshes the
+    kernel-layout weights after (a) a HipAdamW step -- a raw-pointer update no version counter sees --, (b) an in-place torch
+    operation on a weight (load_state_dict, init), (c) the first use; the outputs follow the parameters in every case."""
+    from msmctts_amd.hip import convnet, lib
+    from msmctts_amd.networks.hifigan.common import ResBlock1
+    from msmctts_amd.trainers.optimizers.hip_adamw import HipAdamW
+    L = lib.get()
+    torch.manual_seed(1)
+    blk = ResBlock1(16, 3, (1, 3, 5))
+    x = torch.randn(2, 16, 40)
+
+    def prepares(fn):
+        L.msmc_prof_enable(1)
+        out = fn()
+        names = []
+        import ctypes
+        buf, ms = ctypes.create_string_buffer(128), ctypes.c_float()
+        for i in range(L.msmc_prof_count()):
+            L.msmc_prof_read(i, buf, 128, ctypes.byref(ms))
+            names.append(buf.value.decode())
+        L.msmc_prof_enable(0)
+        return out, sum(1 for n in names if n.startswith('wn_prepare'))
+
+    y0, n0 = prepares(lambda: blk(x))
+    assert n0 == 1                                           # first use: the images are built
+    y1, n1 = prepares(lambda: blk(x))
+    assert n1 == 0 and torch.equal(y0, y1)                   # clean: nothing to refresh
+    opt = HipAdamW(list(blk.parameters()), lr=1e-2)
+    blk(x).square().mean().backward()
+    opt.step()                                               # raw-pointer update of weight_v / weight_g
+    y2, n2 = prepares(lambda: blk(x))
+    assert n2 == 1 and not torch.equal(y2, y1)
+    with torch.no_grad():
+        blk.convs1[0].weight_v.mul_(1.5)                     # in-place torch operation: the version counter moves
+    y3, n3 = prepares(lambda: blk(x))
+    assert n3 == 1 and not torch.equal(y3, y2)
+    sd = {k: v.clone() for k, v in blk.state_dict().items()}
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.add_(0.01)
+    blk.load_state_dict(sd)
+    y4, n4 = prepares(lambda: blk(x))
+    assert n4 == 1 and torch.allclose(y4, y3, atol=1e-6)
+    keep = convnet.SKIP_CLEAN_PREPARE
+    try:
+        convnet.SKIP_CLEAN_PREPARE = False                   # the A/B switch: every forward refreshes
+        _, n5 = prepares(lambda: blk(x))
+        assert n5 == 1
+    finally:
+        convnet.SKIP_CLEAN_PREPARE = keep
