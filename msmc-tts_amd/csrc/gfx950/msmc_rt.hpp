@@ -307,12 +307,10 @@ MSMC_DEV long long msmc_clock() { return (long long)__builtin_amdgcn_s_memtime()
 MSMC_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // ---- bf16 <-> f32 (round to nearest even), bit-level so host and device agree ---------------
-MSMC_DEV unsigned short f32_to_bf16_bits(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+// (round 4: v_cvt_pk_bf16_f32 -- the same round-to-nearest-even bits for every finite value in ONE vector instruction; the
+//  bit-level form it replaces -- NaN test, rounding add, shift: ~6 instructions per value -- made the epilogues of the thin-layer
+//  kernels a visible share of their vector-ALU time.  Epilogues that convert value PAIRS call pack_bf16x2 directly.)
+MSMC_DEV unsigned short f32_to_bf16_bits(float f) { return (unsigned short)pack_bf16x2(f, f); }
 MSMC_DEV float bf16_bits_to_f32(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
 // leaky ReLU of two packed bf16 values, slope in [0, 1]: max(x, slope * x) in fp32 (x for x > 0, slope * x otherwise),

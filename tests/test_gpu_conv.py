@@ -451,6 +451,7 @@ def test_layer_applied_twice_keeps_its_two_weight_gradient_reductions_apart():
     stages with the same accumulator: msmc_conv_wgrad_reduce_pending must not put them into one launch (plain `dw += sum`
     read-modify-writes; round-3 advice).  A bf16 ResBlock at a size where the split-partials generations run, every layer
     twice: the weight gradients match the fp32 chain on the same (bf16-rounded) weights and are bit-identical run to run."""
+    from msmctts_amd.hip import conv as K
     from msmctts_amd.networks.hifigan.common import ResBlock1
     torch.manual_seed(12)
     rb = ResBlock1(64, 3, (1, 3, 5)).to(DEV)
@@ -458,13 +459,24 @@ def test_layer_applied_twice_keeps_its_two_weight_gradient_reductions_apart():
     x = torch.randn(8, 64, 3000, device=DEV)
     go = torch.randn(8, 64, 3000, device=DEV)
     runs = []
-    for _ in range(3):
-        rb.zero_grad()
-        xi = x.clone().requires_grad_(True)
-        y = rb(rb(xi))
-        (y.float() * go).sum().backward()
-        torch.cuda.synchronize()
-        runs.append({n: p.grad.detach().clone() for n, p in rb.named_parameters()})
+    # the no-atomics generation (split partials + second stage) on every layer: the tuner may only pick variant 3 here (the
+    # atomic generations are not reproducible run to run by construction, and they have no second stage to merge)
+    keep = (dict(K.TUNED), K._WGRAD_CANDIDATES, K.TUNE_BORROW)
+    K.TUNED.clear()
+    K._WGRAD_CANDIDATES, K.TUNE_BORROW = ((3, 0),), False
+    try:
+        for _ in range(3):
+            rb.zero_grad()
+            xi = x.clone().requires_grad_(True)
+            y = rb(rb(xi))
+            (y.float() * go).sum().backward()
+            torch.cuda.synchronize()
+            runs.append({n: p.grad.detach().clone() for n, p in rb.named_parameters()})
+        assert rb._bank.deferred.chunks, 'no split weight gradient ran: the test does not exercise the deferred second stage'
+    finally:
+        K.TUNED.clear()
+        K.TUNED.update(keep[0])
+        K._WGRAD_CANDIDATES, K.TUNE_BORROW = keep[1], keep[2]
     for n in runs[0]:
         assert torch.equal(runs[0][n], runs[1][n]) and torch.equal(runs[0][n], runs[2][n]), 'gradient of %s differs run to run' % n
     # fp32 chain on the same weights
@@ -479,4 +491,4 @@ def test_layer_applied_twice_keeps_its_two_weight_gradient_reductions_apart():
     for n, p in rb.named_parameters():
         want, got = p.grad.float(), runs[0][n].float()
         err = ((got - want).norm() / want.norm()).item()
-        assert err <= 3e-2, 'gradient of %s: relative L2 error %.3e against the fp32 chain' % (n, err)
+        assert err <= 8e-2, 'gradient of %s: relative L2 error %.3e against the fp32 chain' % (n, err)     # (bf16 through 24 convolutions; a lost accumulation is an error of order 0.5)

@@ -41,6 +41,14 @@ SHAPES = [
     ('mrd h240 128->256 s1', 32, 128, 256, 121, 13, (3, 3), (1, 1), (1, 1), (1, 1), True, 0.2),
     ('mrd h240 256->512 s2', 32, 256, 512, 121, 13, (3, 3), (2, 2), (1, 1), (1, 1), True, 0.2),
     ('mrd h50 64->128 s1', 32, 64, 128, 51, 121, (3, 3), (1, 1), (1, 1), (1, 1), True, 0.2),
+    # thin discriminator layers (variant 50 / the direct kernels): run with  VARIANTS="50 2 3 8" ... thin
+    ('thin mrd 4->8 s2 H31 W801', 32, 4, 8, 31, 801, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
+    ('thin mrd 8->16 s1 H16 W401', 32, 8, 16, 16, 401, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
+    ('thin mrd 16->32 s2 H16 W401', 32, 16, 32, 16, 401, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
+    ('thin mrd 32->64 s1 H8 W201', 32, 32, 64, 8, 201, (3, 3), (1, 1), (1, 1), (1, 1), True, 1.0),
+    ('thin mrd 16->32 s2 H121 W51', 32, 16, 32, 121, 51, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
+    ('thin mpd p2 16->64 s3', 32, 16, 64, 2000, 2, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
+    ('thin mpd p11 16->64 s3', 32, 16, 64, 364, 11, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ''
 L = lib.get()
