@@ -592,7 +592,7 @@ def main():
     # prepare: v read once, both kernel layouts written (+ the transposing pass's second read); backward: dW read and
     # re-zeroed, v read, gradient written
     timer.wrap_abi(L0, 'msmc_wn_prepare_multi_tiled', wn_bytes(lambda e: 8 + 2 * e))
-    timer.wrap_abi(L0, 'msmc_wn_backward_multi_acc', wn_bytes(lambda e: 16))
+    timer.wrap_abi(L0, 'msmc_wn_backward_multi_rows', wn_bytes(lambda e: 16))
     timer.wrap_abi(L0, 'msmc_opt_clip_adamw', lambda table, nt, nblocks, max_norm, *rest:
                    (0.0, float(nblocks) * chunk * (28 + (4 if max_norm > 0 else 0))))
 

@@ -309,6 +309,11 @@ int msmc_wn_prepare_multi_tiled(const msmc_wn_item* items, int nitems, int total
 int msmc_wn_backward_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream);
 /* accumulate != 0: gv / gg / gb += instead of = (a second backward before the gradients were reset: torch .grad semantics) */
 int msmc_wn_backward_multi_acc(const msmc_wn_item* items, int nitems, int total_blocks, int accumulate, msmc_stream stream);
+/* the same with the longest normalised row (Bc * T parameters) of the items given: rows of up to 4096 parameters run with 128
+ * work-items per row and a row buffer sized to max_row -- up to 16 instead of 6 rows in flight per CU (the pass is a chain of
+ * memory round trips per row) */
+int msmc_wn_backward_multi_rows(const msmc_wn_item* items, int nitems, int total_blocks, int accumulate, int max_row,
+                                msmc_stream stream);
 
 /* Backward of ReflectionPad2d(p) fused with the leaky-ReLU' mask, channels-last:
  *   gx[b][y][x][c] = (sum of gp over the padded positions that reflect onto (y, x)) * (mask_src > 0 ? 1 : slope)

@@ -3373,6 +3373,19 @@ MSMC_DEV float block_sum_fast(float v, float* red4) {
     return (red4[0] + red4[1]) + (red4[2] + red4[3]);
 }
 
+// the same for workgroups of one to four waves (blockDim.x / 64)
+MSMC_DEV float block_sum_waves(float v, float* red4) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = v + wave_xor(v, m);
+    const int w = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red4[w] = v;
+    __syncthreads();
+    float s = red4[0];
+    for (int q = 1; q < nw; ++q) s = s + red4[q];
+    return s;
+}
+
 // Row pass: one workgroup per normalised row a (n = Bc * T parameters, contiguous).  The row is read once in its own
 // order (sum of squares), then written to layout 1 TAP-OUTER: for a fixed tap the Bc elements of the row are consecutive
 // in layout 1 (s1[2] = 1 for every layer the banks build), so a wave stores 64 consecutive elements; the strided re-read
@@ -3404,12 +3417,30 @@ __global__ __launch_bounds__(256) void wn_prepare_kernel(const msmc_wn_item* __r
         if (threadIdx.x == 0) it.inv_norm[a] = 1.f / norm;
     }
     const bool two = it.dst2 && !skip2;
-    for (int t = 0; t < T; ++t) {
-        const long o1 = t * it.s1[0] + a * it.s1[1], o2 = t * it.s2[0] + a * it.s2[1];
-        for (int b = threadIdx.x; b < Bc; b += 256) {
-            const float wv = v[b * T + t] * scale;
-            wn_store(it.dst1, it.dtype, o1 + b * it.s1[2], wv);
-            if (two) wn_store(it.dst2, it.dtype, o2 + b * it.s2[2], wv);
+    // (restrict-qualified locals: without them every load of v has to stay behind the previous store to the layout buffers
+    //  -- the compiler cannot know they do not overlap -- and the loop runs one memory round trip per element)
+    const float* __restrict__ vr = v;
+    if (it.dtype == 0) {
+        float* __restrict__ d1 = (float*)it.dst1;
+        float* __restrict__ d2 = (float*)it.dst2;
+        for (int t = 0; t < T; ++t) {
+            const long o1 = t * it.s1[0] + a * it.s1[1], o2 = t * it.s2[0] + a * it.s2[1];
+            for (int b = threadIdx.x; b < Bc; b += 256) {
+                const float wv = vr[b * T + t] * scale;
+                d1[o1 + b * it.s1[2]] = wv;
+                if (two) d2[o2 + b * it.s2[2]] = wv;
+            }
+        }
+    } else {
+        unsigned short* __restrict__ d1 = (unsigned short*)it.dst1;
+        unsigned short* __restrict__ d2 = (unsigned short*)it.dst2;
+        for (int t = 0; t < T; ++t) {
+            const long o1 = t * it.s1[0] + a * it.s1[1], o2 = t * it.s2[0] + a * it.s2[1];
+            for (int b = threadIdx.x; b < Bc; b += 256) {
+                const unsigned short wv = f32_to_bf16_bits(vr[b * T + t] * scale);
+                d1[o1 + b * it.s1[2]] = wv;
+                if (two) d2[o2 + b * it.s2[2]] = wv;
+            }
         }
     }
 }
@@ -3472,42 +3503,47 @@ __global__ __launch_bounds__(256) void wn_transpose_kernel(const msmc_wn_item* _
 // stores).  Longer rows keep the direct form.
 // (Round 4, measured and reverted: all of a row's dW / v loads issued up front from fully unrolled 24-step register arrays
 //  -- 77 -> 120 us per call: the predicated steps of short rows and the register footprint cost more than the loads in flight
-//  gain; profiles/README.md.)
+//  gain; profiles/README.md.  What the loops needed is below: no store between two loads of one array.)
 #define WN_ROW_MAX 6144
+// NT work-items per row (blockDim.x: 256, or 128 when every row of the bank fits ``row_cap`` <= 4096 floats -- the pass is a chain
+// of four memory round trips per row, so its speed is the number of rows in flight per CU: 6 at 256 work-items and a 24 KB row
+// buffer, up to 16 at 128 work-items and a buffer sized to the bank's longest row)
 __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __restrict__ items, int nitems,
-                                                         int accumulate) {
-    __shared__ float red[4];
-    __shared__ float row[WN_ROW_MAX];
+                                                         int accumulate, int row_cap) {
+    MSMC_DYN_LDS(smem);
+    float* red = (float*)smem;                         // [4]
+    float* row = red + 4;                              // [row_cap]
+    const int NT = (int)blockDim.x;
     const msmc_wn_item it = items[wn_find(items, nitems, blockIdx.x)];
     const int a = blockIdx.x - it.block0;
     const int n = it.Bc * it.T, T = it.T, Bc = it.Bc;
     const float* v = it.v + (size_t)a * n;
     float* dw = (float*)it.dw;
     const int R = it.copies > 1 ? it.copies : 1;
-    const bool staged = n <= WN_ROW_MAX;
+    const bool staged = n <= row_cap;
     float dot = 0.f;
     if (staged) {
+        // LOADS ONLY in this loop: the accumulators are zeroed in a pass of their own at the end.  With `dw[o] = 0` between two
+        // loads of the same array the compiler must keep every load behind the previous store (it cannot prove o' != o), so the
+        // loop ran one memory round trip per element: SQ_WAIT_ANY 89 % of the wave cycles, 18 % of the HBM roofline (round 4).
+        const float* __restrict__ dwr = dw;
         for (int t = 0; t < T; ++t) {
             const long o1 = t * it.s1[0] + a * it.s1[1];
-            for (int b = threadIdx.x; b < Bc; b += 256) {
+            for (int b = threadIdx.x; b < Bc; b += NT) {
                 const long o = o1 + b * it.s1[2];
-                float sum = dw[o];
-                dw[o] = 0.f;                           // each accumulator element has exactly this one reader
-                for (int r = 1; r < R; ++r) {          // privatised copies: fold, leave them zeroed
-                    sum = sum + dw[o + r * it.dw_copy_stride];
-                    dw[o + r * it.dw_copy_stride] = 0.f;
-                }
+                float sum = dwr[o];
+                for (int r = 1; r < R; ++r) sum = sum + dwr[o + r * it.dw_copy_stride];      // privatised copies: fold
                 row[b * T + t] = sum;
             }
         }
         __syncthreads();
         if (it.g)
-            for (int e = threadIdx.x; e < n; e += 256) dot = fmaf(row[e], v[e], dot);
+            for (int e = threadIdx.x; e < n; e += NT) dot = fmaf(row[e], v[e], dot);
     } else {
         int b = 0, t = threadIdx.x;
         while (t >= T) { t -= T; ++b; }
-        const int db_ = 256 / T, dt_ = 256 - db_ * T;  // e += 256 as (b, t) += (db_, dt_) with carry
-        for (int e = threadIdx.x; e < n; e += 256) {
+        const int db_ = NT / T, dt_ = NT - db_ * T;    // e += NT as (b, t) += (db_, dt_) with carry
+        for (int e = threadIdx.x; e < n; e += NT) {
             const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
             float sum = dw[o];
             for (int r = 1; r < R; ++r) {
@@ -3523,7 +3559,7 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     }
     float k1 = 1.f, k2 = 0.f;                          // plain weight: gv = dW
     if (it.g) {
-        dot = block_sum_fast(dot, red);
+        dot = block_sum_waves(dot, red);
         const float inv = it.inv_norm[a], gval = it.g[a];
         if (threadIdx.x == 0) it.gg[a] = accumulate ? it.gg[a] + dot * inv : dot * inv;
         k1 = gval * inv;
@@ -3531,15 +3567,25 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     }
     float* gv = it.gv + (size_t)a * n;
     if (staged) {
-        for (int e = threadIdx.x; e < n; e += 256) {
-            const float gnew = k1 * (row[e] - v[e] * k2);
-            gv[e] = accumulate ? gv[e] + gnew : gnew;
+        const float* __restrict__ vr = v;                  // (v is never written here: its loads may run ahead of the gv stores)
+        float* __restrict__ gvr = gv;
+        if (accumulate) {
+            for (int e = threadIdx.x; e < n; e += NT) gvr[e] = gvr[e] + k1 * (row[e] - vr[e] * k2);
+        } else {
+            for (int e = threadIdx.x; e < n; e += NT) gvr[e] = k1 * (row[e] - vr[e] * k2);
+        }
+        for (int t = 0; t < T; ++t) {                      // each accumulator element has exactly this one reader: leave zeros
+            const long o1 = t * it.s1[0] + a * it.s1[1];
+            for (int b = threadIdx.x; b < Bc; b += NT) {
+                const long o = o1 + b * it.s1[2];
+                for (int r = 0; r < R; ++r) dw[o + r * it.dw_copy_stride] = 0.f;
+            }
         }
     } else {
         int b = 0, t = threadIdx.x;
         while (t >= T) { t -= T; ++b; }
-        const int db_ = 256 / T, dt_ = 256 - db_ * T;
-        for (int e = threadIdx.x; e < n; e += 256) {
+        const int db_ = NT / T, dt_ = NT - db_ * T;
+        for (int e = threadIdx.x; e < n; e += NT) {
             const long o = t * it.s1[0] + a * it.s1[1] + b * it.s1[2];
             const float gnew = k1 * (dw[o] - v[e] * k2);
             gv[e] = accumulate ? gv[e] + gnew : gnew;
@@ -3880,10 +3926,24 @@ int msmc_wn_prepare_multi_tiled(const msmc_wn_item* items, int nitems, int total
     return msmc_check_launch();
 }
 
-int msmc_wn_backward_multi_acc(const msmc_wn_item* items, int nitems, int total_blocks, int accumulate, msmc_stream stream) {
+int msmc_wn_backward_multi_rows(const msmc_wn_item* items, int nitems, int total_blocks, int accumulate, int max_row,
+                                msmc_stream stream) {
     if (!items || nitems <= 0 || total_blocks <= 0) return MSMC_E_SHAPE;
-    MSMC_LAUNCH(wn_backward_kernel, dim3(total_blocks), dim3(256), 0, (msmc_stream_t)stream, items, nitems, accumulate);
+    // max_row: the longest normalised row (Bc * T parameters) among the items, 0 = unknown.  Rows up to 4096 floats: 128
+    // work-items per row and a row buffer of that size (more rows in flight per CU); otherwise the 256 / 24 KB form, whose
+    // rows beyond WN_ROW_MAX take the unstaged path
+    const bool small = max_row > 0 && max_row <= 4096;
+    const int cap = small ? ((max_row + 63) & ~63) : WN_ROW_MAX;
+    const size_t lds = 16 + (size_t)cap * sizeof(float);
+    int rc = msmc_allow_lds((const void*)wn_backward_kernel, (int)lds);
+    if (rc) return rc;
+    MSMC_LAUNCH(wn_backward_kernel, dim3(total_blocks), dim3(small ? 128 : 256), lds, (msmc_stream_t)stream, items, nitems,
+                accumulate, cap);
     return msmc_check_launch();
+}
+
+int msmc_wn_backward_multi_acc(const msmc_wn_item* items, int nitems, int total_blocks, int accumulate, msmc_stream stream) {
+    return msmc_wn_backward_multi_rows(items, nitems, total_blocks, accumulate, 0, stream);
 }
 
 int msmc_wn_backward_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream) {
@@ -3999,8 +4059,8 @@ static int fold_multi_impl(const void* const* gp, const void* const* mask_src, c
         a.items[k] = (long)B[k] * H[k] * W[k] * (C[k] / v);
         if (a.items[k] >= (1L << 31)) return MSMC_E_SHAPE;
         long nb = (a.items[k] + 255) / 256;
-        if (nb > 4L * MSMC_NUM_CU) nb = 4L * MSMC_NUM_CU;
-        a.first[k] = blocks;
+        if (nb > 16L * MSMC_NUM_CU) nb = 16L * MSMC_NUM_CU;       // (one or two items per work-item: an item's loads cannot run ahead of the
+        a.first[k] = blocks;                                      //  previous item's store, so parallelism has to come from the grid)
         blocks += (int)(nb < 1 ? 1 : nb);
     }
     a.first[n] = blocks;

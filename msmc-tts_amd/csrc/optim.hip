@@ -79,6 +79,37 @@ __global__ __launch_bounds__(256) void opt_adamw_kernel(const msmc_opt_tensor* _
     const float coef = norm_coef[1], lr = lr_ptr[0], tt = step[0];
     const float bc1 = 1.f - powf(beta1, tt), bc2 = 1.f - powf(beta2, tt);
     const float step_size = lr / bc1, rs2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
+    // fast path: the whole 4096-element chunk lies inside the tensor and every operand is 16-byte aligned -- all sixteen vector
+    // loads of a work-item are issued before the first store (a load behind a store to an array the compiler cannot tell apart
+    // waits for nothing in hardware, but the compiler keeps program order and the loop ran four round trips deep)
+    if (e0 + OPT_CHUNK <= t.n && (((size_t)(t.p + e0) | (size_t)(t.g + e0) | (size_t)(t.m + e0) | (size_t)(t.v + e0)) & 15) == 0) {
+        f32x4 p4[4], g4[4], m4[4], v4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long e = e0 + threadIdx.x * 4 + 1024 * i;
+            p4[i] = *(const f32x4*)(t.p + e);
+            g4[i] = *(const f32x4*)(t.g + e);
+            m4[i] = *(const f32x4*)(t.m + e);
+            v4[i] = *(const f32x4*)(t.v + e);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long e = e0 + threadIdx.x * 4 + 1024 * i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float gq = g4[i][q] * coef;
+                g4[i][q] = gq;
+                m4[i][q] = beta1 * m4[i][q] + (1.f - beta1) * gq;
+                v4[i][q] = beta2 * v4[i][q] + (1.f - beta2) * gq * gq;
+                p4[i][q] = p4[i][q] * decay - step_size * (m4[i][q] / (sqrtf(v4[i][q]) * rs2 + eps));
+            }
+            *(f32x4*)(t.p + e) = p4[i];
+            *(f32x4*)(t.m + e) = m4[i];
+            *(f32x4*)(t.v + e) = v4[i];
+            if (write_grads) *(f32x4*)(t.g + e) = g4[i];
+        }
+        return;
+    }
     for (int k = threadIdx.x * 4; k < OPT_CHUNK; k += 1024) {
         const long e = e0 + k;
         if (e >= t.n) break;

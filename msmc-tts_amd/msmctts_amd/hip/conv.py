@@ -277,7 +277,7 @@ def _workspace(device, stream, nbytes):
     return t.data_ptr(), t.numel() * 4
 
 
-def _wgrad(desc, g_ptr, dw, db, stream, what):
+def _wgrad(desc, g_ptr, dw, db, stream, what, seen=None):
     L = lib.get()
 
     def fn(dref, gp, dwp, dbp, st, defer=None):
@@ -314,6 +314,8 @@ def _wgrad(desc, g_ptr, dw, db, stream, what):
     if rc != 0 and getattr(desc, '_borrowed', False):        # a neighbour's choice this shape cannot run: library heuristic
         desc.variant, desc.split_shift, desc._borrowed = 0, 0, False
         rc = fn(ctypes.byref(desc), g_ptr, dw.data_ptr(), dbp, stream, defer)
+    if seen is not None:
+        seen.add(int(desc.variant))           # (ConvBank: layers whose weight gradients never use atomics need no privatised copies)
     if rc != 0:
         raise RuntimeError('%s failed with code %d (dtype %d variant %d split_shift %d copies %d, x %dx%dx%dx%d -> %dx%dx%d, '
                            '%d taps)' % (what, rc, desc.dtype, desc.variant, desc.split_shift, desc.dw_copies, desc.B, desc.Hin,
@@ -659,7 +661,7 @@ def conv_transpose1d_dgrad(g, wb, k, stride, padding, Lin, mask_src=None, mask_s
     return gx
 
 
-def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None, db=None, copies=1):
+def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None, db=None, copies=1, seen=None):
     """dW [kh*kw, Cout, Cin] fp32 of ``conv_forward`` (x [B,Hin,Win,Cin] pre-activation, g [B,Hout,Wout,Cout]);
     when ``db`` (fp32 [Cout]) is given the bias gradient is accumulated into it by the same launch."""
     key = ('w', x.dtype, x.shape[0], x.shape[3], g.shape[3], in_slope)
@@ -678,7 +680,7 @@ def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None, db=None, copies=1):
     desc.x = desc.w = desc.out = x.data_ptr()
     desc.bias = desc.mask_src = desc.res = desc.res2 = None
     desc.dw_copies = copies              # dw / db then hold ``copies`` privatised accumulators back to back
-    _wgrad(desc, g.data_ptr(), dw, db, lib.stream(x), 'msmc_conv_wgrad')
+    _wgrad(desc, g.data_ptr(), dw, db, lib.stream(x), 'msmc_conv_wgrad', seen)
     return dw
 
 
@@ -688,7 +690,7 @@ def conv_wgrad_group(items):
     if not _G['WGRAD']:
         for it in items:
             conv_wgrad(it['x'], it['g'], it['geom'], it['n_slices'], in_slope=it.get('in_slope', 1.0), dw=it['dw'],
-                       db=it.get('db'), copies=it.get('copies', 1))
+                       db=it.get('db'), copies=it.get('copies', 1), seen=it.get('seen'))
         return
     stream = lib.stream(items[0]['x'])
     snaps, gs, dws, dbs = [], [], [], []
@@ -698,13 +700,15 @@ def conv_wgrad_group(items):
         key = ('w', x.dtype, x.shape[0], x.shape[3], g.shape[3], in_slope)
         desc = geom.plans.get(key)
         if desc is None or not getattr(desc, '_tuned', False):
-            conv_wgrad(x, g, geom, it['n_slices'], in_slope=in_slope, dw=dw, db=db, copies=copies)   # builds + tunes
+            conv_wgrad(x, g, geom, it['n_slices'], in_slope=in_slope, dw=dw, db=db, copies=copies, seen=it.get('seen'))   # builds + tunes
             continue
         _dev_ok(x)
         _dev_ok(g)
         desc.x = desc.w = desc.out = x.data_ptr()
         desc.bias = desc.mask_src = desc.res = desc.res2 = None
         desc.dw_copies = copies
+        if it.get('seen') is not None:
+            it['seen'].add(int(desc.variant))
         snaps.append(lib.ConvDesc.from_buffer_copy(desc))
         gs.append(g.data_ptr())
         dws.append(dw.data_ptr())
@@ -769,7 +773,7 @@ def conv_wgrad_group(items):
         deferred((single, grouped, g4 or grouped)[_group_choice('wgrad-group', part, grouped, single, g4)[0]])
 
 
-def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None, copies=1):
+def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None, copies=1, seen=None):
     """dW [k, Cin, Cout] fp32 of ``conv_transpose1d_forward`` (x [B,1,Lin,Cin] pre-activation, g [B,1,Lout,Cout]):
     dW[k][ci][co] = sum_q act(x[q][ci]) * g[q*stride + k - padding][co]  -- the weight gradient of the strided
     convolution fine -> coarse with the operand roles swapped (the activation rides on the 'gradient' operand)."""
@@ -785,7 +789,7 @@ def conv_transpose1d_wgrad(x, g, k, stride, padding, in_slope=1.0, dw=None, copi
               mask_slope=in_slope, kind='wgrad')
     lib.ptr(dw, torch.float32)
     d.dw_copies = copies
-    _wgrad(d, lib.ptr(x), dw, None, lib.stream(x), 'msmc_conv_wgrad(convT)')
+    _wgrad(d, lib.ptr(x), dw, None, lib.stream(x), 'msmc_conv_wgrad(convT)', seen)
     return dw
 
 

@@ -120,6 +120,7 @@ class ConvLayer(object):
             self.cin, self.cout = v.shape[0], v.shape[1]
         # filled by the bank
         self.wf = self.wb = self.dw = self.db = None
+        self.wg_variants = set()        # msmc_conv_wgrad variants this layer's weight gradients have run on (see ConvBank._drop_idle_copies)
         self.index = -1
         self._geoms = {}
 
@@ -311,7 +312,10 @@ class ConvBank(object):
             ow, oa, ob, blk = ow + pad8(n), oa + A, ob + l.cout, blk + A
             odw, odb = odw + pad8(n * R), odb + pad8(l.cout * R)
         self.total_blocks, self.total_tile_blocks = blk, tblk
+        self.max_row = max(l.weight.shape[1] * l.taps for l in self.layers)      # longest normalised row (parameters)
         raw = bytes(items)
+        self._items_host = items
+        self._copy_checks = 6              # backward passes after which idle privatised copies are looked for
         self.items_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.dtype = dtype
 
@@ -366,6 +370,27 @@ class ConvBank(object):
         return (((m.bias, l.gb_view), (m.weight, l.gv_view)) if l.plain else
                 ((m.bias, l.gb_view), (m.weight_g, l.gg_view), (m.weight_v, l.gv_view)))
 
+    _NO_ATOMICS = frozenset((3, 4, 5, 6, 7))       # msmc_conv_wgrad variants that accumulate through a second stage into copy 0
+
+    def _drop_idle_copies(self):
+        """Privatised dW / db copies (DW_COPIES per small layer) exist for the ATOMIC weight-gradient generations: same-address
+        atomics retire serially, copies shorten the chain.  A layer whose weight gradients only ever ran on the no-atomics
+        generations writes copy 0 alone, yet the weight-norm backward read, summed and re-zeroed all eight -- more than half of
+        that pass's traffic.  After the tuner has settled (a few passes), such layers go down to one copy: the device item table
+        is patched in place (same address: captured graphs keep working).  A later shape that does pick an atomic kernel then
+        simply runs with one copy."""
+        if self._copy_checks <= 0 or (self.w1.is_cuda and torch.cuda.is_current_stream_capturing()):
+            return
+        self._copy_checks -= 1
+        changed = False
+        for l, it in zip(self.layers, self._items_host):
+            if l.dw_copies > 1 and l.wg_variants and l.wg_variants <= self._NO_ATOMICS:
+                l.dw_copies = 1
+                it.copies = 1
+                changed = True
+        if changed:
+            self.items_dev.copy_(torch.frombuffer(bytearray(bytes(self._items_host)), dtype=torch.uint8))
+
     def node_opened(self):
         self._open_nodes += 1
 
@@ -389,8 +414,10 @@ class ConvBank(object):
         if not early:                   # (held gradients may still be read by other banks' nodes: released with the pass)
             del self._hold[:]
         touched, self._touched = self._touched, set()
-        if not touched:                 # a pass that only propagated through this network (frozen D in the G step)
-            self.deferred.flush(lib.stream(self.w1))
+        if not touched:                 # a pass that only propagated through this network (frozen D in the G step),
+            self.deferred.flush(lib.stream(self.w1))       # or one whose gradients were delivered early
+            if not early:
+                self._drop_idle_copies()
             return
         if self.streams:                # weight-gradient launches ran on the side streams of their forward
             cur = torch.cuda.current_stream()
@@ -409,9 +436,9 @@ class ConvBank(object):
                     for p, gview in self._grad_pairs(l):
                         if not live(p, gview):
                             gview.zero_()
-            lib.check(lib.get().msmc_wn_backward_multi_acc(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
-                                                           1 if accumulate else 0, lib.stream(self.w1)),
-                      'msmc_wn_backward_multi_acc')
+            lib.check(lib.get().msmc_wn_backward_multi_rows(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
+                                                            1 if accumulate else 0, self.max_row, lib.stream(self.w1)),
+                      'msmc_wn_backward_multi_rows')
             for l in self.layers:
                 if l.index not in touched or not l.weight.requires_grad:
                     continue
@@ -424,6 +451,8 @@ class ConvBank(object):
                         p.grad.add_(gview)
                     if GRAD_READY_HOOK is not None:
                         GRAD_READY_HOOK(p)
+            if not early:
+                self._drop_idle_copies()
 
 
 def _tap_grad(g_tap, like):
@@ -519,15 +548,15 @@ class _HipConv(torch.autograd.Function):
         if ctx.need_w:
             if layer.kind == 'conv' and WGRAD_BATCH > 1:       # waits in the bank for company (see WGRAD_BATCH)
                 bank.queue_wgrad(dict(x=x, g=g, geom=layer.geom(x.shape[1], x.shape[2]), n_slices=layer.taps,
-                                      in_slope=ctx.in_slope, dw=layer.dw, db=layer.db, copies=layer.dw_copies))
+                                      in_slope=ctx.in_slope, dw=layer.dw, db=layer.db, copies=layer.dw_copies, seen=layer.wg_variants))
             else:
                 with bank.wgrad_side(x, g):
                     if layer.kind == 'conv':
                         K.conv_wgrad(x, g, layer.geom(x.shape[1], x.shape[2]), layer.taps, in_slope=ctx.in_slope,
-                                     dw=layer.dw, db=layer.db, copies=layer.dw_copies)
+                                     dw=layer.dw, db=layer.db, copies=layer.dw_copies, seen=layer.wg_variants)
                     else:
                         K.conv_transpose1d_wgrad(x, g, layer.kernel[1], layer.stride[1], layer.padding[1],
-                                                 in_slope=ctx.in_slope, dw=layer.dw, copies=layer.dw_copies)
+                                                 in_slope=ctx.in_slope, dw=layer.dw, copies=layer.dw_copies, seen=layer.wg_variants)
                         K.colsum(g.reshape(-1, g.shape[-1]), out=layer.db)
             bank._touched.add(layer.index)
             bank._queue_finish()
@@ -623,7 +652,7 @@ class _HipConvGroup(torch.autograd.Function):
                 d_members.append(k)
             if ctx.need_w[k]:
                 w_items.append(dict(x=x, g=g, geom=geom, n_slices=layer.taps, in_slope=in_slope, dw=layer.dw, db=layer.db,
-                                    copies=layer.dw_copies))
+                                    copies=layer.dw_copies, seen=layer.wg_variants))
                 bank._touched.add(layer.index)
             if has_res:
                 grads[pos + 1] = g

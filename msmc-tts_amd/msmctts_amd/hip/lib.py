@@ -127,6 +127,7 @@ _SIGNATURES.update({
     'msmc_wn_prepare_multi_tiled': (_i, [_vp, _i, _i, _i, _vp]),
     'msmc_wn_backward_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_wn_backward_multi_acc': (_i, [_vp, _i, _i, _i, _vp]),
+    'msmc_wn_backward_multi_rows': (_i, [_vp, _i, _i, _i, _i, _vp]),
     'msmc_reflect_fold_multi': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i),
                                 ctypes.POINTER(_i), _i, _i, _f, _i, _vp]),
     'msmc_reflect_fold_multi_res': (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i),

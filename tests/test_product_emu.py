@@ -1098,13 +1098,13 @@ def test_bench_attributes_work_to_every_kernel_family_of_a_step():
     from msmctts_amd.trainers.optimizers import build_optimizer
     L = lib.get()
     saved = {name: getattr(L, name) for name in list(bench.abi_work_models()) +
-             ['msmc_wn_prepare_multi_tiled', 'msmc_wn_backward_multi_acc', 'msmc_opt_clip_adamw']}
+             ['msmc_wn_prepare_multi_tiled', 'msmc_wn_backward_multi_rows', 'msmc_opt_clip_adamw']}
     timer = bench.KernelTimer()
     try:
         for name, work in bench.abi_work_models().items():
             timer.wrap_abi(L, name, work)
         seen = []
-        for name in ('msmc_wn_prepare_multi_tiled', 'msmc_wn_backward_multi_acc', 'msmc_opt_clip_adamw'):
+        for name in ('msmc_wn_prepare_multi_tiled', 'msmc_wn_backward_multi_rows', 'msmc_opt_clip_adamw'):
             timer.wrap_abi(L, name, (lambda nm: lambda *a: (seen.append(nm), (0.0, 64.0))[1])(name))
         cfg, task = _parity.build_small('cpu')
         tr = build_trainer(cfg, task, num_gpus=0, rank=0)
@@ -1122,7 +1122,7 @@ def test_bench_attributes_work_to_every_kernel_family_of_a_step():
     finally:
         for name, fn in saved.items():
             setattr(L, name, fn)
-    assert set(seen) == {'msmc_wn_prepare_multi_tiled', 'msmc_wn_backward_multi_acc', 'msmc_opt_clip_adamw'}
+    assert set(seen) == {'msmc_wn_prepare_multi_tiled', 'msmc_wn_backward_multi_rows', 'msmc_opt_clip_adamw'}
     called = set(timer.shapes)
     for family in ('msmc_add_ln_fwd', 'msmc_add_ln_bwd', 'msmc_l1_multi_fwd_ws', 'msmc_mse_const_multi_bwd', 'msmc_stft_frames_fwd',
                    'msmc_spec_mag_bwd', 'msmc_vq_backward', 'msmc_vq_prepare', 'msmc_tanh_fwd', 'msmc_gate_bwd'):
