@@ -88,6 +88,41 @@ MSMC_DEV int reflect_index(int i, int n) {
     return i;
 }
 
+// Epilogue of N (4 or 8) consecutive bf16 output channels held as floats: mask (leaky-ReLU derivative from the sign of a packed
+// bf16 operand), two residuals, division by out_div, output leaky-ReLU.  ONE wave-uniform branch per optional operand around
+// all N values: written inside a per-value loop the options were if-converted -- every value paid ~28 vector instructions, an
+// 11-instruction IEEE division included, whether or not the operand was there (SQ counters / ISA, round 4: the epilogue was
+// 460 of a thin-layer tile's ~740 vector instructions).  The division is a multiplication by the reciprocal (<= 1 ulp in fp32,
+// before the bf16 rounding); the fp32 kernels keep the exact division.
+template <int N>
+MSMC_DEV void cv_ep(float (&v)[N], const unsigned int* mk, const unsigned int* r1, const unsigned int* r2, bool has_mask,
+                    bool has_res, bool has_res2, float mslope, float odiv, float oslope) {
+    if (has_mask) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float mj = __uint_as_float((j & 1) ? (mk[j >> 1] & 0xffff0000u) : (mk[j >> 1] << 16));
+            v[j] = v[j] * (mj > 0.f ? 1.f : mslope);
+        }
+    }
+    if (has_res) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = v[j] + __uint_as_float((j & 1) ? (r1[j >> 1] & 0xffff0000u) : (r1[j >> 1] << 16));
+    }
+    if (has_res2) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = __uint_as_float((j & 1) ? (r2[j >> 1] & 0xffff0000u) : (r2[j >> 1] << 16)) + v[j];
+    }
+    if (odiv != 1.f) {
+        const float rdiv = 1.f / odiv;
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = v[j] * rdiv;
+    }
+    if (oslope != 1.f) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * oslope;
+    }
+}
+
 struct CvGeom {
     int TH, TW, IH, IW, dyMin, dxMin, tilesX, tilesY, xt_elems;
 };
@@ -520,15 +555,20 @@ MSMC_DEV void cv2_body(const msmc_conv_desc& d, const CvGeom& G, const int block
         for (int u = 0; u < 4; ++u) {
             if (dst[u] < 0) continue;
             if (slope != 1.f) {
-                alignas(16) T tmp[VEC];
-                *(u32x4*)tmp = vals[u];
+                if (sizeof(T) == 2 && slope >= 0.f && slope <= 1.f) {      // packed: max(x, slope x) on bf16 pairs, one conversion per pair
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) {
-                    float f = Elt<T>::ld(&tmp[q]);
-                    f = f > 0.f ? f : f * slope;
-                    Elt<T>::st(&tmp[q], f);
+                    for (int q = 0; q < 4; ++q) vals[u][q] = bf16x2_leaky(vals[u][q], slope);
+                } else {
+                    alignas(16) T tmp[VEC];
+                    *(u32x4*)tmp = vals[u];
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        float f = Elt<T>::ld(&tmp[q]);
+                        f = f > 0.f ? f : f * slope;
+                        Elt<T>::st(&tmp[q], f);
+                    }
+                    vals[u] = *(const u32x4*)tmp;
                 }
-                vals[u] = *(const u32x4*)tmp;
             }
             *(u32x4*)(xt + dst[u]) = vals[u];
         }
