@@ -79,12 +79,17 @@ def fork_join(streams, thunks, inputs=()):
 
 
 # Weight gradients are off the critical path of a backward pass (only the optimizer reads them): MSMC_WGRAD_STREAMS=n > 0
-# issues them on n side streams -- parallel branches of the captured hipGraph -- while the data-gradient chain continues on
-# the calling stream.  Branches of a hipGraph DO run concurrently on this runtime (tools/graph_overlap_probe.py: two chains
-# of 64-workgroup GEMMs replay 1.6x, four chains 2x faster forked than serial), but every kernel of this step already
-# occupies all 256 CUs (>= 256 workgroups bounded by LDS), so a second branch only gets the tails: measured 30.9 (n = 2)
-# vs 31.1 ms/step (n = 0), later 28.8 vs 29.1 with half the pixel splits per weight gradient -- within noise.  Default off; kept for workloads whose grids under-fill the chip.
-WGRAD_STREAMS = int(os.environ.get('MSMC_WGRAD_STREAMS', '0'))
+# issues them round-robin on n side streams -- parallel branches of the captured hipGraph -- while the data-gradient chain
+# continues on the calling stream.  Branches of a hipGraph DO run concurrently on this runtime (tools/graph_fork_probe.py: two
+# chains of GEMM launches replay 1.5-1.9x faster forked than serial; chains of streaming elementwise launches gain nothing).
+# History: at 29-31 ms/step (round 2) the gain was within noise -- every launch then occupied all 256 CUs for long enough
+# that a second branch only got the tails.  At 17.6 ms/step (round 4; kernels 2x shorter, so the tails and the launch
+# boundaries weigh more) it is measurable: n = 0 / 1 / 2 / 4 / 8 -> 17.62 / 17.60 / 17.12 / 17.02 / 17.05 ms.
+# n = 1 buys nothing: a weight gradient next to the data-gradient chain fills the same LDS-bound slots; the gain is the
+# weight gradients of DIFFERENT layers (partial grids, split-K tails) overlapping each other.
+# (Also tried: the discriminator's resolution and period families as two branches of the step -- 0.15-0.3 ms next to n = 4..8,
+# nothing alone, and a capture_end crash in the runtime after several captures in one process: not kept.)
+WGRAD_STREAMS = int(os.environ.get('MSMC_WGRAD_STREAMS', '8'))
 _SIDE = {}
 
 
@@ -398,7 +403,9 @@ class ConvBank(object):
         """a backward node with a weight gradient has issued it; the last one of the pass completes the bank"""
         if self._open_nodes > 0:
             self._open_nodes -= 1
-            if self._open_nodes == 0 and EARLY_FINISH and self._touched:
+            # (a bank whose backward nodes run on several streams finishes in the end-of-pass callback, on the caller's stream:
+            # nothing orders the caller behind whichever branch happened to close last)
+            if self._open_nodes == 0 and EARLY_FINISH and self._touched and not self.streams:
                 self._finish_backward(early=True)
 
     def _finish_backward(self, early=False):
@@ -414,15 +421,15 @@ class ConvBank(object):
         if not early:                   # (held gradients may still be read by other banks' nodes: released with the pass)
             del self._hold[:]
         touched, self._touched = self._touched, set()
+        if self.streams and self.w1.is_cuda:      # backward launches ran on the side streams of their forward
+            cur = torch.cuda.current_stream(self.w1.device)
+            for st in self.streams:
+                cur.wait_stream(st)
         if not touched:                 # a pass that only propagated through this network (frozen D in the G step),
             self.deferred.flush(lib.stream(self.w1))       # or one whose gradients were delivered early
             if not early:
                 self._drop_idle_copies()
             return
-        if self.streams:                # weight-gradient launches ran on the side streams of their forward
-            cur = torch.cuda.current_stream()
-            for st in self.streams:
-                cur.wait_stream(st)
         # the second stage of every no-atomics weight gradient of this pass, merged (the partial results sat in the arena)
         self.deferred.flush(lib.stream(self.w1))
         with torch.no_grad():
