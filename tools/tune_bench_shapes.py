@@ -7,7 +7,8 @@ forward / data-gradient shape, merging them with the committed timings of the ot
 same for the persistent thin-layer kernel (variant 32), RETUNE=gemm1 for the 1-tap GEMM kernel (variant 34), RETUNE=gather5 for the sixteen-wave staged-tap kernel (variants 40..44), RETUNE=wgrad6 for the direct thin-layer weight gradient (variant 8) and RETUNE=wgrad5 for the general-lattice LDS-DMA weight gradient
 (variant 7; the grouped calls whose members change are re-timed by the run itself).  RETUNE=new keeps every decision
 on file and only adds the shapes and grouped calls the run meets for the first time (after a change of how the step
-groups its launches, e.g. MSMC_WGRAD_BATCH)."""
+groups its launches, e.g. MSMC_WGRAD_BATCH).  RETUNE=all times every decision the run meets again (two passes, the faster
+measurement of each candidate) and replaces those entries, keeping the entries of shapes it does not meet."""
 import os, sys, random, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd'), os.path.join(ROOT, 'tests')]
@@ -85,9 +86,13 @@ if RETUNE == 'wgrad5':                                    # general-lattice LDS-
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
             if k[0] == 'wgrad' and k[1] == 1 and k[5] % 64 == 0 and k[8] % 64 == 0}
     print('timing the general-lattice LDS-DMA weight gradient on %d shapes' % len(kept))
-for rep in range(1 if RETUNE else 2):                     # two passes: keep the faster measurement of each candidate
+fresh = {}
+if RETUNE == 'all':                                       # after a change that moves every kernel (epilogues): the shapes and grouped
+    fresh = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)}      # calls this run meets are timed again and REPLACE their entries;
+    print('re-timing every decision the run meets (%d on file)' % len(fresh))     # the rest of the table stays
+for rep in range(1 if (RETUNE and RETUNE != 'all') else 2):                     # two passes: keep the faster measurement of each candidate
     saved = dict(conv.TUNED)
-    if not RETUNE:
+    if not RETUNE or RETUNE == 'all':
         conv.TUNED.clear()
     cfg, trainer = bench.build(A, dev, 0, 1)
     batch = make_batch(A.batch, A.frames, 80, 300, seed=1234, rank=0, device='cpu')
@@ -114,6 +119,8 @@ for k, v in kept.items():                                 # committed candidates
         times[c] = min(t, times.get(c, t))
     best = min(times, key=times.get) if times else (v[0], v[1])
     conv.TUNED[k] = (best[0], best[1], times)
+for k, v in fresh.items():                                # (decisions of other configurations and of the test-suite's cases)
+    conv.TUNED.setdefault(k, v)
 for k, v in old_groups.items():                           # decisions of calls this run did not meet (other configurations, tests)
     conv.TUNED.setdefault(k, v)
 out = os.path.join(ROOT, 'gpurun_out', 'tuned_gfx950.json')
