@@ -37,6 +37,13 @@ typedef void* msmc_stream;          /* hipStream_t */
 const char* msmc_backend(void);
 int msmc_abi_version(void);
 
+/* Streams of the library's own (hipStreamNonBlocking), for the side branches of a step: the weight gradients' streams and the
+ * resolution discriminators' branch (host side: hip/convnet.py own_streams).  The host framework's stream pool hands the same
+ * few streams out again and again; a side stream that IS the stream another part of the step captures on is not a branch.
+ * No reference counterpart (the reference runs one stream). */
+int msmc_stream_create(msmc_stream* out);
+int msmc_stream_destroy(msmc_stream stream);
+
 /* ---------------------------------------------------------------------------------------------
  * V1/V2  multi-head nearest-codeword search with EMA update.
  * Replaces Quantize.forward / MultiHeadQuantize.forward,

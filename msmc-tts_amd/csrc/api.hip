@@ -7,6 +7,13 @@ extern "C" {
 const char* msmc_backend(void) { return MSMC_BACKEND_NAME; }
 int msmc_abi_version(void) { return 2; }
 
+// ---- streams of the library's own -------------------------------------------------------------------------
+int msmc_stream_create(msmc_stream* out) {
+    if (!out) return MSMC_E_SHAPE;
+    return msmc_rt_stream_create((void**)out);
+}
+int msmc_stream_destroy(msmc_stream stream) { return msmc_rt_stream_destroy((void*)stream); }
+
 // ---- per-launch profiling log (process-wide) ---------------------------------------------------------------
 void msmc_prof_enable(int on) {
     MsmcProfLog& L = msmc_prof_log;

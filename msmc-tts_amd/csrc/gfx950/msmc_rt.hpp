@@ -327,6 +327,14 @@ MSMC_DEV unsigned int bf16x2_leaky(unsigned int w, float slope) {
 #define MSMC_BACKEND_NAME "gfx950"
 #define MSMC_NUM_CU 256              // MI355X: 8 XCDs x 32 CUs
 static inline int msmc_check_launch() { return (int)hipGetLastError(); }
+// a stream of the library's own (outside the host framework's pool): non-blocking with respect to the null stream
+static inline int msmc_rt_stream_create(void** out) {
+    hipStream_t st = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    *out = (void*)st;
+    return (int)e;
+}
+static inline int msmc_rt_stream_destroy(void* st) { return (int)hipStreamDestroy((hipStream_t)st); }
 // Kernels that carve more than 64 KiB of dynamic LDS must opt in once per function.
 static inline int msmc_allow_lds(const void* fn, int bytes) {
     if (bytes <= 64 * 1024) return 0;

@@ -45,8 +45,9 @@ WGRAD_BATCH_GROUPS = os.environ.get('MSMC_WGRAD_BATCH_GROUPS', '1') == '1'    # 
 EARLY_FINISH = os.environ.get('MSMC_EARLY_FINISH', '1') != '0'
 
 
-def fork_join(streams, thunks, inputs=()):
+def fork_join(streams, thunks, inputs=(), main_thunk=None):
     """Run independent launch sequences on side HIP streams and join them back (hipGraph-capturable).
+    ``main_thunk`` (optional) runs on the calling stream between the fork and the join; its result comes last.
 
     The sub-discriminators / parallel ResBlocks are chains of small kernels (tens of workgroups): run back to
     back they leave most of the 256 CUs idle, concurrently they fill the chip.  ``inputs`` are tensors produced
@@ -55,7 +56,7 @@ def fork_join(streams, thunks, inputs=()):
     Autograd replays each backward node on the stream of its forward, so the backward pass forks the same way.
     """
     if not streams or not STREAMS_ENABLED:
-        return [t() for t in thunks]
+        return [t() for t in thunks] + ([main_thunk()] if main_thunk is not None else [])
     main = torch.cuda.current_stream()
     outs = []
     for i, thunk in enumerate(thunks):
@@ -65,6 +66,7 @@ def fork_join(streams, thunks, inputs=()):
             x.record_stream(st)
         with torch.cuda.stream(st):
             outs.append(thunk())
+    tail = [main_thunk()] if main_thunk is not None else []
     for st in streams[:len(thunks)]:
         main.wait_stream(st)
 
@@ -75,7 +77,7 @@ def fork_join(streams, thunks, inputs=()):
             for v in o:
                 mark(v)
     mark(outs)
-    return outs
+    return outs + tail
 
 
 # Weight gradients are off the critical path of a backward pass (only the optimizer reads them): MSMC_WGRAD_STREAMS=n > 0
@@ -87,16 +89,33 @@ def fork_join(streams, thunks, inputs=()):
 # boundaries weigh more) it is measurable: n = 0 / 1 / 2 / 4 / 8 -> 17.62 / 17.60 / 17.12 / 17.02 / 17.05 ms.
 # n = 1 buys nothing: a weight gradient next to the data-gradient chain fills the same LDS-bound slots; the gain is the
 # weight gradients of DIFFERENT layers (partial grids, split-K tails) overlapping each other.
-# (Also tried: the discriminator's resolution and period families as two branches of the step -- 0.15-0.3 ms next to n = 4..8,
-# nothing alone, and a capture_end crash in the runtime after several captures in one process: not kept.)
+# The discriminator's resolution and period families are two more branches (networks/hifigan/discriminator.py D_FORK): another
+# 0.4 ms.  All of these are streams of the library's own (own_streams below), not torch pool streams.
 WGRAD_STREAMS = int(os.environ.get('MSMC_WGRAD_STREAMS', '8'))
 _SIDE = {}
+_OWN = {}
+
+
+def own_streams(device, n, role):
+    """n HIP streams of the library's own (msmc_stream_create) wrapped for torch: created once per process, device and
+    ``role`` (every user of a role shares them -- one step runs at a time) and never returned.  torch.cuda.Stream() draws from
+    a pool of 32 per device and starts over after the 32nd: in a process that builds several trainers, a 'side' stream can then
+    BE the stream a later capture runs on, or another side stream, and a fork onto it is no branch at all (a capture whose
+    branches were pool streams crashed the runtime at capture_end after a few trainers in one process)."""
+    device = torch.device(device)
+    have = _OWN.setdefault((device, role), [])
+    with torch.cuda.device(device):
+        while len(have) < n:
+            h = ctypes.c_void_p()
+            lib.check(lib.get().msmc_stream_create(ctypes.byref(h)), 'msmc_stream_create')
+            have.append(torch.cuda.ExternalStream(h.value, device=device))
+    return have[:n]
 
 
 def _side_streams(device):
     st = _SIDE.get(device)
     if st is None:
-        st = _SIDE[device] = [torch.cuda.Stream(device=device) for _ in range(max(1, WGRAD_STREAMS))]
+        st = _SIDE[device] = own_streams(device, max(1, WGRAD_STREAMS), 'wgrad')
     return st
 
 

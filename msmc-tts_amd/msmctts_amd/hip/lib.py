@@ -21,6 +21,8 @@ _vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_
 _SIGNATURES = {
     'msmc_backend': (ctypes.c_char_p, []),
     'msmc_abi_version': (_i, []),
+    'msmc_stream_create': (_i, [ctypes.POINTER(ctypes.c_void_p)]),
+    'msmc_stream_destroy': (_i, [_vp]),
     'msmc_vq_prepare': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'msmc_vq_search': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'msmc_vq_shortlist_bytes': (_sz, [_i, _i, _i]),

@@ -5,6 +5,8 @@ Quirks reproduced on purpose: LeakyReLU slope is 0.2 here
 maps the trainer sees are *post*-activation (the reference's in-place LeakyReLU aliases the stored
 tensors, discriminator.py:28,71-76) while MPD's are pre-activation (:146-149).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -21,6 +23,10 @@ from .common import get_padding
 # ReflectionPad2d into the load; feature maps are handed to the trainer as NCHW-shaped views.
 
 LRELU_SLOPE = 0.2
+# 1: under grouped execution the resolution family's launches go to a side stream (one of the library's own, hip/convnet.py
+# own_streams) -- a parallel branch of the captured step, forward and backward: 17.0 -> 16.6 ms/step next to the weight
+# gradients' side streams (nothing without them: alone, two chains of chip-filling launches only overlap their tails)
+D_FORK = os.environ.get('MSMC_D_FORK', '1') == '1'
 ACT = dict(out_slope=LRELU_SLOPE, out_masked=True)      # activation in the producer's epilogue, its backward in the consumer
 
 
@@ -170,8 +176,11 @@ class Discriminator(nn.Module):
             mpd = [d.hip_layers() for d in self.mpd.discriminators]
             self._bank = ConvBank([l for ls in mrd + mpd for l in ls])
             self._layers = (mrd, mpd)
-            self._streams = make_streams(next(self.parameters()).device, len(mrd) + len(mpd))
-            self._bank.streams = self._streams
+            dev = next(self.parameters()).device
+            self._streams = make_streams(dev, len(mrd) + len(mpd))
+            # grouped execution: the resolution stacks' chain on ONE side stream, the period stacks' on the caller's (D_FORK)
+            self._fork = convnet.own_streams(dev, 1, 'd-fork') if (convnet.GROUPED and D_FORK and dev.type == 'cuda') else []
+            self._bank.streams = self._streams or self._fork
         return self._bank, self._layers
 
     def spectral_fronts(self, y):
@@ -213,22 +222,33 @@ class Discriminator(nn.Module):
                 wavs = [wav] * len(self.mrd.stfts)
         else:
             wavs, copies = [wav] * len(self.mrd.stfts), None
-        if fronts is not None and fronts.fronts[0].dtype == dtype and fronts.r1 - fronts.r0 == wav.shape[0]:
-            xs = fronts.images(wavs if (fan and wav.requires_grad) else None)
-        else:
-            xs = [stft.image_cl(w, dtype) for w, stft in zip(wavs, self.mrd.stfts)]      # (images written in the compute dtype: no cast launches)
-        r_fmaps = [[] for _ in xs]
-        last = len(mrd[0]) - 1
-        xs = hip_conv_group(bank, [dict(layer=mrd[j][0], x=xs[j], **ACT) for j in range(len(xs))])
-        for i in range(1, last + 1):
-            # (tap: the feature-matching loss reads the alias of map i-1 that layer i hands back, so its gradient is added
-            # in layer i's data-gradient fold -- before the leaky ReLU's derivative, which that fold applies too: in_act)
-            xt = hip_conv_group(bank, [dict(layer=mrd[j][i], x=xs[j], tap=True, in_act=LRELU_SLOPE, **(ACT if i < last else {}))
-                                       for j in range(len(xs))])
-            for j, (x, tap) in enumerate(xt):
-                r_fmaps[j].append(tap.permute(0, 3, 1, 2))      # aliased post-activation map, see module docstring
-            xs = [x for x, _ in xt]
-        r_scores = [x.permute(0, 3, 1, 2) for x in xs]
+
+        def resolution_stacks():
+            if fronts is not None and fronts.fronts[0].dtype == dtype and fronts.r1 - fronts.r0 == wav.shape[0]:
+                xs = fronts.images(wavs if (fan and wav.requires_grad) else None)
+            else:
+                xs = [stft.image_cl(w, dtype) for w, stft in zip(wavs, self.mrd.stfts)]      # (images written in the compute dtype: no cast launches)
+            r_fmaps = [[] for _ in xs]
+            last = len(mrd[0]) - 1
+            xs = hip_conv_group(bank, [dict(layer=mrd[j][0], x=xs[j], **ACT) for j in range(len(xs))])
+            for i in range(1, last + 1):
+                # (tap: the feature-matching loss reads the alias of map i-1 that layer i hands back, so its gradient is added
+                # in layer i's data-gradient fold -- before the leaky ReLU's derivative, which that fold applies too: in_act)
+                xt = hip_conv_group(bank, [dict(layer=mrd[j][i], x=xs[j], tap=True, in_act=LRELU_SLOPE, **(ACT if i < last else {}))
+                                           for j in range(len(xs))])
+                for j, (x, tap) in enumerate(xt):
+                    r_fmaps[j].append(tap.permute(0, 3, 1, 2))      # aliased post-activation map, see module docstring
+                xs = [x for x, _ in xt]
+            return [x.permute(0, 3, 1, 2) for x in xs], r_fmaps
+
+        # the two families are independent chains of grouped launches: a parallel branch of the captured step each (their
+        # backward nodes replay on the stream of their forward, so the backward pass forks the same way)
+        (r_scores, r_fmaps), (p_scores, p_fmaps) = fork_join(
+            self._fork, [resolution_stacks], inputs=tuple(wavs),
+            main_thunk=lambda: self._period_stacks(bank, mpd, y, copies, dtype))
+        return r_scores + p_scores, r_fmaps + p_fmaps
+
+    def _period_stacks(self, bank, mpd, y, copies, dtype):
         ps = []
         if copies is not None:
             for d, x in zip(self.mpd.discriminators, copies):
@@ -253,5 +273,4 @@ class Discriminator(nn.Module):
             for j, (x, tap) in enumerate(pt):
                 p_fmaps[j].append(tap.permute(0, 3, 1, 2))
             ps = [x for x, _ in pt]
-        p_scores = [torch.flatten(x, 1, -1) for x in ps]
-        return r_scores + p_scores, r_fmaps + p_fmaps
+        return [torch.flatten(x, 1, -1) for x in ps], p_fmaps

@@ -288,6 +288,12 @@ class VQGANTrainer(BaseTrainer):
         if lengths is None:
             lengths = batch['mel_length'].tolist()
         starts = [self.rng.randrange(max(1, int(n) - self.frame_lengths)) for n in lengths]
+        # the captured window gather reads wav[start * frameshift : (start + frame_lengths) * frameshift] unchecked: a waveform
+        # shorter than its mel says (wrong hop in the data) must fail here, on the host, not as a GPU memory fault
+        need = (max(starts) + self.frame_lengths) * self.frameshift
+        if g['wav'].shape[1] < need:
+            raise ValueError('batch["wav"] holds %d samples per utterance, the sampled window needs %d (mel_length x frameshift %d)'
+                             % (g['wav'].shape[1], need, self.frameshift))
         g['starts_host'].copy_(torch.tensor(starts, dtype=torch.int64))
         g['starts'].copy_(g['starts_host'], non_blocking=True)
         if batch['mel'].data_ptr() != st.mel.data_ptr():

@@ -314,6 +314,8 @@ MSMC_DEV float fast_exp(float x) { return expf(x); }
 MSMC_DEV long long msmc_clock() { return 0; }
 MSMC_DEV float fast_sqrt(float x) { return sqrtf(x); }
 static inline int msmc_check_launch() { return 0; }
+static inline int msmc_rt_stream_create(void** out) { *out = nullptr; return 0; }      // (the interpreter has one stream)
+static inline int msmc_rt_stream_destroy(void*) { return 0; }
 static inline int msmc_prof_used() { return msmc_prof_log.n < MSMC_PROF_MAX ? msmc_prof_log.n : MSMC_PROF_MAX; }
 static inline const char* msmc_prof_name(const char* name) {
     if (msmc_prof_log.on && msmc_prof_mine >= 0) {
