@@ -183,6 +183,11 @@ class Discriminator(nn.Module):
             self._bank.streams = self._streams or self._fork
         return self._bank, self._layers
 
+    def prepare_weights(self):
+        """refresh the kernel-layout weight images on the calling stream if the parameters changed (forward does it too; a
+        caller that is about to run two passes on two streams does it once, before the fork)"""
+        self._hip()[0].prepare(self.hip_dtype)
+
     def spectral_fronts(self, y):
         """the resolution discriminators' images of waveforms ``y`` (B, L) / (B, 1, L) WITHOUT gradient history, as an
         object later passes can take rows from (``forward(.., fronts=...)``)"""
@@ -243,8 +248,11 @@ class Discriminator(nn.Module):
 
         # the two families are independent chains of grouped launches: a parallel branch of the captured step each (their
         # backward nodes replay on the stream of their forward, so the backward pass forks the same way)
+        # (a pass under no_grad does not fork: the trainer runs the generator step's D(real) pass as a side branch of its
+        # own, and a fork onto a second stream from INSIDE a side branch crashed the runtime at capture_end)
+        fork = self._fork if torch.is_grad_enabled() else []
         (r_scores, r_fmaps), (p_scores, p_fmaps) = fork_join(
-            self._fork, [resolution_stacks], inputs=tuple(wavs),
+            fork, [resolution_stacks], inputs=tuple(wavs),
             main_thunk=lambda: self._period_stacks(bank, mpd, y, copies, dtype))
         return r_scores + p_scores, r_fmaps + p_fmaps
 

@@ -112,6 +112,10 @@ class VQGANTrainer(BaseTrainer):
         self.batch_g_step = os.environ.get('MSMC_BATCH_G_STEP', '0') != '0'
         # the generator step reads the spectral front-end images the D step built from the same waveforms (A/B: 0)
         self.reuse_fronts = os.environ.get('MSMC_REUSE_FRONTS', '1') != '0'
+        # more parallel branches of the step (streams of the library's own, hip/convnet.py own_streams): the spectral loss of
+        # the prediction next to the discriminator step, the no-gradient D(real) pass of the generator step next to D(fake)
+        self.loss_fork = os.environ.get('MSMC_LOSS_FORK', '1') != '0'
+        self.real_fork = os.environ.get('MSMC_REAL_FORK', '1') != '0'
         # hipGraph mode under data parallelism: 'serial' = one flat all-reduce per child between the replayed segments;
         # 'overlap' = the reducer's bucketed all-reduces captured INTO the segments (distributed/distributed.py docstring)
         self.graph_exchange = os.environ.get('MSMC_GRAPH_EXCHANGE', 'serial')
@@ -177,13 +181,25 @@ class VQGANTrainer(BaseTrainer):
             return
         st.predict = predict = out['decoder_outputs'].squeeze(-1).float()
         target = st.target
-        stl = self.stft_criterion(predict, target)
-        if isinstance(stl, dict):
-            for name, term in stl.items():
-                losses[name] = term
-            stl = sum(stl.values())
-        losses['stft_loss'] = stl
-        st.g_loss = hiploss.weighted_sum(g_terms + [stl], g_weights + [self.lambda_stft])     # vq + frame + stft in one launch
+
+        def spectral_loss():
+            stl = self.stft_criterion(predict, target)
+            if isinstance(stl, dict):
+                for name, term in stl.items():
+                    losses[name] = term
+                stl = sum(stl.values())
+            return stl
+        # the spectral loss has no consumer before the generator step: a side branch under the discriminator step (its
+        # backward nodes replay on the same stream, next to the generator step's D(fake) backward)
+        side = (hipconvnet.own_streams(predict.device, 1, 'loss-fork') if (self.loss_fork and predict.is_cuda
+                                                                             and hipconvnet.STREAMS_ENABLED) else [])
+        if side:
+            main = torch.cuda.current_stream(predict.device)
+            side[0].wait_stream(main)
+            with torch.cuda.stream(side[0]):
+                stl = spectral_loss()
+        else:
+            stl = spectral_loss()
         # D(fake.detach()) and D(real) as ONE pass over the concatenated batch (every layer is per-sample, so
         # the scores are those of two separate passes): half the launches, twice the work per launch
         B = predict.shape[0]
@@ -199,6 +215,10 @@ class VQGANTrainer(BaseTrainer):
         losses['d_loss_real'], losses['d_loss_fake'], losses['d_loss'] = d_real, d_fake, d_loss
         self.optimizer.zero_grad(['discriminator'])
         d_loss.backward()
+        if side:
+            main.wait_stream(side[0])
+        losses['stft_loss'] = stl
+        st.g_loss = hiploss.weighted_sum(g_terms + [stl], g_weights + [self.lambda_stft])     # vq + frame + stft in one launch
 
     def _segment_b(self, st):
         losses, disc = st.losses, getattr(self.model, 'discriminator', None)
@@ -215,10 +235,17 @@ class VQGANTrainer(BaseTrainer):
                 real_feats = [[f_[B:].detach() for f_ in fl] for fl in feats]
             elif getattr(st, 'fronts', None) is not None:
                 B = st.predict.shape[0]
-                with _frozen(disc), self._amp():
-                    fake_scores, fake_feats = disc(st.predict, fronts=st.fronts.rows(0, B, wav=st.predict))
+                def real_pass():
                     with torch.no_grad():
-                        _, real_feats = disc(st.target, fronts=st.fronts.rows(B, 2 * B))
+                        return disc(st.target, fronts=st.fronts.rows(B, 2 * B))[1]
+                side = (hipconvnet.own_streams(st.predict.device, 1, 'real-pass')
+                        if (self.real_fork and st.predict.is_cuda) else [])
+                if side and hasattr(disc, 'prepare_weights'):
+                    disc.prepare_weights()          # (the optimizer just stepped: refresh the weight images BEFORE the fork)
+                with _frozen(disc), self._amp():
+                    real_feats, (fake_scores, fake_feats) = hipconvnet.fork_join(
+                        side, [real_pass], inputs=(st.target,),
+                        main_thunk=lambda: disc(st.predict, fronts=st.fronts.rows(0, B, wav=st.predict)))
                 st.fronts = None
             else:
                 with _frozen(disc), self._amp():
@@ -235,6 +262,13 @@ class VQGANTrainer(BaseTrainer):
             losses['fm_loss'], losses['adv_loss'], losses['g_loss'] = fm, adv, st.g_loss
         self.optimizer.zero_grad(['autoencoder'])
         st.g_loss.backward()
+        if st.g_loss.is_cuda and st.phase == 2 and hipconvnet.STREAMS_ENABLED:
+            # (the side branches' backward nodes hand their results to nodes of this stream, which orders them already; the
+            # explicit join costs nothing and does not depend on that)
+            main = torch.cuda.current_stream(st.g_loss.device)
+            for role, on in (('loss-fork', self.loss_fork), ('real-pass', self.real_fork)):
+                if on:
+                    main.wait_stream(hipconvnet.own_streams(st.g_loss.device, 1, role)[0])
 
     def _segment_c(self, st):
         if hasattr(self.optimizer, 'clip_and_step'):           # clip + AdamW of all tensors in three launches
