@@ -91,7 +91,7 @@ def fork_join(streams, thunks, inputs=(), main_thunk=None):
 # weight gradients of DIFFERENT layers (partial grids, split-K tails) overlapping each other.
 # The discriminator's resolution and period families are two more branches (networks/hifigan/discriminator.py D_FORK): another
 # 0.4 ms.  All of these are streams of the library's own (own_streams below), not torch pool streams.
-WGRAD_STREAMS = int(os.environ.get('MSMC_WGRAD_STREAMS', '8'))
+WGRAD_STREAMS = int(os.environ.get('MSMC_WGRAD_STREAMS', '12'))
 _SIDE = {}
 _OWN = {}
 
