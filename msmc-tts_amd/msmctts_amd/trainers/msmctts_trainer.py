@@ -315,19 +315,19 @@ class VQGANTrainer(BaseTrainer):
         reducer = getattr(self.model, 'grad_reducer', None)
         if reducer is not None:
             reducer.hooks_enabled = False        # (serial exchange: no collectives inside capture; overlap: _capture arms them)
-        if g is None:
-            g = self._graphs = self._capture(batch)
-        st = g['state']
         lengths = batch.get('mel_length_host')
         if lengths is None:
             lengths = batch['mel_length'].tolist()
-        starts = [self.rng.randrange(max(1, int(n) - self.frame_lengths)) for n in lengths]
         # the captured window gather reads wav[start * frameshift : (start + frame_lengths) * frameshift] unchecked: a waveform
         # shorter than its mel says (wrong hop in the data) must fail here, on the host, not as a GPU memory fault
-        need = (max(starts) + self.frame_lengths) * self.frameshift
-        if g['wav'].shape[1] < need:
-            raise ValueError('batch["wav"] holds %d samples per utterance, the sampled window needs %d (mel_length x frameshift %d)'
-                             % (g['wav'].shape[1], need, self.frameshift))
+        have, need = batch['wav'].numel() // len(lengths), (int(max(lengths)) - 1) * self.frameshift      # (windows end at frame n - 1)
+        if have < need:
+            raise ValueError('batch["wav"] holds %d samples per utterance, mel_length x frameshift (%d) asks for %d'
+                             % (have, self.frameshift, need))
+        if g is None:
+            g = self._graphs = self._capture(batch)
+        st = g['state']
+        starts = [self.rng.randrange(max(1, int(n) - self.frame_lengths)) for n in lengths]
         g['starts_host'].copy_(torch.tensor(starts, dtype=torch.int64))
         g['starts'].copy_(g['starts_host'], non_blocking=True)
         if batch['mel'].data_ptr() != st.mel.data_ptr():

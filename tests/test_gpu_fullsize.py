@@ -352,6 +352,39 @@ AM_TRAINER = dict(grad_clip_thresh=10.0, training_methods=['mse', 'triple_sum'],
                   lambda_dur=1.0)
 
 
+def test_side_branches_survive_several_trainers_in_one_process():
+    """The captured step has parallel branches (weight gradients, the resolution discriminators, the spectral loss, the
+    generator step's D(real) pass).  They run on streams of the library's own: torch.cuda.Stream() hands out a pool of 32
+    round robin, and with pool streams a later trainer's capture stream could BE an earlier side stream (the fork then
+    crashed hipStreamEndCapture).  Exhaust the pool, then capture and replay three trainers back to back; the windowed
+    waveform contract is checked on the host (a waveform shorter than mel_length x frameshift raises, it does not fault)."""
+    from msmctts_amd.hip import convnet
+    assert convnet.WGRAD_STREAMS > 0, 'the default configuration runs its weight gradients on side streams'
+    burn = [torch.cuda.Stream() for _ in range(40)]
+    cfg = _cfg(4, dropout=False, **CONFIGS['config2'])
+    _, batch = _batch(4, 400, 80)
+    first = None
+    for rep in range(3):
+        burn += [torch.cuda.Stream() for _ in range(7)]
+        tr = _build(cfg, graph=True, dtype=torch.bfloat16, dropout=False)
+        rows = _run_steps(tr, batch, 3)
+        assert all(np.isfinite(v) for row in rows for v in row.values()), rows
+        if first is None:
+            first = rows[0]
+        else:                      # same seed, same batch, same windows: the first step repeats up to atomic-order noise
+            for k in KEYS:
+                assert _rel(rows[0][k], first[k], 1e-3) <= 2e-2, (k, rows[0][k], first[k])
+        if rep == 2:
+            short = dict(batch)
+            short['wav'] = batch['wav'][:, :batch['wav'].shape[1] // 2].contiguous()
+            with pytest.raises(ValueError):
+                tr.train_step(short, 99)
+        del tr
+        torch.cuda.empty_cache()
+    side = convnet.own_streams(DEV, 1, 'wgrad')[0]
+    assert all(side.cuda_stream != s_.cuda_stream for s_ in burn)
+
+
 def test_fp32_predictor_step_matches_oracle_full_size():
     """BASELINE config #4 at the sizes of msmc_vq_gan_am.yaml (600-wide, 6 + 6 FFT blocks, 256-wide per-stage predictions)
     against the frozen CSMSC autoencoder (2 stages, 4 heads x 64): one fp32 PredictorTrainer.train_step of the product

@@ -1,10 +1,10 @@
 set -u
 mkdir -p gpurun_out
 bash tools/profile_round.sh r04 > gpurun_out/r04_profile_round.log 2>&1
-( time python -m pytest tests -m gpu -q 2>&1 | tail -6 ) > gpurun_out/r04_gpu_suite.txt 2>&1
+( time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6 ) > gpurun_out/r04_gpu_suite.txt 2>&1
 SHORT="--cpu-steps 0 --fp32-steps 0 --no-microbench --warmup-phase-steps 0 --kernel-timing-steps 0 --steps 30"
 for c in 1 3 5; do python bench.py --config $c $SHORT > gpurun_out/r04_bench_config$c.json 2> gpurun_out/r04_bench_config$c.log; done
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bf16 -- python bench.py --fp32-steps 0 --no-microbench --cpu-steps 0 --kernel-timing-steps 0 > gpurun_out/r04_bf16_step_under_rocprof.json 2> gpurun_out/r04_bf16_step_under_rocprof.log
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bf16 -- python bench.py --fp32-steps 0 --no-microbench --cpu-steps 0 --kernel-timing-steps 0 > gpurun_out/r04_bf16_step_under_rocprof.json 2> gpurun_out/r04_bf16_step_under_rocprof.log
 cp $(find /tmp/prof_bf16 -name '*kernel_stats.csv' | head -1) gpurun_out/r04_kernel_stats_bf16_step.csv
 python tools/torch_ops_in_step.py > gpurun_out/r04_stock_operators_in_step.txt 2>&1
 tail -3 gpurun_out/r04_gpu_suite.txt
