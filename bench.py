@@ -736,8 +736,10 @@ def main():
         step_roof = dict(roofline_ms_per_step=t_roof, kernel_ms_per_step=t_all, frac=t_roof / max(t_all, 1e-9),
                          attributed_time_frac=t_attr / max(t_all, 1e-9),
                          launches_per_step=sum(rec['launches'] for rec in ks.values()) / float(nst),
+                         frac_of_step_time=t_roof / max(ms_per_step, 1e-9),
                          note='sum over every hand-written launch of max(flops / dense MFMA peak of its dtype, bytes / 8 TB/s) '
-                              'divided by the summed launch durations (HIP events, instrumented single-stream steps)')
+                              'divided by the summed launch durations (HIP events, instrumented single-stream steps); '
+                              'frac_of_step_time divides by the timed step instead (shorter than the sum: the step runs parallel branches)')
         label = max((k for k in kernels if kernels[k]['flops_per_launch'] > 0), key=lambda k: kernels[k]['ms_per_step'])
         k = kernels[label]
         traffic = mfma_util = None

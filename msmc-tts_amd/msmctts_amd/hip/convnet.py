@@ -218,6 +218,7 @@ class ConvBank(object):
         self._side_rr = 0
         self.deferred = K.DeferredReduce()     # partial-result arena + pending second stages of the running backward pass
         self._pending_w = {}            # stream -> (Stream, weight gradients waiting for company), see WGRAD_BATCH
+        self._dw_stream = {}            # accumulator -> side stream of its last launch in the running pass (wgrad_side)
 
     def queue_wgrad(self, item):
         """Backward nodes replay on the stream of their forward (fork_join branches): a waiting list per stream, flushed
@@ -237,21 +238,36 @@ class ConvBank(object):
         if not items:
             return
         with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-            with self.wgrad_side(*([it['x'] for it in items] + [it['g'] for it in items])):
+            with self.wgrad_side(*([it['x'] for it in items] + [it['g'] for it in items]), dws=[it['dw'] for it in items]):
                 K.conv_wgrad_group(items)
 
     def flush_wgrad(self):
         for key in list(self._pending_w):
             self._flush_stream(key)
 
+    def _order_accumulators(self, st, dws):
+        for dw in dws:
+            prev = self._dw_stream.get(dw.data_ptr())
+            if prev is not None and prev.cuda_stream != st.cuda_stream:
+                st.wait_stream(prev)
+            self._dw_stream[dw.data_ptr()] = st
+
     @contextlib.contextmanager
-    def wgrad_side(self, *tensors):
+    def wgrad_side(self, *tensors, dws=()):
         """Context for the weight-gradient launches of one backward node: a side stream ordered after everything the
         calling stream has issued so far.  ``tensors`` (the node's inputs to those launches) stay referenced until the
         join in ``_finish_backward``, so the caching allocator -- eagerly and inside a capture -- cannot hand their
-        memory to a later allocation of the calling stream while the side stream still reads it."""
+        memory to a later allocation of the calling stream while the side stream still reads it.  ``dws``: the accumulators
+        the launches add to -- a layer applied twice in one pass (the two batch halves of a forked block stack) must not have
+        its two accumulations in flight at once (a single-split launch adds to dW without atomics), so the stream chosen
+        here first waits for the stream that ran the previous launch on any of them.
+        (Tried on top of this: a block stack running the two halves of its batch as two branches -- FFT stacks, 50-400
+        workgroups per launch.  16.27 -> 18.44 ms/step: twice the launches at nearly the same duration each, and the
+        branches did not overlap enough to pay for them.  Not kept.)"""
         dev = self.w1.device
         if dev.type != 'cuda' or WGRAD_STREAMS <= 0 or not STREAMS_ENABLED:
+            if dev.type == 'cuda':              # (launches on the calling stream -- which may be one of two branches, see dws)
+                self._order_accumulators(torch.cuda.current_stream(dev), dws)
             K.DEFER_TO = self.deferred          # (second stages of these launches: once, in _finish_backward)
             try:
                 yield
@@ -262,6 +278,7 @@ class ConvBank(object):
         st = sts[self._side_rr % len(sts)]
         self._side_rr += 1
         st.wait_stream(torch.cuda.current_stream(dev))
+        self._order_accumulators(st, dws)
         self._hold.extend(t for t in tensors if t is not None)
         if not any(st is u for u in self._side_used):
             self._side_used.append(st)
@@ -437,6 +454,7 @@ class ConvBank(object):
             for st in self._side_used:
                 cur.wait_stream(st)
             self._side_used = []
+        self._dw_stream.clear()
         if not early:                   # (held gradients may still be read by other banks' nodes: released with the pass)
             del self._hold[:]
         touched, self._touched = self._touched, set()
@@ -576,7 +594,7 @@ class _HipConv(torch.autograd.Function):
                 bank.queue_wgrad(dict(x=x, g=g, geom=layer.geom(x.shape[1], x.shape[2]), n_slices=layer.taps,
                                       in_slope=ctx.in_slope, dw=layer.dw, db=layer.db, copies=layer.dw_copies, seen=layer.wg_variants))
             else:
-                with bank.wgrad_side(x, g):
+                with bank.wgrad_side(x, g, dws=(layer.dw,)):
                     if layer.kind == 'conv':
                         K.conv_wgrad(x, g, layer.geom(x.shape[1], x.shape[2]), layer.taps, in_slope=ctx.in_slope,
                                      dw=layer.dw, db=layer.db, copies=layer.dw_copies, seen=layer.wg_variants)
@@ -709,7 +727,7 @@ class _HipConvGroup(torch.autograd.Function):
             for it in w_items:
                 bank.queue_wgrad(it)
         elif w_items:
-            with bank.wgrad_side(*([it['x'] for it in w_items] + [it['g'] for it in w_items])):
+            with bank.wgrad_side(*([it['x'] for it in w_items] + [it['g'] for it in w_items]), dws=[it['dw'] for it in w_items]):
                 K.conv_wgrad_group(w_items)
         bank._queue_finish()
         if ctx.counted:

@@ -490,19 +490,6 @@ class _StepState(object):
     pass
 
 
-class _SplitBatch(torch.autograd.Function):
-    """the two halves of a [2B, ...] tensor; the backward pass is ONE concatenation (slicing's own backward zero-fills
-    and copies a full-size tensor per half and adds the two: five launches per tensor)"""
-
-    @staticmethod
-    def forward(ctx, x, B):
-        return x[:B], x[B:]
-
-    @staticmethod
-    def backward(ctx, ga, gb):
-        return torch.cat((ga, gb), dim=0), None
-
-
 class DurationLoss(nn.Module):
     """masked MSE between predicted and target phoneme durations (reference msmctts_trainer.py:12-36)"""
 

@@ -26,7 +26,8 @@ VIEWS = {'aten::view', 'aten::reshape', 'aten::permute', 'aten::transpose', 'ate
          'aten::lift_fresh', 'aten::flatten', 'aten::chunk', 'aten::unflatten', 'aten::resolve_conj',
          'aten::resolve_neg', 'aten::set_', 'aten::contiguous', 'aten::to', 'aten::_to_copy', 'aten::clone',
          'aten::zeros', 'aten::zeros_like', 'aten::ones', 'aten::ones_like', 'aten::full', 'aten::new_empty',
-         'aten::new_zeros', 'aten::expand_as', 'aten::movedim', 'aten::unfold', 'aten::size', 'aten::stride'}
+         'aten::new_zeros', 'aten::expand_as', 'aten::movedim', 'aten::unfold', 'aten::size', 'aten::stride',
+         'aten::record_stream'}       # (record_stream: caching-allocator bookkeeping of the side branches, host only)
 
 
 def main():
