@@ -2,9 +2,9 @@
  *
  * The reference's drop-in boundary for this path is a Python plugin registry, not an FFI
  * (reference msmctts/networks/__init__.py:6-11).  This library sits *below* it:
- * every entry point takes plain device pointers, sizes and a HIP stream, allocates nothing, is
- * stream-ordered and re-entrant per stream, and returns 0 (hipSuccess) or a hipError_t / negative MSMC_E*
- * code.  No entry point of this header changes process-global behaviour: kernel choices are per call
+ * every entry point takes plain device pointers, sizes and a HIP stream, allocates nothing (msmc_stream_create, which
+ * makes a HIP stream, is the one exception), is stream-ordered and re-entrant per stream, and returns 0 (hipSuccess) or a
+ * hipError_t / negative MSMC_E* code.  No entry point of this header changes process-global behaviour: kernel choices are per call
  * (msmc_conv_desc.variant / split_shift); what remains global is observational -- the per-thread msmc_conv_last_kernel /
  * msmc_conv_launch_count / msmc_vq_last_kernel tags, the opt-in msmc_prof_* launch log and the per-thread sink of
  * msmc_conv_wgrad_defer_begin / _end.  The A/B switches, ablation masks and the experimental fused ResBlock unit that the perf
