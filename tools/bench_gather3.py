@@ -51,6 +51,8 @@ SHAPES = [
     ('thin mpd p11 16->64 s3', 32, 16, 64, 364, 11, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ''
+if os.environ.get('MSMC_PROBE_LIB'):       # a sensitivity build of the library (tools/r04_pad_probe.sh)
+    lib._lib = lib.load(os.environ['MSMC_PROBE_LIB'])
 L = lib.get()
 
 
