@@ -229,6 +229,8 @@ def abi_work_models():
             (0.0, float(N * C * E(dt) * (3 + (1 if res else 0)) + 8 * N)),
         'msmc_add_ln_bwd': lambda g, v, mean, rstd, gamma, keep, gx, gres, dga, dbe, ws, wsb, N, C, p, seed, salt, acc, dt, st:
             (0.0, float(N * C * E(dt) * (3 + (1 if gres else 0)) + 8 * N)),
+        'msmc_add_ln_param_multi': lambda items, n, st:
+            (0.0, float(sum(items[i].nblocks * 2 * items[i].C * 4 + 2 * items[i].C * 4 for i in range(n)))),
         'msmc_attn_fwd': lambda qkv, bias, out, lse, B, T, H, Tp, *a:
             (4.0 * T * T * HEAD * B * H, float(B * T * H * (3 * HEAD + HEAD) * 2)),
         'msmc_attn_bwd': lambda qkv, bias, out, lse, dout, dqkv, dsum, B, T, H, Tp, *a:

@@ -474,11 +474,30 @@ int msmc_add_ln_fwd(const void* x, const void* res, const float* gamma, const fl
                     void* y, void* v, float* mean, float* rstd, long N, int C, float eps, float p_drop,
                     const long long* seed, long long salt, int dtype, msmc_stream stream);
 size_t msmc_add_ln_bwd_workspace(long N, int C);
-/* gx = d/dx, gres = d/dres (may be NULL), dgamma / dbeta fp32 [C] (accumulate != 0: +=), fixed reduction order. */
+/* gx = d/dx, gres = d/dres (may be NULL), dgamma / dbeta fp32 [C] (accumulate != 0: +=), fixed reduction order.
+ * dgamma == dbeta == NULL: only the per-workgroup partials are produced -- they stay in `workspace`
+ * ([ceil(N / 16)][2][C] fp32, which the caller then keeps) for msmc_add_ln_param_multi. */
 int msmc_add_ln_bwd(const void* g, const void* v, const float* mean, const float* rstd, const float* gamma,
                     const unsigned char* keep_row, void* gx, void* gres, float* dgamma, float* dbeta, void* workspace,
                     size_t workspace_bytes, long N, int C, float p_drop, const long long* seed, long long salt, int accumulate,
                     int dtype, msmc_stream stream);
+/* The parameter gradients of several LayerNorms from the partials their msmc_add_ln_bwd calls left behind, in launches of up
+ * to MSMC_LN_PARAM_MAX items (the 24 LayerNorms of the FFT stacks: one launch at the end of the backward pass instead of one
+ * 10 us launch behind every LayerNorm backward, on the critical path of the block chain).  `items` is a HOST array (passed to
+ * the kernel by value); same fixed reduction order as msmc_add_ln_bwd's own second stage; two items must not name the same
+ * dgamma / dbeta.  Reference: the weight / bias gradients autograd derives for nn.LayerNorm in
+ * acoustic_models/transformer.py:270-288,330-352. */
+#define MSMC_LN_PARAM_MAX 32
+typedef struct {
+    const float* part;      /* the workspace of the msmc_add_ln_bwd call: [nblocks][2][C] */
+    float* dgamma;
+    float* dbeta;
+    int nblocks;            /* ceil(N / 16) of that call */
+    int C;
+    int accumulate;         /* != 0: += */
+    int reserved;
+} msmc_ln_param_item;
+int msmc_add_ln_param_multi(const msmc_ln_param_item* items, int nitems, msmc_stream stream);
 /* Head of FFTBlocks.forward (reference msmctts/networks/acoustic_models/transformer.py:375-395) with the positions of
  * vqgantts/msmc_vqgan.py:56-58 folded in: out[b][t][:] = seq[b][t][:] + table[t < len[b] ? t + 1 : 0][:] (seq / out
  * [B][T][C] in in_dtype / out_dtype, table fp32 [table_rows][C], T + 1 <= table_rows), keep_row[b T + t] = t < len[b],

@@ -232,12 +232,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ g
 
 // dgamma[c] (+)= sum_b part[b][0][c], dbeta[c] (+)= sum_b part[b][1][c].  A workgroup owns 16 columns of one of the two
 // vectors; its 16 slices each sum a contiguous range of blocks in order, then the slices are added in order (deterministic).
-__global__ __launch_bounds__(256) void add_ln_param_kernel(const float* __restrict__ part, int nblocks, int C,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           int accumulate) {
+MSMC_DEV void add_ln_param_body(const float* __restrict__ part, int nblocks, int C, float* __restrict__ dgamma,
+                                float* __restrict__ dbeta, int accumulate, const int block) {
     __shared__ float red[16][16];
     const int groups = (C + 15) / 16;
-    const int k = blockIdx.x / groups, c = (blockIdx.x - k * groups) * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+    const int k = block / groups, c = (block - k * groups) * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
     const int per = (nblocks + 15) / 16, b0 = sl * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
     float s = 0.f;
     if (c < C)
@@ -251,6 +250,25 @@ __global__ __launch_bounds__(256) void add_ln_param_kernel(const float* __restri
         float* dst = k == 0 ? dgamma : dbeta;
         dst[c] = accumulate ? dst[c] + t : t;
     }
+}
+__global__ __launch_bounds__(256) void add_ln_param_kernel(const float* __restrict__ part, int nblocks, int C,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           int accumulate) {
+    add_ln_param_body(part, nblocks, C, dgamma, dbeta, accumulate, (int)blockIdx.x);
+}
+// the same reduction for up to MSMC_LN_PARAM_MAX LayerNorms in one launch (the backward passes of a step leave their partials
+// in caller-kept workspaces; one launch at the end of the pass instead of one per LayerNorm): item i owns blocks
+// [first[i], first[i + 1])
+struct LnParamArgs {
+    msmc_ln_param_item item[MSMC_LN_PARAM_MAX];
+    int first[MSMC_LN_PARAM_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void add_ln_param_multi_kernel(LnParamArgs a) {
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.first[i + 1]) ++i;
+    const msmc_ln_param_item& it = a.item[i];
+    add_ln_param_body(it.part, it.nblocks, it.C, it.dgamma, it.dbeta, it.accumulate, (int)blockIdx.x - a.first[i]);
 }
 
 // ---- gate / tanh ---------------------------------------------------------------------------------------------
@@ -374,7 +392,7 @@ int msmc_add_ln_bwd(const void* g, const void* v, const float* mean, const float
                     const unsigned char* keep_row, void* gx, void* gres, float* dgamma, float* dbeta, void* workspace,
                     size_t workspace_bytes, long N, int C, float p_drop, const long long* seed, long long salt, int accumulate,
                     int dtype, msmc_stream stream) {
-    if (!g || !v || !mean || !rstd || !gamma || !gx || !dgamma || !dbeta || N < 0 || C <= 0 || C > 64 * NM_MAXE) return MSMC_E_SHAPE;
+    if (!g || !v || !mean || !rstd || !gamma || !gx || (!dgamma != !dbeta) || N < 0 || C <= 0 || C > 64 * NM_MAXE) return MSMC_E_SHAPE;
     const int rows = NM_BWD_ROWS;
     const int nblocks = (int)((N + rows - 1) / rows);
     if (workspace_bytes < msmc_add_ln_bwd_workspace(N, C) || (nblocks && !workspace)) return MSMC_E_WORKSPACE;
@@ -391,9 +409,31 @@ int msmc_add_ln_bwd(const void* g, const void* v, const float* mean, const float
         int rc = msmc_check_launch();
         if (rc) return rc;
     }
+    if (!dgamma) return 0;           // the partials stay in the workspace: msmc_add_ln_param_multi reduces them later
     MSMC_LAUNCH(add_ln_param_kernel, dim3((unsigned)(2 * ((C + 15) / 16))), dim3(256), 0, (msmc_stream_t)stream,
                 (const float*)workspace, nblocks, C, dgamma, dbeta, accumulate);
     return msmc_check_launch();
+}
+
+int msmc_add_ln_param_multi(const msmc_ln_param_item* items, int nitems, msmc_stream stream) {
+    if (nitems < 0 || (nitems && !items)) return MSMC_E_SHAPE;
+    for (int i0 = 0; i0 < nitems; i0 += MSMC_LN_PARAM_MAX) {
+        LnParamArgs a;
+        a.n = nitems - i0 < MSMC_LN_PARAM_MAX ? nitems - i0 : MSMC_LN_PARAM_MAX;
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const msmc_ln_param_item& it = items[i0 + i];
+            if (!it.part || !it.dgamma || !it.dbeta || it.nblocks < 0 || it.C <= 0 || it.C > 64 * NM_MAXE) return MSMC_E_SHAPE;
+            a.item[i] = it;
+            a.first[i] = blocks;
+            blocks += 2 * ((it.C + 15) / 16);
+        }
+        a.first[a.n] = blocks;
+        MSMC_LAUNCH(add_ln_param_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
+        int rc = msmc_check_launch();
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int msmc_fft_prologue(const void* seq, const void* lengths, int len_is_64, const float* table, int table_rows, void* out,

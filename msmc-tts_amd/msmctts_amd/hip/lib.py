@@ -143,6 +143,7 @@ _SIGNATURES.update({
     'msmc_add_ln_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _i, _f, _f, _vp, ctypes.c_longlong,
                         _i, _vp]),
     'msmc_add_ln_bwd_workspace': (_sz, [ctypes.c_long, _i]),
+    'msmc_add_ln_param_multi': (_i, [_vp, _i, _vp]),
     'msmc_add_ln_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, ctypes.c_long, _i, _f, _vp,
                         ctypes.c_longlong, _i, _i, _vp]),
     'msmc_fft_prologue': (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -173,6 +174,12 @@ _DEBUG_SIGNATURES = {
     'msmc_conv_set_wgrad_tpw': (None, [_i]),
     'msmc_resunit_forward': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
 }
+
+
+class LnParamItem(ctypes.Structure):
+    """msmc_ln_param_item (include/msmc_hip.h)"""
+    _fields_ = [('part', ctypes.c_void_p), ('dgamma', ctypes.c_void_p), ('dbeta', ctypes.c_void_p), ('nblocks', ctypes.c_int),
+                ('C', ctypes.c_int), ('accumulate', ctypes.c_int), ('reserved', ctypes.c_int)]
 
 
 def exported_symbols():

@@ -9,6 +9,9 @@ replay draws fresh masks.
 """
 import itertools
 
+import ctypes
+import os
+
 import torch
 
 from . import lib
@@ -57,6 +60,10 @@ class _AddLayerNorm(torch.autograd.Function):
                   'msmc_add_ln_fwd')
         ctx.save_for_backward(v, mean, rstd, gamma, keep_row)
         ctx.p_drop, ctx.salt, ctx.has_res = float(p_drop), salt, res is not None
+        # leaf parameters: their gradients can leave in the pass's ONE parameter-gradient launch (_ln_flush) instead of a launch
+        # behind every LayerNorm backward; anything else (a non-leaf gamma) keeps autograd's own route
+        leaf = lambda t: t.requires_grad and t.is_leaf and t.dtype == torch.float32 and t.is_contiguous()
+        ctx.params = (gamma, beta) if (LN_PARAM_DEFER and leaf(gamma) and leaf(beta)) else None
         return y
 
     @staticmethod
@@ -67,8 +74,11 @@ class _AddLayerNorm(torch.autograd.Function):
         L = lib.get()
         gx = torch.empty_like(v)
         gres = torch.empty_like(v) if ctx.has_res else None
-        dgamma = torch.empty(C, dtype=torch.float32, device=v.device)
-        dbeta = torch.empty(C, dtype=torch.float32, device=v.device)
+        defer = ctx.params is not None and _ln_defer_ok()
+        dgamma = dbeta = None
+        if not defer:
+            dgamma = torch.empty(C, dtype=torch.float32, device=v.device)
+            dbeta = torch.empty(C, dtype=torch.float32, device=v.device)
         nbytes = int(L.msmc_add_ln_bwd_workspace(N, C))
         ws = torch.empty(max(1, (nbytes + 3) // 4), dtype=torch.float32, device=v.device)
         seed = seed_word(v.device) if ctx.p_drop > 0 else None
@@ -76,7 +86,75 @@ class _AddLayerNorm(torch.autograd.Function):
                                     lib.ptr(keep_row, torch.uint8), lib.ptr(gx), lib.ptr(gres), lib.ptr(dgamma), lib.ptr(dbeta),
                                     lib.ptr(ws), ws.numel() * 4, N, C, ctx.p_drop, lib.ptr(seed), ctx.salt, 0, _DT[v.dtype],
                                     lib.stream(v)), 'msmc_add_ln_bwd')
+        if defer:
+            _ln_queue(ws, (N + 15) // 16, C, ctx.params[0], ctx.params[1])
         return gx, gres, dgamma, dbeta, None, None, None, None
+
+
+# ---- parameter gradients of all LayerNorms of a backward pass in one launch --------------------------------------------
+# Every LayerNorm backward leaves per-workgroup partial sums of dgamma / dbeta in its workspace; their reduction is a 10 us
+# launch of 32 workgroups, and behind each of the 24 LayerNorms of the FFT stacks it sits on the critical path of the block
+# chain.  With LN_PARAM_DEFER the workspaces wait until the end of the backward pass (an autograd-engine callback, as
+# ConvBank's weight gradients do) and ONE msmc_add_ln_param_multi launch reduces them all, in the same fixed order; the
+# gradients are then delivered to ``.grad`` directly (torch semantics: a live gradient is added to, in the kernel).  A
+# caller that asks for these gradients through ``torch.autograd.grad`` gets None for them -- use ``.backward()``, or
+# MSMC_LN_PARAM_DEFER=0.
+LN_PARAM_DEFER = os.environ.get('MSMC_LN_PARAM_DEFER', '1') != '0'
+_LN_PENDING = {'task': None, 'items': []}
+
+
+def _ln_defer_ok():
+    return hasattr(torch._C, '_current_graph_task_id') and torch._C._current_graph_task_id() >= 0
+
+
+def _ln_queue(ws, nblocks, C, gamma, beta):
+    from torch.autograd import Variable
+    task = torch._C._current_graph_task_id()
+    if _LN_PENDING['task'] != task:          # (a pass that raised before its callback leaves nothing behind for the next)
+        _LN_PENDING['task'], _LN_PENDING['items'] = task, []
+        Variable._execution_engine.queue_callback(_ln_flush)
+    _LN_PENDING['items'].append((ws, nblocks, C, gamma, beta))
+
+
+def _ln_flush():
+    from . import convnet
+    items, _LN_PENDING['items'], _LN_PENDING['task'] = _LN_PENDING['items'], [], None
+    while items:
+        batch, rest, seen = [], [], set()
+        for it in items:                      # a LayerNorm applied twice in one pass: its second reduction in a later launch
+            key = it[3].data_ptr()
+            (rest if key in seen else batch).append(it)
+            seen.add(key)
+        items = rest
+        arr = (lib.LnParamItem * len(batch))()
+        fresh = []
+        with torch.no_grad():
+            for slot, (ws, nblocks, C, gamma, beta) in zip(arr, batch):
+                targets = []
+                for p in (gamma, beta):
+                    live = p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() and \
+                        p.grad.device == ws.device
+                    t = p.grad if live else torch.empty(C, dtype=torch.float32, device=ws.device)
+                    targets.append((p, t, live))
+                slot.part, slot.nblocks, slot.C = ws.data_ptr(), nblocks, C
+                slot.dgamma, slot.dbeta = targets[0][1].data_ptr(), targets[1][1].data_ptr()
+                slot.accumulate = 1 if (targets[0][2] and targets[1][2]) else 0
+                if targets[0][2] != targets[1][2]:        # (one of the two live: never in practice -- route both through buffers)
+                    targets = [(p, torch.empty(C, dtype=torch.float32, device=ws.device), False) for p, _, _ in targets]
+                    slot.dgamma, slot.dbeta, slot.accumulate = targets[0][1].data_ptr(), targets[1][1].data_ptr(), 0
+                fresh.append(targets)
+            dev = batch[0][0]
+            lib.check(lib.get().msmc_add_ln_param_multi(arr, len(batch), lib.stream(dev)),
+                      'msmc_add_ln_param_multi')
+            for targets in fresh:
+                for p, t, live in targets:
+                    if not live:
+                        if p.grad is None:
+                            p.grad = t
+                        else:
+                            p.grad.add_(t.to(p.grad.dtype))
+                    if convnet.GRAD_READY_HOOK is not None:
+                        convnet.GRAD_READY_HOOK(p)
 
 
 def add_layer_norm(x, res, gamma, beta, keep_row=None, p_drop=0.0, salt=0, eps=1e-5):
