@@ -5,6 +5,8 @@ Replaces the arithmetic of ``Quantize.forward`` / ``MultiHeadQuantize.forward``
 """
 import os
 
+import contextlib
+
 import torch
 
 from . import lib
@@ -93,9 +95,48 @@ def vq_search(x, embed_t, enorm, shortlist=None):
     return _VQSearch.apply(x, embed_t, enorm, image, bool(shortlist))
 
 
+# The EMA update of a stage has no reader before the next step's search (the quantised values of this step came from the
+# codebook as it was), yet its two launches (statistics 87 us + update 34 us per stage) sat in the middle of the autoencoder's
+# forward chain.  Inside ``ema_side(device)`` -- MSMCVQGAN.forward around its quantiser -- they go to a side stream of the
+# library's own (a parallel branch of the captured step, next to the frame decoder and the vocoder); ``join_ema`` at the end of
+# that forward orders the caller behind them.  Stand-alone use of the quantiser modules keeps them on the calling stream.
+EMA_SIDE = os.environ.get('MSMC_VQ_EMA_SIDE', '1') != '0'
+_EMA = {'side': None, 'used': None}
+
+
+@contextlib.contextmanager
+def ema_side(device):
+    from . import convnet
+    keep = _EMA['side']
+    if EMA_SIDE and torch.device(device).type == 'cuda' and convnet.STREAMS_ENABLED:
+        _EMA['side'] = convnet.own_streams(device, 1, 'vq-ema')[0]
+    try:
+        yield
+    finally:
+        _EMA['side'] = keep
+
+
+def join_ema(device):
+    """the calling stream waits for the EMA updates issued inside ema_side since the last join"""
+    st = _EMA['used']
+    if st is not None:
+        torch.cuda.current_stream(device).wait_stream(st)
+        _EMA['used'] = None
+
+
 def vq_ema_update(x, ind, length, embed, cluster_size, embed_avg, decay, eps, workspace=None):
     """In-place EMA update of the packed buffers embed [H,d,K], cluster_size [H,K], embed_avg [H,d,K]
     from the valid frames of x [B,T,D] / ind [B,T,H] (t < length[b])."""
+    side = _EMA['side'] if x.is_cuda else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        _EMA['used'] = side
+        with torch.cuda.stream(side):
+            return _vq_ema_update(x, ind, length, embed, cluster_size, embed_avg, decay, eps, workspace)
+    return _vq_ema_update(x, ind, length, embed, cluster_size, embed_avg, decay, eps, workspace)
+
+
+def _vq_ema_update(x, ind, length, embed, cluster_size, embed_avg, decay, eps, workspace=None):
     B, T, D = x.shape
     H, d, K = embed.shape
     L = lib.get()

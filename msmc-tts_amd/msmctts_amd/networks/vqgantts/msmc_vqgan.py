@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 from ...hip import losses as hiploss
 from ...hip import norm as hipnorm
+from ...hip import vq as hipvq
 from ...hip.convnet import ConvBank, ConvLayer, hip_conv
 from ...utils.utils import get_mask_from_lengths
 from ..acoustic_models.transformer import FFTBlocks
@@ -310,7 +311,8 @@ class MSMCVQGAN(nn.Module):
             hipnorm.advance_seed(mel.device)        # fresh dropout masks for the fused kernels of this step
         hip = self._hip_ready(mel.device)
         enc = self.encoder(self._linear(self.in_linear, mel, hip), mel_length)
-        qs = self.quantizer(enc)
+        with hipvq.ema_side(mel.device):              # (the codebooks' EMA updates: a side branch, joined before this returns)
+            qs = self.quantizer(enc)
         feats, lens = zip(*enc)
         out = {'encoder_outputs': feats[::-1], 'encoder_lengths': lens[::-1],
                'encoder_indices': qs['quantizer_indices'], 'encoder_diffs': qs['quantizer_diffs'],
@@ -325,6 +327,8 @@ class MSMCVQGAN(nn.Module):
                 assert len(window) == dec_in.shape[0]
                 dec_in = torch.stack([dec_in[i, s:e] for i, (s, e) in enumerate(window)], dim=0)
             out['decoder_outputs'] = self.decoder(dec_in.transpose(1, 2)).transpose(1, 2)
+        if mel.is_cuda:
+            hipvq.join_ema(mel.device)
         return out
 
     def analysis(self, mel, mel_length):
