@@ -1,6 +1,6 @@
 set -u
 mkdir -p gpurun_out
-bash tools/profile_round.sh r04 > gpurun_out/r04_profile_round.log 2>&1
+SKIP_VQ=1 bash tools/profile_round.sh r04 > gpurun_out/r04_profile_round.log 2>&1
 ( time timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6 ) > gpurun_out/r04_gpu_suite.txt 2>&1
 SHORT="--cpu-steps 0 --fp32-steps 0 --no-microbench --warmup-phase-steps 0 --kernel-timing-steps 0 --steps 30"
 for c in 1 3 5; do python bench.py --config $c $SHORT > gpurun_out/r04_bench_config$c.json 2> gpurun_out/r04_bench_config$c.log; done
