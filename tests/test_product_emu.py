@@ -1076,6 +1076,58 @@ def test_fft_stack_with_the_fused_prologue_equals_the_stack_called_with_position
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
+def test_layernorm_parameter_gradients_delivered_once_per_pass():
+    """hip/norm.py: the dgamma / dbeta reductions of a backward pass leave in one msmc_add_ln_param_multi launch from an
+    end-of-pass callback.  A LayerNorm applied TWICE in one pass (its second reduction goes out in a later launch of the same
+    flush), a second backward without zero_grad (live gradients are added to, in the kernel), and MSMC_LN_PARAM_DEFER off --
+    all against torch.nn.functional.layer_norm."""
+    from msmctts_amd.hip import lib, norm
+    torch.manual_seed(3)
+    N, C = 45, 96
+    x1, x2 = torch.randn(N, C), torch.randn(N, C)
+    g1, g2 = torch.randn(N, C), torch.randn(N, C)
+
+    def reference(passes):
+        gm, bt = torch.full((C,), 1.25, requires_grad=True), torch.full((C,), -0.5, requires_grad=True)
+        om, ob = torch.ones(C, requires_grad=True), torch.zeros(C, requires_grad=True)
+        for _ in range(passes):
+            a = torch.nn.functional.layer_norm(x1, (C,), gm, bt)
+            b = torch.nn.functional.layer_norm(a + x2, (C,), gm, bt)          # the same parameters a second time
+            c = torch.nn.functional.layer_norm(b, (C,), om, ob)
+            ((a * g1).sum() + (c * g2).sum()).backward()
+        return [t.grad.clone() for t in (gm, bt, om, ob)]
+
+    def product(passes, defer):
+        keep = norm.LN_PARAM_DEFER
+        norm.LN_PARAM_DEFER = defer
+        calls = []
+        real = lib.get().msmc_add_ln_param_multi
+        try:
+            gm, bt = torch.full((C,), 1.25, requires_grad=True), torch.full((C,), -0.5, requires_grad=True)
+            om, ob = torch.ones(C, requires_grad=True), torch.zeros(C, requires_grad=True)
+            setattr(lib.get(), 'msmc_add_ln_param_multi', lambda items, n, st: (calls.append(n), real(items, n, st))[1])
+            for _ in range(passes):
+                a = norm.add_layer_norm(x1, None, gm, bt)
+                b = norm.add_layer_norm(a, x2, gm, bt)
+                c = norm.add_layer_norm(b, None, om, ob)
+                ((a * g1).sum() + (c * g2).sum()).backward()
+            return [t.grad.clone() for t in (gm, bt, om, ob)], calls
+        finally:
+            setattr(lib.get(), 'msmc_add_ln_param_multi', real)
+            norm.LN_PARAM_DEFER = keep
+
+    for passes in (1, 2):
+        want = reference(passes)
+        got, calls = product(passes, True)
+        assert calls == [2, 1] * passes, calls        # per pass: {first use of (gm, bt), (om, ob)} then the second use of (gm, bt)
+        for a, b in zip(got, want):
+            assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), (passes, float((a - b).abs().max()))
+        got0, calls0 = product(passes, False)
+        assert calls0 == []
+        for a, b in zip(got0, want):
+            assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
+
+
 def test_train_steps_match_reference_with_the_fused_fft_prologue():
     """the same reference fixture with MSMC_FFT_PROLOGUE on (FFT stacks called with lengths instead of positions)"""
     from msmctts_amd.networks.acoustic_models import transformer
