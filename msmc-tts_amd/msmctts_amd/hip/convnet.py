@@ -43,6 +43,7 @@ WGRAD_BATCH = int(os.environ.get('MSMC_WGRAD_BATCH', '8'))
 WGRAD_BATCH_GROUPS = os.environ.get('MSMC_WGRAD_BATCH_GROUPS', '1') == '1'    # grouped calls' members join the waiting list too
 # 1: a bank delivers its parameter gradients as soon as its last backward node has run (see ConvBank._open_nodes)
 EARLY_FINISH = os.environ.get('MSMC_EARLY_FINISH', '1') != '0'
+FINISH_SIDE = os.environ.get('MSMC_FINISH_SIDE', '1') != '0'     # ... and does so on a side stream (see ConvBank.node_closed)
 
 
 def fork_join(streams, thunks, inputs=(), main_thunk=None):
@@ -219,6 +220,7 @@ class ConvBank(object):
         self.deferred = K.DeferredReduce()     # partial-result arena + pending second stages of the running backward pass
         self._pending_w = {}            # stream -> (Stream, weight gradients waiting for company), see WGRAD_BATCH
         self._dw_stream = {}            # accumulator -> side stream of its last launch in the running pass (wgrad_side)
+        self._finish_stream = None      # side stream an early delivery of the running pass was issued on (node_closed)
 
     def queue_wgrad(self, item):
         """Backward nodes replay on the stream of their forward (fork_join branches): a waiting list per stream, flushed
@@ -442,12 +444,27 @@ class ConvBank(object):
             # (a bank whose backward nodes run on several streams finishes in the end-of-pass callback, on the caller's stream:
             # nothing orders the caller behind whichever branch happened to close last)
             if self._open_nodes == 0 and EARLY_FINISH and self._touched and not self.streams:
-                self._finish_backward(early=True)
+                # The bank's second stages and its weight-norm backward have no reader before the optimizer: on a GPU they
+                # leave on a side stream of the library's own (ordered behind everything the calling stream has issued), so
+                # that the backward chain of the networks upstream -- the frame decoder, quantiser and encoders behind the
+                # vocoder -- does not queue behind them; the end-of-pass callback joins that stream.
+                dev = self.w1.device
+                if FINISH_SIDE and dev.type == 'cuda' and STREAMS_ENABLED:
+                    fin = own_streams(dev, 1, 'finish')[0]
+                    fin.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(fin):
+                        self._finish_backward(early=True)
+                    self._finish_stream = fin
+                else:
+                    self._finish_backward(early=True)
 
     def _finish_backward(self, early=False):
         if not early:
             self._queued = False
             self._open_nodes = 0        # (whatever the count missed -- unused outputs -- ends with the pass)
+            if self._finish_stream is not None:       # the early delivery of this pass ran on a side stream: join it
+                torch.cuda.current_stream(self.w1.device).wait_stream(self._finish_stream)
+                self._finish_stream = None
         self.flush_wgrad()
         if self._side_used:             # weight-gradient branches join here, before their inputs are released
             cur = torch.cuda.current_stream(self.w1.device)
