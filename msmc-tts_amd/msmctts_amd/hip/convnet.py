@@ -393,6 +393,7 @@ class ConvBank(object):
             self._queued = False
             self._touched = set()
             del self._hold[:]
+            self._dw_stream.clear()
         versions = self._versions()
         if SKIP_CLEAN_PREPARE and not force and not self.dirty and versions == self._clean_versions:
             return
