@@ -1,7 +1,13 @@
 #!/usr/bin/env python
 """bench.py -- MSMC-VQ-GAN GAN-phase train step throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by ``torch.distributed.run`` (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) or directly -- with WORLD_SIZE unset, ``--gpus N`` starts its own N ranks through ``torch.distributed.run`` on
+127.0.0.1 (``self_spawn``), forwards their output and exit code, and kills the whole job after ``--job-timeout`` seconds.
+Every rank runs a watchdog (``--stall-timeout``): a step or collective that does not finish turns into exit code 5, not a hang.
+``--dry --backend gloo`` checks the launcher / process group / gradient reducer on CPU with a toy model (no GPU, not a benchmark).
 
 One "step" = one full ``VQGANTrainer.train_step`` in the GAN phase (autoencoder forward, mel/STFT
 loss, D step, G step, clipping, both optimizer steps, gradient all-reduces when N>1) on one
@@ -428,6 +434,144 @@ def vq_microbench(device, H, K, D=256, N=1 << 20, iters=20, shortlist=None):
     return out
 
 
+def self_spawn(argv, n, job_timeout):
+    """``python bench.py --gpus N`` with WORLD_SIZE unset: start the N ranks ourselves (reference launcher train_dist.py:14-36
+    starts one process per GPU the same way).  Returns the job's exit code; a job that outlives ``job_timeout`` seconds is
+    killed (its own process group) and reported as 124."""
+    import signal
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this driver (RCCL across processes)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, host_cores() // n)))
+    say('starting %d ranks: %s' % (n, ' '.join(cmd[1:])))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=job_timeout)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write('bench.py: the %d-rank job did not finish within %d s: killing it\n' % (n, job_timeout))
+        # exactly the processes we started: torch.distributed.run (a session of its own) and its descendants -- the ranks
+        # sit in sessions the elastic agent opened for them, so the process-group signal alone would leave them running
+        pids = [proc.pid]
+        try:
+            import psutil
+            pids += [c.pid for c in psutil.Process(proc.pid).children(recursive=True)]
+        except Exception:
+            pass
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        for pid in pids:
+            try:
+                os.kill(pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        proc.wait()
+        return 124
+
+
+class Watchdog(object):
+    """Turns a wedged step / collective into a non-zero exit: the main thread reports progress (``beat``), a daemon thread
+    ends the process with code 5 when nothing was reported for ``limit`` seconds (a collective stuck inside a replayed graph
+    cannot be recovered in-process; torch.distributed.run then stops the other ranks)."""
+
+    def __init__(self, limit, rank=0):
+        import threading
+        self.limit, self.rank, self.last, self.what = float(limit), rank, time.perf_counter(), 'start'
+        if self.limit > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def beat(self, what):
+        self.last, self.what = time.perf_counter(), what
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            idle = time.perf_counter() - self.last
+            if idle > self.limit:
+                sys.stderr.write('bench.py: rank %d made no progress for %.0f s (last: %s) -- giving up\n' % (self.rank, idle, self.what))
+                sys.stderr.flush()
+                os._exit(5)
+
+
+def dry_run(args, rank, world, wd):
+    """--dry: the launcher, the process group and the gradient reducer on a TOY model (two children of three linear layers, the
+    way the trainer steps them: D backward, exchange, G backward, exchange) -- runs on CPU over gloo.  Not a benchmark: the
+    line says so in ``data``; what it proves is that N ranks start, exchange gradients in buckets, stay bit-identical and
+    that rank 0 prints one line carrying the world size it saw."""
+    import torch.nn as nn
+    from msmctts_amd.distributed.distributed import apply_gradient_allreduce
+    torch.manual_seed(7)
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0'))) if args.backend == 'nccl' else torch.device('cpu')
+    mk = lambda: nn.Sequential(nn.Linear(64, 128), nn.Tanh(), nn.Linear(128, 128), nn.Tanh(), nn.Linear(128, 64))
+    model = nn.ModuleDict(dict(autoencoder=mk(), discriminator=mk())).to(dev)
+    if rank != 0:                                            # (start-up broadcast must repair this)
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    if world > 1:
+        apply_gradient_allreduce(model, bucket_bytes=32 * 1024)
+    reducer = getattr(model, 'grad_reducer', None)
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    gen = torch.Generator().manual_seed(100 + rank)
+
+    def step():
+        x = torch.randn(args.batch, 64, generator=gen).to(dev)
+        opt.zero_grad()
+        model['discriminator'](model['autoencoder'](x).detach()).pow(2).mean().backward()
+        if reducer is not None:
+            reducer.finish()
+        (model['discriminator'](model['autoencoder'](x)) - x).pow(2).mean().backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+    for i in range(args.warmup):
+        step()
+        wd.beat('dry warm-up %d' % i)
+    if rank == world - 1 and os.environ.get('MSMC_BENCH_TEST_STALL'):      # (tests: a rank that wedges must end the job, not hang it)
+        time.sleep(float(os.environ['MSMC_BENCH_TEST_STALL']))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step()
+        wd.beat('dry step %d' % i)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).double()
+    spread, per_rank = 0.0, [elapsed / args.steps * 1e3]
+    if world > 1:
+        lo, hi = flat.clone(), flat.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        spread = float((hi - lo).abs().max())
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank = [float(t) / args.steps * 1e3 for t in every]
+        elapsed = max(float(t) for t in every)
+    if rank != 0:
+        return 0
+    out = {'metric': 'dry run: toy-model steps/s (launcher + process group + gradient reducer check, NOT the benchmark)',
+           'value': args.steps * world / elapsed, 'unit': 'rank-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32', 'data': 'synthetic (toy model, dry run)', 'dry': True, 'backend': args.backend,
+           'world_size_seen': dist.get_world_size() if world > 1 else 1, 'per_rank_ms_per_step': per_rank,
+           'config': {'workload': 'dry run', 'gradient_exchange': 'bucketed from hooks' if world > 1 else None,
+                      'buckets': len(reducer.buckets) if reducer is not None else 0},
+           'ranks_identical': spread == 0.0, 'max_parameter_spread': spread}
+    print(json.dumps(out))
+    return 0 if spread == 0.0 else 6
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -458,10 +602,18 @@ def main():
                          'segments (no host launch cost: the eager step is paced by the host); eager: multi-stream eager '
                          'step with bucketed all-reduce overlapped with backward')
     ap.add_argument('--graph', action='store_true', help='same as --exec graph')
-    ap.add_argument('--exchange', default=os.environ.get('MSMC_GRAPH_EXCHANGE', 'serial'), choices=['serial', 'overlap'],
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend (gloo: --dry only)')
+    ap.add_argument('--dry', action='store_true',
+                    help='launcher / process-group / gradient-reducer check on a toy model (runs on CPU with --backend gloo); not a benchmark')
+    ap.add_argument('--job-timeout', type=int, default=int(os.environ.get('MSMC_BENCH_JOB_TIMEOUT', '1500')),
+                    help='self-spawned N > 1 job: seconds before the launcher kills it (exit 124)')
+    ap.add_argument('--stall-timeout', type=int, default=int(os.environ.get('MSMC_BENCH_STALL_TIMEOUT', '300')),
+                    help='seconds without progress before a rank gives up (exit 5); also the process-group timeout')
+    ap.add_argument('--exchange', default=os.environ.get('MSMC_GRAPH_EXCHANGE', 'serial'), choices=['serial', 'overlap', 'both'],
                     help='graph mode, N > 1: serial = one flat all-reduce per child between the replayed segments (default); '
                          'overlap = bucketed all-reduces captured into the segments on the RCCL stream (DESIGN.md section 6: '
-                         'only ever run on one GPU)')
+                         'only ever run on one GPU); both = serial is the headline, the overlap mode is timed after it in the same '
+                         'run and reported under exchange_modes')
     ap.add_argument('--kernel-timing-steps', type=int, default=3, help='extra steps timed kernel by kernel (rank 0)')
     ap.add_argument('--kernels-out', default=os.path.join(ROOT, 'gpurun_out', 'bench_kernels.json'),
                     help='JSON side file for the per-kernel-symbol table (the printed line only names it)')
@@ -482,17 +634,43 @@ def main():
     args.batch = args.batch if args.batch is not None else preset['per_gpu_batch']
     args.in_dim = args.model_kw.get('in_dim', 80)
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # launched the way the one-GPU line is launched: start the ranks ourselves and hand their line / exit code on
+        sys.exit(self_spawn(sys.argv[1:], args.gpus, args.job_timeout))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     args.graph = args.graph or args.exec_mode in ('graph', 'auto')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (torch.distributed.run --nproc-per-node must match)' % (args.gpus, world))
+    wd = Watchdog(args.stall_timeout, rank)
+    if args.backend == 'gloo' and not args.dry:
+        raise SystemExit('bench.py: --backend gloo is for --dry (the product path has no CPU execution path)')
+    if args.dry and args.backend == 'gloo':
+        if world > 1:
+            import datetime
+            dist.init_process_group('gloo', init_method='env://', world_size=world, rank=rank,
+                                    timeout=datetime.timedelta(seconds=max(10, args.stall_timeout)))
+        rc = dry_run(args, rank, world, wd)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(rc)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
-        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank)
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+        import datetime
+        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank,
+                                timeout=datetime.timedelta(seconds=max(10, args.stall_timeout)))
+    if args.dry:
+        rc = dry_run(args, rank, world, wd)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(rc)
+    both_modes = args.exchange == 'both'
+    if both_modes:
+        args.exchange = 'serial'
 
     from msmctts_amd.hip import lib, vq as hipvq
     from msmctts_amd.synthetic import make_batch
@@ -615,25 +793,54 @@ def main():
     for i in range(args.warmup):
         step(i)
         torch.cuda.synchronize()
+        wd.beat('warm-up step %d' % i)
         say('warm-up step %d done' % i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # per-step durations from events recorded on the step's stream between the steps (no host synchronisation inside the
-    # timed region: the headline stays the wall clock over all K steps; the events give the median SURVEY 8d asks for)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        log = step(args.warmup + i)
-        marks[i + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    def timed_steps(first):
+        '''exactly K steps between barrier + synchronize on both sides; per-step durations from events recorded on the step's
+        stream between the steps (no host synchronisation inside the timed region: the headline stays the wall clock over all
+        K steps; the events give the median SURVEY 8d asks for)'''
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(args.steps):
+            log_ = step(first + i)
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        wd.beat('timed steps')
+        return dt, sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)), log_
+
+    def over_ranks(dt):
+        '''(max over ranks, per-rank ms/step)'''
+        if world == 1:
+            return dt, [dt / args.steps * 1e3]
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        return max(float(t) for t in every), [float(t) / args.steps * 1e3 for t in every]
+
+    elapsed, per_step, log = timed_steps(args.warmup)
+    exchange_modes = None
+    if both_modes and world > 1 and args.graph:
+        # the same K steps with the bucketed all-reduces captured INTO the segments (DESIGN.md section 6), after a fresh capture
+        e_serial, ranks_serial = over_ranks(elapsed)
+        trainer._graphs, trainer.graph_exchange = None, 'overlap'
+        for i in range(max(2, args.warmup)):
+            step(i)
+            torch.cuda.synchronize()
+            wd.beat('overlap warm-up step %d' % i)
+        e_over, _, _ = timed_steps(args.warmup)
+        e_over, ranks_over = over_ranks(e_over)
+        exchange_modes = {'serial': dict(ms_per_step=e_serial / args.steps * 1e3, per_rank_ms_per_step=ranks_serial),
+                          'overlap': dict(ms_per_step=e_over / args.steps * 1e3, per_rank_ms_per_step=ranks_over)}
+        trainer._graphs, trainer.graph_exchange = None, 'serial'
     ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     # second pass over the same steps with HIP events around every hand-written launch (the events cost a
     # few percent of host time, so the headline value above is taken without them)
@@ -657,6 +864,7 @@ def main():
         torch.cuda.synchronize()
         ms_instr = (time.perf_counter() - t1) / args.kernel_timing_steps * 1e3
         timer.stop()
+        wd.beat('instrumented steps')
         if args.calls_out:
             with open(args.calls_out, 'w') as f:
                 json.dump(timer.by_call(args.kernel_timing_steps), f, indent=0)
@@ -676,6 +884,7 @@ def main():
         torch.cuda.synchronize()
         warm_ms = (time.perf_counter() - t1) / args.warmup_phase_steps * 1e3
         trainer.warmup_steps = keep
+        wd.beat('warm-up phase steps')
     # the same step in fp32 end to end (the configuration the parity tests prove): eager, after two untimed steps
     fp32_ms = fp32_err = None
     if rank == 0 and world == 1 and args.fp32_steps > 0 and args.dtype != 'fp32':
@@ -696,17 +905,17 @@ def main():
             say('fp32 eager steps failed: ' + fp32_err)
         finally:
             trainer.use_graphs, trainer.amp_dtype = keep
+        wd.beat('fp32 steps')
     if world > 1:
         dist.barrier()
+    elapsed, per_rank_ms = over_ranks(elapsed)
     if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
         fr = torch.tensor([float(sum(lengths_host))], device=device, dtype=torch.float64)
         dist.all_reduce(fr)
         frames_per_step = float(fr.item())
     else:
         frames_per_step = float(sum(lengths_host))
+    wd.beat('reductions over ranks')
     ms_per_step = elapsed / args.steps * 1e3
     value = frames_per_step / (elapsed / args.steps)
     say('timed %d steps: %.2f ms/step' % (args.steps, ms_per_step))
@@ -767,7 +976,9 @@ def main():
                         % nst)
     out = {
         'metric': 'mel-frames/sec MSMC-VQ-GAN train step (GAN phase)', 'value': value, 'unit': 'mel-frames/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'n_gpus': world, 'world_size_seen': dist.get_world_size() if world > 1 else 1, 'backend': 'nccl (RCCL)' if world > 1 else None,
+        'per_rank_ms_per_step': per_rank_ms, 'exchange_modes': exchange_modes,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'ms_per_step_median': ms_median, 'ms_per_step_min': per_step[0], 'ms_per_step_max': per_step[-1],
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': '%s: %d-stage %d-head x %d-codeword VQ + HifiGAN + MPD/MRD, GAN phase'
@@ -805,6 +1016,8 @@ def main():
                                 vq_microbench(device, args.heads, args.codewords, shortlist=False),
                                 vq_microbench(device, 4, 64, shortlist=False)]
         say('vq microbench done')
+        wd.beat('vq microbench')
+        wd.limit = max(wd.limit, 900.0)        # (the oracle's CPU steps below run without reporting)
     if world == 1 and args.cpu_steps > 0:
         cores = host_cores()
         r = random.Random(99)

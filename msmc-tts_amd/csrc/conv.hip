@@ -822,6 +822,7 @@ static int cv_geometry(const msmc_conv_desc* d, CvGeom* G, int elt_bytes, int XS
 #include "gather4.inc"
 #include "gemm1.inc"
 #include "gather5.inc"
+#include "gather7.inc"
 #include "gather6.inc"
 #include "resunit.inc"
 
@@ -1333,6 +1334,10 @@ extern "C" int msmc_conv_gather(const msmc_conv_desc* d, msmc_stream stream) {
         const int rc = cv5_launch(d, stream);
         return rc < 0 ? rc : rc == 1 ? 0 : MSMC_E_SHAPE;
     }
+    if (cv7_is_variant(d->variant)) {           // seventh generation (bf16, eight waves of 64 x 64, two workgroups per CU): E_SHAPE outside its scope
+        const int rc = cv7_launch(d, stream);
+        return rc < 0 ? rc : rc == 1 ? 0 : MSMC_E_SHAPE;
+    }
     if (cv6_is_variant(d->variant)) {           // thin-channel kernel (bf16, Cin 8 / 16 / 32, fragments straight from global memory)
         const int rc = cv6_launch(d, stream);
         return rc < 0 ? rc : rc == 1 ? 0 : MSMC_E_SHAPE;
@@ -1798,6 +1803,12 @@ static int cv_group_launch(const msmc_conv_desc* descs, int n, msmc_stream strea
         const int rc = cv5_group_launch(descs, n, stream, done5);
         if (rc) return rc;
         for (int i = 0; i < n; ++i) done4[i] = done4[i] || done5[i];
+    }
+    {
+        bool done7[MSMC_GROUP_LIMIT];                           // seventh-generation members: one grid per configuration
+        const int rc = cv7_group_launch(descs, n, stream, done7);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) done4[i] = done4[i] || done7[i];
     }
     {
         bool done6[MSMC_GROUP_LIMIT];                           // thin-channel members (variant 50): one grid per channel count

@@ -68,6 +68,7 @@ class _Bucket(object):
         self.params = params
         self.ready = []
         self.pending = set(id(p) for p in params)
+        self.streams = []            # streams the bucket's gradients became ready on (see GradReducer._on_grad)
 
 
 class GradReducer(object):
@@ -113,16 +114,30 @@ class GradReducer(object):
         if id(p) in b.pending:
             b.pending.discard(id(p))
             b.ready.append(p)
+            # A gradient is ready ON THE STREAM ITS HOOK FIRES ON, not on whichever stream later completes the bucket: a
+            # convolution bank delivers its gradients from a side stream of its own (hip/convnet.py ConvBank.node_closed,
+            # FINISH_SIDE) while the parameters of stock modules in the same bucket become ready on the calling stream --
+            # the stream that launches the bucket waits for every stream that contributed to it.
+            if p.grad.is_cuda:
+                st = torch.cuda.current_stream(p.grad.device)
+                if not any(st == u for u in b.streams):
+                    b.streams.append(st)
             if not b.pending:
                 self._launch(b)
 
     def _launch(self, b):
         ps = [p for p in b.params if any(p is r for r in b.ready)]   # fixed (registration) order on every rank
         if ps:
+            if b.streams:
+                cur = torch.cuda.current_stream(ps[0].grad.device)
+                for st in b.streams:
+                    if st != cur:
+                        cur.wait_stream(st)
             flat = torch.cat([p.grad.reshape(-1) for p in ps]).to(self.exchange_dtype)
             work = dist.all_reduce(flat, group=self.group, async_op=True)
             self._inflight.append((work, flat, ps))
         b.ready = []
+        b.streams = []
         b.pending = set(id(p) for p in b.params)
 
     def allreduce_child(self, child, grads=None):
@@ -145,6 +160,7 @@ class GradReducer(object):
         torch._foreach_div_(grads, float(self.world))           # (in the gradients' own fp32, whatever the wire format)
         for b in self.buckets:                      # drop hook state recorded while capturing
             b.ready = []
+            b.streams = []
             b.pending = set(id(q) for q in b.params)
         self._inflight = []
 

@@ -186,6 +186,16 @@ def params_updated(owner, params):
             bank.dirty = True
 
 
+def graphs_replayed():
+    """a captured optimizer segment was replayed: the parameters moved, and so did the weight images of the banks the graphs
+    refresh -- but neither the ``dirty`` flags nor torch's version counters saw it (the update and the refresh are graph
+    nodes).  The graphs keep themselves consistent; an EAGER forward in the same process (validation, synthesis, the bench's
+    instrumented steps) must refresh before it computes: every built bank is marked for that."""
+    for bank in list(_BANKS):
+        if bank._sig is not None:
+            bank.eager_stale = True
+
+
 def refresh_stale_banks():
     """eager refresh of every bank whose parameters changed behind a captured step's back (checkpoint load between replays,
     the roll-back of the capture warm-up): the replayed graphs only refresh a bank where the capture saw it dirty"""
@@ -204,6 +214,7 @@ class ConvBank(object):
         # net for passes the count cannot see through: outputs nobody used, exceptions)
         self._open_nodes = 0
         self.dirty = True               # kernel-layout weights older than the parameters (see SKIP_CLEAN_PREPARE)
+        self.eager_stale = False        # ... as far as an EAGER pass can tell: graph replays moved the parameters (graphs_replayed)
         self._clean_versions = None
         self._owner_hits = {}
         self._ptrs = None
@@ -394,13 +405,18 @@ class ConvBank(object):
             self._touched = set()
             del self._hold[:]
             self._dw_stream.clear()
+            self._open_nodes, self._side_used, self._finish_stream = 0, [], None
         versions = self._versions()
-        if SKIP_CLEAN_PREPARE and not force and not self.dirty and versions == self._clean_versions:
+        capturing = self.w1.is_cuda and torch.cuda.is_current_stream_capturing()
+        stale = self.eager_stale and not capturing
+        if SKIP_CLEAN_PREPARE and not force and not self.dirty and not stale and versions == self._clean_versions:
             return
         lib.check(lib.get().msmc_wn_prepare_multi_tiled(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
                                                         self.total_tile_blocks, lib.stream(self.w1)),
                   'msmc_wn_prepare_multi_tiled')
         self.dirty, self._clean_versions = False, versions
+        if not capturing:
+            self.eager_stale = False
 
     # -- end-of-backward: kernel-layout dW -> parameter gradients --------------------------------------
     def _queue_finish(self):

@@ -343,6 +343,7 @@ class VQGANTrainer(BaseTrainer):
         if not g['overlap']:
             self._sync_grads_static('autoencoder', g)
         g['c'].replay()
+        hipconvnet.graphs_replayed()                 # (an eager pass after this must refresh its weight images)
         vec = g['loss_vec'].clone()                  # the graph's outputs are static buffers: hand out a snapshot
         return {'loss': {k: vec[i] for i, k in enumerate(g['loss_keys'])}}
 

@@ -8,6 +8,7 @@
 """
 import os
 import socket
+import subprocess
 import sys
 
 import pytest
@@ -263,3 +264,54 @@ def test_vqgan_trainer_sync_codebook_stats_keeps_codebooks_identical():
         assert torch.equal(s0[k], s1[k]), k
         n += k.endswith(('.embed', '.cluster_size', '.embed_avg'))
     assert n >= 6
+
+
+# ---- bench.py as the driver launches it: ``python bench.py --gpus N`` with WORLD_SIZE unset must start its own ranks ----
+def _bench(argv, env=None, timeout=300):
+    e = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + argv, env=e, timeout=timeout,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_bench_starts_its_own_ranks_and_prints_one_line(world):
+    """the launcher logic of ``bench.py --gpus N`` on CPU (``--dry --backend gloo``: toy model, the product's GradReducer):
+    N ranks come up through torch.distributed.run on 127.0.0.1, the start-up broadcast repairs a deliberately divergent
+    rank, the bucketed exchange keeps the ranks bit-identical, rank 0 prints ONE JSON line with n_gpus, the world size the
+    process group reported and a step time per rank; exit code 0"""
+    import json
+    r = _bench(['--gpus', str(world), '--dry', '--backend', 'gloo', '--steps', '4', '--warmup', '1'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == world and out['world_size_seen'] == world and out['backend'] == 'gloo'
+    assert len(out['per_rank_ms_per_step']) == world and all(t > 0 for t in out['per_rank_ms_per_step'])
+    assert out['ranks_identical'] and out['config']['gradient_exchange'] == 'bucketed from hooks' and out['config']['buckets'] >= 2
+    assert out['steps'] == 4 and out['dry'] is True
+
+
+def test_bench_turns_a_wedged_rank_into_a_nonzero_exit():
+    """a rank that stops making progress (here: the last rank sleeps before its timed steps, the others wait in the
+    barrier) ends the job with a non-zero exit code within the stall timeout -- no line, no hang"""
+    import time
+    t0 = time.time()
+    r = _bench(['--gpus', '2', '--dry', '--backend', 'gloo', '--steps', '2', '--warmup', '1', '--stall-timeout', '5'],
+               env={'MSMC_BENCH_TEST_STALL': '120'}, timeout=200)
+    assert r.returncode != 0
+    assert time.time() - t0 < 100
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert 'no progress' in r.stderr or 'imeout' in r.stderr, r.stderr[-1500:]
+
+
+def test_bench_launcher_kills_a_job_that_outlives_its_limit():
+    """the self-spawned job is killed (its own session) when it outlives --job-timeout: exit code 124"""
+    r = _bench(['--gpus', '2', '--dry', '--backend', 'gloo', '--steps', '2', '--warmup', '1', '--stall-timeout', '0',
+                '--job-timeout', '8'], env={'MSMC_BENCH_TEST_STALL': '120'}, timeout=200)
+    assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = _bench(['--gpus', '2', '--dry', '--backend', 'gloo'], env={'WORLD_SIZE': '1', 'RANK': '0'}, timeout=120)
+    assert r.returncode != 0 and 'WORLD_SIZE' in r.stderr

@@ -814,6 +814,86 @@ def test_gather_fifth_generation_variants(variant):
         conv._PLANS.clear()
 
 
+@pytest.mark.parametrize('variant', [56, 57, 58, 59, 60, 61, 62, 63])
+def test_gather_seventh_generation_variants(variant):
+    """variants 56..63 (gather7.inc: eight waves of 64 x 64 -- 2 x 2 accumulators per wave --, the k16-steps of a stage split
+    over 1 / 2 / 4 wave groups whose partial blocks meet in LDS by recursive halving, double-buffered super-stages of 1, 2 or
+    ntaps stages per barrier): every tile shape where it applies, forward and data gradient -- ragged pixel and channel tiles,
+    dilation, stride, reflection, 2-D taps, two taps, odd and even stage counts against the super-stage length, several
+    chunks with an input activation (in-place pass on the chunk whose tap 0 sits in the MIDDLE of a super-stage), more pixel
+    tiles than one XCD group -- every epilogue operand against the second generation, grouped calls equal to single launches,
+    1-tap layers refused"""
+    from msmctts_amd.hip import conv, lib
+    cases = [('g7 k3 64->128', 2, 64, 128, 1, 150, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
+             ('g7 k11 d5 128->136', 1, 128, 136, 1, 70, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
+             ('g7 k5x1 s3 64->256', 1, 64, 256, 40, 3, (5, 1), (3, 1), (1, 1), (2, 0), False, 0.2),
+             ('g7 3x3 reflect s2 64->72', 1, 64, 72, 13, 18, (3, 3), (2, 2), (1, 1), (1, 1), True, 1.0),
+             ('g7 k2 192->128', 1, 192, 128, 1, 45, (1, 2), (1, 1), (1, 1), (0, 1), False, 1.0),
+             ('g7 k3 many tiles 64->128', 1, 64, 128, 1, 1300, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
+             ('g7 ffn 256->512 relu', 2, 256, 512, 1, 100, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.0),
+             ('g7 k3 192->64 lrelu chunk starts mid super-stage', 1, 192, 64, 1, 90, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
+             ('g7 k5 128->128 lrelu', 2, 128, 128, 1, 75, (1, 5), (1, 1), (1, 2), (0, 4), False, 0.2),
+             ('g7 k7 d3 64->64 thin', 1, 64, 64, 1, 700, (1, 7), (1, 1), (1, 3), (0, 9), False, 0.1),
+             ('g7 k5x1 512->128 deep', 1, 512, 128, 30, 5, (5, 1), (1, 1), (1, 1), (2, 0), False, 0.2)]
+    real = conv._build_desc
+    state = {'variant': variant}
+
+    def forced(*a, **k):
+        d = real(*a, **k)
+        if d.dtype == 1:
+            d.variant = state['variant']
+        return d
+    conv._build_desc = forced
+    ran = 0
+    try:
+        for case in cases:
+            for part in ('fwd', 'dgrad'):
+                conv._PLANS.clear()
+                try:
+                    _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=(part,))
+                    assert b'conv_gather7_kernel' in lib.get().msmc_conv_last_kernel(), (case[0], part)
+                    ran += 1
+                except RuntimeError as e:             # MSMC_E_SHAPE: this configuration does not apply to the layer
+                    assert 'msmc_conv_gather' in str(e), e
+        assert ran >= 3, (variant, ran)
+        torch.manual_seed(0)
+        B, Ci, Co, Lx = 2, 128, 264, 150
+        geom = conv.Geometry(1, Lx, (1, 3), (1, 1), (1, 2), (0, 2), False)
+        x = torch.randn(B, 1, Lx, Ci).bfloat16()
+        w = (torch.randn(3, Co, Ci) / (3 * Ci) ** 0.5).bfloat16()
+        bias, res, res2 = torch.randn(Co), torch.randn(B, 1, Lx, Co).bfloat16(), torch.randn(B, 1, Lx, Co).bfloat16()
+        outs = []
+        for v in (variant, 2):
+            state['variant'] = v
+            conv._PLANS.clear()
+            fresh = conv.Geometry(1, Lx, (1, 3), (1, 1), (1, 2), (0, 2), False)         # (a geometry keeps its descriptors)
+            outs.append(conv.conv_forward(x, w, fresh, bias=bias, in_slope=0.1, res=res, res2=res2, out_div=3.0, out_slope=0.2))
+        assert b'conv_gather2' in lib.get().msmc_conv_last_kernel()
+        assert _convcases.rel(outs[0], outs[1]) < 1e-2
+        # grouped call: members of one configuration share a grid, results of single launches
+        state['variant'] = variant
+        geom3b = conv.Geometry(1, Lx, (1, 3), (1, 1), (1, 1), (0, 1), False)
+        items = [dict(x=x, w=w, geom=geom, bias=bias, res=res),
+                 dict(x=x, w=(torch.randn(3, Co, Ci) / (3 * Ci) ** 0.5).bfloat16(), geom=geom3b, bias=bias, in_slope=0.1),
+                 dict(x=x[:1], w=w, geom=geom, res=res[:1])]
+        conv._PLANS.clear()
+        singles = [conv.conv_forward(**it) for it in items]
+        n0 = lib.get().msmc_conv_launch_count()
+        grouped = conv.conv_forward_group(items)
+        assert lib.get().msmc_conv_launch_count() - n0 == 1
+        assert b'conv_gather7_group_kernel' in lib.get().msmc_conv_last_kernel()
+        for a, b in zip(grouped, singles):
+            assert torch.equal(a, b)
+        # outside the scope: a 1-tap layer -> MSMC_E_SHAPE surfaces as an error
+        conv._PLANS.clear()
+        with pytest.raises(RuntimeError, match='msmc_conv_gather'):
+            _convcases.check_conv_case(('g7 k1', 1, 64, 128, 1, 40, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+                                       torch.bfloat16, 2e-2, 'cpu', parts=('fwd',))
+    finally:
+        conv._build_desc = real
+        conv._PLANS.clear()
+
+
 @pytest.mark.parametrize('g1v', [34, 35])
 def test_gather_one_tap_gemm_variant_fp32(g1v):
     """variants 34 / 35 on fp32 operands (exact fp32 multiplies on v_mfma_f32_32x32x2_f32, fp32 output): the framed-DFT and

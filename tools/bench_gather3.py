@@ -107,14 +107,14 @@ for name, B, Cin, Cout, H, W, k, s_, dil, pad, reflect, slope in SHAPES:
         elif t3 < best[0]:
             best = (t3, v)
     if os.environ.get('ABLATE'):
-        v = int(os.environ['ABLATE'])
-        row = []
-        for abl in [int(a) for a in os.environ.get('ABLS', '0 1 2 4 8 9 6 7 15').split()]:
-            d3 = lib.ConvDesc.from_buffer_copy(desc)
-            d3.variant, d3.split_shift = v, abl
-            t3 = timed(d3, stream)
-            row.append('abl%-2d %s' % (abl, '%.1f' % t3 if t3 else '-'))
-        print('%-28s v%d: %s' % (name, v, '  '.join(row)), flush=True)
+        for v in [int(a) for a in os.environ['ABLATE'].split()]:
+            row = []
+            for abl in [int(a) for a in os.environ.get('ABLS', '0 1 2 4 8 9 6 7 15').split()]:
+                d3 = lib.ConvDesc.from_buffer_copy(desc)
+                d3.variant, d3.split_shift = v, abl
+                t3 = timed(d3, stream)
+                row.append('abl%-2d %s' % (abl, '%.1f' % t3 if t3 else '-'))
+            print('%-28s v%d: %s' % (name, v, '  '.join(row)), flush=True)
         continue
     print('%-28s %9.2f %7.1f | %s | best v%d %.1f us = %.1f TF/s (x%.2f)' % (name, gflop, t2, ' '.join(cells), best[1], best[0],
-                                                                           gflop / best[0] * 1e-3, t2 / best[0]), flush=True)
+                                                                           gflop / best[0] * 1e3, t2 / best[0]), flush=True)
