@@ -434,6 +434,294 @@ def vq_microbench(device, H, K, D=256, N=1 << 20, iters=20, shortlist=None):
     return out
 
 
+def make_timer():
+    """KernelTimer with a work model attached to every entry point of the library a train step goes through (algorithmic
+    flops / bytes per call from the call's own arguments); ``register_banks()`` must run once the model's banks exist"""
+    from msmctts_amd.hip import lib, vq as hipvq
+    timer = KernelTimer()
+    from msmctts_amd.hip import conv as hipconv
+    def esz(t):
+        return t.element_size()
+
+    def vq_work(x, et, en):
+        n = x.numel() // x.shape[-1]
+        return 2.0 * n * x.shape[-1] * et.shape[1], n * vq_bytes_per_frame(x.shape[-1], et.shape[0])
+
+    timer.wrap(hipvq, 'vq_search', lambda: 'vq_search_reg_kernel', lambda x, et, en, shortlist=None: vq_work(x, et, en))
+
+    # algorithmic work of one call: flops = 2 * output points * Cout * Cin * taps; bytes = every operand once
+    def conv_work(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, **k):
+        pts = x.shape[0] * geom.Hout * geom.Wout
+        extra = sum(1 for t in (res, res2) if t is not None)
+        return (2.0 * pts * w.shape[1] * w.shape[2] * w.shape[0],
+                (x.numel() + pts * w.shape[1] * (1 + extra) + w.numel()) * esz(x))
+
+    def dgrad_work(g, wb, geom, mask_src=None, mask_slope=1.0, res=None, **k):
+        pts = g.shape[0] * geom.Hout * geom.Wout
+        Hx, Wx = geom.dgrad_plan()[:2]
+        nx = g.shape[0] * Hx * Wx * wb.shape[1]
+        return (2.0 * pts * wb.shape[1] * wb.shape[2] * wb.shape[0],
+                (g.numel() + nx * (2 if mask_src is not None else 1) + wb.numel()) * esz(g))
+
+    def wgrad_work(x, g, geom, n_slices, *a, **k):       # (also called with the keyword items of conv_wgrad_group)
+        pts = x.shape[0] * geom.Hout * geom.Wout
+        return (2.0 * pts * g.shape[3] * x.shape[3] * n_slices,
+                (x.numel() + g.numel()) * esz(x) + 8.0 * n_slices * g.shape[3] * x.shape[3])
+
+    def convt_work(x, w, kk, stride, padding, *a, **k):   # every input pixel meets every tap once
+        Lout = (x.shape[2] - 1) * stride - 2 * padding + kk
+        return (2.0 * x.shape[0] * x.shape[2] * w.shape[1] * w.shape[2] * kk,
+                (x.numel() + x.shape[0] * Lout * w.shape[1] + w.numel()) * esz(x))
+
+    def convt_dgrad_work(g, wb, kk, stride, padding, Lin, mask_src=None, **k):
+        nx = g.shape[0] * Lin * wb.shape[1]
+        return (2.0 * g.shape[0] * Lin * wb.shape[1] * wb.shape[2] * kk,
+                (g.numel() + nx * (2 if mask_src is not None else 1) + wb.numel()) * esz(g))
+
+    def convt_wgrad_work(x, g, kk, stride, padding, *a, **k):
+        return (2.0 * x.shape[0] * x.shape[2] * x.shape[3] * g.shape[3] * kk,
+                (x.numel() + g.numel()) * esz(x) + 8.0 * kk * x.shape[3] * g.shape[3])
+
+    def last_kernel():
+        return lib.get().msmc_conv_last_kernel().decode()
+
+    def group_work(one):
+        def work(items):
+            f = b = 0.0
+            for it in items:
+                df, db_ = one(**it)
+                f, b = f + df, b + db_
+            return f, b
+        return work
+
+    def split_gemm_work(x, wimg, cout):                   # the THREE bf16 products it executes (priced against the bf16 peak);
+        m = x.numel() // x.shape[-1]                      # x, out and the matrix image once
+        return 6.0 * m * x.shape[-1] * cout, 4.0 * (x.numel() + m * cout) + 2.0 * wimg.numel()
+
+    timer.wrap(hipconv, 'const_gemm_split', last_kernel, split_gemm_work)
+    for fn, work in (('conv_forward', conv_work), ('conv_dgrad', dgrad_work), ('conv_wgrad', wgrad_work),
+                     ('conv_transpose1d_forward', convt_work), ('conv_transpose1d_dgrad', convt_dgrad_work),
+                     ('conv_transpose1d_wgrad', convt_wgrad_work)):
+        timer.wrap(hipconv, fn, last_kernel, work)
+    # grouped calls (several members per launch) are attributed to the symbol of their last launch
+    for fn, one in (('conv_forward_group', conv_work), ('conv_dgrad_group', dgrad_work), ('conv_wgrad_group', wgrad_work)):
+        timer.wrap(hipconv, fn, last_kernel, group_work(one))
+
+    # every other hand-written kernel: C-ABI level (sizes are the call's own arguments)
+    L0 = lib.get()
+    for name, work in abi_work_models().items():
+        timer.wrap_abi(L0, name, work)
+    # weight-norm passes and the fused optimizer take device tables: their sizes come from the objects that own the tables
+    wn_elems, chunk = {}, L0.msmc_opt_chunk()
+
+    def wn_bytes(per_elem_of):
+        def work(items, nitems, *rest):
+            n, e = wn_elems.get(_val(items), (0, 2))
+            return 0.0, float(n * per_elem_of(e))
+        return work
+    # prepare: v read once, both kernel layouts written (+ the transposing pass's second read); backward: dW read and
+    # re-zeroed, v read, gradient written
+    timer.wrap_abi(L0, 'msmc_wn_prepare_multi_tiled', wn_bytes(lambda e: 8 + 2 * e))
+    timer.wrap_abi(L0, 'msmc_wn_backward_multi_rows', wn_bytes(lambda e: 16))
+    timer.wrap_abi(L0, 'msmc_opt_clip_adamw', lambda table, nt, nblocks, max_norm, *rest:
+                   (0.0, float(nblocks) * chunk * (28 + (4 if max_norm > 0 else 0))))
+
+    def register_banks():
+        import gc
+        from msmctts_amd.hip.convnet import ConvBank
+        for o in gc.get_objects():
+            if isinstance(o, ConvBank) and getattr(o, 'items_dev', None) is not None:
+                wn_elems[o.items_dev.data_ptr()] = (o.w1.numel(), o.w1.element_size())
+
+    return timer, register_banks
+
+
+def summarize_kernels(timer, dtype, nsteps, ms_per_step):
+    """per-symbol table, the dominant kernel's roofline object and the step-level figure from the instrumented steps"""
+    ks = timer.summary()
+    roof, kernels = None, {}
+    mfma_peak = MFMA_PEAK_TFLOPS[dtype]
+    nst = max(1, nsteps)
+    for label, rec in ks.items():
+        # fp32 kernels (spectral DFT projections, VQ search) are priced against the fp32 MFMA peak
+        peak = MFMA_PEAK_TFLOPS['fp32'] if ('float' in label or label.startswith('vq_')) else mfma_peak
+        t_mfma, t_hbm = rec['flops'] / (peak * 1e12), rec['bytes'] / (HBM_PEAK_GBS * 1e9)
+        sec = max(rec['total_ms'] * 1e-3, 1e-12)
+        kernels[label] = dict(launches=rec['launches'], avg_us=rec['total_ms'] * 1e3 / rec['launches'],
+                              ms_per_step=rec['total_ms'] / nst, tflops=rec['flops'] / sec / 1e12,
+                              gbps=rec['bytes'] / sec / 1e9, bound='mfma' if t_mfma >= t_hbm else 'hbm',
+                              mfma_peak_tflops=peak, frac_mfma=t_mfma / sec, frac_hbm=t_hbm / sec,
+                              bytes_per_launch=rec['bytes'] / rec['launches'],
+                              flops_per_launch=rec['flops'] / rec['launches'])
+    step_roof = None
+    if kernels:
+        # step-level figure: the time the step's launches would take at their rooflines / the time they took
+        t_roof = sum(max(rec['flops'] / ((MFMA_PEAK_TFLOPS['fp32'] if ('float' in label or label.startswith('vq_')) else mfma_peak) * 1e12),
+                         rec['bytes'] / (HBM_PEAK_GBS * 1e9)) for label, rec in ks.items()) / nst * 1e3
+        t_all = sum(rec['total_ms'] for rec in ks.values()) / nst
+        t_attr = sum(rec['total_ms'] for rec in ks.values() if rec['flops'] > 0 or rec['bytes'] > 0) / nst
+        step_roof = dict(roofline_ms_per_step=t_roof, kernel_ms_per_step=t_all, frac=t_roof / max(t_all, 1e-9),
+                         attributed_time_frac=t_attr / max(t_all, 1e-9),
+                         launches_per_step=sum(rec['launches'] for rec in ks.values()) / float(nst),
+                         frac_of_step_time=t_roof / max(ms_per_step, 1e-9),
+                         note='sum over every hand-written launch of max(flops / dense MFMA peak of its dtype, bytes / 8 TB/s) '
+                              'divided by the summed launch durations (HIP events, instrumented single-stream steps); '
+                              'frac_of_step_time divides by the timed step instead (shorter than the sum: the step runs parallel branches)')
+        label = max((k for k in kernels if kernels[k]['flops_per_launch'] > 0), key=lambda k: kernels[k]['ms_per_step'])
+        k = kernels[label]
+        traffic = mfma_util = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            traffic = pmc['kernels'][label]['hbm_bytes_per_launch']
+            mfma_util = pmc['kernels'][label].get('mfma_util_percent')
+        except Exception:
+            pass
+        if k['bound'] == 'mfma':
+            roof = dict(bound='mfma', achieved=k['tflops'], peak=k['mfma_peak_tflops'], unit='TFLOP/s',
+                        frac=k['frac_mfma'], traffic=traffic)
+        else:
+            roof = dict(bound='hbm', achieved=k['gbps'], peak=HBM_PEAK_GBS, unit='GB/s', frac=k['frac_hbm'],
+                        traffic=traffic)
+        roof.update(mfma_util_percent_pmc=mfma_util, kernel=label, launches=k['launches'], avg_us=k['avg_us'], ms_per_step=k['ms_per_step'],
+                    bytes_per_launch=k['bytes_per_launch'], flops_per_launch=k['flops_per_launch'])
+        roof['note'] = ('dominant hand-written kernel by summed HIP-event time (one event pair per launch, recorded on the '
+                        'launch stream by the library: msmc_prof_*) over %d instrumented single-stream steps; achieved = '
+                        'algorithmic flops (or bytes) of its launches / their summed durations; bound = the roofline '
+                        'that prices those launches higher; traffic = PMC HBM bytes per launch from '
+                        'profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command), null if not collected'
+                        % nst)
+    return kernels, roof, step_roof
+
+
+def bench_predictor(args, device, wd):
+    """--config 4 (BASELINE.json: CSMSC msmc_vq_gan_am.yaml, predictor training, one GPU): one step = one
+    ``PredictorTrainer.train_step`` (reference msmctts_trainer.py:222-286) -- analysis of the mel batch by the frozen autoencoder
+    (configuration #2's architecture, random weights, eval mode), text -> per-stage predictions through the 600-wide FFT stacks,
+    'mse' + 'triple_sum' embedding losses and the duration loss, backward, clipping, Adam.  Same line layout as the headline:
+    value = mel frames of the batch per second, roofline of the dominant hand-written kernel from the instrumented steps,
+    cpu_baseline = oracle/predictor.py (plain PyTorch fp32) on the first utterances of the same batch."""
+    import random
+    from msmctts_amd.configs import BASELINE_CONFIGS, am_config, csmsc_config
+    from msmctts_amd.hip import convnet, lib
+    from msmctts_amd.synthetic import make_batch, make_text_batch
+    from msmctts_amd.tasks import build_task
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    from msmctts_amd.utils.config import Config
+    preset = BASELINE_CONFIGS[4]
+    acfg = Config(csmsc_config(batch_size=args.batch, warmup_steps=0, **args.model_kw))
+    torch.manual_seed(acfg.seed)
+    atask = build_task(acfg, mode='train').to(device).eval()
+    cfg = Config(am_config(batch_size=args.batch))
+    torch.manual_seed(cfg.seed + 1)
+    task = build_task(cfg, mode='train').to(device).train()
+    tr = build_trainer(cfg, task, num_gpus=0, rank=0)
+    tr.autoencoder = atask.autoencoder
+    tr.optimizer = build_optimizer(task, cfg.optimizer)
+    tr.amp_dtype = torch.bfloat16 if args.dtype == 'bf16' else None
+    for m in atask.modules():                       # (the frozen analysis pass computes in the same type)
+        if hasattr(m, 'hip_dtype'):
+            m.hip_dtype = tr.amp_dtype or torch.float32
+    cpu_batch = make_batch(args.batch, args.frames, 80, 300, seed=1234, rank=0, device='cpu')
+    cpu_batch.pop('wav'); cpu_batch.pop('wav_length')
+    cpu_batch.update(make_text_batch(cpu_batch['mel_length'].tolist()))
+    batch = {k: v.to(device) for k, v in cpu_batch.items()}
+    frames_per_step = float(cpu_batch['mel_length'].sum())
+    timer, register_banks = make_timer()
+
+    def step(i):
+        task.zero_grad()
+        return tr.train_step(batch, i)
+    say('built predictor + frozen autoencoder; starting warm-up')
+    for i in range(args.warmup):
+        step(i)
+        torch.cuda.synchronize()
+        wd.beat('predictor warm-up %d' % i)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(args.steps):
+        log = step(args.warmup + i)
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    wd.beat('predictor timed steps')
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ms_per_step = elapsed / args.steps * 1e3
+    ms_instr = None
+    if args.kernel_timing_steps > 0:
+        convnet.STREAMS_ENABLED = False             # one stream: an event pair brackets exactly one kernel
+        step(0)
+        register_banks()
+        timer.start(lib.get())
+        t1 = time.perf_counter()
+        for i in range(args.kernel_timing_steps):
+            torch.cuda._sleep(int(2.0e8))
+            step(1 + i)
+        torch.cuda.synchronize()
+        ms_instr = (time.perf_counter() - t1) / args.kernel_timing_steps * 1e3
+        timer.stop()
+        convnet.STREAMS_ENABLED = True
+        wd.beat('predictor instrumented steps')
+    kernels, roof, step_roof = summarize_kernels(timer, args.dtype, args.kernel_timing_steps, ms_per_step)
+    out = {
+        'metric': 'mel-frames/sec multi-stage predictor train step (BASELINE config #4)', 'value': frames_per_step / (elapsed / args.steps),
+        'unit': 'mel-frames/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'ms_per_step_median': per_step[len(per_step) // 2], 'ms_per_step_min': per_step[0], 'ms_per_step_max': per_step[-1],
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': '%s: text -> 2-stage predictions, mse + triple_sum + duration losses; frozen autoencoder %d heads x %d codewords'
+                               % (preset['name'], args.heads, args.codewords),
+                   'baseline_config': 4, 'per_gpu_batch': args.batch, 'global_batch': args.batch, 'frames': args.frames,
+                   'mel_frames_per_step': frames_per_step, 'phonemes_per_step': int(cpu_batch['text_length'].sum()),
+                   'parallelism': 'dp1', 'execution': 'eager (the length regulator sizes its output on the host)'},
+        'roofline': roof, 'roofline_step': step_roof, 'kernels': kernels, 'ms_per_step_instrumented': ms_instr,
+        'losses': {k: float(v) for k, v in log['loss'].items()} if isinstance(log, dict) and 'loss' in log else None,
+    }
+    if out['losses'] and any(v != v or v in (float('inf'), float('-inf')) for v in out['losses'].values()):
+        sys.stderr.write('bench.py: non-finite losses after the timed steps: %s\n' % out['losses'])
+        sys.exit(3)
+    if args.cpu_steps > 0:
+        from oracle import predictor as op
+        from oracle.step import prepare_params
+        cores = host_cores()
+        threads = args.cpu_threads or min(cores, 32)
+        torch.set_num_threads(threads)
+        nsample = args.cpu_batch or min(args.batch, 8)
+        sub = {k: v[:nsample].clone() for k, v in cpu_batch.items()}
+        tl = int(sub['text_length'].max())
+        sub['text'], sub['dur'] = sub['text'][:, :tl], sub['dur'][:, :tl]
+        fr = int(sub['mel_length'].max())
+        sub['mel'] = sub['mel'][:, :fr]
+        P = {k: v.detach().float().cpu().clone() for k, v in task.state_dict().items()}
+        for k, v in P.items():
+            if not k.endswith('position.weight'):
+                v.requires_grad_(True)
+        P_ae = prepare_params({k: v.detach().float().cpu() for k, v in atask.state_dict().items()})
+        am = cfg.to_dict() if hasattr(cfg, 'to_dict') else am_config(args.batch)
+        times = []
+        for i in range(args.cpu_warmup + args.cpu_steps):
+            for v in P.values():
+                v.grad = None
+            t1 = time.perf_counter()
+            op.predictor_step(P, am['task']['predictor'], P_ae, acfg.task.to_dict()['autoencoder'], sub,
+                              am['trainer']['training_methods'], am['trainer']['loss_weights'], am['trainer']['lambda_dur'],
+                              am['trainer']['grad_clip_thresh'])
+            times.append(time.perf_counter() - t1)
+            wd.beat('oracle predictor step %d' % i)
+        times = sorted(times[args.cpu_warmup:])
+        sec = times[len(times) // 2]
+        sample_frames = float(sub['mel_length'].sum())
+        out['cpu_baseline'] = dict(value=sample_frames / sec, unit='mel-frames/s', cores=threads, kind='port',
+                                   sample='oracle/predictor.py (plain PyTorch fp32, dropout as configured) predictor train step on the first %d '
+                                          'utterances (%d mel frames) of the same batch with the same weights; median of %d timed steps after '
+                                          '%d warm-ups; %d of %d visible cores; %s; torch %s'
+                                          % (nsample, sample_frames, args.cpu_steps, args.cpu_warmup, threads, cores, cpu_model(), torch.__version__),
+                                   s_per_step=sec, cpu_model=cpu_model())
+        out['speedup_vs_cpu'] = out['value'] / out['cpu_baseline']['value']
+    print(emit_line(out, args.kernels_out))
+
+
 def self_spawn(argv, n, job_timeout):
     """``python bench.py --gpus N`` with WORLD_SIZE unset: start the N ranks ourselves (reference launcher train_dist.py:14-36
     starts one process per GPU the same way).  Returns the job's exit code; a job that outlives ``job_timeout`` seconds is
@@ -577,10 +865,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--config', type=int, default=2, choices=[1, 2, 3, 5],
+    ap.add_argument('--config', type=int, default=2, choices=[1, 2, 3, 4, 5],
                     help='BASELINE.json configuration (msmctts_amd/configs.py BASELINE_CONFIGS): 2 = the headline (CSMSC, 2 stages, '
                          '4 heads x 256, B=16, one GPU); 1 = 1 stage, 1 head x 64, B=4; 3 = the LJSpeech-named copy of #2 meant for '
-                         '--gpus 8; 5 = 1024-wide input, 8 heads x 512, meant for --gpus 8.  --batch/--heads/--codewords override.')
+                         '--gpus 8; 4 = predictor training (msmc_vq_gan_am.yaml, B=64) against a frozen autoencoder of #2; 5 = 1024-wide '
+                         'input, 8 heads x 512, meant for --gpus 8.  --batch/--heads/--codewords override.')
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--frames', type=int, default=400)
     ap.add_argument('--heads', type=int, default=None)
@@ -675,6 +964,11 @@ def main():
     from msmctts_amd.hip import lib, vq as hipvq
     from msmctts_amd.synthetic import make_batch
     assert lib.backend() == 'gfx950'
+    if args.config == 4:
+        if world != 1:
+            raise SystemExit('bench.py --config 4 is a one-GPU line')
+        bench_predictor(args, device, wd)
+        return
     if args.microbench_only:
         print(json.dumps({'vq_microbench': [vq_microbench(device, args.heads, args.codewords, iters=5),
                                             vq_microbench(device, 4, 64, iters=5), vq_microbench(device, 8, 512, iters=5)]}))
@@ -688,100 +982,7 @@ def main():
     import random
     trainer.rng = random.Random(1234 + rank)
 
-    timer = KernelTimer()
-    from msmctts_amd.hip import conv as hipconv
-    def esz(t):
-        return t.element_size()
-
-    def vq_work(x, et, en):
-        n = x.numel() // x.shape[-1]
-        return 2.0 * n * x.shape[-1] * et.shape[1], n * vq_bytes_per_frame(x.shape[-1], et.shape[0])
-
-    timer.wrap(hipvq, 'vq_search', lambda: 'vq_search_reg_kernel', lambda x, et, en, shortlist=None: vq_work(x, et, en))
-
-    # algorithmic work of one call: flops = 2 * output points * Cout * Cin * taps; bytes = every operand once
-    def conv_work(x, w, geom, bias=None, in_slope=1.0, res=None, res2=None, **k):
-        pts = x.shape[0] * geom.Hout * geom.Wout
-        extra = sum(1 for t in (res, res2) if t is not None)
-        return (2.0 * pts * w.shape[1] * w.shape[2] * w.shape[0],
-                (x.numel() + pts * w.shape[1] * (1 + extra) + w.numel()) * esz(x))
-
-    def dgrad_work(g, wb, geom, mask_src=None, mask_slope=1.0, res=None, **k):
-        pts = g.shape[0] * geom.Hout * geom.Wout
-        Hx, Wx = geom.dgrad_plan()[:2]
-        nx = g.shape[0] * Hx * Wx * wb.shape[1]
-        return (2.0 * pts * wb.shape[1] * wb.shape[2] * wb.shape[0],
-                (g.numel() + nx * (2 if mask_src is not None else 1) + wb.numel()) * esz(g))
-
-    def wgrad_work(x, g, geom, n_slices, *a, **k):       # (also called with the keyword items of conv_wgrad_group)
-        pts = x.shape[0] * geom.Hout * geom.Wout
-        return (2.0 * pts * g.shape[3] * x.shape[3] * n_slices,
-                (x.numel() + g.numel()) * esz(x) + 8.0 * n_slices * g.shape[3] * x.shape[3])
-
-    def convt_work(x, w, kk, stride, padding, *a, **k):   # every input pixel meets every tap once
-        Lout = (x.shape[2] - 1) * stride - 2 * padding + kk
-        return (2.0 * x.shape[0] * x.shape[2] * w.shape[1] * w.shape[2] * kk,
-                (x.numel() + x.shape[0] * Lout * w.shape[1] + w.numel()) * esz(x))
-
-    def convt_dgrad_work(g, wb, kk, stride, padding, Lin, mask_src=None, **k):
-        nx = g.shape[0] * Lin * wb.shape[1]
-        return (2.0 * g.shape[0] * Lin * wb.shape[1] * wb.shape[2] * kk,
-                (g.numel() + nx * (2 if mask_src is not None else 1) + wb.numel()) * esz(g))
-
-    def convt_wgrad_work(x, g, kk, stride, padding, *a, **k):
-        return (2.0 * x.shape[0] * x.shape[2] * x.shape[3] * g.shape[3] * kk,
-                (x.numel() + g.numel()) * esz(x) + 8.0 * kk * x.shape[3] * g.shape[3])
-
-    def last_kernel():
-        return lib.get().msmc_conv_last_kernel().decode()
-
-    def group_work(one):
-        def work(items):
-            f = b = 0.0
-            for it in items:
-                df, db_ = one(**it)
-                f, b = f + df, b + db_
-            return f, b
-        return work
-
-    def split_gemm_work(x, wimg, cout):                   # the THREE bf16 products it executes (priced against the bf16 peak);
-        m = x.numel() // x.shape[-1]                      # x, out and the matrix image once
-        return 6.0 * m * x.shape[-1] * cout, 4.0 * (x.numel() + m * cout) + 2.0 * wimg.numel()
-
-    timer.wrap(hipconv, 'const_gemm_split', last_kernel, split_gemm_work)
-    for fn, work in (('conv_forward', conv_work), ('conv_dgrad', dgrad_work), ('conv_wgrad', wgrad_work),
-                     ('conv_transpose1d_forward', convt_work), ('conv_transpose1d_dgrad', convt_dgrad_work),
-                     ('conv_transpose1d_wgrad', convt_wgrad_work)):
-        timer.wrap(hipconv, fn, last_kernel, work)
-    # grouped calls (several members per launch) are attributed to the symbol of their last launch
-    for fn, one in (('conv_forward_group', conv_work), ('conv_dgrad_group', dgrad_work), ('conv_wgrad_group', wgrad_work)):
-        timer.wrap(hipconv, fn, last_kernel, group_work(one))
-
-    # every other hand-written kernel: C-ABI level (sizes are the call's own arguments)
-    L0 = lib.get()
-    for name, work in abi_work_models().items():
-        timer.wrap_abi(L0, name, work)
-    # weight-norm passes and the fused optimizer take device tables: their sizes come from the objects that own the tables
-    wn_elems, chunk = {}, L0.msmc_opt_chunk()
-
-    def wn_bytes(per_elem_of):
-        def work(items, nitems, *rest):
-            n, e = wn_elems.get(_val(items), (0, 2))
-            return 0.0, float(n * per_elem_of(e))
-        return work
-    # prepare: v read once, both kernel layouts written (+ the transposing pass's second read); backward: dW read and
-    # re-zeroed, v read, gradient written
-    timer.wrap_abi(L0, 'msmc_wn_prepare_multi_tiled', wn_bytes(lambda e: 8 + 2 * e))
-    timer.wrap_abi(L0, 'msmc_wn_backward_multi_rows', wn_bytes(lambda e: 16))
-    timer.wrap_abi(L0, 'msmc_opt_clip_adamw', lambda table, nt, nblocks, max_norm, *rest:
-                   (0.0, float(nblocks) * chunk * (28 + (4 if max_norm > 0 else 0))))
-
-    def register_banks():
-        import gc
-        from msmctts_amd.hip.convnet import ConvBank
-        for o in gc.get_objects():
-            if isinstance(o, ConvBank) and getattr(o, 'items_dev', None) is not None:
-                wn_elems[o.items_dev.data_ptr()] = (o.w1.numel(), o.w1.element_size())
+    timer, register_banks = make_timer()
 
     def step(i):
         if not trainer.use_graphs:
@@ -922,58 +1123,7 @@ def main():
 
     if rank != 0:
         return
-    ks = timer.summary()
-    roof, kernels = None, {}
-    mfma_peak = MFMA_PEAK_TFLOPS[args.dtype]
-    nst = max(1, args.kernel_timing_steps)
-    for label, rec in ks.items():
-        # fp32 kernels (spectral DFT projections, VQ search) are priced against the fp32 MFMA peak
-        peak = MFMA_PEAK_TFLOPS['fp32'] if ('float' in label or label.startswith('vq_')) else mfma_peak
-        t_mfma, t_hbm = rec['flops'] / (peak * 1e12), rec['bytes'] / (HBM_PEAK_GBS * 1e9)
-        sec = max(rec['total_ms'] * 1e-3, 1e-12)
-        kernels[label] = dict(launches=rec['launches'], avg_us=rec['total_ms'] * 1e3 / rec['launches'],
-                              ms_per_step=rec['total_ms'] / nst, tflops=rec['flops'] / sec / 1e12,
-                              gbps=rec['bytes'] / sec / 1e9, bound='mfma' if t_mfma >= t_hbm else 'hbm',
-                              mfma_peak_tflops=peak, frac_mfma=t_mfma / sec, frac_hbm=t_hbm / sec,
-                              bytes_per_launch=rec['bytes'] / rec['launches'],
-                              flops_per_launch=rec['flops'] / rec['launches'])
-    step_roof = None
-    if kernels:
-        # step-level figure: the time the step's launches would take at their rooflines / the time they took
-        t_roof = sum(max(rec['flops'] / ((MFMA_PEAK_TFLOPS['fp32'] if ('float' in label or label.startswith('vq_')) else mfma_peak) * 1e12),
-                         rec['bytes'] / (HBM_PEAK_GBS * 1e9)) for label, rec in ks.items()) / nst * 1e3
-        t_all = sum(rec['total_ms'] for rec in ks.values()) / nst
-        t_attr = sum(rec['total_ms'] for rec in ks.values() if rec['flops'] > 0 or rec['bytes'] > 0) / nst
-        step_roof = dict(roofline_ms_per_step=t_roof, kernel_ms_per_step=t_all, frac=t_roof / max(t_all, 1e-9),
-                         attributed_time_frac=t_attr / max(t_all, 1e-9),
-                         launches_per_step=sum(rec['launches'] for rec in ks.values()) / float(nst),
-                         frac_of_step_time=t_roof / max(ms_per_step, 1e-9),
-                         note='sum over every hand-written launch of max(flops / dense MFMA peak of its dtype, bytes / 8 TB/s) '
-                              'divided by the summed launch durations (HIP events, instrumented single-stream steps); '
-                              'frac_of_step_time divides by the timed step instead (shorter than the sum: the step runs parallel branches)')
-        label = max((k for k in kernels if kernels[k]['flops_per_launch'] > 0), key=lambda k: kernels[k]['ms_per_step'])
-        k = kernels[label]
-        traffic = mfma_util = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-            traffic = pmc['kernels'][label]['hbm_bytes_per_launch']
-            mfma_util = pmc['kernels'][label].get('mfma_util_percent')
-        except Exception:
-            pass
-        if k['bound'] == 'mfma':
-            roof = dict(bound='mfma', achieved=k['tflops'], peak=k['mfma_peak_tflops'], unit='TFLOP/s',
-                        frac=k['frac_mfma'], traffic=traffic)
-        else:
-            roof = dict(bound='hbm', achieved=k['gbps'], peak=HBM_PEAK_GBS, unit='GB/s', frac=k['frac_hbm'],
-                        traffic=traffic)
-        roof.update(mfma_util_percent_pmc=mfma_util, kernel=label, launches=k['launches'], avg_us=k['avg_us'], ms_per_step=k['ms_per_step'],
-                    bytes_per_launch=k['bytes_per_launch'], flops_per_launch=k['flops_per_launch'])
-        roof['note'] = ('dominant hand-written kernel by summed HIP-event time (one event pair per launch, recorded on the '
-                        'launch stream by the library: msmc_prof_*) over %d instrumented single-stream steps; achieved = '
-                        'algorithmic flops (or bytes) of its launches / their summed durations; bound = the roofline '
-                        'that prices those launches higher; traffic = PMC HBM bytes per launch from '
-                        'profiles/pmc_traffic.json (rocprofv3 --pmc passes of this command), null if not collected'
-                        % nst)
+    kernels, roof, step_roof = summarize_kernels(timer, args.dtype, args.kernel_timing_steps, ms_per_step)
     out = {
         'metric': 'mel-frames/sec MSMC-VQ-GAN train step (GAN phase)', 'value': value, 'unit': 'mel-frames/s',
         'n_gpus': world, 'world_size_seen': dist.get_world_size() if world > 1 else 1, 'backend': 'nccl (RCCL)' if world > 1 else None,
@@ -1000,7 +1150,8 @@ def main():
         'losses': {k: float(v) for k, v in log['loss'].items()},
         'warmup_phase': None if warm_ms is None else dict(
             ms_per_step=warm_ms, value=frames_per_step / (warm_ms * 1e-3), unit='mel-frames/s',
-            note='iteration < warmup_steps (no vocoder, no discriminator), eager, %d steps' % args.warmup_phase_steps),
+            note='iteration < warmup_steps (no vocoder, no discriminator), %s, %d steps'
+                 % ('hipGraph replay (forward | backward | update)' if (args.graph and trainer.graph_warmup) else 'eager', args.warmup_phase_steps)),
         'runtime': {'DEBUG_CLR_GRAPH_PACKET_CAPTURE': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'),
                     'note': 'hipGraph memset nodes are mis-ordered on the AQL packet-capture path of ROCm 7.2 '
                             '(tools/repro_graph_memset.py); the package disables that path before the first HIP call'},

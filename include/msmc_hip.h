@@ -4,11 +4,11 @@
  * (reference msmctts/networks/__init__.py:6-11).  This library sits *below* it:
  * every entry point takes plain device pointers, sizes and a HIP stream, allocates nothing (msmc_stream_create, which
  * makes a HIP stream, is the one exception), is stream-ordered and re-entrant per stream, and returns 0 (hipSuccess) or a
- * hipError_t / negative MSMC_E* code.  No entry point of this header changes process-global behaviour: kernel choices are per call
- * (msmc_conv_desc.variant / split_shift); what remains global is observational -- the per-thread msmc_conv_last_kernel /
- * msmc_conv_launch_count / msmc_vq_last_kernel tags, the opt-in msmc_prof_* launch log and the per-thread sink of
- * msmc_conv_wgrad_defer_begin / _end.  The A/B switches, ablation masks and the experimental fused ResBlock unit that the perf
- * tools and the tests use live in include/msmc_hip_debug.h, outside the product ABI.  The Python host side (msmc-tts_amd/msmctts_amd) binds these with
+ * hipError_t / negative MSMC_E* code.  No entry point of this header changes or observes process-global state: kernel choices are
+ * per call (msmc_conv_desc.variant / split_shift); the one piece of per-thread state is the sink of msmc_conv_wgrad_defer_begin
+ * / _end, armed around single calls.  The A/B switches, ablation masks, the profiling observers (last-kernel tags, launch
+ * counter, the msmc_prof_* launch log) that the perf tools, bench.py's kernel table and the tests use live in
+ * include/msmc_hip_debug.h, outside the product ABI.  The Python host side (msmc-tts_amd/msmctts_amd) binds these with
  * ctypes from modules that carry the reference's class names; INTEGRATION.md shows the stub a
  * reference maintainer would add.
  *
@@ -77,9 +77,6 @@ int msmc_vq_prepare_shortlist(const float* embed_t, const float* enorm, void* im
 int msmc_vq_search_shortlist(const float* x, const float* embed_t, const float* enorm, const void* image, float* quant,
                              float* diff, int64_t* ind, unsigned long long* slow_count, int N, int D, int H, int K,
                              msmc_stream stream);
-
-/* Symbol of the search kernel the calling thread's most recent msmc_vq_search launched (profiling aid). */
-const char* msmc_vq_last_kernel(void);
 
 /* Bytes of scratch msmc_vq_ema_update needs for these sizes. */
 size_t msmc_vq_ema_workspace(int N, int D, int H, int K);
@@ -207,20 +204,6 @@ int msmc_attn_fwd(const void* qkv, const float* bias, void* out, float* lse, int
 int msmc_attn_bwd(const void* qkv, const float* bias, const void* out, const float* lse, const void* dout, void* dqkv,
                   float* dsum, int B, int T, int H, int Tp, float scale, float p_drop, const long long* seed, long long salt,
                   msmc_stream stream);
-
-/* Per-launch profiling log (process-wide; bench.py's kernel table): while enabled, every kernel this library launches
- * -- from any thread: the backward pass runs on the autograd engine's -- is bracketed by a HIP event pair recorded on the launch's own stream and logged under the
- * symbol rocprofv3 prints for it (template arguments included where the launcher knows the instantiation, the template's
- * name otherwise).  msmc_prof_enable(1) clears the log and starts recording, (0) stops; msmc_prof_read synchronises
- * on the record's end event and returns its duration in milliseconds (0 on success).  At most 16384 records; off by
- * default (cost when off: one thread-local flag test per launch). */
-void msmc_prof_enable(int on);
-int msmc_prof_count(void);
-int msmc_prof_read(int i, char* name, int cap, float* ms);
-/* Symbol of the kernel the calling thread's most recent msmc_conv_gather / msmc_conv_wgrad launched (profiling aid). */
-const char* msmc_conv_last_kernel(void);
-/* Number of kernels the calling thread's msmc_conv_gather / msmc_conv_wgrad calls have launched so far. */
-long msmc_conv_launch_count(void);
 
 /* out[q] = epilogue( sum_t sum_ci w[tap_w[t]][co][ci] * act(x[in(q, t)][ci]) + bias[co] ). */
 int msmc_conv_gather(const msmc_conv_desc* desc, msmc_stream stream);

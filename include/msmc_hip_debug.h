@@ -1,7 +1,7 @@
 /* msmc_hip_debug.h -- NOT part of the product ABI (include/msmc_hip.h).
  *
- * Process-global A/B switches, ablation masks and one experimental entry point that libmsmc_hip.so also exports for the
- * perf tools (tools/), the CPU kernel-interpreter tests and the forced-variant GPU tests.  A production caller never
+ * Process-global A/B switches, ablation masks and the profiling observers that libmsmc_hip.so also exports for the perf
+ * tools (tools/), bench.py's per-kernel table, the CPU kernel-interpreter tests and the forced-variant GPU tests.  A production caller never
  * includes this header: every kernel choice that matters to a caller is per call (msmc_conv_desc.variant / split_shift),
  * and the product package (msmc-tts_amd/msmctts_amd) touches none of these except the two environment-driven sweeps read
  * once in hip/lib.py (MSMC_WGRAD_TPW, MSMC_GATHER4_GROUPING).  All switches are plain ints read at launch time.
@@ -47,14 +47,22 @@ void msmc_conv_set_grouping(int on);
  * weight gradient, 2 its LDS-DMA stream; results are then garbage. */
 void msmc_conv_set_wgrad4_ablate(int mask);
 
-/* EXPERIMENTAL (measured by tools/bench_resunit.py, not on the train step's path): one ResBlock1 unit (reference
- * msmctts/networks/hifigan/common.py:44-51, one (c1, c2) pair) as ONE launch, bf16, C = 32 / 64 channels, odd k <= 11:
- *   a = lrelu(conv1d(lrelu(x), w1, dilation dil1) + b1);  y = conv1d(a, w2, dilation 1) + b2 + x
- * x, a, y [B][L][C]; w1, w2 [k][C][C] in the forward layout (tap, output channel, input channel); b1, b2 fp32 [C];
- * nt = tiles of 32 rows per wave step (2 or 3; anything else: chosen from the LDS footprint). */
-int msmc_resunit_forward(const void* x, const void* w1, const float* b1, const void* w2, const float* b2, void* a, void* y,
-                         int B, int L, int C, int k, int dil1, float slope, int nt, msmc_stream stream);
-
+/* ---- observers (read-only: nothing here changes what a product call computes or launches) ---- */
+/* Symbol of the search kernel the calling thread's most recent msmc_vq_search launched (profiling aid). */
+const char* msmc_vq_last_kernel(void);
+/* Per-launch profiling log (process-wide; bench.py's kernel table): while enabled, every kernel this library launches
+ * -- from any thread: the backward pass runs on the autograd engine's -- is bracketed by a HIP event pair recorded on the launch's own stream and logged under the
+ * symbol rocprofv3 prints for it (template arguments included where the launcher knows the instantiation, the template's
+ * name otherwise).  msmc_prof_enable(1) clears the log and starts recording, (0) stops; msmc_prof_read synchronises
+ * on the record's end event and returns its duration in milliseconds (0 on success).  At most 16384 records; off by
+ * default (cost when off: one thread-local flag test per launch). */
+void msmc_prof_enable(int on);
+int msmc_prof_count(void);
+int msmc_prof_read(int i, char* name, int cap, float* ms);
+/* Symbol of the kernel the calling thread's most recent msmc_conv_gather / msmc_conv_wgrad launched (profiling aid). */
+const char* msmc_conv_last_kernel(void);
+/* Number of kernels the calling thread's msmc_conv_gather / msmc_conv_wgrad calls have launched so far. */
+long msmc_conv_launch_count(void);
 #ifdef __cplusplus
 }
 #endif

@@ -824,7 +824,6 @@ static int cv_geometry(const msmc_conv_desc* d, CvGeom* G, int elt_bytes, int XS
 #include "gather5.inc"
 #include "gather7.inc"
 #include "gather6.inc"
-#include "resunit.inc"
 
 template <typename T, int NT, int MT>
 static int cv_try_pipe(const msmc_conv_desc* d, msmc_stream stream, bool* done) {

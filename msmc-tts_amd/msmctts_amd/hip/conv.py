@@ -18,8 +18,6 @@ from . import lib
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
-# diagnostic switches (tools/nan_bisect.py): "0" makes one grouped entry point issue its members one by one
-_G = {k: os.environ.get('MSMC_G_' + k, '1') != '0' for k in ('FWD', 'DGRAD', 'WGRAD', 'LRELU', 'FOLD')}
 
 
 class Geometry(object):
@@ -540,8 +538,6 @@ def conv_forward_group(items):
     """``items``: list of dicts with the arguments of ``conv_forward`` -- independent convolutions (the parallel
     ResBlocks of a generator stage, one layer of several sub-discriminators) issued as one grouped launch where their
     kernel choices coincide.  Returns the outputs in order."""
-    if not _G['FWD']:
-        return [conv_forward(**it) for it in items]
     stream = lib.stream(items[0]['x'])
     snaps, outs = [], []
     for it in items:
@@ -615,8 +611,6 @@ def conv_dgrad(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
 
 def conv_dgrad_group(items):
     """``items``: list of dicts with the arguments of ``conv_dgrad``; all phases of all members in one grouped call"""
-    if not _G['DGRAD']:
-        return [conv_dgrad(**it) for it in items]
     stream = lib.stream(items[0]['g'])
     snaps, outs = [], []
     for it in items:
@@ -687,11 +681,6 @@ def conv_wgrad(x, g, geom, n_slices, in_slope=1.0, dw=None, db=None, copies=1, s
 def conv_wgrad_group(items):
     """``items``: list of dicts with the arguments of ``conv_wgrad`` (``dw`` required): independent weight gradients
     issued as grouped launches (msmc_conv_wgrad_group)."""
-    if not _G['WGRAD']:
-        for it in items:
-            conv_wgrad(it['x'], it['g'], it['geom'], it['n_slices'], in_slope=it.get('in_slope', 1.0), dw=it['dw'],
-                       db=it.get('db'), copies=it.get('copies', 1), seen=it.get('seen'))
-        return
     stream = lib.stream(items[0]['x'])
     snaps, gs, dws, dbs = [], [], [], []
     for it in items:
@@ -808,18 +797,6 @@ def colsum(g2d, out=None):
     return out
 
 
-def resunit_forward(x, w1, b1, w2, b2, dilation, slope, nt=0):
-    """EXPERIMENTAL (tools/bench_resunit.py): one ResBlock1 unit in one launch (msmc_resunit_forward).  x [B, 1, L, C] bf16,
-    w1 / w2 [k, C, C] (forward layout), b1 / b2 fp32 [C] -> (a, y) = (lrelu(conv(lrelu(x), w1, dilation) + b1),
-    conv(a, w2) + b2 + x)."""
-    B, _, L, C = x.shape
-    assert x.dtype == torch.bfloat16 and x.is_contiguous() and w1.shape == w2.shape == (w1.shape[0], C, C)
-    a, y = torch.empty_like(x), torch.empty_like(x)
-    lib.check(lib.get().msmc_resunit_forward(lib.ptr(x), lib.ptr(w1), lib.ptr(b1), lib.ptr(w2), lib.ptr(b2), lib.ptr(a),
-                                             lib.ptr(y), B, L, C, w1.shape[0], int(dilation), float(slope), int(nt),
-                                             lib.stream(x)), 'msmc_resunit_forward')
-    return a, y
-
 
 def reflect_fold(gp, H, W, p=1, mask_src=None, slope=1.0):
     """Backward of ReflectionPad2d(p) (+ leaky-ReLU' mask): gp [B,H+2p,W+2p,C] -> gx [B,H,W,C]."""
@@ -843,8 +820,6 @@ def lrelu_bwd(g, y, slope):
 
 def lrelu_bwd_group(pairs, slope):
     """[(g, y), ...] -> [g * (y > 0 ? 1 : slope), ...] in launches of up to six tensors (msmc_lrelu_bwd_multi)."""
-    if not _G['LRELU']:
-        return [lrelu_bwd(g, y, slope) for g, y in pairs]
     outs = []
     L = lib.get()
     for i in range(0, len(pairs), 6):
@@ -870,12 +845,6 @@ def reflect_fold_group(items, p=1, slope=1.0, tap_first=False):
     per launch (msmc_reflect_fold_multi_res).  ``tap_first``: (fold + res) * lrelu'(mask_src) instead -- the input is an
     activated map and res the gradient of its other reader (msmc_reflect_fold_multi_tap)."""
     items = [tuple(it) + (None,) * (5 - len(it)) for it in items]
-    if not _G['FOLD'] and not tap_first:
-        outs = []
-        for gp, H, W, mask, res in items:
-            gx = reflect_fold(gp, H, W, p, mask_src=mask, slope=slope)
-            outs.append(gx if res is None else gx + res)
-        return outs
     outs = []
     L = lib.get()
     for i in range(0, len(items), 6):

@@ -28,7 +28,6 @@ _SIGNATURES = {
     'msmc_vq_shortlist_bytes': (_sz, [_i, _i, _i]),
     'msmc_vq_prepare_shortlist': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'msmc_vq_search_shortlist': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    'msmc_vq_last_kernel': (ctypes.c_char_p, []),
     'msmc_vq_ema_workspace': (_sz, [_i, _i, _i, _i]),
     'msmc_vq_ema_update': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _f, _f, _vp]),
     'msmc_vq_ema_stats': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
@@ -106,8 +105,6 @@ _SIGNATURES.update({
     'msmc_masked_mean_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'msmc_conv_gather': (_i, [ctypes.POINTER(ConvDesc), _vp]),
     'msmc_conv_gather_group': (_i, [ctypes.POINTER(ConvDesc), _i, _vp]),
-    'msmc_conv_last_kernel': (ctypes.c_char_p, []),
-    'msmc_conv_launch_count': (ctypes.c_long, []),
     'msmc_conv_wgrad': (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     'msmc_conv_wgrad_group': (_i, [ctypes.POINTER(ConvDesc), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                               _i, _vp]),
@@ -122,9 +119,6 @@ _SIGNATURES.update({
     'msmc_conv_wgrad_reduce_pending': (_i, [ctypes.POINTER(WgPending), _i, _vp]),
     'msmc_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, ctypes.c_longlong, _vp]),
     'msmc_attn_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, ctypes.c_longlong, _vp]),
-    'msmc_prof_enable': (None, [_i]),
-    'msmc_prof_count': (_i, []),
-    'msmc_prof_read': (_i, [_i, ctypes.c_char_p, _i, ctypes.POINTER(ctypes.c_float)]),
     'msmc_wn_prepare_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_wn_prepare_multi_tiled': (_i, [_vp, _i, _i, _i, _vp]),
     'msmc_wn_backward_multi': (_i, [_vp, _i, _i, _vp]),
@@ -160,6 +154,12 @@ _SIGNATURES.update({
 # include/msmc_hip_debug.h: process-global A/B switches, ablation masks and the experimental fused ResBlock unit -- exported by
 # the library for tools/ and tests/, not part of the product ABI
 _DEBUG_SIGNATURES = {
+    'msmc_vq_last_kernel': (ctypes.c_char_p, []),
+    'msmc_conv_last_kernel': (ctypes.c_char_p, []),
+    'msmc_conv_launch_count': (ctypes.c_long, []),
+    'msmc_prof_enable': (None, [_i]),
+    'msmc_prof_count': (_i, []),
+    'msmc_prof_read': (_i, [_i, ctypes.c_char_p, _i, ctypes.POINTER(ctypes.c_float)]),
     'msmc_vq_set_shortlist_ablate': (None, [_i]),
     'msmc_vq_set_variant': (None, [_i]),
     'msmc_conv_set_grouping': (None, [_i]),
@@ -172,7 +172,6 @@ _DEBUG_SIGNATURES = {
     'msmc_conv_set_gather_generation': (None, [_i]),
     'msmc_conv_set_narrow': (None, [_i]),
     'msmc_conv_set_wgrad_tpw': (None, [_i]),
-    'msmc_resunit_forward': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
 }
 
 

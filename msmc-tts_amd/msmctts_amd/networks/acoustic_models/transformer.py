@@ -6,11 +6,11 @@ with -inf, conv feed-forward, output zeroed on padding after both sub-layers.  O
 forward: the fused-QKV and output projections are 1-tap convolutions on the gfx950 implicit-GEMM
 kernels (bias fused, activations stay in the compute dtype: no cast kernels), the position-wise convolutions run on
 the same kernels, and ``layer_norm(dropout(h) + residual) * non_pad_mask`` is one fused kernel per sub-layer
-(csrc/norm.hip, masks regenerated in the backward pass).  The (T <= 2400, d_k = 64) softmax-attention core is PyTorch-ROCm's fused
-``scaled_dot_product_attention`` on strided views of the QKV projection.  ``MSMC_FFT_HIP=0`` / ``use_hip = False``
-keeps the stock operator chain (stand-alone use, A/B runs).
+(csrc/norm.hip, masks regenerated in the backward pass).  The softmax-attention core runs on csrc/attn.hip (bf16, head size 64:
+the benchmarked configuration); fp32 runs -- the parity configuration -- and other head sizes use PyTorch-ROCm's fused
+``scaled_dot_product_attention`` on strided views of the QKV projection.  There is no stock-operator version of the block
+stack: on a device without the library (or the test interpreter) the forward raises.
 """
-import math
 import os
 
 import numpy as np
@@ -45,38 +45,19 @@ def get_non_pad_mask(seq):
     return seq.ne(0).unsqueeze(-1)
 
 
-# fused scaled_dot_product_attention for the FFT blocks (stock PyTorch-ROCm operator); MSMC_SDPA=0 keeps the bmm chain
-USE_SDPA = os.environ.get('MSMC_SDPA', '1') != '0'
-USE_HIP_ATTENTION = os.environ.get('MSMC_HIP_ATTENTION', '1') != '0'     # 0: stock fused attention also in bf16 (A/B)
 # 1 (default): the head of FFTBlocks.forward as one launch when the caller passes ``lengths`` (20.59 -> 20.41 ms/step, round 4);
 # MSMC_FFT_PROLOGUE=0 keeps the operator chain (A/B)
 FFT_PROLOGUE = os.environ.get('MSMC_FFT_PROLOGUE', '1') == '1'
 
 
 class ScaledDotProductAttention(nn.Module):
+    """temperature and dropout probability of the attention core (the core itself: MultiHeadAttention.forward_hip)"""
+
     def __init__(self, temperature, attn_dropout=0.1, name=None):
         super().__init__()
         self.temperature, self.name = temperature, name
         if attn_dropout > 0:
             self.dropout = nn.Dropout(attn_dropout)
-
-    def forward(self, q, k, v, mask=None, acts=None):
-        if USE_SDPA and mask is not None:
-            # PyTorch-ROCm's fused attention: same math (softmax(QK^T / sqrt(d) + key-padding mask) V, dropout on the
-            # probabilities) in one or two kernels instead of six; the probabilities themselves are not materialised
-            # (no caller of the training path reads them)
-            p = self.dropout.p if (hasattr(self, 'dropout') and self.training) else 0.0
-            out = F.scaled_dot_product_attention(q.unsqueeze(0), k.unsqueeze(0), v.unsqueeze(0),
-                                                 attn_mask=(~mask).unsqueeze(0), dropout_p=p,
-                                                 scale=1.0 / self.temperature)
-            return out.squeeze(0), None
-        attn = torch.bmm(q, k.transpose(1, 2)) / self.temperature
-        if mask is not None:
-            attn = attn.masked_fill(mask, -math.inf)
-        attn = torch.softmax(attn, dim=2)
-        if hasattr(self, 'dropout'):
-            attn = self.dropout(attn)
-        return torch.bmm(attn, v), attn
 
 
 class _SplitHeads(torch.autograd.Function):
@@ -138,30 +119,6 @@ class MultiHeadAttention(nn.Module):
         return hipnorm.add_layer_norm(h, x, self.layer_norm.weight, self.layer_norm.bias, keep_row=keep_row, p_drop=pd,
                                       salt=self._salt, eps=self.layer_norm.eps)
 
-    def forward(self, x, mask=None, acts=None):
-        bs, T, _ = x.shape
-        H, dk, dv = self.n_head, self.d_k, self.d_v
-        if USE_SDPA and mask is not None:
-            # heads as a strided view of the fused QKV projection and the key-padding mask broadcast over heads: no
-            # permute / repeat copies around the fused attention operator
-            qkv = self.linear(x).view(bs, T, H, 2 * dk + dv).transpose(1, 2)             # [bs, H, T, 2dk+dv]
-            att = self.attention
-            p = att.dropout.p if (hasattr(att, 'dropout') and att.training) else 0.0
-            # a key-padding mask arrives expanded over the query axis (stride 0): invert the [bs, 1, T_k] original
-            # (6 400 elements), not the [bs, T_q, T_k] expansion (2.5 M), and let the operator broadcast it
-            keep = ~(mask[:, :1, :] if mask.stride(1) == 0 else mask)
-            out = F.scaled_dot_product_attention(qkv[..., :dk], qkv[..., dk:2 * dk], qkv[..., 2 * dk:],
-                                                 attn_mask=keep.unsqueeze(1), dropout_p=p, scale=1.0 / att.temperature)
-            out = out.transpose(1, 2).reshape(bs, T, H * dv)
-            out = self.dropout(self.fc(out)) + x
-            return self.layer_norm(out), None
-        qkv = self.linear(x).view(bs, T, H, 2 * dk + dv).permute(2, 0, 1, 3).reshape(H * bs, T, 2 * dk + dv)
-        q, k, v = qkv[..., :dk], qkv[..., dk:2 * dk], qkv[..., 2 * dk:]
-        out, attn = self.attention(q, k, v, mask=None if mask is None else mask.repeat(H, 1, 1))
-        out = out.view(H, bs, T, dv).permute(1, 2, 0, 3).reshape(bs, T, H * dv)
-        out = self.dropout(self.fc(out)) + x
-        return self.layer_norm(out), attn
-
 
 class PositionwiseFeedForward(nn.Module):
     def __init__(self, d_in, d_hid, fft_conv1d_kernel, fft_conv1d_padding, dropout, name, fused_layernorm=False):
@@ -192,17 +149,6 @@ class PositionwiseFeedForward(nn.Module):
         return hipnorm.add_layer_norm(h, x, self.layer_norm.weight, self.layer_norm.bias, keep_row=keep_row, p_drop=pd,
                                       salt=self._salt, eps=self.layer_norm.eps)
 
-    def forward(self, x, acts=None, hip=None):
-        if hip is None:         # stock operators (stand-alone use of the block)
-            h = self.w_2(F.relu(self.w_1(x.transpose(1, 2)))).transpose(1, 2)
-        else:
-            # [B, T, C] IS the channels-last layout of a 1-D convolution: no transposes; the ReLU between the two
-            # convolutions runs in the first one's epilogue (leaky slope 0)
-            bank, (l1, l2), dtype = hip
-            x4 = x.unsqueeze(1).to(dtype)
-            h = hip_conv(bank, l2, hip_conv(bank, l1, x4, out_slope=0.0, out_masked=True), in_act=0.0).squeeze(1)
-        return self.layer_norm(self.dropout(h) + x)
-
 
 class FFTBlock(nn.Module):
     def __init__(self, d_model, d_inner, n_head, d_k, d_v, fft_conv1d_kernel, fft_conv1d_padding, dropout, name,
@@ -214,12 +160,6 @@ class FFTBlock(nn.Module):
 
     def forward_hip(self, x, keep_row, key_keep, hip_attn, hip_ffn):
         return self.pos_ffn.forward_hip(self.slf_attn.forward_hip(x, keep_row, key_keep, hip_attn), keep_row, hip_ffn)
-
-    def forward(self, input, non_pad_mask=None, slf_attn_mask=None, acts=None, hip=None):
-        keep = non_pad_mask.to(input.dtype)
-        out, attn = self.slf_attn(input, mask=slf_attn_mask)
-        out = self.pos_ffn(out * keep, hip=hip) * keep
-        return out, attn
 
 
 class FFTBlocks(nn.Module):
@@ -234,8 +174,6 @@ class FFTBlocks(nn.Module):
                      '%s.layer_stack.%d' % (name, i), attn_dropout, fused_layernorm) for i in range(n_layers)])
 
         self.hip_dtype = torch.float32        # compute dtype of the HIP convolutions (trainer: bfloat16 in bf16 runs)
-        # position-wise convolutions on the gfx950 kernels (csrc/conv.hip); MSMC_FFT_HIP=0 keeps the stock operators (A/B)
-        self.use_hip = os.environ.get('MSMC_FFT_HIP', '1') != '0'
         self._bank = None
 
     def _hip(self):
@@ -248,10 +186,11 @@ class FFTBlocks(nn.Module):
         """``lengths`` (optional, per-utterance frame counts): with MSMC_FFT_PROLOGUE=1 the positions 1 .. len / 0, the
         positional-embedding add, the cast, the row mask and the key-padding bias are ONE launch (hip/norm.py
         fft_prologue) and ``pos`` may be None."""
-        if (FFT_PROLOGUE and lengths is not None and self.use_hip and (seq.is_cuda or _interpreter_bound())
-                and seq.dtype in (torch.float32, torch.bfloat16)):
+        if not (seq.is_cuda or _interpreter_bound()):
+            raise RuntimeError('FFTBlocks runs on the gfx950 kernels only: move the module to the GPU (tests: bind the interpreter build)')
+        if FFT_PROLOGUE and lengths is not None and seq.dtype in (torch.float32, torch.bfloat16):
             att0 = self.layer_stack[0].slf_attn
-            if USE_HIP_ATTENTION and hipattn.supported(self.hip_dtype, att0.d_k, att0.d_v):
+            if hipattn.supported(self.hip_dtype, att0.d_k, att0.d_v):
                 bank, layers = self._hip()
                 bank.prepare(self.hip_dtype)
                 B, T = seq.shape[0], seq.shape[1]
@@ -265,25 +204,20 @@ class FFTBlocks(nn.Module):
             pos = steps * (steps <= lengths.to(seq.device).unsqueeze(1))
         keep = get_non_pad_mask(pos)
         out = seq + self.position(pos)
-        if self.use_hip and (out.is_cuda or _interpreter_bound()):
-            bank, layers = self._hip()
-            bank.prepare(self.hip_dtype)          # one launch: kernel-layout weights of the 4 x n_layers GEMMs / convolutions
-            keep_row = pos.ne(0).to(torch.uint8).reshape(-1)
-            # additive key-padding bias, built ONCE per stack in the compute dtype and broadcast over heads and queries (a
-            # boolean mask is converted to this by every attention call: a where + fills per layer)
-            att0 = self.layer_stack[0].slf_attn
-            if USE_HIP_ATTENTION and hipattn.supported(self.hip_dtype, att0.d_k, att0.d_v):
-                key_keep = (hipattn.pad_key_bias(pos),)      # csrc/attn.hip (bf16, head size 64)
-            else:                                            # the stock fused operator (fp32 parity runs, other head sizes)
-                key_keep = torch.zeros(pos.shape[0], 1, 1, pos.shape[1], dtype=self.hip_dtype, device=pos.device).masked_fill_(
-                    pos.eq(0).view(pos.shape[0], 1, 1, pos.shape[1]), float('-inf'))
-            out = out.to(self.hip_dtype)
-            for layer, (attn, ffn) in zip(self.layer_stack, layers):
-                out = layer.forward_hip(out, keep_row, key_keep, (bank, attn), (bank, ffn))
-            return out, keep
-        mask = get_attn_key_pad_mask(pos, pos)
-        for layer in self.layer_stack:
-            out, _ = layer(out, non_pad_mask=keep, slf_attn_mask=mask, hip=None)
+        bank, layers = self._hip()
+        bank.prepare(self.hip_dtype)          # one launch: kernel-layout weights of the 4 x n_layers GEMMs / convolutions
+        keep_row = pos.ne(0).to(torch.uint8).reshape(-1)
+        # additive key-padding bias, built ONCE per stack in the compute dtype and broadcast over heads and queries (a
+        # boolean mask is converted to this by every attention call: a where + fills per layer)
+        att0 = self.layer_stack[0].slf_attn
+        if hipattn.supported(self.hip_dtype, att0.d_k, att0.d_v):
+            key_keep = (hipattn.pad_key_bias(pos),)      # csrc/attn.hip (bf16, head size 64)
+        else:                                            # the stock fused operator (fp32 parity runs, other head sizes)
+            key_keep = torch.zeros(pos.shape[0], 1, 1, pos.shape[1], dtype=self.hip_dtype, device=pos.device).masked_fill_(
+                pos.eq(0).view(pos.shape[0], 1, 1, pos.shape[1]), float('-inf'))
+        out = out.to(self.hip_dtype)
+        for layer, (attn, ffn) in zip(self.layer_stack, layers):
+            out = layer.forward_hip(out, keep_row, key_keep, (bank, attn), (bank, ffn))
         return out, keep
 
 

@@ -147,7 +147,7 @@ class MultiStageQuantizer(nn.Module):
                 k = u * 2 if u % 2 == 0 else u * 2 + 1
                 self.transposed_conv.append(nn.ConvTranspose1d(n_model_size, n_model_size, k, u, padding=(k - u) // 2))
         self.hip_dtype = torch.float32        # compute dtype of the HIP GEMMs (trainer: bfloat16 in bf16 runs)
-        self.use_hip = os.environ.get('MSMC_QUANT_HIP', '1') != '0' and not norm
+        self.use_hip = not norm            # (the normalised variant -- no shipped configuration uses it -- keeps stock operators)
         self._bank = None
 
     # -- the 1x1 channel GEMMs, the prior predictor's WaveNet stack and their Tanh / gate on the gfx950 kernels ---------
@@ -281,7 +281,7 @@ class MSMCVQGAN(nn.Module):
         if pred_mel:
             self.mel_predictor = nn.Linear(n_model_size, in_dim)
         self.hip_dtype = torch.float32
-        self.use_hip = os.environ.get('MSMC_QUANT_HIP', '1') != '0'
+        self.use_hip = True
         self._bank = None
 
     def _hip_ready(self, dev):

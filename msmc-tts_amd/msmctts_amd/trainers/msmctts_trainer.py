@@ -109,7 +109,6 @@ class VQGANTrainer(BaseTrainer):
             self.stft_criterion = MultiResolutionSTFTLoss(**dict(stft_loss_config or {}))
         self.rng = random              # python global RNG, like the reference (:214); tests inject their own
         self._amp_applied = None
-        self.batch_g_step = os.environ.get('MSMC_BATCH_G_STEP', '0') != '0'
         # the generator step reads the spectral front-end images the D step built from the same waveforms (A/B: 0)
         self.reuse_fronts = os.environ.get('MSMC_REUSE_FRONTS', '1') != '0'
         # more parallel branches of the step (streams of the library's own, hip/convnet.py own_streams): the spectral loss of
@@ -119,8 +118,10 @@ class VQGANTrainer(BaseTrainer):
         # hipGraph mode under data parallelism: 'serial' = one flat all-reduce per child between the replayed segments;
         # 'overlap' = the reducer's bucketed all-reduces captured INTO the segments (distributed/distributed.py docstring)
         self.graph_exchange = os.environ.get('MSMC_GRAPH_EXCHANGE', 'serial')
-        self.use_graphs = False        # replay the GAN-phase step as three hipGraphs (static shapes)
-        self._graphs = None
+        self.use_graphs = False        # replay the step from hipGraphs (static shapes): the GAN phase as three segments, the
+        self._graphs = None            # warm-up phase (the reference trains 50 000 steps in it, msmc_vq_gan.yaml:91) as two
+        self._graphs_warm = None
+        self.graph_warmup = os.environ.get('MSMC_GRAPH_WARMUP', '1') != '0'     # A/B: 0 keeps the warm-up phase eager
         self.amp_autocast = True       # False: only the HIP conv stacks compute in amp_dtype, stock operators stay fp32
         self.amp_dtype = None          # e.g. torch.bfloat16: autocast for the GEMM/conv bodies (VQ search stays fp32)
 
@@ -225,15 +226,7 @@ class VQGANTrainer(BaseTrainer):
         if st.phase == 2:
             self.optimizer.step(['discriminator'])
             # generator step against the updated D; D's own gradients are not needed
-            if self.batch_g_step:
-                # one pass over [fake; real]: the real half only feeds the (detached) feature-matching targets
-                B = st.predict.shape[0]
-                with _frozen(disc), self._amp():
-                    scores, feats = disc(torch.cat((st.predict, st.target), dim=0))
-                fake_scores = [s_[:B] for s_ in scores]
-                fake_feats = [[f_[:B] for f_ in fl] for fl in feats]
-                real_feats = [[f_[B:].detach() for f_ in fl] for fl in feats]
-            elif getattr(st, 'fronts', None) is not None:
+            if getattr(st, 'fronts', None) is not None:
                 B = st.predict.shape[0]
                 def real_pass():
                     with torch.no_grad():
@@ -283,13 +276,16 @@ class VQGANTrainer(BaseTrainer):
             return 0
         return 2 if iteration > self.warmup_steps else 1
 
+    def _graphed_phase(self, phase):
+        return bool(self.use_graphs) and (phase == 2 or (phase == 0 and self.graph_warmup))
+
     def replays(self, iteration):
-        return bool(self.use_graphs) and self._phase(iteration) == 2
+        return self._graphed_phase(self._phase(iteration))
 
     def train_step(self, batch, iteration):
         phase = self._phase(iteration)
-        if self.use_graphs and phase == 2:
-            return self._train_step_graphed(batch)
+        if self._graphed_phase(phase):
+            return self._train_step_graphed(batch, phase)
         reducer = getattr(self.model, 'grad_reducer', None)
         if reducer is not None:
             reducer.hooks_enabled = True         # eager step: bucketed all-reduce from the gradient hooks
@@ -310,8 +306,8 @@ class VQGANTrainer(BaseTrainer):
         return {'loss': {k: (v.detach() if torch.is_tensor(v) else v) for k, v in st.losses.items()}}
 
     # -- hipGraph replay of the GAN-phase step -----------------------------------------------------
-    def _train_step_graphed(self, batch):
-        g = self._graphs
+    def _train_step_graphed(self, batch, phase=2):
+        g = self._graphs if phase == 2 else self._graphs_warm
         reducer = getattr(self.model, 'grad_reducer', None)
         if reducer is not None:
             reducer.hooks_enabled = False        # (serial exchange: no collectives inside capture; overlap: _capture arms them)
@@ -320,24 +316,31 @@ class VQGANTrainer(BaseTrainer):
             lengths = batch['mel_length'].tolist()
         # the captured window gather reads wav[start * frameshift : (start + frame_lengths) * frameshift] unchecked: a waveform
         # shorter than its mel says (wrong hop in the data) must fail here, on the host, not as a GPU memory fault
-        have, need = batch['wav'].numel() // len(lengths), (int(max(lengths)) - 1) * self.frameshift      # (windows end at frame n - 1)
-        if have < need:
-            raise ValueError('batch["wav"] holds %d samples per utterance, mel_length x frameshift (%d) asks for %d'
-                             % (have, self.frameshift, need))
+        if phase == 2:
+            have, need = batch['wav'].numel() // len(lengths), (int(max(lengths)) - 1) * self.frameshift      # (windows end at frame n - 1)
+            if have < need:
+                raise ValueError('batch["wav"] holds %d samples per utterance, mel_length x frameshift (%d) asks for %d'
+                                 % (have, self.frameshift, need))
         if g is None:
-            g = self._graphs = self._capture(batch)
+            g = self._capture(batch, phase)
+            if phase == 2:
+                self._graphs = g
+            else:
+                self._graphs_warm = g
         st = g['state']
-        starts = [self.rng.randrange(max(1, int(n) - self.frame_lengths)) for n in lengths]
-        g['starts_host'].copy_(torch.tensor(starts, dtype=torch.int64))
-        g['starts'].copy_(g['starts_host'], non_blocking=True)
+        if phase == 2:
+            starts = [self.rng.randrange(max(1, int(n) - self.frame_lengths)) for n in lengths]
+            g['starts_host'].copy_(torch.tensor(starts, dtype=torch.int64))
+            g['starts'].copy_(g['starts_host'], non_blocking=True)
         if batch['mel'].data_ptr() != st.mel.data_ptr():
             st.mel.copy_(batch['mel'], non_blocking=True)
             st.mel_length.copy_(batch['mel_length'], non_blocking=True)
-            g['wav'].copy_(batch['wav'].reshape(g['wav'].shape), non_blocking=True)
+            if phase == 2:
+                g['wav'].copy_(batch['wav'].reshape(g['wav'].shape), non_blocking=True)
         hipconvnet.refresh_stale_banks()               # (parameters changed behind the graphs' back: checkpoint load ...)
         g['a'].replay()
         self._sync_codebooks(g['codebooks'])
-        if not g['overlap']:
+        if phase == 2 and not g['overlap']:
             self._sync_grads_static('discriminator', g)
         g['b'].replay()
         if not g['overlap']:
@@ -399,8 +402,11 @@ class VQGANTrainer(BaseTrainer):
                                                                       device=starts.device).unsqueeze(0)
         st.target = torch.gather(g['wav'], 1, sidx)
 
-    def _capture(self, batch):
-        """Warm up eagerly on a side stream, then record segments A, B, C into three graphs sharing one pool."""
+    def _capture(self, batch, phase=2):
+        """Warm up eagerly on a side stream, then record segments A, B, C into three graphs sharing one pool.  ``phase`` 2: the
+        GAN-phase step; 0: the warm-up phase (autoencoder forward + losses | backward | clip + update -- no vocoder window, no
+        discriminator; the same three segments, so the gradient exchange of the data-parallel path sits where it sits in
+        phase 2: between B and C).  Each phase owns its graphs, static batch buffers, gradient tensors and memory pool."""
         dev = batch['mel'].device
         B = batch['mel'].shape[0]
         from ..hip import graphs as hipgraphs
@@ -408,14 +414,17 @@ class VQGANTrainer(BaseTrainer):
             raise RuntimeError(hipgraphs.HINT)
         snap = self._snapshot_state()
         st = _StepState()
-        st.phase = 2
+        st.phase = phase
         st.mel, st.mel_length = batch['mel'].clone(), batch['mel_length'].clone()
-        g = {'state': st, 'wav': batch['wav'].reshape(B, -1).clone(),
-             'starts': torch.zeros(B, dtype=torch.int64, device=dev),
-             'starts_host': torch.zeros(B, dtype=torch.int64).pin_memory()}
+        st.frame_window = st.target = None
+        g = {'state': st}
+        if phase == 2:
+            g.update(wav=batch['wav'].reshape(B, -1).clone(), starts=torch.zeros(B, dtype=torch.int64, device=dev),
+                     starts_host=torch.zeros(B, dtype=torch.int64).pin_memory())
 
         def run_eager():
-            self._build_windows(g, st)
+            if phase == 2:
+                self._build_windows(g, st)
             self._segment_a(st)
             hipvq.flush_codebook_sync(local=True)
             self._segment_b(st)                      # (no gradient exchange: the warm-up's updates are rolled back)
@@ -432,7 +441,7 @@ class VQGANTrainer(BaseTrainer):
         # Drop every reference to the warm-up autograd graphs (their AccumulateGrad nodes are bound to a
         # stream) and capture on the SAME side stream the warm-up ran on, so that gradient accumulation is
         # recorded into the graphs instead of running on another stream.
-        for name in ('losses', 'g_loss', 'predict', 'target', 'frame_window', 'fronts'):
+        for name in ('losses', 'g_loss', 'predict', 'fronts') + (('target', 'frame_window') if phase == 2 else ()):
             setattr(st, name, None)
         self.grad_norm = None
         import gc as _gc
@@ -453,16 +462,19 @@ class VQGANTrainer(BaseTrainer):
                 reducer.finish()
                 reducer.hooks_enabled = False
         with torch.cuda.graph(ga, stream=side, capture_error_mode=mode):
-            self._build_windows(g, st)
-            if overlap:
+            if phase == 2:
+                self._build_windows(g, st)
+            if overlap and phase == 2:
                 reducer.hooks_enabled = True
             self._segment_a(st)
-            exchange_in_graph()
+            if phase == 2:
+                exchange_in_graph()
         g['codebooks'] = list(hipvq.PENDING)    # (sync_codebook_stats: the stages whose statistics segment A refills)
         del hipvq.PENDING[:]
         torch.cuda.synchronize()
         prepare = getattr(self.optimizer, 'prepare', lambda names=None: None)
-        prepare(['discriminator'])              # (tensor tables over the static gradients segment A just allocated)
+        if phase == 2:
+            prepare(['discriminator'])          # (tensor tables over the static gradients segment A just allocated)
         with torch.cuda.graph(gb, pool=ga.pool(), stream=side, capture_error_mode=mode):
             if overlap:
                 reducer.hooks_enabled = True
@@ -477,7 +489,7 @@ class VQGANTrainer(BaseTrainer):
         torch.cuda.synchronize()
         # the static gradient tensors each segment writes, per child, in parameter order (identical on every rank)
         grads = {name: [p.grad for p in getattr(self.model, name).parameters() if p.requires_grad and p.grad is not None]
-                 for name in ('discriminator', 'autoencoder') if hasattr(self.model, name)}
+                 for name in (('discriminator', 'autoencoder') if phase == 2 else ('autoencoder',)) if hasattr(self.model, name)}
         g.update(a=ga, b=gb, c=gc, loss_vec=loss_vec, loss_keys=keys, grads=grads)
         self._restore_state(snap)
         # the graphs refresh a bank's kernel-layout weights only where the capture saw it dirty (the discriminator's: after
@@ -518,6 +530,18 @@ class PredictorTrainer(BaseTrainer):
         self.training_methods, self.loss_weights = list(training_methods), loss_weights
         self.grad_clip_thresh, self.eval_inteval_iters = grad_clip_thresh, eval_inteval_iters
         self.dur_loss = DurationLoss(lambda_dur)
+        self.amp_dtype = None          # e.g. torch.bfloat16: the FFT stacks' GEMM / convolution bodies and the attention core in
+        self._amp_applied = None       # that type (autocast); embeddings, losses and the optimizer stay fp32
+
+    def _amp(self):
+        if self._amp_applied is not self.amp_dtype:          # tell the HIP stacks their compute dtype
+            for m in self.model.modules():
+                if hasattr(m, 'hip_dtype'):
+                    m.hip_dtype = self.amp_dtype or torch.float32
+            self._amp_applied = self.amp_dtype
+        if self.amp_dtype is None:
+            return contextlib.nullcontext()
+        return torch.autocast(device_type=next(self.model.parameters()).device.type, dtype=self.amp_dtype)
 
     def build_autoencoder(self):
         """the frozen autoencoder named by ``task.autoencoder._checkpoint`` / ``_config`` (reference :288-295)"""
@@ -540,7 +564,9 @@ class PredictorTrainer(BaseTrainer):
         # (analysis only), so without this every predictor step would draw the SAME masks
         from ..hip import norm as hipnorm
         hipnorm.advance_seed(batch['feat'][0].device)
-        output = self.model.predictor(**batch)
+        with self._amp():
+            output = self.model.predictor(**batch)
+        output['feat'] = [f.float() for f in output['feat']]
         losses = {'total_loss': 0}
         emb = self.autoencoder.compute_embedding_loss(output['feat'], output['feat_length'], qs,
                                                       methods=self.training_methods, loss_weights=self.loss_weights)

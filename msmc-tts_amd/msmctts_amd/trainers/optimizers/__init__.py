@@ -4,9 +4,7 @@ One optimizer per top-level child of the task (``autoencoder``, ``discriminator`
 ``optimizer.<child>`` or ``optimizer._default``; ``zero_grad``/``step`` take child names.  On the GPU AdamW (and Adam
 without weight decay, which is the same update) is ``HipAdamW``: gradient-norm clipping + update of every tensor of a
 child in three launches (csrc/optim.hip), learning rate / step count on the device (hipGraph-replayable).
-``MSMC_HIP_ADAMW=0`` keeps ``torch.optim``'s fused kernels (A/B runs).
 """
-import os
 import re
 
 import torch
@@ -15,7 +13,6 @@ from torch.optim import Adam, AdamW
 from .hip_adamw import HipAdamW
 from .radam import RAdam
 
-HIP_ADAMW = os.environ.get('MSMC_HIP_ADAMW', '1') != '0'
 
 
 def get_optimizer(parameters, config, capturable=False):
@@ -27,7 +24,7 @@ def get_optimizer(parameters, config, capturable=False):
     cls = {'Adam': Adam, 'AdamW': AdamW}[name]
     fused = any(p.is_cuda for p in parameters)
     from ...hip import lib
-    if HIP_ADAMW and (fused or lib._host_pointers_ok) and (name == 'AdamW' or config.weight_decay == 0):
+    if (fused or lib._host_pointers_ok) and (name == 'AdamW' or config.weight_decay == 0):
         return HipAdamW(parameters, *args)
     if fused and capturable:         # hipGraph replay: step counters and lr live on the device
         dev = next(p.device for p in parameters if p.is_cuda)

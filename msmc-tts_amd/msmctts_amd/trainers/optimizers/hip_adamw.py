@@ -63,9 +63,12 @@ class HipAdamW(Optimizer):
             return None, None, 0, 0
         live = [p for p in ps if p.grad is not None]
         sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in live)
-        cached = group.get('table')
-        if cached is not None and cached[0] == sig:
-            return cached[1:5]
+        # one table per gradient-storage signature, all kept: captured steps of different phases (warm-up / GAN) each replay
+        # with the table of THEIR static gradient tensors, and a table a graph points at must not be freed
+        tables = group.setdefault('tables', {})
+        cached = tables.get(sig)
+        if cached is not None:
+            return cached
         chunk = lib.get().msmc_opt_chunk()
         items = (lib.OptTensor * max(1, len(live)))()
         blocks = 0
@@ -82,8 +85,8 @@ class HipAdamW(Optimizer):
                                'call optimizer.prepare() between the backward pass and the captured step')
         table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
         partial = torch.empty(max(1, blocks), dtype=torch.float32, device=dev)
-        group['table'] = (sig, table, partial, len(live), blocks)
-        return table, partial, len(live), blocks
+        tables[sig] = (table, partial, len(live), blocks)
+        return tables[sig]
 
     def prepare(self):
         """build the flat state and the tensor table for the gradients that exist now (before capturing a step)"""
@@ -117,7 +120,7 @@ class HipAdamW(Optimizer):
         super().load_state_dict(state_dict)
         for group in self.param_groups:
             group.pop('flat', None)
-            group.pop('table', None)
+            group.pop('tables', None)
             if not torch.is_tensor(group['lr']):
                 dev = group['params'][0].device
                 group['lr'] = torch.tensor(float(group['lr']), dtype=torch.float32, device=dev)
@@ -130,7 +133,7 @@ class HipAdamW(Optimizer):
         sd = super().state_dict()
         for g in sd['param_groups']:
             g.pop('flat', None)
-            g.pop('table', None)
+            g.pop('tables', None)
             if torch.is_tensor(g['lr']):
                 g['lr'] = float(g['lr'])
         for st in sd['state'].values():           # torch.optim.AdamW layout: a 0-dim fp32 ``step`` per parameter

@@ -419,31 +419,6 @@ def test_one_tap_gemm_fp32_forced_on_the_spectral_shapes(g1v):
     assert not bad, bad
 
 
-@pytest.mark.parametrize('C,L,k,dil,nt', [(32, 12000, 3, 1, 0), (32, 12000, 7, 3, 3), (32, 12000, 11, 5, 2), (32, 3001, 11, 1, 3),
-                                            (64, 6000, 3, 5, 0), (64, 777, 3, 1, 2)])
-def test_resblock_unit_in_one_launch_equals_the_two_launch_chain(C, L, k, dil, nt):
-    """csrc/resunit.inc (experimental entry point msmc_resunit_forward): the fused unit against the product's chain of
-    two convolutions (activation in the producer's epilogue, residual in the second launch's) and the stock operators"""
-    from msmctts_amd.hip import conv
-    dev = torch.device('cuda')
-    torch.manual_seed(C + L + k)
-    B = 4
-    x = torch.randn(B, 1, L, C, device=dev).to(torch.bfloat16)
-    w1 = (torch.randn(k, C, C, device=dev) / (C * k) ** 0.5).to(torch.bfloat16)
-    w2 = (torch.randn(k, C, C, device=dev) / (C * k) ** 0.5).to(torch.bfloat16)
-    b1, b2 = torch.randn(C, device=dev) * 0.1, torch.randn(C, device=dev) * 0.1
-    a, y = conv.resunit_forward(x, w1, b1, w2, b2, dil, 0.1, nt=nt)
-    g1 = conv.Geometry(1, L, (1, k), (1, 1), (1, dil), (0, dil * (k - 1) // 2), False)
-    g2 = conv.Geometry(1, L, (1, k), (1, 1), (1, 1), (0, (k - 1) // 2), False)
-    a0 = conv.conv_forward(x, w1, g1, bias=b1, in_slope=0.1, out_slope=0.1)
-    y0 = conv.conv_forward(a0, w2, g2, bias=b2, res=x)
-    assert rel(a.float(), a0.float()) <= 1e-2 and rel(y.float(), y0.float()) <= 1e-2
-    xc = x.float().squeeze(1).transpose(1, 2)
-    wt = lambda w: w.float().permute(1, 2, 0).contiguous()
-    a_ref = F.leaky_relu(F.conv1d(F.leaky_relu(xc, 0.1), wt(w1), b1, 1, dil * (k - 1) // 2, dil), 0.1)
-    y_ref = F.conv1d(a_ref.to(torch.bfloat16).float(), wt(w2), b2, 1, (k - 1) // 2, 1) + xc
-    assert rel(a.float().squeeze(1).transpose(1, 2), a_ref) <= 1e-2
-    assert rel(y.float().squeeze(1).transpose(1, 2), y_ref) <= 1e-2
 
 
 def test_layer_applied_twice_keeps_its_two_weight_gradient_reductions_apart():

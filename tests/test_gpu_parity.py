@@ -215,7 +215,16 @@ def test_graphed_step_matches_eager():
     graphed_vs_eager()
 
 
-def graphed_vs_eager(arm_reducer=False, exchange='serial'):
+def test_graphed_warmup_phase_matches_eager_and_hands_over_to_the_gan_phase():
+    """the warm-up phase (iteration < warmup_steps: no vocoder, no discriminator -- the reference trains 50 000 steps in it)
+    replayed from its own hipGraphs against the eager steps, then -- same trainer -- the switch through the one eager step at
+    iteration == warmup_steps into the captured GAN phase: two sets of graphs, static gradient tensors and optimizer tables alive
+    side by side"""
+    graphed_vs_eager(iterations=(0, 1), warmup_steps=4)
+    graphed_vs_eager(iterations=(2, 3, 4, 5, 6), warmup_steps=4)
+
+
+def graphed_vs_eager(arm_reducer=False, exchange='serial', iterations=(6, 7), warmup_steps=None):
     import random
     from msmctts_amd.synthetic import make_batch
     from msmctts_amd.trainers import build_trainer
@@ -234,17 +243,18 @@ def graphed_vs_eager(arm_reducer=False, exchange='serial'):
         tr.use_graphs = graphed
         tr.graph_exchange = exchange
         tr.rng = random.Random(3)
-        if graphed:
-            log = tr.train_step(batch, 6)        # capture (its eager warm-up is rolled back) + first replay
-            log = {'loss': {k: float(v) for k, v in log['loss'].items()}}
-            log2 = tr.train_step(batch, 7)
-        else:
-            task.zero_grad()
-            log = tr.train_step(batch, 6)
-            task.zero_grad()
-            log2 = tr.train_step(batch, 7)
-        results.append(({k: float(v) for k, v in log['loss'].items()}, {k: float(v) for k, v in log2['loss'].items()},
-                        {k: v.detach().clone() for k, v in task.state_dict().items()}))
+        if warmup_steps is not None:
+            tr.warmup_steps = warmup_steps
+        logs = []
+        for it in iterations:
+            if not tr.replays(it):               # (a replayed step owns static gradient buffers; capture happens on first use,
+                task.zero_grad()                 #  its eager warm-up is rolled back)
+            log = tr.train_step(batch, it)
+            logs.append({k: float(v) for k, v in log['loss'].items()})
+        if graphed and warmup_steps is not None:
+            assert tr._graphs_warm is not None and (tr._graphs is not None) == (max(iterations) > warmup_steps)
+        log, log2 = logs[0], logs[-1]
+        results.append((log, log2, {k: v.detach().clone() for k, v in task.state_dict().items()}))
     (e1, e2, es), (g1, g2, gs) = results
     assert set(e1) == set(g1)
     for a, b in ((e1, g1), (e2, g2)):
@@ -284,6 +294,48 @@ def test_rccl_gradient_reducer_single_rank_matches_reference():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and 'REDUCER-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+DELAYED_DELIVERY = (
+    "from msmctts_amd.hip import convnet\n"
+    "_orig_finish = convnet.ConvBank._finish_backward\n"
+    "def _slow_finish(self, early=False):\n"
+    "    if early and self.w1.is_cuda:\n"
+    "        torch.cuda._sleep(int(2e8))      # the early delivery's launches sit ~0.1 s behind the host (on the side stream)\n"
+    "    return _orig_finish(self, early)\n"
+    "convnet.ConvBank._finish_backward = _slow_finish\n")
+
+
+def test_reducer_waits_for_the_stream_a_bank_delivered_its_gradients_on():
+    """A bucket that mixes convolution-bank parameters (gradients delivered EARLY, from a side stream of the bank's own:
+    hip/convnet.py FINISH_SIDE) with parameters of stock modules (ready on the calling stream) must not be concatenated
+    before the side stream has written the bank's gradients (round-4 review).  Here every early delivery is held back by a
+    0.1 s sleep on its stream while the host -- and the calling stream -- run on: the golden eager steps with the reducer
+    armed (RCCL, one rank: averaging is the identity) must still match the reference's losses, gradients and post-step
+    parameters.  Buckets of 64 KB so that many of them complete on the calling stream."""
+    import subprocess, sys, os, socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch, torch.distributed as dist\n"
+        "sys.path[:0] = [%r, %r, %r]\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d', world_size=1, rank=0)\n"
+        "import _parity\n"
+        "from msmctts_amd.distributed import distributed\n"
+        "distributed.DEFAULT_BUCKET_BYTES = 64 * 1024\n"
+        "distributed.apply_gradient_allreduce.__defaults__ = (64 * 1024, None)\n"
+        + DELAYED_DELIVERY +
+        "assert convnet.FINISH_SIDE and convnet.EARLY_FINISH\n"
+        "_parity.check_train_steps('cuda:0', arm_reducer=True)\n"
+        "dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()\n"
+        "print('DELAYED-OK')\n" % (root, os.path.join(root, 'msmc-tts_amd'), os.path.join(root, 'tests'), port))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and 'DELAYED-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
 def test_multi_resolution_stft_loss_matches_reference():

@@ -1093,27 +1093,6 @@ def test_weight_gradients_waiting_in_the_bank_equal_immediate_ones(batch):
         convnet.WGRAD_BATCH = keep
 
 
-@pytest.mark.parametrize('C,k,dil,L,nt', [(32, 3, 1, 200, 0), (32, 7, 3, 77, 3), (32, 11, 5, 150, 2), (64, 3, 3, 90, 0),
-                                            (32, 11, 1, 54, 3)])
-def test_resblock_unit_in_one_launch(C, k, dil, L, nt):
-    """csrc/resunit.inc (experimental entry point, tools/bench_resunit.py): a = lrelu(conv(lrelu(x), w1, dil) + b1),
-    y = conv(a, w2) + b2 + x in one launch against the stock operators (reference hifigan/common.py:44-51)."""
-    import torch.nn.functional as F
-    from msmctts_amd.hip import conv
-    torch.manual_seed(C + k + L)
-    B = 2
-    x = torch.randn(B, 1, L, C).to(torch.bfloat16)
-    w1 = (torch.randn(k, C, C) / (C * k) ** 0.5).to(torch.bfloat16)
-    w2 = (torch.randn(k, C, C) / (C * k) ** 0.5).to(torch.bfloat16)
-    b1, b2 = torch.randn(C) * 0.1, torch.randn(C) * 0.1
-    a, y = conv.resunit_forward(x, w1, b1, w2, b2, dil, 0.1, nt=nt)
-    xc = x.float().squeeze(1).transpose(1, 2)                                  # (B, C, L)
-    wt = lambda w: w.float().permute(1, 2, 0).contiguous()                     # [k][co][ci] -> (co, ci, k)
-    a_ref = F.leaky_relu(F.conv1d(F.leaky_relu(xc, 0.1), wt(w1), b1, 1, dil * (k - 1) // 2, dil), 0.1)
-    a_q = a_ref.to(torch.bfloat16).float()                                     # the second convolution reads the stored bf16
-    y_ref = F.conv1d(a_q, wt(w2), b2, 1, (k - 1) // 2, 1) + xc
-    _parity.close(a.float().squeeze(1).transpose(1, 2), a_ref, 1e-2, 1e-2, what='a')
-    _parity.close(y.float().squeeze(1).transpose(1, 2), y_ref, 2e-2, 2e-2, what='y')
 
 
 def test_fft_stack_prologue_equals_the_operator_chain():

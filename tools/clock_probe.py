@@ -28,7 +28,7 @@ SHAPES = [
     ('mpd p2 512->512 s1', 32, 512, 512, 75, 2, (5, 1), (1, 1), (1, 1), (2, 0), False, 0.2),
 ]
 flt = sys.argv[1] if len(sys.argv) > 1 else ''
-VARIANTS = [int(v) for v in os.environ.get('VARIANTS', '56 57 59 60').split()]
+VARIANTS = [int(v) for v in os.environ.get('VARIANTS', '56 57 58 60 63').split()]
 ABLS = [int(v) for v in os.environ.get('ABLS', '0 46').split()]
 for name, B, Cin, Cout, H, W, k, s_, dil, pad, reflect, slope in SHAPES:
     if flt not in name:

@@ -11,7 +11,7 @@ shift
 for what in "$@"; do
 case $what in
 micro)
-  VARIANTS="${VARIANTS:-40 41 42 44 45 46 56 57 58 59 60 61 62 63}" python tools/bench_gather3.py ${FILTER:-} 2>&1 | grep -v "^thin" > gpurun_out/${TAG}_gather7_microbench.txt
+  VARIANTS="${VARIANTS:-40 41 42 44 45 46 56 57 58 59 60 61 62 63}" env -u ABLATE python tools/bench_gather3.py ${FILTER:-} 2>&1 | grep -v "^thin" > gpurun_out/${TAG}_gather7_microbench.txt
   ABLATE="${ABLATE:-56 57 58}" ABLS="0 2 4 8 32 46" python tools/bench_gather3.py ffn >> gpurun_out/${TAG}_gather7_microbench.txt 2>&1
   cat gpurun_out/${TAG}_gather7_microbench.txt ;;
 conv)
@@ -30,5 +30,8 @@ k=json.load(open('gpurun_out/${TAG}_bench_kernels.json'))['kernels']
 for n,v in sorted(k.items(), key=lambda kv:-kv[1]['ms_per_step'])[:26]: print('%.3f %5.1f %6.1f %s' % (v['ms_per_step'], v['launches']/3, v['avg_us'], n[:70]))
 PY
   ;;
+bench4)
+  python bench.py --config 4 --kernels-out gpurun_out/${TAG}_bench_config4_kernels.json --steps 10 --warmup 3 --cpu-steps ${CPU_STEPS:-2} --cpu-warmup 1 > gpurun_out/${TAG}_bench_config4.json 2> gpurun_out/${TAG}_bench_config4.log || tail -n 25 gpurun_out/${TAG}_bench_config4.log
+  cut -c1-1500 gpurun_out/${TAG}_bench_config4.json ;;
 esac
 done
