@@ -65,7 +65,7 @@ _PLANS = {}
 # (msmc_conv_desc.variant / .split_shift) once and keeps the fastest -- tile heuristics cannot see L2 / LDS effects
 # that differ by 2x between layers of equal arithmetic.  Off inside hipGraph capture and on the interpreter.
 AUTOTUNE = os.environ.get('MSMC_AUTOTUNE', '1') != '0'
-_GATHER_CANDIDATES = tuple((int(v), 0) for v in os.environ.get('MSMC_GATHER_VARIANTS', '1,2,3,4,5,8,9,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,34,35,40,41,42,43,44,45,46,47,50,56,57,58,59,60,61,62,63').split(','))
+_GATHER_CANDIDATES = tuple((int(v), 0) for v in os.environ.get('MSMC_GATHER_VARIANTS', '1,2,3,4,5,8,9,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,34,35,40,41,42,43,44,45,46,47,50,56,59,60,61,63').split(','))
 _WGRAD_CANDIDATES = ((4, 0), (4, -1), (7, 0), (8, 0), (3, 0), (3, -1), (3, -2), (3, 1), (2, 0), (2, -1), (2, 1), (1, 0))
 TUNED = {}                                    # (kind, shape signature) -> (variant, split_shift, {candidate: ms})
 TUNE_CACHE = os.environ.get('MSMC_TUNE_CACHE', os.path.join(os.path.dirname(os.path.abspath(__file__)),
@@ -74,28 +74,55 @@ TUNE_CACHE = os.environ.get('MSMC_TUNE_CACHE', os.path.join(os.path.dirname(os.p
 
 def load_tuned(path=None):
     """Choices measured earlier on this GPU model (tools/tune_bench_shapes.py writes them): shapes found here skip
-    the timing launches; unseen shapes are still tuned on first use.  A missing or unreadable file is ignored."""
+    the timing launches; unseen shapes are still tuned on first use.  A missing or unreadable file is ignored.  Two files:
+    the DECISIONS (``tuned_gfx950.json``: one row per line, sorted by key -- a re-tune shows up in ``git diff`` as exactly the
+    decisions that changed) and, beside it, the candidates' timings the decisions were taken from
+    (``tuned_gfx950_timings.json``: optional, merged by ``tools/tune_bench_shapes.py`` when it re-times one kernel family)."""
     import json
+    path = path or TUNE_CACHE
     try:
-        with open(path or TUNE_CACHE) as f:
+        with open(path) as f:
             rows = json.load(f)['choices']
     except Exception:
         return
+    timings = {}
+    try:
+        with open(_timings_path(path)) as f:
+            timings = {repr(_thaw(r['key'])): r['ms'] for r in json.load(f)['timings']}
+    except Exception:
+        pass
     for row in rows:
         try:
-            TUNED[tuple(_thaw(row['key']))] = (int(row['variant']), int(row['split_shift']),
-                                               {tuple(_thaw(k)): v for k, v in row.get('ms', [])})
+            key = tuple(_thaw(row['key']))
+            ms = row.get('ms', timings.get(repr(key), []))          # ('ms' inside the row: the single-file format of rounds 1-4)
+            TUNED[key] = (int(row['variant']), int(row['split_shift']), {tuple(_thaw(k)): v for k, v in ms})
         except Exception:
             continue
 
 
+def _timings_path(path):
+    root, ext = os.path.splitext(path)
+    return root + '_timings' + ext
+
+
 def save_tuned(path=None):
     import json
-    rows = [dict(key=_freeze(k), variant=v[0], split_shift=v[1], ms=[[_freeze(c), t] for c, t in v[2].items()])
-            for k, v in sorted(TUNED.items(), key=lambda kv: repr(kv[0]))]
-    with open(path or TUNE_CACHE, 'w') as f:
-        json.dump(dict(device='gfx950', note='per-layer-shape kernel choices (msmc_conv_desc.variant / split_shift) '
-                       'timed on MI355X; regenerate with tools/tune_bench_shapes.py', choices=rows), f, indent=0)
+    path = path or TUNE_CACHE
+    items = sorted(TUNED.items(), key=lambda kv: repr(kv[0]))
+    enc = lambda o: json.dumps(o, separators=(',', ':'))
+    head = dict(device='gfx950', note='per-layer-shape kernel choices (msmc_conv_desc.variant / split_shift) timed on MI355X; '
+                'regenerate with tools/tune_bench_shapes.py; one decision per line, sorted by key; candidate timings in '
+                + os.path.basename(_timings_path(path)))
+    with open(path, 'w') as f:
+        f.write('{"device":%s,"note":%s,"choices":[\n' % (enc(head['device']), enc(head['note'])))
+        f.write(',\n'.join(enc(dict(key=_freeze(k), variant=v[0], split_shift=v[1])) for k, v in items))
+        f.write('\n]}\n')
+    with open(_timings_path(path), 'w') as f:
+        f.write('{"device":"gfx950","note":"milliseconds per candidate (variant, split_shift) behind the decisions of %s","timings":[\n'
+                % os.path.basename(path))
+        f.write(',\n'.join(enc(dict(key=_freeze(k), ms=[[_freeze(c), round(t, 5)] for c, t in sorted(v[2].items(), key=lambda ct: repr(ct[0]))]))
+                            for k, v in items))
+        f.write('\n]}\n')
 
 
 def _freeze(x):
@@ -463,7 +490,7 @@ def _snapshot(desc, stream):
 _GROUP_CODES = {'single': 0, 'group': 1, 'group4': 2, 'uniform': 3}
 # grouped forward / data-gradient calls whose members chose different kernel families become several launches; the tuner
 # also times the call with ONE variant imposed on every member (where all of them accept it): a single grid
-_UNIFORM_CANDIDATES = tuple(int(v) for v in os.environ.get('MSMC_UNIFORM_VARIANTS', '2,3,4,5,8,9,16,17,20,21,24,25,26,27,28,29,30,31,40,41,42,44,45,46,47,50,56,57,58,59,60,61,62,63').split(',') if v)
+_UNIFORM_CANDIDATES = tuple(int(v) for v in os.environ.get('MSMC_UNIFORM_VARIANTS', '2,3,4,5,8,9,16,17,20,21,24,25,26,27,28,29,30,31,40,41,42,44,45,46,47,50,56,59,60,61,63').split(',') if v)
 
 
 def _group_choice(kind, snaps, grouped_fn, single_fn, group4_fn=None, uniform_fn=None):

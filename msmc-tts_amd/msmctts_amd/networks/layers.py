@@ -1,9 +1,9 @@
 """Weight-normalised convolution layers holding the reference's parameter names.
 
-These modules are parameter holders: inside the HifiGAN generator and the discriminators the arithmetic
-runs through ``hip_layer()`` on the gfx950 implicit-GEMM kernels (msmctts_amd/hip/convnet.py).  Their
-``forward`` (stock ATen ops) serves the small prior-predictor stack, which SURVEY.md 8a leaves on
-PyTorch-ROCm operators in this round.
+These modules are parameter holders: inside the HifiGAN generator, the discriminators and the quantiser's prior predictor
+the arithmetic runs through ``hip_layer()`` on the gfx950 implicit-GEMM kernels (msmctts_amd/hip/convnet.py).  Their
+``forward`` (stock ATen operators) is reached only by the ``norm=True`` variant of the multi-stage quantiser, which no shipped
+configuration selects (networks/vqgantts/msmc_vqgan.py ``use_hip``).
 
 The reference wraps ``torch.nn.Conv*`` in old-style ``torch.nn.utils.weight_norm`` (e.g.
 hifigan/common.py:24-41, generator.py:22-35, discriminator.py:23-25,125-132, vqgantts/modules.py:209-226),

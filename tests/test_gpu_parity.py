@@ -319,11 +319,13 @@ def test_reducer_waits_for_the_stream_a_bank_delivered_its_gradients_on():
     port = s.getsockname()[1]
     s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
+    head = (
         "import sys, torch, torch.distributed as dist\n"
         "sys.path[:0] = [%r, %r, %r]\n"
         "torch.cuda.set_device(0)\n"
         "dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d', world_size=1, rank=0)\n"
+        % (root, os.path.join(root, 'msmc-tts_amd'), os.path.join(root, 'tests'), port))
+    code = head + (
         "import _parity\n"
         "from msmctts_amd.distributed import distributed\n"
         "distributed.DEFAULT_BUCKET_BYTES = 64 * 1024\n"
@@ -332,7 +334,7 @@ def test_reducer_waits_for_the_stream_a_bank_delivered_its_gradients_on():
         "assert convnet.FINISH_SIDE and convnet.EARLY_FINISH\n"
         "_parity.check_train_steps('cuda:0', arm_reducer=True)\n"
         "dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()\n"
-        "print('DELAYED-OK')\n" % (root, os.path.join(root, 'msmc-tts_amd'), os.path.join(root, 'tests'), port))
+        "print('DELAYED-OK')\n")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and 'DELAYED-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

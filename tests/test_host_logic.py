@@ -285,3 +285,34 @@ def test_the_reference_yaml_files_load_unchanged(name, mode, children):
     if name == 'msmc_vq_gan.yaml':
         want = json.load(open(os.path.join(GOLDEN, 'schedule.json')))['csmsc_state_dict']
         assert want == [[k, list(v.shape)] for k, v in sd.items()]
+
+
+def test_interpreter_runtime_declares_the_same_primitives_as_the_gfx950_runtime():
+    """tests/emu/msmc_rt.hpp is a hand-kept CPU twin of csrc/gfx950/msmc_rt.hpp (the kernels include whichever the build
+    puts on the include path): every device primitive, macro and vector type one of them declares must exist in the other,
+    so that a primitive added for a new kernel cannot silently be missing -- or mean something else by accident of a stale
+    copy -- on the interpreter.  (Internals of the gfx950 file that kernels never call are listed.)"""
+    def names(path):
+        s = open(path).read()
+        fn = set(re.findall(r'MSMC_DEV(?:_INLINE)?\s+[\w:<>\*& ]+?\s+(\w+)\s*\(', s))
+        mac = set(re.findall(r'#define\s+(MSMC_\w+)', s))
+        typ = set(re.findall(r'typedef\s+[^;]*?\s(\w+)\s+__attribute__', s))
+        return s, fn, mac, typ
+    gs, gfn, gmac, gtyp = names(os.path.join(ROOT, 'msmc-tts_amd', 'csrc', 'gfx950', 'msmc_rt.hpp'))
+    es, efn, emac, etyp = names(os.path.join(ROOT, 'tests', 'emu', 'msmc_rt.hpp'))
+    internal = {'wave_dpp_t', 'wave_xor16_u', 'wave_xor32_u'}           # building blocks of wave_sum / wave_xor16 / wave_xor32
+    local_types = {'bf16x2_', 'f32x2_', 's16x4_'}                       # typedefs inside function bodies
+    missing = [n for n in sorted(gfn - internal) if not re.search(r'\b%s\s*\(' % n, es)]
+    assert not missing, 'primitives of the gfx950 runtime the interpreter does not provide: %s' % missing
+    extra = [n for n in sorted(efn) if not re.search(r'\b%s\s*\(' % n, gs)]
+    assert not extra, 'interpreter-only primitives (a kernel using one would not build for the GPU): %s' % extra
+    assert gmac == emac, (sorted(gmac - emac), sorted(emac - gmac))
+    assert gtyp - local_types == etyp - local_types, (sorted(gtyp - etyp), sorted(etyp - gtyp))
+    # every primitive the kernel sources call is one both files know
+    csrc = os.path.join(ROOT, 'msmc-tts_amd', 'csrc')
+    used = set()
+    for f in os.listdir(csrc):
+        if f.endswith(('.hip', '.inc')):
+            text = open(os.path.join(csrc, f)).read()
+            used |= {n for n in gfn if re.search(r'\b%s\s*(<[^;(]*>)?\s*\(' % n, text)}
+    assert len(used) >= 25, sorted(used)

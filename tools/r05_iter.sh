@@ -11,8 +11,8 @@ shift
 for what in "$@"; do
 case $what in
 micro)
-  VARIANTS="${VARIANTS:-40 41 42 44 45 46 56 57 58 59 60 61 62 63}" env -u ABLATE python tools/bench_gather3.py ${FILTER:-} 2>&1 | grep -v "^thin" > gpurun_out/${TAG}_gather7_microbench.txt
-  ABLATE="${ABLATE:-56 57 58}" ABLS="0 2 4 8 32 46" python tools/bench_gather3.py ffn >> gpurun_out/${TAG}_gather7_microbench.txt 2>&1
+  VARIANTS="${VARIANTS:-40 41 42 44 45 46 56 59 60 61 63}" env -u ABLATE python tools/bench_gather3.py ${FILTER:-} 2>&1 | grep -v "^thin" > gpurun_out/${TAG}_gather7_microbench.txt
+  ABLATE="${ABLATE:-56 59 63}" ABLS="0 2 4 8 32 46" python tools/bench_gather3.py ffn >> gpurun_out/${TAG}_gather7_microbench.txt 2>&1
   cat gpurun_out/${TAG}_gather7_microbench.txt ;;
 conv)
   timeout 900 python -m pytest tests/test_gpu_conv.py -m gpu -x -q 2>&1 | tail -5 ;;

@@ -4,7 +4,7 @@ GPU test-suite's layer cases) and write the choices to msmctts_amd/hip/tuned_gfx
 RETUNE=wgrad4 keeps the committed table and re-times only the single-launch bf16 weight gradients the fourth-generation
 kernel can serve (one pass).  RETUNE=gather3x keeps it too and times only the LDS-DMA halo variants (24..31) of every bf16
 forward / data-gradient shape, merging them with the committed timings of the other candidates; RETUNE=gather4 does the
-same for the persistent thin-layer kernel (variant 32), RETUNE=gemm1 for the 1-tap GEMM kernel (variant 34), RETUNE=gather5 for the sixteen-wave staged-tap kernel (variants 40..47), RETUNE=gather7 for the eight-wave 64 x 64-per-wave kernel (variants 56..63), RETUNE=wgrad6 for the direct thin-layer weight gradient (variant 8) and RETUNE=wgrad5 for the general-lattice LDS-DMA weight gradient
+same for the persistent thin-layer kernel (variant 32), RETUNE=gemm1 for the 1-tap GEMM kernel (variant 34), RETUNE=gather5 for the sixteen-wave staged-tap kernel (variants 40..47), RETUNE=gather7 for the eight-wave 64 x 64-per-wave kernel (variants 56, 59, 60, 61, 63), RETUNE=wgrad6 for the direct thin-layer weight gradient (variant 8) and RETUNE=wgrad5 for the general-lattice LDS-DMA weight gradient
 (variant 7; the grouped calls whose members change are re-timed by the run itself).  RETUNE=new keeps every decision
 on file and only adds the shapes and grouped calls the run meets for the first time (after a change of how the step
 groups its launches, e.g. MSMC_WGRAD_BATCH).  RETUNE=all times every decision the run meets again (two passes, the faster
@@ -69,7 +69,7 @@ if RETUNE == 'gather5':                                   # sixteen-wave staged-
             if k[0] == 'gather' and k[1] == 1 and k[5] % 64 == 0 and k[15] >= 2}
     print('timing the fifth-generation forward / data-gradient kernel on %d shapes' % len(kept))
 if RETUNE == 'gather7':                                   # eight-wave 64 x 64-per-wave kernel (variants 56..63): the same scope
-    conv._GATHER_CANDIDATES = tuple((v, 0) for v in range(56, 64))
+    conv._GATHER_CANDIDATES = tuple((v, 0) for v in (56, 59, 60, 61, 63))
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
             if k[0] == 'gather' and k[1] == 1 and k[5] % 64 == 0 and k[15] >= 2}
     print('timing the seventh-generation forward / data-gradient kernel on %d shapes' % len(kept))
