@@ -593,23 +593,17 @@ def summarize_kernels(timer, dtype, nsteps, ms_per_step):
     return kernels, roof, step_roof
 
 
-def bench_predictor(args, device, wd):
-    """--config 4 (BASELINE.json: CSMSC msmc_vq_gan_am.yaml, predictor training, one GPU): one step = one
-    ``PredictorTrainer.train_step`` (reference msmctts_trainer.py:222-286) -- analysis of the mel batch by the frozen autoencoder
-    (configuration #2's architecture, random weights, eval mode), text -> per-stage predictions through the 600-wide FFT stacks,
-    'mse' + 'triple_sum' embedding losses and the duration loss, backward, clipping, Adam.  Same line layout as the headline:
-    value = mel frames of the batch per second, roofline of the dominant hand-written kernel from the instrumented steps,
-    cpu_baseline = oracle/predictor.py (plain PyTorch fp32) on the first utterances of the same batch."""
-    import random
-    from msmctts_amd.configs import BASELINE_CONFIGS, am_config, csmsc_config
-    from msmctts_amd.hip import convnet, lib
+def build_predictor(args, device):
+    """trainer, predictor task, frozen autoencoder task, their configurations and one synthetic batch (device / host copies) of
+    BASELINE configuration #4 (also used by tools/tune_bench_shapes.py CONFIG=4)"""
+    from msmctts_amd.configs import am_config, csmsc_config
     from msmctts_amd.synthetic import make_batch, make_text_batch
     from msmctts_amd.tasks import build_task
     from msmctts_amd.trainers import build_trainer
     from msmctts_amd.trainers.optimizers import build_optimizer
     from msmctts_amd.utils.config import Config
-    preset = BASELINE_CONFIGS[4]
-    acfg = Config(csmsc_config(batch_size=args.batch, warmup_steps=0, **args.model_kw))
+    model_kw = getattr(args, 'model_kw', None) or dict(n_heads=args.heads, embedding_sizes=args.codewords)
+    acfg = Config(csmsc_config(batch_size=args.batch, warmup_steps=0, **model_kw))
     torch.manual_seed(acfg.seed)
     atask = build_task(acfg, mode='train').to(device).eval()
     cfg = Config(am_config(batch_size=args.batch))
@@ -623,9 +617,24 @@ def bench_predictor(args, device, wd):
         if hasattr(m, 'hip_dtype'):
             m.hip_dtype = tr.amp_dtype or torch.float32
     cpu_batch = make_batch(args.batch, args.frames, 80, 300, seed=1234, rank=0, device='cpu')
-    cpu_batch.pop('wav'); cpu_batch.pop('wav_length')
+    cpu_batch.pop('wav')
+    cpu_batch.pop('wav_length')
     cpu_batch.update(make_text_batch(cpu_batch['mel_length'].tolist()))
     batch = {k: v.to(device) for k, v in cpu_batch.items()}
+    return tr, task, atask, cfg, acfg, batch, cpu_batch
+
+
+def bench_predictor(args, device, wd):
+    """--config 4 (BASELINE.json: CSMSC msmc_vq_gan_am.yaml, predictor training, one GPU): one step = one
+    ``PredictorTrainer.train_step`` (reference msmctts_trainer.py:222-286) -- analysis of the mel batch by the frozen autoencoder
+    (configuration #2's architecture, random weights, eval mode), text -> per-stage predictions through the 600-wide FFT stacks,
+    'mse' + 'triple_sum' embedding losses and the duration loss, backward, clipping, Adam.  Same line layout as the headline:
+    value = mel frames of the batch per second, roofline of the dominant hand-written kernel from the instrumented steps,
+    cpu_baseline = oracle/predictor.py (plain PyTorch fp32) on the first utterances of the same batch."""
+    from msmctts_amd.configs import BASELINE_CONFIGS, am_config
+    from msmctts_amd.hip import convnet, lib
+    preset = BASELINE_CONFIGS[4]
+    tr, task, atask, cfg, acfg, batch, cpu_batch = build_predictor(args, device)
     frames_per_step = float(cpu_batch['mel_length'].sum())
     timer, register_banks = make_timer()
 

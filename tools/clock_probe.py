@@ -2,8 +2,8 @@
 """GPU probe: where a seventh-generation forward-convolution launch spends its time.  Needs a probe build of the library
 (csrc/conv.hip compiled with -DCV7_CLOCKS, linked as lib/libmsmc_hip_clk.so: tools/r05_clock_probe.sh): with bit 64 of the
 diagnostics mask the kernel stamps the shader clock at its phase boundaries per workgroup.  Prints, per (shape, variant):
-the launch's wall time between the first workgroup's entry and the last one's exit, the distribution of the phases (table
-build, first data landed, main loop, exchange, epilogue incl. store drain), the workgroups' start skew and how many share a CU.
+the distribution over the workgroups of the phases (entry -> first requests issued, first data landed, main loop, exchange of
+the contraction groups, epilogue incl. store drain) as min / median / max shader cycles.
 
     MSMC_PROBE_LIB=msmc-tts_amd/lib/libmsmc_hip_clk.so python tools/clock_probe.py [filter]
 """
@@ -57,16 +57,10 @@ for name, B, Cin, Cout, H, W, k, s_, dil, pad, reflect, slope in SHAPES:
             torch.cuda.synchronize()
             st = stamps.cpu()
             st = st[st[:, 0] != 0]
-            t0 = st[:, 0].min()
-            rel = (st[:, :6] - t0).double()
-            hw, xcc = st[:, 7], st[:, 6] & 15
-            cu = (xcc * 65536 + ((hw >> 8) & 0xffff)).tolist()
-            per_cu = {}
-            for c in cu:
-                per_cu[c] = per_cu.get(c, 0) + 1
+            # (the shader clock is per XCD: only differences INSIDE a workgroup are meaningful -- no launch-wide total, no start skew)
+            rel = (st[:, :6] - st[:, :1]).double()
             q = lambda t: '%6.0f/%6.0f/%6.0f' % (t.min().item(), t.median().item(), t.max().item())
-            print('%-26s v%d abl%-3d wgs %4d on %3d CUs (max %d per CU) | total %7.0f clk | start skew %s | tables %s | first data %s | '
-                  'loop %s | exchange %s | epilogue %s' % (
-                      name, v, abl, st.shape[0], len(per_cu), max(per_cu.values()), rel[:, 5].max().item(), q(rel[:, 0]),
-                      q(rel[:, 1] - rel[:, 0]), q(rel[:, 2] - rel[:, 1]), q(rel[:, 3] - rel[:, 2]), q(rel[:, 4] - rel[:, 3]),
-                      q(rel[:, 5] - rel[:, 4])), flush=True)
+            print('%-26s v%d abl%-3d workgroups %4d | requests issued %s | first data %s | loop %s | exchange %s | epilogue + store drain %s | '
+                  'workgroup total %s' % (
+                      name, v, abl, st.shape[0], q(rel[:, 1] - rel[:, 0]), q(rel[:, 2] - rel[:, 1]), q(rel[:, 3] - rel[:, 2]),
+                      q(rel[:, 4] - rel[:, 3]), q(rel[:, 5] - rel[:, 4]), q(rel[:, 5])), flush=True)

@@ -8,7 +8,9 @@ same for the persistent thin-layer kernel (variant 32), RETUNE=gemm1 for the 1-t
 (variant 7; the grouped calls whose members change are re-timed by the run itself).  RETUNE=new keeps every decision
 on file and only adds the shapes and grouped calls the run meets for the first time (after a change of how the step
 groups its launches, e.g. MSMC_WGRAD_BATCH).  RETUNE=all times every decision the run meets again (two passes, the faster
-measurement of each candidate) and replaces those entries, keeping the entries of shapes it does not meet."""
+measurement of each candidate) and replaces those entries, keeping the entries of shapes it does not meet.
+CONFIG=4 (with RETUNE=new) runs the predictor step of BASELINE configuration #4 (600 / 1536-wide FFT stacks at B = 64) instead of
+the GAN-phase step and adds its shapes."""
 import os, sys, random, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd'), os.path.join(ROOT, 'tests')]
@@ -99,16 +101,23 @@ for rep in range(1 if (RETUNE and RETUNE != 'all') else 2):                     
     saved = dict(conv.TUNED)
     if not RETUNE or RETUNE == 'all':
         conv.TUNED.clear()
-    cfg, trainer = bench.build(A, dev, 0, 1)
-    batch = make_batch(A.batch, A.frames, 80, 300, seed=1234, rank=0, device='cpu')
-    lengths = batch['mel_length'].tolist()
-    batch = {k: v.to(dev) for k, v in batch.items()}
-    batch['mel_length_host'] = lengths
-    trainer.rng = random.Random(1234)
-    for i in range(2):
-        trainer.model.zero_grad()
-        trainer.optimizer.zero_grad()
-        trainer.train_step(batch, 10 + i)
+    if os.environ.get('CONFIG', '2') == '4':                # BASELINE configuration #4: the predictor step (bench.py --config 4)
+        A.batch = 64
+        trainer, task4, _, _, _, batch, _ = bench.build_predictor(A, dev)
+        for i in range(2):
+            task4.zero_grad()
+            trainer.train_step(batch, i)
+    else:
+        cfg, trainer = bench.build(A, dev, 0, 1)
+        batch = make_batch(A.batch, A.frames, 80, 300, seed=1234, rank=0, device='cpu')
+        lengths = batch['mel_length'].tolist()
+        batch = {k: v.to(dev) for k, v in batch.items()}
+        batch['mel_length_host'] = lengths
+        trainer.rng = random.Random(1234)
+        for i in range(2):
+            trainer.model.zero_grad()
+            trainer.optimizer.zero_grad()
+            trainer.train_step(batch, 10 + i)
     torch.cuda.synchronize()
     for k, v in saved.items():
         if k in conv.TUNED:
