@@ -901,6 +901,9 @@ def main():
                          'step with bucketed all-reduce overlapped with backward')
     ap.add_argument('--graph', action='store_true', help='same as --exec graph')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend (gloo: --dry only)')
+    ap.add_argument('--share-gpu', action='store_true',
+                    help='TEST MODE (tests/test_gpu_parity.py): the N ranks share the visible GPUs round robin and exchange over gloo '
+                         '(--backend gloo) -- the whole N > 1 code path of this file on a one-GPU box; its numbers are not a measurement')
     ap.add_argument('--dry', action='store_true',
                     help='launcher / process-group / gradient-reducer check on a toy model (runs on CPU with --backend gloo); not a benchmark')
     ap.add_argument('--job-timeout', type=int, default=int(os.environ.get('MSMC_BENCH_JOB_TIMEOUT', '1500')),
@@ -942,8 +945,11 @@ def main():
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (torch.distributed.run --nproc-per-node must match)' % (args.gpus, world))
     wd = Watchdog(args.stall_timeout, rank)
-    if args.backend == 'gloo' and not args.dry:
-        raise SystemExit('bench.py: --backend gloo is for --dry (the product path has no CPU execution path)')
+    if args.backend == 'gloo' and not (args.dry or args.share_gpu):
+        raise SystemExit('bench.py: --backend gloo is for --dry (the product path has no CPU execution path) or --share-gpu (test mode)')
+    if args.share_gpu and (args.backend != 'gloo' or args.exchange != 'serial'):
+        raise SystemExit('bench.py: --share-gpu needs --backend gloo and the serial exchange (RCCL refuses two ranks on one device; '
+                         'gloo collectives cannot be captured)')
     if args.dry and args.backend == 'gloo':
         if world > 1:
             import datetime
@@ -955,11 +961,13 @@ def main():
         sys.exit(rc)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the product path has no CPU fallback)')
+    if args.share_gpu:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         import datetime
-        dist.init_process_group('nccl', init_method='env://', world_size=world, rank=rank,
+        dist.init_process_group(args.backend, init_method='env://', world_size=world, rank=rank,
                                 timeout=datetime.timedelta(seconds=max(10, args.stall_timeout)))
     if args.dry:
         rc = dry_run(args, rank, world, wd)
@@ -1031,7 +1039,7 @@ def main():
         '''(max over ranks, per-rank ms/step)'''
         if world == 1:
             return dt, [dt / args.steps * 1e3]
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt], device=device if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
         every = [torch.zeros_like(tt) for _ in range(world)]
         dist.all_gather(every, tt)
         return max(float(t) for t in every), [float(t) / args.steps * 1e3 for t in every]
@@ -1135,7 +1143,7 @@ def main():
     kernels, roof, step_roof = summarize_kernels(timer, args.dtype, args.kernel_timing_steps, ms_per_step)
     out = {
         'metric': 'mel-frames/sec MSMC-VQ-GAN train step (GAN phase)', 'value': value, 'unit': 'mel-frames/s',
-        'n_gpus': world, 'world_size_seen': dist.get_world_size() if world > 1 else 1, 'backend': 'nccl (RCCL)' if world > 1 else None,
+        'n_gpus': world, 'world_size_seen': dist.get_world_size() if world > 1 else 1, 'backend': ('nccl (RCCL)' if args.backend == 'nccl' else 'gloo, ranks sharing a GPU (test mode: not a measurement)') if world > 1 else None,
         'per_rank_ms_per_step': per_rank_ms, 'exchange_modes': exchange_modes,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'ms_per_step_median': ms_median, 'ms_per_step_min': per_step[0], 'ms_per_step_max': per_step[-1],

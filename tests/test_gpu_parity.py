@@ -430,3 +430,26 @@ def test_split_bf16_constant_matrix_gemm_and_spectral_chain():
 
 def test_wave_fan_out_matches_cast_pad_and_gradient_accumulation():
     _parity.check_wave_fan(DEV)
+
+
+def test_bench_two_ranks_sharing_the_gpu_run_the_whole_data_parallel_path():
+    """``python bench.py --gpus 2`` the way the driver starts the one-GPU line (WORLD_SIZE unset: the launcher starts the
+    ranks), on a ONE-GPU box: ``--share-gpu --backend gloo`` puts both ranks on the device and exchanges over gloo, so every
+    N > 1 branch of bench.py and of the trainer runs -- start-up broadcast, capture with a process group alive, the flat
+    gradient exchange between the replayed segments, barrier + max-over-ranks timing, one rank-0 line.  The numbers are not a
+    measurement (the ranks share the chip); the line's shape and the ranks' lock step are what is checked."""
+    import json, subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--share-gpu', '--backend', 'gloo', '--batch', '4',
+                          '--steps', '3', '--warmup', '2', '--no-microbench', '--cpu-steps', '0', '--fp32-steps', '0',
+                          '--kernel-timing-steps', '0', '--warmup-phase-steps', '0', '--stall-timeout', '240', '--job-timeout', '500'],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['world_size_seen'] == 2 and 'gloo' in line['backend']
+    assert len(line['per_rank_ms_per_step']) == 2 and all(t > 0 for t in line['per_rank_ms_per_step'])
+    assert line['config']['global_batch'] == 8 and line['config']['gradient_exchange'] == 'serial' and line['config']['parallelism'] == 'dp2'
+    assert line['value'] > 0 and all(v == v for v in line['losses'].values())
