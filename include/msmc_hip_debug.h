@@ -3,8 +3,8 @@
  * Process-global A/B switches, ablation masks and the profiling observers that libmsmc_hip.so also exports for the perf
  * tools (tools/), bench.py's per-kernel table, the CPU kernel-interpreter tests and the forced-variant GPU tests.  A production caller never
  * includes this header: every kernel choice that matters to a caller is per call (msmc_conv_desc.variant / split_shift),
- * and the product package (msmc-tts_amd/msmctts_amd) touches none of these except the two environment-driven sweeps read
- * once in hip/lib.py (MSMC_WGRAD_TPW, MSMC_GATHER4_GROUPING).  All switches are plain ints read at launch time.
+ * and the product package (msmc-tts_amd/msmctts_amd) touches none of these.
+ * All switches are plain ints read at launch time.
  */
 #ifndef MSMC_HIP_DEBUG_H
 #define MSMC_HIP_DEBUG_H

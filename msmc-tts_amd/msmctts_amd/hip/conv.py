@@ -65,7 +65,8 @@ _PLANS = {}
 # (msmc_conv_desc.variant / .split_shift) once and keeps the fastest -- tile heuristics cannot see L2 / LDS effects
 # that differ by 2x between layers of equal arithmetic.  Off inside hipGraph capture and on the interpreter.
 AUTOTUNE = os.environ.get('MSMC_AUTOTUNE', '1') != '0'
-_GATHER_CANDIDATES = tuple((int(v), 0) for v in os.environ.get('MSMC_GATHER_VARIANTS', '1,2,3,4,5,8,9,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,34,35,40,41,42,43,44,45,46,47,50,56,59,60,61,63').split(','))
+_GATHER_CANDIDATES = tuple((v, 0) for v in (1, 2, 3, 4, 5, 8, 9, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 34, 35,
+                                             40, 41, 42, 43, 44, 45, 46, 47, 50, 56, 59, 60, 61, 63))
 _WGRAD_CANDIDATES = ((4, 0), (4, -1), (7, 0), (8, 0), (3, 0), (3, -1), (3, -2), (3, 1), (2, 0), (2, -1), (2, 1), (1, 0))
 TUNED = {}                                    # (kind, shape signature) -> (variant, split_shift, {candidate: ms})
 TUNE_CACHE = os.environ.get('MSMC_TUNE_CACHE', os.path.join(os.path.dirname(os.path.abspath(__file__)),
@@ -236,7 +237,7 @@ def _gather(desc, stream, what):
 # ``DeferredReduce`` armed (``DEFER_TO``; hip/convnet.py arms the ConvBank's around its backward launches) the calls
 # run their first stage into an arena that lives until the end of the backward pass, and ``flush`` adds everything up in
 # ceil(records / 16) launches (msmc_conv_wgrad_reduce_pending) -- same sums, same order, bit-identical results.
-DEFER = os.environ.get('MSMC_WGRAD_DEFER', '1') != '0'
+DEFER = True                 # (module switch for A/B runs from tools/: False reduces every weight gradient at once)
 DEFER_TO = None             # the DeferredReduce the running weight-gradient calls record into (None: reduce at once)
 
 
@@ -490,7 +491,7 @@ def _snapshot(desc, stream):
 _GROUP_CODES = {'single': 0, 'group': 1, 'group4': 2, 'uniform': 3}
 # grouped forward / data-gradient calls whose members chose different kernel families become several launches; the tuner
 # also times the call with ONE variant imposed on every member (where all of them accept it): a single grid
-_UNIFORM_CANDIDATES = tuple(int(v) for v in os.environ.get('MSMC_UNIFORM_VARIANTS', '2,3,4,5,8,9,16,17,20,21,24,25,26,27,28,29,30,31,40,41,42,44,45,46,47,50,56,59,60,61,63').split(',') if v)
+_UNIFORM_CANDIDATES = (2, 3, 4, 5, 8, 9, 16, 17, 20, 21, 24, 25, 26, 27, 28, 29, 30, 31, 40, 41, 42, 44, 45, 46, 47, 50, 56, 59, 60, 61, 63)
 
 
 def _group_choice(kind, snaps, grouped_fn, single_fn, group4_fn=None, uniform_fn=None):

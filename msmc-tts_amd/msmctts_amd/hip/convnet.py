@@ -29,7 +29,7 @@ from . import lib
 # data-parallel reducer that a parameter gradient produced outside autograd's accumulation is ready.
 GRAD_READY_HOOK = None
 
-DW_COPIES = int(os.environ.get('MSMC_DW_COPIES', '8'))
+DW_COPIES = 8
 DW_COPIES_MAX_ELEMS = 256 * 1024
 
 # False: fork_join runs its branches back to back on the calling stream (bench.py's per-kernel timing pass)

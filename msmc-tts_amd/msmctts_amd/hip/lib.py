@@ -212,11 +212,6 @@ def get():
     global _lib
     if _lib is None:
         _lib = load()
-        cap = os.environ.get('MSMC_WGRAD_TPW')          # perf sweeps (tools/): accumulators per wave of the weight gradient
-        if cap:
-            _lib.msmc_conv_set_wgrad_tpw(int(cap))
-        if os.environ.get('MSMC_GATHER4_GROUPING'):     # (A/B: variant-32 members of a grouped call on one persistent grid)
-            _lib.msmc_conv_set_gather4_grouping(int(os.environ['MSMC_GATHER4_GROUPING']))
     return _lib
 
 

@@ -15,8 +15,8 @@ from . import lib
 # serves the shapes it takes once frames x codewords reaches SHORTLIST_MIN_WORK -- measured cross-over against the exact
 # register-resident kernel on MI355X (profiles/r03_vq_shortlist.md: K = 64 from 131 072 frames, K = 256 from 32 768,
 # K = 512 from 16 384; below it the eight-wave workgroups leave most of the chip idle and the exact kernel's smaller tiles
-# win); below that, and for every other shape, the exact kernel runs.  MSMC_VQ_SHORTLIST=0 turns it off.
-SHORTLIST = os.environ.get('MSMC_VQ_SHORTLIST', '1') != '0'
+# win); below that, and for every other shape, the exact kernel runs (``SHORTLIST = False`` from a tool or test turns it off).
+SHORTLIST = True
 SHORTLIST_MIN_WORK = int(os.environ.get('MSMC_VQ_SHORTLIST_MIN_WORK', str(1 << 23)))
 SLOW_COUNT = None           # tests / bench: an int64 [2] device tensor counting 16-frame tiles (per head) that took the
                             # two-candidate exact re-rank [0] / the full exact re-search [1]

@@ -882,3 +882,69 @@ def check_wave_fan(dev):
             loss.backward()                      # (the last copy has no consumer: its gradient arrives as None)
             lref.backward()
             close(y.grad, yr.grad, tol * max(1.0, float(yr.grad.abs().max())), what='wave fan gradient')
+
+
+def check_reducer_stream_order(device, delay_cycles=int(2e8)):
+    """A stock module FOLLOWED by a convolution bank in one reducer bucket, the way predictor-style models are built (stock
+    ``nn.Linear`` between bank-backed stacks): in the backward pass the bank delivers its gradients EARLY from its side stream
+    (hip/convnet.py FINISH_SIDE) -- held back here by ``delay_cycles`` on that stream -- and the stock module's gradients
+    arrive afterwards on the calling stream and complete the bucket there.  Returns the largest deviation of the averaged
+    gradients (one rank: the identity) from the same backward without a reducer.  Needs an initialised process group."""
+    import torch.nn as nn
+    from msmctts_amd.distributed.distributed import GradReducer
+    from msmctts_amd.hip import convnet
+    from msmctts_amd.networks.layers import WNConv1d
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.pre = nn.Linear(64, 64)                    # stock operator: its gradients are ready on the calling stream
+            self.conv = WNConv1d(64, 64, 3, padding=1)      # convolution bank: gradients delivered by hand
+            self._layer = self.conv.hip_layer()
+            self._bank = convnet.ConvBank([self._layer])
+
+        def forward(self, x):
+            self._bank.prepare(torch.float32)
+            return convnet.hip_conv(self._bank, self._layer, self.pre(x).unsqueeze(1).contiguous())
+
+    torch.manual_seed(11)
+    model = nn.ModuleDict({'net': Net()}).to(device)
+    x = torch.randn(4, 200, 64, device=device)
+    go = torch.randn(4, 1, 200, 64, device=device)
+
+    def grads():
+        model.zero_grad()
+        (model['net'](x) * go).sum().backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    want = grads()                                          # no reducer, no delay
+    assert convnet.FINISH_SIDE and convnet.EARLY_FINISH and convnet.STREAMS_ENABLED
+    seen = []
+    orig = convnet.ConvBank._finish_backward
+
+    def slow(self, early=False):
+        if early and self.w1.is_cuda:
+            seen.append(torch.cuda.current_stream(self.w1.device))
+            torch.cuda._sleep(delay_cycles)                 # the delivery's launches sit behind this on the side stream
+        return orig(self, early=early)
+    reducer = GradReducer(model, bucket_bytes=1 << 30)      # everything in ONE bucket
+    keep_hook = convnet.GRAD_READY_HOOK
+    convnet.GRAD_READY_HOOK = reducer._on_grad
+    convnet.ConvBank._finish_backward = slow
+    try:
+        for p in model.parameters():                        # poison what a too-early concatenation would read
+            if p.grad is not None:
+                p.grad.fill_(float('nan'))
+        model.zero_grad()
+        (model['net'](x) * go).sum().backward()
+        reducer.finish()
+        torch.cuda.synchronize()
+    finally:
+        convnet.ConvBank._finish_backward = orig
+        convnet.GRAD_READY_HOOK = keep_hook
+    assert seen and seen[0] != torch.cuda.current_stream(torch.device(device)), 'the bank did not deliver early from a side stream'
+    worst = 0.0
+    for n, p in model.named_parameters():
+        err = (p.grad - want[n]).abs().max().item()
+        worst = max(worst, float('inf') if err != err else err / max(1e-6, want[n].abs().max().item()))
+    return worst

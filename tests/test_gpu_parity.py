@@ -296,48 +296,34 @@ def test_rccl_gradient_reducer_single_rank_matches_reference():
     assert out.returncode == 0 and 'REDUCER-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
-DELAYED_DELIVERY = (
-    "from msmctts_amd.hip import convnet\n"
-    "_orig_finish = convnet.ConvBank._finish_backward\n"
-    "def _slow_finish(self, early=False):\n"
-    "    if early and self.w1.is_cuda:\n"
-    "        torch.cuda._sleep(int(2e8))      # the early delivery's launches sit ~0.1 s behind the host (on the side stream)\n"
-    "    return _orig_finish(self, early)\n"
-    "convnet.ConvBank._finish_backward = _slow_finish\n")
-
-
 def test_reducer_waits_for_the_stream_a_bank_delivered_its_gradients_on():
     """A bucket that mixes convolution-bank parameters (gradients delivered EARLY, from a side stream of the bank's own:
     hip/convnet.py FINISH_SIDE) with parameters of stock modules (ready on the calling stream) must not be concatenated
-    before the side stream has written the bank's gradients (round-4 review).  Here every early delivery is held back by a
-    0.1 s sleep on its stream while the host -- and the calling stream -- run on: the golden eager steps with the reducer
-    armed (RCCL, one rank: averaging is the identity) must still match the reference's losses, gradients and post-step
-    parameters.  Buckets of 64 KB so that many of them complete on the calling stream."""
+    before the side stream has written the bank's gradients (round-4 review).  ``_parity.check_reducer_stream_order``: a
+    stock ``nn.Linear`` in front of a one-layer convolution bank, ONE bucket, the bank's early delivery held back 0.1 s on its
+    stream, its gradient buffers poisoned with NaN beforehand -- the bucket completes on the calling stream when the Linear's
+    gradients arrive.  RCCL at world size 1 (averaging is the identity) in a subprocess with a hard timeout.
+    ``tools/probes/reducer_race_probe.py`` is the same scenario with round 4's reducer."""
     import subprocess, sys, os, socket
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    head = (
+    code = (
         "import sys, torch, torch.distributed as dist\n"
         "sys.path[:0] = [%r, %r, %r]\n"
         "torch.cuda.set_device(0)\n"
         "dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d', world_size=1, rank=0)\n"
-        % (root, os.path.join(root, 'msmc-tts_amd'), os.path.join(root, 'tests'), port))
-    code = head + (
         "import _parity\n"
-        "from msmctts_amd.distributed import distributed\n"
-        "distributed.DEFAULT_BUCKET_BYTES = 64 * 1024\n"
-        "distributed.apply_gradient_allreduce.__defaults__ = (64 * 1024, None)\n"
-        + DELAYED_DELIVERY +
-        "assert convnet.FINISH_SIDE and convnet.EARLY_FINISH\n"
-        "_parity.check_train_steps('cuda:0', arm_reducer=True)\n"
+        "worst = _parity.check_reducer_stream_order('cuda:0')\n"
         "dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()\n"
-        "print('DELAYED-OK')\n")
+        "print('WORST %%.3e' %% worst)\n"
+        "assert worst < 1e-5, worst\n"
+        "print('ORDERED-OK')\n" % (root, os.path.join(root, 'msmc-tts_amd'), os.path.join(root, 'tests'), port))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env)
-    assert out.returncode == 0 and 'DELAYED-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.returncode == 0 and 'ORDERED-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
 def test_multi_resolution_stft_loss_matches_reference():
