@@ -256,6 +256,7 @@ def abi_work_models():
             (0.0, float(B * C * ((H + 2 * p) * (W + 2 * p) + H * W * (2 if mask else 1)) * E(dt))),
         'msmc_colsum': lambda g, out, rows, C, dt, st: (0.0, float(rows * C * E(dt) + 4 * C)),
         'msmc_colsum_ws': lambda g, out, rows, C, dt, acc, ws, wsb, st: (0.0, float(rows * C * E(dt) + 4 * C)),
+        'msmc_triple_loss': lambda p, trg, et, en, lossh, gp, N, D, H, K, margin, mean, st: (4.0 * _val(N) * _val(D) * _val(K), 8.0 * _val(N) * _val(D)),
         'msmc_masked_mean_fwd': lambda a, b, ln, l64, B, T, C, adt, bdt, mode, part, out, st:
             (0.0, float(B * T * C * (E(adt) + (E(bdt) if mode else 0)))),
         'msmc_masked_mean_bwd': lambda a, b, ln, l64, B, T, C, adt, bdt, mode, out, gout, ga, gb, st:
@@ -613,6 +614,7 @@ def build_predictor(args, device):
     tr.autoencoder = atask.autoencoder
     tr.optimizer = build_optimizer(task, cfg.optimizer)
     tr.amp_dtype = torch.bfloat16 if args.dtype == 'bf16' else None
+    tr.use_graphs = bool(getattr(args, 'graph', False))
     for m in atask.modules():                       # (the frozen analysis pass computes in the same type)
         if hasattr(m, 'hip_dtype'):
             m.hip_dtype = tr.amp_dtype or torch.float32
@@ -639,7 +641,8 @@ def bench_predictor(args, device, wd):
     timer, register_banks = make_timer()
 
     def step(i):
-        task.zero_grad()
+        if not tr.use_graphs:
+            task.zero_grad()
         return tr.train_step(batch, i)
     say('built predictor + frozen autoencoder; starting warm-up')
     for i in range(args.warmup):
@@ -659,8 +662,10 @@ def bench_predictor(args, device, wd):
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     ms_per_step = elapsed / args.steps * 1e3
     ms_instr = None
+    graphs_were = tr.use_graphs
     if args.kernel_timing_steps > 0:
-        convnet.STREAMS_ENABLED = False             # one stream: an event pair brackets exactly one kernel
+        tr.use_graphs = False                       # per-launch HIP events need the eager path ...
+        convnet.STREAMS_ENABLED = False             # ... and one stream: an event pair brackets exactly one kernel
         step(0)
         register_banks()
         timer.start(lib.get())
@@ -672,6 +677,7 @@ def bench_predictor(args, device, wd):
         ms_instr = (time.perf_counter() - t1) / args.kernel_timing_steps * 1e3
         timer.stop()
         convnet.STREAMS_ENABLED = True
+        tr.use_graphs = graphs_were
         wd.beat('predictor instrumented steps')
     kernels, roof, step_roof = summarize_kernels(timer, args.dtype, args.kernel_timing_steps, ms_per_step)
     out = {
@@ -683,7 +689,8 @@ def bench_predictor(args, device, wd):
                                % (preset['name'], args.heads, args.codewords),
                    'baseline_config': 4, 'per_gpu_batch': args.batch, 'global_batch': args.batch, 'frames': args.frames,
                    'mel_frames_per_step': frames_per_step, 'phonemes_per_step': int(cpu_batch['text_length'].sum()),
-                   'parallelism': 'dp1', 'execution': 'eager (the length regulator sizes its output on the host)'},
+                   'parallelism': 'dp1',
+                   'execution': 'hipGraph replay (forward + backward | clip + update)' if graphs_were else 'eager, host-paced'},
         'roofline': roof, 'roofline_step': step_roof, 'kernels': kernels, 'ms_per_step_instrumented': ms_instr,
         'losses': {k: float(v) for k, v in log['loss'].items()} if isinstance(log, dict) and 'loss' in log else None,
     }

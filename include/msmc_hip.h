@@ -441,6 +441,15 @@ int msmc_masked_mean_fwd(const void* a, const void* b, const void* lengths, int 
 int msmc_masked_mean_bwd(const void* a, const void* b, const void* lengths, int len_is_64, int B, int T, int C, int a_dtype,
                          int b_dtype, int mode, const float* out, const float* gout, void* ga, void* gb, msmc_stream stream);
 
+/* Triple (hinge) loss of predictor training against a frozen codebook (BASELINE configuration #4): Quantize.compute_triple_loss,
+ * reference msmctts/networks/vqgantts/modules.py:86-116, for all heads of a MultiHeadQuantize (:152-168) in one launch.
+ *   p [N][D] fp32 predictions, trg [N][H] int64 target indices, embed_t [H][K][D/H] / enorm [H][K] from msmc_vq_prepare;
+ *   lossh [N][H] = reduce_k [t_k != 0] max(t_k + margin, 0) / d,  t_k = sum_c (p_c - e_trg,c)^2 - ((|p|^2 - 2 p.e_k) + |e_k|^2),
+ *   reduce = sum (mean == 0) or mean over the K codewords;  gp [N][D] = d lossh[n][h] / d p (the caller scales it by the
+ *   incoming gradient and takes the mean over heads).  d = D/H in {16, 32, 64, 128}; (K d + K) floats of LDS. */
+int msmc_triple_loss(const float* p, const int64_t* trg, const float* embed_t, const float* enorm, float* lossh, float* gp, int N,
+                     int D, int H, int K, float margin, int mean, msmc_stream stream);
+
 /* ---------------------------------------------------------------------------------------------
  * E1/V3  fused element-wise / row-normalisation kernels of the FFT blocks and the quantiser glue (csrc/norm.hip).
  * Replace the stock-kernel chains behind

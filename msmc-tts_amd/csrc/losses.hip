@@ -316,7 +316,119 @@ static int masked_mean_dispatch(const void* a, const void* b, const void* len, i
     return MSMC_E_SHAPE;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Triple (hinge) loss of predictor training against a frozen codebook -- Quantize.compute_triple_loss, reference
+// msmctts/networks/vqgantts/modules.py:86-116 (+ the head loop :152-168), the 'masked version':
+//   dist_k = (|p|^2 - 2 p.e_k) + |e_k|^2,  pos = sum_c (p_c - e_trg,c)^2,  t_k = pos - dist_k,
+//   loss = reduce_k [t_k != 0] max(t_k + margin, 0) / d           (reduce = sum or mean over the K codewords)
+// and its gradient, which does not depend on p beyond the active set:  d loss / d p = (2 / d) sum_{k active} (e_k - e_trg)
+// (x 1 / K for the mean).  One work-item per (frame, head): p and the running sum of active codewords in registers, the head's
+// codebook rows [K][d] and squared norms in LDS (every work-item reads the same row: broadcast), 2 x K x d multiply-adds per
+// pair.  The stock chain materialises the [frames x K] distance matrix of every head several times (26 MB per head at B = 64).
+// lossh [N][H] (the caller takes the mean over heads), gp [N][H d] = d lossh[n][h] / d p[n][h d ..].
+template <int D4>
+__global__ __launch_bounds__(256) void triple_loss_kernel(const float* __restrict__ p, const long long* __restrict__ trg,
+                                                         const float* __restrict__ embed_t, const float* __restrict__ enorm,
+                                                         float* __restrict__ lossh, float* __restrict__ gp, int N, int H, int K,
+                                                         float margin, int mean) {
+    MSMC_DYN_LDS(smem);
+    constexpr int d = 4 * D4;
+    float* erow = (float*)smem;                                 // [K][d]
+    float* en = erow + (size_t)K * d;                           // [K]
+    const int h = blockIdx.y, tid = threadIdx.x;
+    const float* eh = embed_t + (size_t)h * K * d;
+    for (int e = tid; e < K * d / 4; e += 256) *(f32x4*)(erow + 4 * e) = *(const f32x4*)(eh + 4 * e);
+    for (int k = tid; k < K; k += 256) en[k] = enorm[(size_t)h * K + k];
+    __syncthreads();
+    const int n = blockIdx.x * 256 + tid;
+    if (n >= N) return;
+    const int D = H * d;
+    f32x4 x[D4], s[D4];
+    float pp = 0.f;
+#pragma unroll
+    for (int c = 0; c < D4; ++c) {
+        x[c] = *(const f32x4*)(p + (size_t)n * D + h * d + 4 * c);
+        s[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pp = pp + x[c][j] * x[c][j];
+    }
+    long long t = trg[(size_t)n * H + h];
+    t = t < 0 ? 0 : (t >= K ? K - 1 : t);
+    const float* et = erow + (size_t)t * d;
+    float pos = 0.f;
+#pragma unroll
+    for (int c = 0; c < D4; ++c) {
+        const f32x4 e = *(const f32x4*)(et + 4 * c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float df = x[c][j] - e[j];
+            pos = pos + df * df;
+        }
+    }
+    const float invd = 1.f / (float)d;
+    float loss = 0.f, nact = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float* ek = erow + (size_t)k * d;
+        float dot = 0.f;
+        f32x4 e[D4];
+#pragma unroll
+        for (int c = 0; c < D4; ++c) {
+            e[c] = *(const f32x4*)(ek + 4 * c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dot = dot + x[c][j] * e[c][j];
+        }
+        const float dist = (pp - 2.f * dot) + en[k];
+        const float tr = pos - dist;
+        const float v = tr + margin;
+        const float a = (tr != 0.f && v > 0.f) ? 1.f : 0.f;
+        loss = loss + a * (v * invd);
+        nact = nact + a;
+#pragma unroll
+        for (int c = 0; c < D4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[c][j] = s[c][j] + a * e[c][j];
+    }
+    const float scale = mean ? 1.f / (float)K : 1.f;
+    lossh[(size_t)n * H + h] = loss * scale;
+    const float gs = 2.f * invd * scale;
+#pragma unroll
+    for (int c = 0; c < D4; ++c) {
+        const f32x4 e = *(const f32x4*)(et + 4 * c);
+        f32x4 g4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g4[j] = gs * (s[c][j] - nact * e[j]);
+        *(f32x4*)(gp + (size_t)n * D + h * d + 4 * c) = g4;
+    }
+}
+
 extern "C" {
+int msmc_triple_loss(const float* p, const int64_t* trg, const float* embed_t, const float* enorm, float* lossh, float* gp, int N,
+                     int D, int H, int K, float margin, int mean, msmc_stream stream) {
+    if (!p || !trg || !embed_t || !enorm || !lossh || !gp || N < 0 || H <= 0 || K <= 0 || D <= 0 || D % H) return MSMC_E_SHAPE;
+    const int d = D / H;
+    if (d % 4 || (((size_t)p | (size_t)embed_t | (size_t)gp) & 15)) return MSMC_E_SHAPE;
+    const size_t lds = ((size_t)K * d + K) * sizeof(float);
+    if (lds > 160 * 1024) return MSMC_E_SHAPE;
+    if (N == 0) return 0;
+    const dim3 grid((unsigned)((N + 255) / 256), (unsigned)H);
+#define TRIPLE_GO(D4_)                                                                                              \
+    do {                                                                                                           \
+        int rc = msmc_allow_lds((const void*)triple_loss_kernel<D4_>, (int)lds);                                   \
+        if (rc) return rc;                                                                                         \
+        MSMC_LAUNCH((triple_loss_kernel<D4_>), grid, dim3(256), lds, (msmc_stream_t)stream, p, (const long long*)trg, embed_t, \
+                    enorm, lossh, gp, N, H, K, margin, mean);                                                      \
+    } while (0)
+    switch (d) {
+        case 16: TRIPLE_GO(4); break;
+        case 32: TRIPLE_GO(8); break;
+        case 64: TRIPLE_GO(16); break;
+        case 128: TRIPLE_GO(32); break;
+        default: return MSMC_E_SHAPE;
+    }
+#undef TRIPLE_GO
+    return msmc_check_launch();
+}
 int msmc_masked_mean_parts(int B) { return B * MM_BX; }
 int msmc_masked_mean_fwd(const void* a, const void* b, const void* lengths, int len_is_64, int B, int T, int C, int a_dtype,
                          int b_dtype, int mode, float* partial, float* out, msmc_stream stream) {

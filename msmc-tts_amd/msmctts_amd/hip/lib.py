@@ -100,6 +100,7 @@ _SIGNATURES.update({
     'msmc_l1_multi_bwd': (_i, [ctypes.POINTER(TensorTable), _vp, _vp]),
     'msmc_mse_const_multi_fwd': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp]),
     'msmc_mse_const_multi_bwd': (_i, [ctypes.POINTER(TensorTable), _f, _vp, _vp]),
+    'msmc_triple_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
     'msmc_masked_mean_parts': (_i, [_i]),
     'msmc_masked_mean_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'msmc_masked_mean_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -183,6 +183,35 @@ def masked_mean(a, lengths, b=None):
     return _MaskedMean.apply(a.contiguous(), None if b is None else b.contiguous(), lengths.contiguous(), 0 if b is None else 1)
 
 
+class _TripleLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, trg, embed_t, enorm, margin, mean):
+        N, D = p.shape
+        H, K = enorm.shape
+        lossh = torch.empty(N, H, dtype=torch.float32, device=p.device)
+        gp = torch.empty(N, D, dtype=torch.float32, device=p.device)
+        lib.check(lib.get().msmc_triple_loss(lib.ptr(p, torch.float32), lib.ptr(trg, torch.int64), lib.ptr(embed_t, torch.float32),
+                                             lib.ptr(enorm, torch.float32), lib.ptr(lossh), lib.ptr(gp), N, D, H, K, float(margin),
+                                             int(mean), lib.stream(p)), 'msmc_triple_loss')
+        ctx.save_for_backward(gp)
+        ctx.heads = H
+        return lossh
+
+    @staticmethod
+    def backward(ctx, glossh):
+        gp, = ctx.saved_tensors
+        N, D = gp.shape
+        H = ctx.heads
+        g = glossh.reshape(N, H, 1).to(gp.dtype)
+        return (gp.view(N, H, D // H) * g).view(N, D), None, None, None, None, None
+
+
+def triple_loss(p, trg, embed_t, enorm, reduction='sum', margin=1e-6):
+    """per-(frame, head) triple loss of predictions ``p`` [N, D] against target indices ``trg`` [N, H] and the prepared codebook
+    (``hip/vq.py vq_prepare``: embed_t [H, K, d], enorm [H, K]) in one launch (msmc_triple_loss) -> [N, H]"""
+    return _TripleLoss.apply(p.contiguous().float(), trg.contiguous().long(), embed_t, enorm, float(margin), reduction == 'mean')
+
+
 def usable(*tensors):
     """the fused loss ops run on the GPU (or on the kernel interpreter in the CPU tests)"""
     return all(t is None or t.is_cuda or lib._host_pointers_ok for t in tensors)

@@ -227,8 +227,9 @@ def _interpreter_bound():
 
 
 class DurationPredictor(nn.Module):
-    """conv-ReLU-LN-dropout x2 + linear on the phoneme axis (reference transformer.py:481-534); a few hundred phonemes
-    per batch: stock operators."""
+    """conv-ReLU-LN-dropout x2 + linear on the phoneme axis (reference transformer.py:481-534).  The two convolutions run
+    on the gfx950 kernels with the ReLU in their epilogue (one small ConvBank); LayerNorm, dropout and the 256 -> 1 linear
+    are a few thousand phonemes of work on stock operators."""
 
     def __init__(self, input_size, filter_size, kernel, dropout, fused_layernorm=False):
         super().__init__()
@@ -242,11 +243,25 @@ class DurationPredictor(nn.Module):
         self.layer_norm_2 = nn.LayerNorm(filter_size)
         self.dropout_2 = nn.Dropout(dropout)
         self.linear_layer = nn.Linear(filter_size, 1, bias=True)
+        self.hip_dtype = torch.float32        # compute dtype of the two convolutions (trainer: bfloat16 in bf16 runs)
+        self._bank = None
+
+    def _conv_relu(self, conv, x, hip):
+        if not hip:
+            return F.relu(conv(x.transpose(1, 2)).transpose(1, 2))
+        return hip_conv(self._bank, self._layers[id(conv)], x.to(self.hip_dtype).contiguous().unsqueeze(1), out_slope=0.0).squeeze(1)
 
     def forward(self, input, input_mask):
         out = input * input_mask.to(input.dtype)
-        out = self.dropout_1(self.layer_norm_1(self.relu_1(self.conv1d_1(out.transpose(1, 2)).transpose(1, 2))))
-        out = self.dropout_2(self.layer_norm_2(self.relu_2(self.conv1d_2(out.transpose(1, 2)).transpose(1, 2))))
+        hip = out.is_cuda or _interpreter_bound()
+        if hip:
+            if self._bank is None:
+                self._layers = {id(m): ConvLayer(m, 'conv', (1, m.kernel_size[0]), (1, 1), (1, 1), (0, m.padding[0]), plain=True)
+                                for m in (self.conv1d_1, self.conv1d_2)}
+                self._bank = ConvBank(list(self._layers.values()))
+            self._bank.prepare(self.hip_dtype)
+        out = self.dropout_1(self.layer_norm_1(self._conv_relu(self.conv1d_1, out, hip)))
+        out = self.dropout_2(self.layer_norm_2(self._conv_relu(self.conv1d_2, out, hip)))
         out = self.linear_layer(out) * input_mask.to(out.dtype)
         return out.squeeze(-1)
 
@@ -260,22 +275,25 @@ class LengthRegulator(nn.Module):
         self.duration_predictor = DurationPredictor(input_size, duration_predictor_filter_size,
                                                     duration_predictor_kernel_size, dropout, fused_layernorm)
 
-    def forward(self, input, input_mask, target=None, alpha=1.0):
+    def forward(self, input, input_mask, target=None, alpha=1.0, width=None):
         duration = self.duration_predictor(input, input_mask)
         if self.training:
-            output, pos = self.get_output(input, target, alpha)
+            output, pos = self.get_output(input, target, alpha, width)
             return output, pos, duration
         duration = torch.clamp_min(duration, 0) if target is None else target
-        output, pos = self.get_output(input, duration, alpha)
+        output, pos = self.get_output(input, duration, alpha, width)
         return output, pos, torch.round(duration).long()
 
-    def get_output(self, input, duration, alpha):
+    def get_output(self, input, duration, alpha, width=None):
         """one gather for the whole batch: frame t of utterance b copies phoneme searchsorted(cumsum(repeats_b), t);
-        zero-padded to the longest utterance, positions 1..len (0 on padding) like the reference's pad_sequence"""
+        zero-padded to the longest utterance, positions 1..len (0 on padding) like the reference's pad_sequence.
+        ``width``: the caller's frame count (a host integer at least as large as the longest utterance): no device read-back,
+        the step stays hipGraph-capturable; the extra frames are padding (zeros, position 0) like the rest."""
         repeats = torch.round(duration.float() * alpha).long().clamp_min(0)
         ends = repeats.cumsum(1)                                              # [B, P]
         total = ends[:, -1]
-        width = int(total.max())
+        if width is None:
+            width = int(total.max())
         t = torch.arange(width, device=input.device).unsqueeze(0).expand(input.shape[0], -1)
         src = torch.searchsorted(ends, t.contiguous(), right=True).clamp_max(input.shape[1] - 1)
         valid = t < total.unsqueeze(1)

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ...hip import losses as hiploss
 from ...hip import vq as hipvq
 from ..layers import WNConv1d
 
@@ -73,9 +74,14 @@ class Quantize(nn.Module):
 
     def compute_triple_loss(self, prd_quant, trg_quant, reduction='mean', margin=1e-6, adaptive_margin=False):
         """hinge of (squared distance to the target codeword) against the squared distance to every codeword (reference
-        modules.py:86-116, the 'masked version'): [B, T] per-frame loss.  Predictor training only (a few thousand
-        frames per step): stock operators on the expanded distance matrix, like the reference."""
+        modules.py:86-116, the 'masked version'): [B, T] per-frame loss.  On the GPU one launch per call (round 5); the stock
+        operator chain on the expanded distance matrix below serves reduction='none' and odd codeword widths."""
         B, T, D = prd_quant.shape
+        if reduction in ('mean', 'sum') and hiploss.usable(prd_quant) and self.dim % 16 == 0 and self.dim <= 128:
+            # one launch: all K distances, the hinge and its gradient per frame (csrc/losses.hip triple_loss_kernel)
+            embed_t, enorm = hipvq.vq_prepare(self.embed.unsqueeze(0).contiguous(), frames=0)
+            return hiploss.triple_loss(prd_quant.reshape(-1, D), trg_quant.reshape(-1, 1), embed_t, enorm, reduction,
+                                       margin).reshape(B, T)
         flat = prd_quant.reshape(-1, self.dim)
         dist = (flat.pow(2).sum(1, keepdim=True) - 2 * flat @ self.embed + self.embed.pow(2).sum(0, keepdim=True)).reshape(B, T, -1)
         pos = F.mse_loss(prd_quant, self.embed_code(trg_quant), reduction='none').sum(-1)
@@ -125,6 +131,16 @@ class MultiHeadQuantize(nn.Module):
 
     def compute_triple_loss(self, prd_quant, trg_quant, reduction='mean', margin=1e-6, adaptive_margin=False):
         """mean over heads of the per-head triple loss (reference modules.py:152-168); trg_quant [B, T, H] indices"""
+        d = self.dim // self.n_head
+        if (reduction in ('mean', 'sum') and hiploss.usable(prd_quant) and d % 16 == 0 and d <= 128
+                and trg_quant.shape[-1] == self.n_head):
+            # all heads in one launch on the packed codebook; the mean over heads as the reference's sum(losses) / len(losses)
+            B, T, D = prd_quant.shape
+            embed, _, _ = self._packed()
+            embed_t, enorm = hipvq.vq_prepare(embed, frames=0)            # (no shortlist image: only rows and squared norms)
+            lossh = hiploss.triple_loss(prd_quant.reshape(-1, D), trg_quant.reshape(-1, self.n_head), embed_t, enorm, reduction,
+                                        margin)
+            return (lossh.sum(-1) / self.n_head).reshape(B, T)
         prds = torch.chunk(prd_quant, self.n_head, dim=-1)
         trgs = torch.chunk(trg_quant, self.n_head, dim=-1)
         losses = []

@@ -532,6 +532,8 @@ class PredictorTrainer(BaseTrainer):
         self.dur_loss = DurationLoss(lambda_dur)
         self.amp_dtype = None          # e.g. torch.bfloat16: the FFT stacks' GEMM / convolution bodies and the attention core in
         self._amp_applied = None       # that type (autocast); embeddings, losses and the optimizer stay fp32
+        self.use_graphs = False        # replay the step from two hipGraphs (static shapes; HipAdamW: device-side lr / step count)
+        self._graphs = None
 
     def _amp(self):
         if self._amp_applied is not self.amp_dtype:          # tell the HIP stacks their compute dtype
@@ -550,13 +552,15 @@ class PredictorTrainer(BaseTrainer):
         self.autoencoder = load_model('autoencoder', acfg._checkpoint, acfg._config if hasattr(acfg, '_config') else None)
         self.autoencoder = self.autoencoder.to(next(self.model.parameters()).device)
 
-    def train_step(self, batch, iteration):
+    # the step in two halves around the gradient exchange of the data-parallel path: forward (frozen analysis, predictor,
+    # losses) + backward | clip + update
+    def _forward_backward(self, batch, static=False):
+        """``static``: hipGraph capture -- no length is read back from the device (``MultiStagePredictor.forward(frames=)``)"""
         batch = dict(batch)
-        if not hasattr(self, 'autoencoder'):
-            self.build_autoencoder()
         self.autoencoder.eval()
+        mel = batch.pop('mel')
         with torch.no_grad():
-            qs = self.autoencoder.analysis(batch.pop('mel'), batch.pop('mel_length').int())
+            qs = self.autoencoder.analysis(mel, batch.pop('mel_length').int())
         batch['feat'] = [f.float() for f in qs['quantizer_outputs']]
         batch['feat_length'] = qs['quantizer_lengths']
         # fresh dropout masks for the fused kernels of this step: the masks are hash(seed word, salt, element) and
@@ -565,7 +569,7 @@ class PredictorTrainer(BaseTrainer):
         from ..hip import norm as hipnorm
         hipnorm.advance_seed(batch['feat'][0].device)
         with self._amp():
-            output = self.model.predictor(**batch)
+            output = self.model.predictor(frames=mel.shape[1], **batch) if static else self.model.predictor(**batch)
         output['feat'] = [f.float() for f in output['feat']]
         losses = {'total_loss': 0}
         emb = self.autoencoder.compute_embedding_loss(output['feat'], output['feat_length'], qs,
@@ -577,11 +581,117 @@ class PredictorTrainer(BaseTrainer):
         losses.update(dur)
         self.optimizer.zero_grad(['predictor'])
         losses['total_loss'].backward()
-        self._sync_grads()
+        return losses
+
+    def _update(self, losses):
         if self.grad_clip_thresh is not None and hasattr(self.optimizer, 'clip_and_step'):
             losses['grad_norm'] = self.optimizer.clip_and_step('predictor', self.grad_clip_thresh)
         else:
             if self.grad_clip_thresh is not None:
                 losses['grad_norm'] = nn.utils.clip_grad_norm_(self.model.predictor.parameters(), self.grad_clip_thresh)
             self.optimizer.step(['predictor'])
+
+    def replays(self, iteration):
+        return bool(self.use_graphs)
+
+    def train_step(self, batch, iteration):
+        if not hasattr(self, 'autoencoder'):
+            self.build_autoencoder()
+        if self.use_graphs:
+            return self._train_step_graphed(batch)
+        losses = self._forward_backward(batch)
+        self._sync_grads()
+        self._update(losses)
         return {'loss': {k: (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()}}
+
+    # -- hipGraph replay (static shapes: the batch the graphs were captured on fixes text width and frame count; a batch of
+    #    another shape is stepped eagerly).  Same scheme as VQGANTrainer: eager warm-up on a side stream, rolled back; two graphs
+    #    sharing a pool -- forward + backward | clip + update -- with the gradient exchange between them.
+    _KEYS = ('text', 'text_length', 'dur', 'mel', 'mel_length')
+
+    def _train_step_graphed(self, batch):
+        g = self._graphs
+        shapes = tuple((k, tuple(batch[k].shape)) for k in self._KEYS)
+        if g is not None and g['shapes'] != shapes:
+            losses = self._forward_backward(batch)
+            self._sync_grads()
+            self._update(losses)
+            return {'loss': {k: (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()}}
+        reducer = getattr(self.model, 'grad_reducer', None)
+        if reducer is not None:
+            reducer.hooks_enabled = False
+        if g is None:
+            g = self._graphs = self._capture(batch, shapes)
+        for k in self._KEYS:
+            if batch[k].data_ptr() != g['batch'][k].data_ptr():
+                g['batch'][k].copy_(batch[k], non_blocking=True)
+        hipconvnet.refresh_stale_banks()
+        g['ab'].replay()
+        if reducer is not None:
+            reducer.allreduce_child(self.model.predictor, grads=g['grads'])
+        g['c'].replay()
+        hipconvnet.graphs_replayed()
+        vec = g['loss_vec'].clone()
+        return {'loss': {k: vec[i] for i, k in enumerate(g['loss_keys'])}}
+
+    def _snapshot_state(self):
+        opt = []
+        for o in self.optimizer.optimizers.values():
+            if hasattr(o, '_ensure_state'):
+                for group in o.param_groups:
+                    o._ensure_state(group)
+            for st in o.state.values():
+                opt.extend(v for v in st.values() if torch.is_tensor(v))
+        return {'model': {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+                'opt': [(t, t.detach().clone()) for t in opt]}
+
+    def _restore_state(self, snap):
+        with torch.no_grad():
+            live = self.model.state_dict()
+            for k, saved in snap['model'].items():
+                live[k].copy_(saved)
+            for t, saved in snap['opt']:
+                t.copy_(saved)
+            known = set(id(t) for t, _ in snap['opt'])
+            for o in self.optimizer.optimizers.values():
+                for st in o.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v) and id(v) not in known:
+                            v.zero_()
+
+    def _capture(self, batch, shapes):
+        from ..hip import graphs as hipgraphs
+        dev = batch['mel'].device
+        if not hipgraphs.memset_nodes_ordered(dev):
+            raise RuntimeError(hipgraphs.HINT)
+        snap = self._snapshot_state()
+        static = {k: batch[k].clone() for k in self._KEYS}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):                                   # eager warm-up (tuning, lazy buffers, optimizer state): rolled back below
+                self.model.zero_grad(set_to_none=True)
+                self._update(self._forward_backward(static, static=True))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        import gc as _gc
+        _gc.collect()
+        self.model.zero_grad(set_to_none=True)                   # gradients get (static) graph-pool storage during capture
+        gab, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        import torch.distributed as dist
+        mode = 'thread_local' if dist.is_available() and dist.is_initialized() else 'global'
+        with torch.cuda.graph(gab, stream=side, capture_error_mode=mode):
+            losses = self._forward_backward(static, static=True)
+        torch.cuda.synchronize()
+        prepare = getattr(self.optimizer, 'prepare', lambda names=None: None)
+        prepare(['predictor'])                                   # (tensor tables over the static gradients the capture allocated)
+        with torch.cuda.graph(gc, pool=gab.pool(), stream=side, capture_error_mode=mode):
+            self._update(losses)
+            keys = [k for k, v in losses.items() if torch.is_tensor(v)]
+            loss_vec = torch.stack([losses[k].detach().float().reshape(()) for k in keys])
+        torch.cuda.synchronize()
+        grads = [p.grad for p in self.model.predictor.parameters() if p.requires_grad and p.grad is not None]
+        self._restore_state(snap)
+        hipconvnet.refresh_stale_banks()
+        torch.cuda.synchronize()
+        return dict(ab=gab, c=gc, batch=static, shapes=shapes, loss_vec=loss_vec, loss_keys=keys, grads=grads)

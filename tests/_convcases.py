@@ -68,6 +68,9 @@ def csmsc_layers(B=16):
             out['fft'].append(('fft 1x1 T%d %d->%d' % (T, ci, co), B, ci, co, 1, T, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0))
     out['fft'].append(('fft ffn k3 256->1024', B, 256, 1024, 1, 400, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0))
     out['fft'].append(('fft ffn k3 1024->256 relu', B, 1024, 256, 1, 400, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.0))
+    # the 600 / 1536-wide feed-forward layers of the predictor's FFT blocks (configs.am_config): channel counts that end inside a tile of 64
+    out['fft'].append(('am ffn k3 600->1536', B, 600, 1536, 1, 100, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0))
+    out['fft'].append(('am ffn k3 1536->600 relu', B, 1536, 600, 1, 100, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.0))
     out['gen'].append(('gen conv_pre k7 256->512', B, 256, 512, 1, 40, (1, 7), (1, 1), (1, 1), (0, 3), False, 1.0))
     for C, L in ((256, 240), (128, 1200), (64, 6000), (32, 12000)):
         for k in (3, 7, 11):

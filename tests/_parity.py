@@ -948,3 +948,97 @@ def check_reducer_stream_order(device, delay_cycles=int(2e8)):
         err = (p.grad - want[n]).abs().max().item()
         worst = max(worst, float('inf') if err != err else err / max(1e-6, want[n].abs().max().item()))
     return worst
+
+
+def check_predictor_graphed_vs_eager(device, steps=3):
+    """PredictorTrainer with ``use_graphs`` (forward + backward | clip + update replayed from two hipGraphs, no length read back
+    from the device) against the eager trainer on the fixture's batch and weights: every loss of ``steps`` consecutive steps and
+    the parameters afterwards (the small predictor has dropout: zeroed here, the masks of the two runs are not aligned)."""
+    from msmctts_amd.tasks import build_task
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    from msmctts_amd.utils.config import Config
+    z = load_npz('small_predictor.npz')
+    pc = small_predictor_cfg()
+    for key in ('encoder_config', 'decoder_config', 'adaptor_config'):
+        pc[key] = dict(pc[key], dropout=0.0)
+        if key != 'adaptor_config':
+            pc[key]['attn_dropout'] = 0.0
+    _, atask = build_small(device)
+    batch = {k[len('batch.'):]: t(v).to(device) for k, v in z.items() if k.startswith('batch.')}
+    runs = []
+    for graphed in (False, True):
+        cfg = Config({'id': 'small_predictor_graph', 'task': {'_name': 'MSMCTTS', '_mode': 'train_predictor', 'predictor': pc},
+                      'trainer': dict(PREDICTOR_TRAINER, _name='PredictorTrainer'),
+                      'optimizer': {'_default': dict(_name='Adam', learning_rate=2e-4, betas=[0.9, 0.98], eps=1e-9, weight_decay=0)},
+                      'dataset': dict(samplerate=24000, feature=['mel', 'wav'], frameshift=[300, 1])})
+        task = build_task(cfg, mode='train')
+        task.load_state_dict({k[len('state.'):]: t(v) for k, v in z.items() if k.startswith('state.')})
+        task = task.to(device).train()
+        for m in task.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        tr = build_trainer(cfg, task, num_gpus=0, rank=0)
+        tr.autoencoder = atask.autoencoder
+        tr.optimizer = build_optimizer(task, cfg.optimizer, capturable=True)
+        tr.use_graphs = graphed
+        logs = []
+        for i in range(steps):
+            if not tr.replays(i):
+                task.zero_grad()
+            log = tr.train_step({k: v.clone() for k, v in batch.items()}, i)
+            logs.append({k: float(v) for k, v in log['loss'].items()})
+        if graphed:
+            assert tr._graphs is not None
+        runs.append((logs, {k: v.detach().clone() for k, v in task.state_dict().items()}))
+    (el, es), (gl, gs) = runs
+    for a, b in zip(el, gl):
+        assert set(a) == set(b), (sorted(a), sorted(b))
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * max(1.0, abs(a[k])), (k, a[k], b[k])
+    for k in es:
+        if es[k].dtype.is_floating_point:
+            close(gs[k], es[k], 2e-3, 1e-3, k)
+
+
+def check_triple_loss(device):
+    """csrc/losses.hip triple_loss_kernel (Quantize / MultiHeadQuantize.compute_triple_loss on the GPU: reference
+    vqgantts/modules.py:86-116, 152-168) against the stock operator chain it replaces: per-frame loss and the gradient of a
+    random weighted sum of it, 'sum' and 'mean' reductions, one head and four, predictions near codewords (small hinge sets)
+    and far (all codewords active)."""
+    from msmctts_amd.networks.vqgantts.modules import MultiHeadQuantize, Quantize
+    from msmctts_amd.hip import losses as hiploss
+    torch.manual_seed(5)
+
+    def stock(q, p, trg, reduction):
+        B, T, D = p.shape
+        flat = p.reshape(-1, q.dim)
+        dist = (flat.pow(2).sum(1, keepdim=True) - 2 * flat @ q.embed + q.embed.pow(2).sum(0, keepdim=True)).reshape(B, T, -1)
+        pos = torch.nn.functional.mse_loss(p, q.embed_code(trg), reduction='none').sum(-1)
+        triple = pos.unsqueeze(-1) - dist
+        triple = (triple != 0) * (torch.clamp(triple + 1e-6, min=0) / q.dim)
+        return triple.mean(-1) if reduction == 'mean' else triple.sum(-1)
+    for H, dim, K in ((1, 64, 64), (4, 256, 256), (2, 64, 48)):
+        mod = (Quantize(dim, K) if H == 1 else MultiHeadQuantize(dim, K, H)).to(device)
+        heads = [mod] if H == 1 else list(mod.quantizers)
+        B, T = 3, 37
+        trg = torch.randint(0, K, (B, T, H), device=device)
+        for spread in (0.05, 3.0):
+            near = torch.cat([q.embed_code(trg[..., h]) for h, q in enumerate(heads)], dim=-1)
+            p0 = (near + spread * torch.randn(B, T, dim, device=device)).detach()
+            wts = torch.rand(B, T, device=device)
+            for reduction in ('sum', 'mean'):
+                p1 = p0.clone().requires_grad_(True)
+                got = mod.compute_triple_loss(p1, trg[..., 0] if H == 1 else trg, reduction=reduction)
+                (got * wts).sum().backward()
+                p2 = p0.clone().requires_grad_(True)
+                want = sum(stock(q, c, trg[..., h], reduction) for h, (q, c) in enumerate(zip(heads, torch.chunk(p2, H, dim=-1)))) / H
+                (want * wts).sum().backward()
+                scale = max(1e-6, want.abs().max().item())
+                # (the target's own codeword enters the hinge as pos - dist = rounding noise of two fp32 routes to one number,
+                #  reference and kernel alike: an absolute floor of a few 1e-6 / d)
+                assert (got - want).abs().max().item() <= 2e-4 * scale + 5e-6, (H, dim, K, spread, reduction, (got - want).abs().max().item(), scale)
+                gscale = max(1e-9, p2.grad.abs().max().item())
+                # (a codeword whose hinge argument sits within rounding of zero may be counted by one side only: 1 / (d K) of the scale)
+                assert (p1.grad - p2.grad).abs().max().item() <= 2e-3 * gscale + 1e-7, (H, dim, K, spread, reduction)
+    assert hiploss.usable(p0)

@@ -348,6 +348,17 @@ def test_fft_stack_prologue_is_bit_identical_to_the_operator_chain():
     _parity.check_fft_prologue(DEV, B=16, T=400, C=256)
 
 
+def test_predictor_step_replayed_from_graphs_matches_eager():
+    """BASELINE config #4 on the graph path (round 5): PredictorTrainer.use_graphs -- the frozen analysis, the predictor, its
+    losses and the backward pass as one hipGraph, clipping + Adam as a second -- against the eager trainer, three steps"""
+    _parity.check_predictor_graphed_vs_eager(DEV)
+
+
+def test_triple_loss_kernel_matches_the_operator_chain():
+    """csrc/losses.hip triple_loss_kernel on the device against the stock operator chain (values and gradients)"""
+    _parity.check_triple_loss(DEV)
+
+
 def test_hip_adamw_matches_torch_adamw_with_clipping():
     _parity.check_hip_adamw(DEV)
 

@@ -362,6 +362,8 @@ WG4_CASES = [
     ('valid k3 64->64', 1, 64, 64, 1, 37, (1, 3), (1, 1), (1, 1), (0, 0), False, 1.0),
     ('wide pad k3 64->64', 1, 64, 64, 1, 20, (1, 3), (1, 1), (1, 1), (0, 2), False, 1.0),
     ('tiny L3 k11 d5 C64', 1, 64, 64, 1, 3, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
+    ('ffn k3 88->200 (channel counts that end inside a tile of 64)', 2, 88, 200, 1, 70, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.0),
+    ('k3 136->72 lrelu', 1, 136, 72, 1, 45, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
 ]
 
 
@@ -385,6 +387,9 @@ def test_wgrad_fourth_generation_ring(gen):
         geom = conv.Geometry(H, W, k, s, dil, pad, reflect)
         x, g = torch.randn(B, H, W, Cin).bfloat16(), torch.randn(B, geom.Hout, geom.Wout, Cout).bfloat16()
         conv.conv_wgrad(x, g, geom, k[0] * k[1], db=torch.zeros(Cout))
+        assert b'conv_wgrad4_kernel' in L.msmc_conv_last_kernel()
+        x, g = torch.randn(2, 1, 70, 88).bfloat16(), torch.randn(2, 1, 70, 200).bfloat16()     # (600 / 1536-wide FFT blocks: tiles of 64 that end past the channels)
+        conv.conv_wgrad(x, g, conv.Geometry(1, 70, (1, 3), (1, 1), (1, 1), (0, 1), False), 3, db=torch.zeros(200))
         assert b'conv_wgrad4_kernel' in L.msmc_conv_last_kernel()
         conv._PLANS.clear()
         _convcases.check_conv_case(_convcases.SMALL[5], torch.bfloat16, 2e-2, 'cpu', parts=('wgrad',))
@@ -834,7 +839,9 @@ def test_gather_seventh_generation_variants(variant):
              ('g7 k3 192->64 lrelu chunk starts mid super-stage', 1, 192, 64, 1, 90, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
              ('g7 k5 128->128 lrelu', 2, 128, 128, 1, 75, (1, 5), (1, 1), (1, 2), (0, 4), False, 0.2),
              ('g7 k7 d3 64->64 thin', 1, 64, 64, 1, 700, (1, 7), (1, 1), (1, 3), (0, 9), False, 0.1),
-             ('g7 k5x1 512->128 deep', 1, 512, 128, 30, 5, (5, 1), (1, 1), (1, 1), (2, 0), False, 0.2)]
+             ('g7 k5x1 512->128 deep', 1, 512, 128, 30, 5, (5, 1), (1, 1), (1, 1), (2, 0), False, 0.2),
+             ('g7 k3 88->136: the last chunk ends inside its 64 channels', 2, 88, 136, 1, 100, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
+             ('g7 k3 200->72 relu, three whole chunks and eight channels', 1, 200, 72, 1, 90, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.0)]
     real = conv._build_desc
     state = {'variant': variant}
 
@@ -1093,6 +1100,11 @@ def test_weight_gradients_waiting_in_the_bank_equal_immediate_ones(batch):
         convnet.WGRAD_BATCH = keep
 
 
+
+
+def test_triple_loss_kernel_matches_the_operator_chain():
+    """csrc/losses.hip triple_loss_kernel on the interpreter (tests/_parity.py check_triple_loss)"""
+    _parity.check_triple_loss('cpu')
 
 
 def test_fft_stack_prologue_equals_the_operator_chain():

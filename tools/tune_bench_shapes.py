@@ -9,7 +9,8 @@ same for the persistent thin-layer kernel (variant 32), RETUNE=gemm1 for the 1-t
 on file and only adds the shapes and grouped calls the run meets for the first time (after a change of how the step
 groups its launches, e.g. MSMC_WGRAD_BATCH).  RETUNE=all times every decision the run meets again (two passes, the faster
 measurement of each candidate) and replaces those entries, keeping the entries of shapes it does not meet.
-CONFIG=4 (with RETUNE=new) runs the predictor step of BASELINE configuration #4 (600 / 1536-wide FFT stacks at B = 64) instead of
+RETUNE=tails drops the decisions of bf16 layers whose channel counts are multiples of 8 but not of 64 (and of the grouped calls
+with such members) and times them afresh.  CONFIG=4 (with RETUNE=new or tails) runs the predictor step of BASELINE configuration #4 (600 / 1536-wide FFT stacks at B = 64) instead of
 the GAN-phase step and adds its shapes."""
 import os, sys, random, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -84,6 +85,14 @@ if RETUNE == 'wgrad6':                                    # direct thin-layer we
     kept = {k: conv.TUNED.pop(k) for k in list(conv.TUNED)
             if k[0] == 'wgrad' and k[1] == 1 and min(k[5], k[8]) <= 16}
     print('timing the direct thin-layer weight gradient on %d shapes' % len(kept))
+if RETUNE == 'tails':                                     # channel counts that end inside a tile of 64 (the predictor's 600-wide
+    def _tail(m):                                         # FFT blocks: gather7.inc / wgrad4.inc read zeros past them): time those
+        return m[0] == 1 and min(m[4], m[7]) >= 64 and (m[4] % 64 or m[7] % 64) and m[4] % 8 == 0 and m[7] % 8 == 0       # shapes and their groups afresh
+    dropped = [k for k in conv.TUNED if (k[0] in ('gather', 'wgrad') and _tail(k[1:])) or
+               (k[0].endswith('-group') and any(_tail(m) for m in k[1:] if isinstance(m, tuple)))]
+    for k in dropped:
+        del conv.TUNED[k]
+    print('re-timing %d decisions on layers whose channel counts end inside a tile of 64' % len(dropped))
 old_groups = {}
 if RETUNE == 'groups':                                    # grouped-versus-single decisions only (every single shape stays cached)
     old_groups = {k: conv.TUNED.pop(k) for k in list(conv.TUNED) if k[0].endswith('-group')}
