@@ -144,7 +144,12 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
 // backward: gy = g * live; dxhat = gy * gamma; dv = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat));
 // gres = dv; gx = dv * dropmask * scale.  Parameter-gradient partials per workgroup: part[block][0][c] = sum gy*xhat,
 // part[block][1][c] = sum gy (reduced in a fixed order by add_ln_param_kernel).
-template <typename T, int V>
+// NG: 64 V-element lane groups per row (C <= 64 V NG: the registers of a 256-wide row are a quarter of a 1024-wide one's), RW: rows
+// a wave keeps in flight -- all loads of RW rows issued before the first reduction.  Measured at 25 600 x 600 / x 1024 bf16
+// (profiles/r05_norm_kernels.txt): RW = 2 is SLOWER than one row at a time (56 against 48 us, 106 against 86 us: the registers
+// cost more occupancy than the second row buys), 4 / 8 / 12 / 16 rows per workgroup all land within 3 % -- the pass streams at
+// 2.6 TB/s whatever the chain length.  Production: RW = 1.  Rows are accumulated into the parameter partials in row order.
+template <typename T, int V, int NG, int RW>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ g, const T* __restrict__ v_in,
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          const float* __restrict__ gamma,
@@ -152,7 +157,6 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ g
                                                          T* __restrict__ gres, float* __restrict__ part, long N, int C,
                                                          float p_drop, const long long* seed, long long salt, int rows_per_block) {
     MSMC_DYN_LDS(smem);
-    constexpr int NG = NM_MAXE / V;
     float* acc = (float*)smem;                     // [4 waves][2][C]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned long long key = nm_key(seed, salt);
@@ -167,48 +171,69 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ g
         if (c < C) nm_ldv<V>(gamma, c, gm[jj]);
     }
     const long r0 = (long)blockIdx.x * rows_per_block;
-    for (long row = r0 + w; row < r0 + rows_per_block && row < N; row += 4) {
-        const bool live = !keep_row || keep_row[row] != 0;
-        const float mean = mean_in[row], rstd = rstd_in[row];
-        float dx[NG][V], xh[NG][V];
-        float s1 = 0.f, s2 = 0.f;
+    long rend = r0 + rows_per_block;
+    if (rend > N) rend = N;
+    for (long rbase = r0 + w; rbase < rend; rbase += 4 * RW) {
+        float dx[RW][NG][V], xh[RW][NG][V];          // loaded as (gy, v), turned into (dxhat, xhat) in place
+        bool live[RW];
+        float mean[RW], rstd[RW];
 #pragma unroll
-        for (int jj = 0; jj < NG; ++jj) {
-            const int c = (lane + 64 * jj) * V;
+        for (int u = 0; u < RW; ++u) {
+            const long row = rbase + 4 * u;
+            const bool has = row < rend;
+            live[u] = has && (!keep_row || keep_row[has ? row : r0] != 0);
+            mean[u] = has ? mean_in[row] : 0.f;
+            rstd[u] = has ? rstd_in[row] : 0.f;
 #pragma unroll
-            for (int q = 0; q < V; ++q) dx[jj][q] = xh[jj][q] = 0.f;
-            if (c < C) {
-                const long i = row * C + c;
-                float gy[V], vv[V];
-                nm_ldv<V>(g, i, gy);
-                nm_ldv<V>(v_in, i, vv);
+            for (int jj = 0; jj < NG; ++jj) {
+                const int c = (lane + 64 * jj) * V;
 #pragma unroll
-                for (int q = 0; q < V; ++q) {
-                    if (!live) gy[q] = 0.f;
-                    xh[jj][q] = (vv[q] - mean) * rstd;
-                    dx[jj][q] = gy[q] * gm[jj][q];
-                    s1 = s1 + dx[jj][q];
-                    s2 = fmaf(dx[jj][q], xh[jj][q], s2);
-                    dg[jj][q] = fmaf(gy[q], xh[jj][q], dg[jj][q]);
-                    dbt[jj][q] = dbt[jj][q] + gy[q];
+                for (int q = 0; q < V; ++q) dx[u][jj][q] = xh[u][jj][q] = 0.f;
+                if (has && c < C) {
+                    nm_ldv<V>(g, row * C + c, dx[u][jj]);
+                    nm_ldv<V>(v_in, row * C + c, xh[u][jj]);
                 }
             }
         }
-        const float m1 = nm_wave_sum(s1) / C, m2 = nm_wave_sum(s2) / C;
 #pragma unroll
-        for (int jj = 0; jj < NG; ++jj) {
-            const int c = (lane + 64 * jj) * V;
-            if (c < C) {
-                const long i = row * C + c;
-                float dv[V], d[V];
+        for (int u = 0; u < RW; ++u) {
+            const long row = rbase + 4 * u;
+            if (row >= rend) break;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int q = 0; q < V; ++q) {
-                    dv[q] = rstd * (dx[jj][q] - m1 - xh[jj][q] * m2);
-                    d[q] = dv[q];
-                    if (thresh) d[q] = nm_keep(key, (unsigned long long)(i + q), thresh) ? dv[q] * scale : 0.f;
+            for (int jj = 0; jj < NG; ++jj) {
+                const int c = (lane + 64 * jj) * V;
+                if (c < C) {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) {
+                        const float gy = live[u] ? dx[u][jj][q] : 0.f;
+                        const float x_ = (xh[u][jj][q] - mean[u]) * rstd[u];
+                        const float d_ = gy * gm[jj][q];
+                        xh[u][jj][q] = x_;
+                        dx[u][jj][q] = d_;
+                        s1 = s1 + d_;
+                        s2 = fmaf(d_, x_, s2);
+                        dg[jj][q] = fmaf(gy, x_, dg[jj][q]);
+                        dbt[jj][q] = dbt[jj][q] + gy;
+                    }
                 }
-                if (gres) nm_stv<V>(gres, i, dv);
-                nm_stv<V>(gx, i, d);
+            }
+            const float m1 = nm_wave_sum(s1) / C, m2 = nm_wave_sum(s2) / C;
+#pragma unroll
+            for (int jj = 0; jj < NG; ++jj) {
+                const int c = (lane + 64 * jj) * V;
+                if (c < C) {
+                    const long i = row * C + c;
+                    float dv[V], d[V];
+#pragma unroll
+                    for (int q = 0; q < V; ++q) {
+                        dv[q] = rstd[u] * (dx[u][jj][q] - m1 - xh[u][jj][q] * m2);
+                        d[q] = dv[q];
+                        if (thresh) d[q] = nm_keep(key, (unsigned long long)(i + q), thresh) ? dv[q] * scale : 0.f;
+                    }
+                    if (gres) nm_stv<V>(gres, i, dv);
+                    nm_stv<V>(gx, i, d);
+                }
             }
         }
     }
@@ -398,13 +423,21 @@ int msmc_add_ln_bwd(const void* g, const void* v, const float* mean, const float
     if (workspace_bytes < msmc_add_ln_bwd_workspace(N, C) || (nblocks && !workspace)) return MSMC_E_WORKSPACE;
     const size_t lds = (size_t)4 * 2 * C * sizeof(float);
     if (nblocks) {
-#define NM_BWD(T_, V_)                                                                                                  \
-    MSMC_LAUNCH((add_ln_bwd_kernel<T_, V_>), dim3((unsigned)nblocks), dim3(256), lds, (msmc_stream_t)stream, (const T_*)g,   \
+#define NM_BWD(T_, V_, NG_, RW_)                                                                                        \
+    MSMC_LAUNCH((add_ln_bwd_kernel<T_, V_, NG_, RW_>), dim3((unsigned)nblocks), dim3(256), lds, (msmc_stream_t)stream, (const T_*)g, \
                 (const T_*)v, mean, rstd, gamma, keep_row, (T_*)gx, (T_*)gres, (float*)workspace, N, C, p_drop, seed, salt, rows)
+#define NM_BWD_VEC(T_)                                                                                                  \
+    do {                                                                                                                \
+        if (C <= 256) NM_BWD(T_, 4, 1, 1);                                                                              \
+        else if (C <= 512) NM_BWD(T_, 4, 2, 1);                                                                         \
+        else if (C <= 768) NM_BWD(T_, 4, 3, 1);                                                                         \
+        else NM_BWD(T_, 4, 4, 1);                                                                                       \
+    } while (0)
         const bool vec = (C % 4) == 0;
-        if (dtype == 0) { if (vec) NM_BWD(float, 4); else NM_BWD(float, 1); }
-        else if (dtype == 1) { if (vec) NM_BWD(unsigned short, 4); else NM_BWD(unsigned short, 1); }
+        if (dtype == 0) { if (vec) NM_BWD_VEC(float); else NM_BWD(float, 1, 16, 1); }
+        else if (dtype == 1) { if (vec) NM_BWD_VEC(unsigned short); else NM_BWD(unsigned short, 1, 16, 1); }
         else return MSMC_E_SHAPE;
+#undef NM_BWD_VEC
 #undef NM_BWD
         int rc = msmc_check_launch();
         if (rc) return rc;

@@ -742,11 +742,19 @@ int msmc_vq_search_shortlist(const float* x, const float* embed_t, const float* 
     // profiles/r03_vq_shortlist.md); the DIAG instantiations carry the ablation mask and the phase timers
     const int nsub = 2, nw = 8;
     if ((double)N * D * 4.0 >= 4294967296.0) return MSMC_E_SHAPE;     // (the kernel addresses frames with 32-bit byte offsets)
-    vq_search_sl_fn fn;
-    if (vqs_ablate) fn = d == 64 ? (vq_search_sl_fn)vq_search_sl_kernel<4, 2, 8, true> : (vq_search_sl_fn)vq_search_sl_kernel<2, 2, 8, true>;
-    else fn = d == 64 ? (vq_search_sl_fn)vq_search_sl_kernel<4, 2, 8, false> : (vq_search_sl_fn)vq_search_sl_kernel<2, 2, 8, false>;
     const int blob = (int)vqs_blob_bytes(d, K);
-    const size_t lds = (size_t)(mode == 1 ? H : 2) * blob;
+    size_t lds = (size_t)(mode == 1 ? H : 2) * blob;
+    // resident images with room to spare: the fp32 codebook rows next to them (winner rows and exact-path rows from LDS)
+    int erows_off = 0;
+    if (mode == 1 && !vqs_no_lds_rows && lds + (size_t)H * K * d * 4 <= 156 * 1024 && (H * K) % (1024 / (4 * d)) == 0) {
+        erows_off = (int)lds;
+        lds += (size_t)H * K * d * 4;
+    }
+    vq_search_sl_fn fn;
+    if (vqs_ablate) fn = d == 64 ? (vq_search_sl_fn)vq_search_sl_kernel<4, 2, 8, true, false> : (vq_search_sl_fn)vq_search_sl_kernel<2, 2, 8, true, false>;
+    else if (erows_off) fn = d == 64 ? (vq_search_sl_fn)vq_search_sl_kernel<4, 2, 8, false, true> : (vq_search_sl_fn)vq_search_sl_kernel<2, 2, 8, false, true>;
+    else fn = d == 64 ? (vq_search_sl_fn)vq_search_sl_kernel<4, 2, 8, false, false> : (vq_search_sl_fn)vq_search_sl_kernel<2, 2, 8, false, false>;
+    if (vqs_ablate) { lds -= erows_off ? (size_t)H * K * d * 4 : 0; erows_off = 0; }     // (the diagnostics instantiations read rows from L2)
     int rc = msmc_allow_lds((const void*)fn, (int)lds);
     if (rc) return rc;
     int bits = 0;
@@ -761,7 +769,7 @@ int msmc_vq_search_shortlist(const float* x, const float* embed_t, const float* 
     const int numIters = (numTiles + nw - 1) / nw;
     const int grid = numIters < MSMC_NUM_CU ? numIters : MSMC_NUM_CU;
     MSMC_LAUNCH(fn, dim3(grid), dim3(64 * nw), lds, (msmc_stream_t)stream, x, embed_t, enorm, (const char*)image,
-                quant, diff, ind, slow_count, N, D, H, K, mode == 1 ? 1 : 0, blob, ibmask, c_approx, vqs_ablate);
+                quant, diff, ind, slow_count, N, D, H, K, mode == 1 ? 1 : 0, blob, ibmask, c_approx, vqs_ablate, erows_off);
     msmc_vq_last = msmc_prof_name("vq_search_sl_kernel");
     return msmc_check_launch();
 }

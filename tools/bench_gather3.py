@@ -22,6 +22,9 @@ SHAPES = [
     ('ffn w2 T400 1024->256 k3', 16, 1024, 256, 1, 400, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
     ('ffn w1 T100 256->1024 k3', 16, 256, 1024, 1, 100, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
     ('ffn w2 T100 1024->256 k3', 16, 1024, 256, 1, 100, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
+    # the predictor's FFT blocks at B = 64 (configs.am_config): channel counts that end inside a tile of 64
+    ('am w1 T400 600->1536 k3', 64, 600, 1536, 1, 400, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
+    ('am w2 T400 1536->600 k3', 64, 1536, 600, 1, 400, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
     ('rb C256 L240 k3', 16, 256, 256, 1, 240, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
     ('rb C256 L240 k11 d5', 16, 256, 256, 1, 240, (1, 11), (1, 1), (1, 5), (0, 25), False, 0.1),
     ('rb C128 L1200 k3', 16, 128, 128, 1, 1200, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
