@@ -230,7 +230,10 @@ int msmc_conv_wgrad_group(const msmc_conv_desc* descs, const void* const* g, flo
  * Fourth generation (desc->variant 4 / 5 / 6, msmc-tts_amd/csrc/wgrad4.inc): same contract and second stage; the
  * workgroup's pixel tiles (output gradient rows + the x rows all its taps touch) stream global -> LDS through a ring
  * filled by global_load_lds_dwordx4 while the matrix cores work on the previous tile.  Inside msmc_conv_wgrad_group_ws
- * such members join the shared grid as third-generation members. */
+ * such members join the shared grid as third-generation members.  Channel counts: multiples of 8 (tiles of 64 that end past the
+ * channels read zeros).  desc->variant 9 (msmc-tts_amd/csrc/wgrad7.inc): the same scope and contract on 128 x 128 channel tiles,
+ * eight waves per workgroup, for layers with >= 128 channels on both sides and enough pixels to fill the chip at that size (the
+ * 600 <-> 1536 feed-forward layers of the predictor at B = 64); always a launch of its own inside a group call. */
 size_t msmc_conv_wgrad_workspace(const msmc_conv_desc* desc, const void* g);
 int msmc_conv_wgrad_ws(const msmc_conv_desc* desc, const void* g, float* dw, float* db, void* workspace,
                        size_t workspace_bytes, msmc_stream stream);

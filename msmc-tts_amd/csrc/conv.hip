@@ -2968,6 +2968,7 @@ static int wg4_launch(const msmc_conv_desc* d, const void* g, float* dw, float* 
 
 #include "wgrad5.inc"
 #include "wgrad6.inc"
+#include "wgrad7.inc"
 
 // general-lattice weight gradient with LDS-DMA staging (variant 7: interpreter-tested, not yet timed on the GPU)
 static int wg5_launch(const msmc_conv_desc* d, const void* g, float* dw, float* db, msmc_stream stream, float* ws,
@@ -3024,6 +3025,7 @@ extern "C" int msmc_conv_wgrad_ws(const msmc_conv_desc* d, const void* g, float*
         e.variant = gen;                                      // (the generation switch selects the third one too)
         if (gen == 7) return wg5_launch(&e, g, dw, db, stream, (float*)workspace, workspace_bytes / sizeof(float));
         if (gen == 8) return wg6_launch(&e, g, dw, db, stream);      // direct thin-layer kernel (E_SHAPE outside its scope)
+        if (gen == 9) return wg7_launch(&e, g, dw, db, stream, (float*)workspace, workspace_bytes / sizeof(float));   // 128 x 128 channel tiles
         if (gen >= 4) {
             if (gen > 6) return MSMC_E_SHAPE;
             const int rc = wg4_launch(&e, g, dw, db, stream, (float*)workspace, workspace_bytes / sizeof(float));
@@ -3044,6 +3046,10 @@ extern "C" size_t msmc_conv_wgrad_workspace(const msmc_conv_desc* d, const void*
     if (gen == 7) {
         Wg5Plan p5;
         return wg5_plan(d, g, &p5) == 0 ? p5.ws_floats * sizeof(float) : 0;
+    }
+    if (gen == 9) {
+        Wg4Plan p7;
+        return wg7_plan(d, g, &p7) == 0 ? p7.ws_floats * sizeof(float) : 0;
     }
     if (gen >= 4 && gen <= 6) {                     // (inside a shared grid the member runs as third generation: the larger)
         Wg4Plan p4;
@@ -3286,7 +3292,7 @@ extern "C" int msmc_conv_wgrad_group_ws4(const msmc_conv_desc* descs, const void
         const int gen = d->variant > 0 ? d->variant : msmc_wgrad_generation;
         // (fourth-generation members join a shared grid as third-generation members: the host layer times the shared
         //  grid against one launch per member, where each runs the kernel of its own choice)
-        if (!msmc_conv_grouping || d->dtype != 1 || gen == 1 || gen == 7 || gen == 8 || n == 1) {
+        if (!msmc_conv_grouping || d->dtype != 1 || gen == 1 || gen == 7 || gen == 8 || gen == 9 || n == 1) {
             size_t need = msmc_conv_wgrad_workspace(d, g[i]) / sizeof(float);
             if (need > ws_left) return MSMC_E_WORKSPACE;
             int rc = msmc_conv_wgrad_ws(d, g[i], dw[i], db ? db[i] : nullptr, wsp, need * sizeof(float), stream);

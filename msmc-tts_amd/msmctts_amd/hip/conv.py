@@ -67,7 +67,7 @@ _PLANS = {}
 AUTOTUNE = os.environ.get('MSMC_AUTOTUNE', '1') != '0'
 _GATHER_CANDIDATES = tuple((v, 0) for v in (1, 2, 3, 4, 5, 8, 9, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 34, 35,
                                              40, 41, 42, 43, 44, 45, 46, 47, 50, 56, 59, 60, 61, 63))
-_WGRAD_CANDIDATES = ((4, 0), (4, -1), (7, 0), (8, 0), (3, 0), (3, -1), (3, -2), (3, 1), (2, 0), (2, -1), (2, 1), (1, 0))
+_WGRAD_CANDIDATES = ((4, 0), (4, -1), (9, 0), (9, -1), (7, 0), (8, 0), (3, 0), (3, -1), (3, -2), (3, 1), (2, 0), (2, -1), (2, 1), (1, 0))
 TUNED = {}                                    # (kind, shape signature) -> (variant, split_shift, {candidate: ms})
 TUNE_CACHE = os.environ.get('MSMC_TUNE_CACHE', os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                                             'tuned_gfx950.json'))

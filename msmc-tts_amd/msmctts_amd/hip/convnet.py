@@ -430,7 +430,7 @@ class ConvBank(object):
         return (((m.bias, l.gb_view), (m.weight, l.gv_view)) if l.plain else
                 ((m.bias, l.gb_view), (m.weight_g, l.gg_view), (m.weight_v, l.gv_view)))
 
-    _NO_ATOMICS = frozenset((3, 4, 5, 6, 7))       # msmc_conv_wgrad variants that accumulate through a second stage into copy 0
+    _NO_ATOMICS = frozenset((3, 4, 5, 6, 7, 9))       # msmc_conv_wgrad variants that accumulate through a second stage into copy 0
 
     def _drop_idle_copies(self):
         """Privatised dW / db copies (DW_COPIES per small layer) exist for the ATOMIC weight-gradient generations: same-address

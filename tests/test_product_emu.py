@@ -399,6 +399,46 @@ def test_wgrad_fourth_generation_ring(gen):
         L.msmc_conv_set_wgrad_split(0)
 
 
+WG7_CASES = [
+    ('w7 ffn k3 136->200 (both channel counts end inside the second tile half)', 2, 136, 200, 1, 70, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.0),
+    ('w7 k3 256->128 lrelu', 1, 256, 128, 1, 45, (1, 3), (1, 1), (1, 1), (0, 1), False, 0.1),
+    ('w7 k5 d2 128->264: two tap groups', 2, 128, 264, 1, 75, (1, 5), (1, 1), (1, 2), (0, 4), False, 1.0),
+    ('w7 1-tap 384->128', 2, 384, 128, 1, 100, (1, 1), (1, 1), (1, 1), (0, 0), False, 1.0),
+    ('w7 k5x1 128->128 over [H][W]', 2, 128, 128, 22, 3, (5, 1), (1, 1), (1, 1), (2, 0), False, 0.2),
+    ('w7 tiny L3 k3 128->128', 1, 128, 128, 1, 3, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0),
+]
+
+
+def test_wgrad_128_channel_tiles():
+    """variant 9 (wgrad7.inc: the fourth generation's ring and pixel geometry on 128 x 128 channel tiles, eight waves of 64 x 32 x taps)
+    against PyTorch on the interpreter: model split, one split (direct accumulation, the ring wraps) and forced splits; channel
+    counts that end inside a tile, two tap groups, one tap, k x 1 taps over images; layers under 128 channels are refused"""
+    from msmctts_amd.hip import conv, lib
+    L = lib.get()
+    real = conv._build_desc
+
+    def forced(*a, **k):
+        d = real(*a, **k)
+        if d.dtype == 1:
+            d.variant = 9
+        return d
+    conv._build_desc = forced
+    try:
+        for split in (0, 1, 3):
+            L.msmc_conv_set_wgrad_split(split)
+            for case in WG7_CASES:
+                conv._PLANS.clear()
+                _convcases.check_conv_case(case, torch.bfloat16, 2e-2, 'cpu', parts=('wgrad',))
+                assert b'conv_wgrad7_kernel' in L.msmc_conv_last_kernel() or b'reduce' in L.msmc_conv_last_kernel(), (case[0], L.msmc_conv_last_kernel())
+        L.msmc_conv_set_wgrad_split(0)
+        conv._PLANS.clear()
+        with pytest.raises(RuntimeError):
+            _convcases.check_conv_case(('thin', 1, 64, 128, 1, 40, (1, 3), (1, 1), (1, 1), (0, 1), False, 1.0), torch.bfloat16, 2e-2, 'cpu', parts=('wgrad',))
+    finally:
+        conv._build_desc = real
+        L.msmc_conv_set_wgrad_split(0)
+
+
 def test_wgrad_general_lattice_dma_staging():
     """variant 7 (wgrad5.inc: the third generation's lattice tiles and table-driven fragment rows with both operands
     staged by LDS-DMA into a two-stage ring) on strided, 2-D, reflection-padded and dilated layers, model split, one
