@@ -749,12 +749,22 @@ int msmc_vq_search_shortlist(const float* x, const float* embed_t, const float* 
     if (mode == 1 && !vqs_no_lds_rows && lds + (size_t)H * K * d * 4 <= 156 * 1024 && (H * K) % (1024 / (4 * d)) == 0) {
         erows_off = (int)lds;
         lds += (size_t)H * K * d * 4;
+    } else if (mode == 2 && d == 64 && !vqs_no_lds_rows && (size_t)blob + (size_t)K * d * 4 <= 156 * 1024) {
+        // one head at a time: ONE image buffer + that head's rows, each refilled while the other is in use (vq_shortlist.inc).
+        // Measured on one box against two image buffers with the rows from L2 (tools/bench_vq.py, ABLATE=64): 4 x 256 (d = 64)
+        // 983 -> 963 us at N = 2^20 and 143 -> 128 us at N = 131 072; 8 x 512 (d = 32) 1591 -> 1622 us and 231 -> 224 us: taken
+        // for d = 64 only.  The steps of these shapes are bound by instruction issue, not by the latency this removes.
+        erows_off = blob;
+        lds = (size_t)blob + (size_t)K * d * 4;
     }
     vq_search_sl_fn fn;
     if (vqs_ablate) fn = d == 64 ? (vq_search_sl_fn)vq_search_sl_kernel<4, 2, 8, true, false> : (vq_search_sl_fn)vq_search_sl_kernel<2, 2, 8, true, false>;
     else if (erows_off) fn = d == 64 ? (vq_search_sl_fn)vq_search_sl_kernel<4, 2, 8, false, true> : (vq_search_sl_fn)vq_search_sl_kernel<2, 2, 8, false, true>;
     else fn = d == 64 ? (vq_search_sl_fn)vq_search_sl_kernel<4, 2, 8, false, false> : (vq_search_sl_fn)vq_search_sl_kernel<2, 2, 8, false, false>;
-    if (vqs_ablate) { lds -= erows_off ? (size_t)H * K * d * 4 : 0; erows_off = 0; }     // (the diagnostics instantiations read rows from L2)
+    if (vqs_ablate && erows_off) {                  // (the diagnostics instantiations read rows from L2)
+        lds = (size_t)(mode == 1 ? H : 2) * blob;
+        erows_off = 0;
+    }
     int rc = msmc_allow_lds((const void*)fn, (int)lds);
     if (rc) return rc;
     int bits = 0;
