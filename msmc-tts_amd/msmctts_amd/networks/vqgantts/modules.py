@@ -77,7 +77,8 @@ class Quantize(nn.Module):
         modules.py:86-116, the 'masked version'): [B, T] per-frame loss.  On the GPU one launch per call (round 5); the stock
         operator chain on the expanded distance matrix below serves reduction='none' and odd codeword widths."""
         B, T, D = prd_quant.shape
-        if reduction in ('mean', 'sum') and hiploss.usable(prd_quant) and self.dim % 16 == 0 and self.dim <= 128:
+        if (reduction in ('mean', 'sum') and hiploss.usable(prd_quant) and self.dim in (16, 32, 64, 128)
+                and (self.n_embed * self.dim + self.n_embed) * 4 <= 160 * 1024):       # (the head's codebook sits in LDS)
             # one launch: all K distances, the hinge and its gradient per frame (csrc/losses.hip triple_loss_kernel)
             embed_t, enorm = hipvq.vq_prepare(self.embed.unsqueeze(0).contiguous(), frames=0)
             return hiploss.triple_loss(prd_quant.reshape(-1, D), trg_quant.reshape(-1, 1), embed_t, enorm, reduction,
@@ -132,8 +133,8 @@ class MultiHeadQuantize(nn.Module):
     def compute_triple_loss(self, prd_quant, trg_quant, reduction='mean', margin=1e-6, adaptive_margin=False):
         """mean over heads of the per-head triple loss (reference modules.py:152-168); trg_quant [B, T, H] indices"""
         d = self.dim // self.n_head
-        if (reduction in ('mean', 'sum') and hiploss.usable(prd_quant) and d % 16 == 0 and d <= 128
-                and trg_quant.shape[-1] == self.n_head):
+        if (reduction in ('mean', 'sum') and hiploss.usable(prd_quant) and d in (16, 32, 64, 128)
+                and (self.n_embed * d + self.n_embed) * 4 <= 160 * 1024 and trg_quant.shape[-1] == self.n_head):
             # all heads in one launch on the packed codebook; the mean over heads as the reference's sum(losses) / len(losses)
             B, T, D = prd_quant.shape
             embed, _, _ = self._packed()
