@@ -95,6 +95,41 @@ def test_wgrad_fourth_generation_matches_pytorch(variant):
         conv.TUNED.update(saved[1])
 
 
+def test_wgrad_128_channel_tiles_every_step_count_and_ring_depth():
+    """wgrad7.inc (descriptor variant 9) forced on layers that walk every code path of its tile loop on the hardware: 4 to 8
+    sixteen-pixel steps per tile (T = 64 .. 128), ring depths 2 and 3, one to four taps per workgroup and two or three tap
+    groups (k = 1, 2, 3, 5, 7, 11 with dilation), several tiles per workgroup (the ring wraps), channel counts that end
+    inside a tile, input activation, bias -- against PyTorch fp32, model split and one split.  (The first form of this kernel
+    spilled registers and was wrong on the GPU for 7 steps x 3 taps only, while the interpreter passed.)"""
+    from msmctts_amd.hip import conv, lib
+    from _convcases import conv_case_data
+    L = lib.get()
+    saved = (conv._WGRAD_CANDIDATES, dict(conv.TUNED), conv.TUNE_BORROW)
+    conv.TUNE_BORROW = False
+    bad, ran = [], 0
+    try:
+        for split in (0, 1):
+            L.msmc_conv_set_wgrad_split(split)
+            for T in (64, 70, 96, 100, 112, 128, 200, 400):
+                for k, dil, ci, co, slope in ((3, 1, 128, 128, 1.0), (1, 1, 256, 136, 1.0), (2, 1, 128, 256, 0.1), (5, 2, 136, 128, 0.2),
+                                              (7, 1, 128, 128, 0.0), (11, 5, 128, 128, 0.1)):
+                    if split == 1 and T > 128 and k > 5:
+                        continue                                   # (one workgroup column walking every tile: keep the sweep short)
+                    span = dil * (k - 1)
+                    case = ('w7 T%d k%d d%d %d->%d' % (T, k, dil, ci, co), 4, ci, co, 1, T, (1, k), (1, 1), (1, dil), (0, span // 2), False, slope)
+                    data = conv_case_data(case, torch.bfloat16, DEV)
+                    errs, n = _forced('wgrad', (9, 0), data, ('wgrad',), conv)
+                    ran += n
+                    bad.extend((case[0], split, part, e) for part, e in errs.items() if not e < 2e-2)
+    finally:
+        L.msmc_conv_set_wgrad_split(0)
+        conv._WGRAD_CANDIDATES, conv.TUNE_BORROW = saved[0], saved[2]
+        conv.TUNED.clear()
+        conv.TUNED.update(saved[1])
+    assert not bad, bad[:20]
+    assert ran >= 60, ran
+
+
 def test_wgrad_fourth_generation_grouped_matches_single_launches():
     """msmc_conv_wgrad_group_ws4(group4 = 1) on the three parallel ResBlock convolutions of a generator stage (k = 3, 7,
     11: one shared grid, the widest member sets the accumulator budget) against one launch per member"""
