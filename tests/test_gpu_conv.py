@@ -95,6 +95,31 @@ def test_wgrad_fourth_generation_matches_pytorch(variant):
         conv.TUNED.update(saved[1])
 
 
+def test_seventh_generation_gather_with_channel_counts_that_end_inside_a_chunk():
+    """gather7.inc with Cin = 64 m + 8 t for every tail length t = 1 .. 7 (the pieces of the last 64-channel chunk past Cin come
+    from the zero page on both operand sides), forward and data gradient, every variant that takes the layer, against PyTorch"""
+    from msmctts_amd.hip import conv
+    from _convcases import conv_case_data
+    saved = (conv._GATHER_CANDIDATES, dict(conv.TUNED), conv.TUNE_BORROW)
+    conv.TUNE_BORROW = False
+    bad, ran = [], 0
+    try:
+        for ci, co, k, T in ((72, 128, 3, 300), (80, 136, 3, 100), (88, 64, 5, 500), (168, 128, 3, 200), (104, 256, 7, 150),
+                             (112, 128, 3, 90), (248, 120, 3, 400), (600, 192, 3, 128)):
+            case = ('g7 tail %d->%d k%d T%d' % (ci, co, k, T), 4, ci, co, 1, T, (1, k), (1, 1), (1, 1), (0, k // 2), False, 0.1 if k == 5 else 1.0)
+            data = conv_case_data(case, torch.bfloat16, DEV)
+            for v in (56, 59, 60, 61, 63):
+                errs, n = _forced('gather', (v, 0), data, ('fwd', 'dgrad'), conv)
+                ran += n
+                bad.extend((case[0], v, part, e) for part, e in errs.items() if not e < 2e-2)
+    finally:
+        conv._GATHER_CANDIDATES, conv.TUNE_BORROW = saved[0], saved[2]
+        conv.TUNED.clear()
+        conv.TUNED.update(saved[1])
+    assert not bad, bad[:20]
+    assert ran >= 30, ran
+
+
 def test_wgrad_128_channel_tiles_every_step_count_and_ring_depth():
     """wgrad7.inc (descriptor variant 9) forced on layers that walk every code path of its tile loop on the hardware: 4 to 8
     sixteen-pixel steps per tile (T = 64 .. 128), ring depths 2 and 3, one to four taps per workgroup and two or three tap
