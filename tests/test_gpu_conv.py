@@ -120,6 +120,34 @@ def test_seventh_generation_gather_with_channel_counts_that_end_inside_a_chunk()
     assert ran >= 30, ran
 
 
+def test_wgrad_fourth_generation_with_channel_counts_that_end_inside_a_tile():
+    """wgrad4.inc (variants 4 / 5 / 6) with channel counts 64 m + 8 t on either side, t = 1 .. 7: the pieces past the last channel read
+    the zero chunk, their rows / columns of dW and db are not stored; against PyTorch, model split and one split"""
+    from msmctts_amd.hip import conv, lib
+    from _convcases import conv_case_data
+    L = lib.get()
+    saved = (conv._WGRAD_CANDIDATES, dict(conv.TUNED), conv.TUNE_BORROW)
+    conv.TUNE_BORROW = False
+    bad, ran = [], 0
+    try:
+        for split in (0, 1):
+            L.msmc_conv_set_wgrad_split(split)
+            for ci, co, k, T in ((72, 128, 3, 300), (128, 80, 3, 100), (88, 104, 5, 500), (168, 120, 1, 200), (112, 248, 7, 150), (600, 72, 3, 128)):
+                case = ('w4 tail %d->%d k%d T%d' % (ci, co, k, T), 4, ci, co, 1, T, (1, k), (1, 1), (1, 1), (0, k // 2), False, 0.1 if k == 5 else 1.0)
+                data = conv_case_data(case, torch.bfloat16, DEV)
+                for v in (4, 5, 6):
+                    errs, n = _forced('wgrad', (v, 0), data, ('wgrad',), conv)
+                    ran += n
+                    bad.extend((case[0], v, split, part, e) for part, e in errs.items() if not e < 2e-2)
+    finally:
+        L.msmc_conv_set_wgrad_split(0)
+        conv._WGRAD_CANDIDATES, conv.TUNE_BORROW = saved[0], saved[2]
+        conv.TUNED.clear()
+        conv.TUNED.update(saved[1])
+    assert not bad, bad[:20]
+    assert ran >= 30, ran
+
+
 def test_wgrad_128_channel_tiles_every_step_count_and_ring_depth():
     """wgrad7.inc (descriptor variant 9) forced on layers that walk every code path of its tile loop on the hardware: 4 to 8
     sixteen-pixel steps per tile (T = 64 .. 128), ring depths 2 and 3, one to four taps per workgroup and two or three tap
