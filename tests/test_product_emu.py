@@ -607,7 +607,8 @@ def test_attention_kernels_match_the_reference_chain():
 
 @pytest.mark.parametrize('H,K,D,N', [
     (4, 64, 256, 100),     # all heads' images resident in LDS; ragged last tile
-    (4, 256, 256, 70),     # one head at a time, double-buffered LDS-DMA
+    (4, 256, 256, 70),     # one head at a time: one image buffer + one fp32 rows buffer in LDS, refilled in turns (d = 64)
+    (2, 256, 128, 900),    # the same over several persistent iterations per workgroup, idle waves in the last one
     (8, 512, 256, 45),     # d = 32: one 32-wide contraction step, nine index bits
     (2, 48, 64, 33),       # codeword tiles that are not a power of two, two heads (index store of a partial head group)
     (1, 16, 64, 300),      # single head, several persistent iterations per workgroup
