@@ -58,8 +58,13 @@ def run(task, testset, output_dir, batch_size=1):
         raise ValueError('No saved features')
     loader = DataLoader(testset, batch_size=batch_size, num_workers=0, shuffle=False, drop_last=False,
                         sampler=SequentialSampler(testset), collate_fn=getattr(testset, 'collate_fn', None))
+    from msmctts_amd.hip import lib as hiplib
     if torch.cuda.is_available():
         task = task.cuda()
+    elif not hiplib._host_pointers_ok:
+        # Every network of this package computes on the gfx950 kernels; there is no CPU execution path (the reference can
+        # synthesise on the CPU, this package cannot): say so here, not from the first encoder call
+        raise RuntimeError('infer.py needs an MI355X (gfx950) GPU: msmctts_amd has no CPU execution path')
     task.eval()
     dirs = {}
     for name, _, _ in task.config.save_features:

@@ -529,7 +529,18 @@ def _group_choice(kind, snaps, grouped_fn, single_fn, group4_fn=None, uniform_fn
     return hit[0], hit[1]
 
 
-def _gather_group(snaps, stream, what):
+# Measured and NOT kept (round 6, profiles/r06_group_fork_ab.txt): a grouped forward / data-gradient call whose members chose
+# different kernel families is several grids issued back to back, and so is a call the tuner keeps as single launches --
+# independent convolutions, each alone on the chip.  Issuing those grids on side streams (parallel branches of the captured
+# step, joined before the call returns) made the step SLOWER, 15.57 -> 15.78 ms with only the generator's calls forked: a
+# dependency that crosses streams costs 5-15 us in a replayed hipGraph (tools/step_timeline.sh: the gap in front of every
+# kernel that waits for another branch) against ~0 between two kernels of one stream, so a fork + join around 15-30 us kernels
+# loses what the overlap wins.  From INSIDE a side branch (the discriminator's families) such a fork crashes hipStreamEndCapture
+# on this runtime.  Branches pay off for CHAINS of launches (one fork and one join per chain), not for single launches.
+GROUP_PHASES = os.environ.get('MSMC_GROUP_PHASES', '1') != '0'            # stride phases of a transposed convolution as one grouped call
+
+
+def _gather_group(snaps, stream, what, device=None):
     """independent launches issued together (msmc_conv_gather_group) when that is the faster way for these shapes"""
     L = lib.get()
 
@@ -572,7 +583,7 @@ def conv_forward_group(items):
         desc, out = _forward_desc(**it)
         snaps.append(_snapshot(desc, stream))
         outs.append(out)
-    _gather_group(snaps, stream, 'msmc_conv_gather_group')
+    _gather_group(snaps, stream, 'msmc_conv_gather_group', items[0]['x'].device)
     return outs
 
 
@@ -646,7 +657,7 @@ def conv_dgrad_group(items):
         snaps.extend(_snapshot(d, stream) for d in live)
         outs.append(gx)
     for i in range(0, len(snaps), 16):                   # msmc_conv_gather_group carries at most 16 members
-        _gather_group(snaps[i:i + 16], stream, 'msmc_conv_gather_group(dgrad)')
+        _gather_group(snaps[i:i + 16], stream, 'msmc_conv_gather_group(dgrad)', items[0]['g'].device)
     return outs
 
 
@@ -657,14 +668,22 @@ def conv_transpose1d_forward(x, w, k, stride, padding, bias=None, in_slope=1.0):
     Cout = w.shape[1]
     Lout = (Lin - 1) * stride - 2 * padding + k
     out = torch.empty((B, 1, Lout, Cout), dtype=x.dtype, device=x.device)
-    L = lib.get()
+    stream = lib.stream(x)
+    snaps = []
     for r, n, taps1 in _phases(Lout, k, stride, 1, padding):
         assert taps1, 'kernel_size >= stride expected'
         taps = [(0, off, kk) for off, kk in taps1]
         lattice = (1, n, 0, 1, r, stride, 1, 1, 0, 0)
         d = _fill(None, x, w, out, B, 1, Lin, Cin, 1, Lout, Cout, lattice, taps, 0, bias=bias,
                   in_slope=in_slope)
-        _gather(d, lib.stream(x), 'msmc_conv_gather(convT)')
+        if not GROUP_PHASES:
+            _gather(d, stream, 'msmc_conv_gather(convT)')
+        else:
+            snaps.append(_snapshot(d, stream))
+    # the stride phases write disjoint output positions: independent launches, issued like the members of a grouped call
+    # (one grid where their kernel choices coincide, parallel branches otherwise) instead of back to back
+    for i in range(0, len(snaps), 16):
+        _gather_group(snaps[i:i + 16], stream, 'msmc_conv_gather_group(convT)', x.device)
     return out
 
 

@@ -204,6 +204,58 @@ def refresh_stale_banks():
             bank.prepare(bank.dtype)
 
 
+# A model is several banks (the autoencoder: in / out projections, two encoder stacks, quantiser, frame decoder, vocoder) whose
+# parameters ONE optimizer step moves together, so at the head of the next forward pass all of them are stale -- and each
+# refreshed its images when its module was reached: six calls of two launches, 12 nodes and 0.26 ms on the critical chain of
+# the step (profiles/r06_step_timeline_start_of_round.txt).  ``prepare_together`` refreshes every stale bank of a list in
+# ONE msmc_wn_prepare_multi_tiled call over the concatenation of their item tables (block offsets re-based); the banks' own
+# ``prepare`` calls further down then find themselves clean.  MSMC_PREPARE_TOGETHER=0: each bank on its own (A/B).
+PREPARE_TOGETHER = os.environ.get('MSMC_PREPARE_TOGETHER', '1') != '0'
+_TOGETHER = {}
+
+
+def prepare_together(pairs):
+    """``pairs``: [(bank, dtype), ...] -- banks about to be used by one forward pass.  No effect on numerics or on what a
+    bank considers clean; fewer than two stale banks are left to their own ``prepare``."""
+    if not PREPARE_TOGETHER:
+        return
+    stale = []
+    for bank, dtype in pairs:
+        need, versions, capturing = bank._stale(dtype)
+        if need:
+            stale.append((bank, versions, capturing))
+    if len(stale) < 2:
+        return
+    banks = [b for b, _, _ in stale]
+    # (keyed by the banks' builds: the fields the two prepare kernels read -- pointers, extents, strides, block offsets -- change
+    #  with a rebuild only; ``copies``, which _drop_idle_copies patches later, is the backward pass's)
+    key = tuple((id(b), b._build_version) for b in banks)
+    hit = _TOGETHER.get(key)
+    if hit is None:
+        K._bounded(_TOGETHER, 64)
+        n = sum(len(b.layers) for b in banks)
+        items = (lib.WnItem * n)()
+        k = blk = tblk = 0
+        for b in banks:
+            for it in b._items_host:
+                ctypes.memmove(ctypes.byref(items[k]), ctypes.byref(it), ctypes.sizeof(lib.WnItem))
+                items[k].block0 = it.block0 + blk
+                items[k].tblock0 = it.tblock0 + tblk
+                k += 1
+            blk += b.total_blocks
+            tblk += b.total_tile_blocks
+        dev = banks[0].w1.device
+        if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            return                      # (a table built during capture would be a host-to-device copy node: banks one by one)
+        table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
+        hit = _TOGETHER[key] = (table, n, blk, tblk, [weakref.ref(b) for b in banks])
+    table, n, blk, tblk, _ = hit
+    lib.check(lib.get().msmc_wn_prepare_multi_tiled(lib.ptr(table), n, blk, tblk, lib.stream(banks[0].w1)),
+              'msmc_wn_prepare_multi_tiled(together)')
+    for bank, versions, capturing in stale:
+        bank._refreshed(versions, capturing)
+
+
 class ConvBank(object):
     def __init__(self, layers):
         self.layers = list(layers)
@@ -372,6 +424,7 @@ class ConvBank(object):
         self._copy_checks = 6              # backward passes after which idle privatised copies are looked for
         self.items_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.dtype = dtype
+        self._build_version = getattr(self, '_build_version', 0) + 1       # (prepare_together: combined tables are rebuilt)
 
     def _weight_params(self):
         for l in self.layers:
@@ -387,9 +440,9 @@ class ConvBank(object):
             self._ptrs = (self._sig, frozenset(p.data_ptr() for p in self._weight_params()))
         return self._ptrs[1]
 
-    def prepare(self, dtype, force=False):
-        """Refresh kernel-layout weights from (weight_v, weight_g): one call (two launches) for the whole network -- skipped
-        while the bank is clean (see SKIP_CLEAN_PREPARE)."""
+    def _stale(self, dtype, force=False):
+        """(build the device buffers where parameters moved / the dtype changed, clear what a failed pass left behind and)
+        tell whether the kernel-layout weight images must be refreshed now: (stale, versions, capturing)"""
         sig = self._signature(dtype)
         if sig != self._sig:
             self._build(dtype)
@@ -409,14 +462,24 @@ class ConvBank(object):
         versions = self._versions()
         capturing = self.w1.is_cuda and torch.cuda.is_current_stream_capturing()
         stale = self.eager_stale and not capturing
-        if SKIP_CLEAN_PREPARE and not force and not self.dirty and not stale and versions == self._clean_versions:
+        clean = SKIP_CLEAN_PREPARE and not force and not self.dirty and not stale and versions == self._clean_versions
+        return (not clean), versions, capturing
+
+    def _refreshed(self, versions, capturing):
+        self.dirty, self._clean_versions = False, versions
+        if not capturing:
+            self.eager_stale = False
+
+    def prepare(self, dtype, force=False):
+        """Refresh kernel-layout weights from (weight_v, weight_g): one call (two launches) for the whole network -- skipped
+        while the bank is clean (see SKIP_CLEAN_PREPARE)."""
+        stale, versions, capturing = self._stale(dtype, force)
+        if not stale:
             return
         lib.check(lib.get().msmc_wn_prepare_multi_tiled(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
                                                         self.total_tile_blocks, lib.stream(self.w1)),
                   'msmc_wn_prepare_multi_tiled')
-        self.dirty, self._clean_versions = False, versions
-        if not capturing:
-            self.eager_stale = False
+        self._refreshed(versions, capturing)
 
     # -- end-of-backward: kernel-layout dW -> parameter gradients --------------------------------------
     def _queue_finish(self):

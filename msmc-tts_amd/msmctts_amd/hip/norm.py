@@ -74,7 +74,16 @@ class _AddLayerNorm(torch.autograd.Function):
         L = lib.get()
         gx = torch.empty_like(v)
         gres = torch.empty_like(v) if ctx.has_res else None
-        defer = ctx.params is not None and _ln_defer_ok()
+        # the parameter gradients: both accumulated into .grad by this pass and deferrable -> partial sums now, ONE reduction
+        # launch at the end of the pass (_ln_flush writes .grad); a pass restricted to other inputs (backward(inputs=[...]))
+        # -> none delivered; torch.autograd.grad() (gradients travel on the edges, nothing is accumulated) or one of the two
+        # only -> autograd's own route
+        want_g, want_b, on_edges = ctx.needs_input_grad[2], ctx.needs_input_grad[3], False
+        if ctx.params is not None:
+            want_g, want_b = _ln_wanted(ctx.params[0], want_g), _ln_wanted(ctx.params[1], want_b)
+        if want_g is None or want_b is None:
+            want_g, want_b, on_edges = ctx.needs_input_grad[2], ctx.needs_input_grad[3], True
+        defer = ctx.params is not None and want_g and want_b and not on_edges and _ln_defer_ok()
         dgamma = dbeta = None
         if not defer:
             dgamma = torch.empty(C, dtype=torch.float32, device=v.device)
@@ -88,7 +97,7 @@ class _AddLayerNorm(torch.autograd.Function):
                                     lib.stream(v)), 'msmc_add_ln_bwd')
         if defer:
             _ln_queue(ws, (N + 15) // 16, C, ctx.params[0], ctx.params[1])
-        return gx, gres, dgamma, dbeta, None, None, None, None
+        return gx, gres, (dgamma if want_g else None), (dbeta if want_b else None), None, None, None, None
 
 
 # ---- parameter gradients of all LayerNorms of a backward pass in one launch --------------------------------------------
@@ -96,11 +105,27 @@ class _AddLayerNorm(torch.autograd.Function):
 # launch of 32 workgroups, and behind each of the 24 LayerNorms of the FFT stacks it sits on the critical path of the block
 # chain.  With LN_PARAM_DEFER the workspaces wait until the end of the backward pass (an autograd-engine callback, as
 # ConvBank's weight gradients do) and ONE msmc_add_ln_param_multi launch reduces them all, in the same fixed order; the
-# gradients are then delivered to ``.grad`` directly (torch semantics: a live gradient is added to, in the kernel).  A
-# caller that asks for these gradients through ``torch.autograd.grad`` gets None for them -- use ``.backward()``, or
-# MSMC_LN_PARAM_DEFER=0.
+# gradients are then delivered to ``.grad`` directly (torch semantics: a live gradient is added to, in the kernel).
+# ``.backward()`` and ``.backward(inputs=[...])`` see exactly what autograd's route gives them (a pass restricted to other
+# inputs delivers nothing for the LayerNorm parameters); a ``torch.autograd.grad()`` pass accumulates nothing into ``.grad``
+# -- its gradients are captured on the edges -- so there the parameter gradients take autograd's own route (``_ln_wanted``;
+# tests/test_product_emu.py::test_layernorm_parameter_gradients_under_restricted_passes).
 LN_PARAM_DEFER = os.environ.get('MSMC_LN_PARAM_DEFER', '1') != '0'
 _LN_PENDING = {'task': None, 'items': []}
+
+
+def _ln_wanted(p, needs):
+    """will the running backward pass accumulate into ``p.grad``?  None: it is a torch.autograd.grad() pass (the engine refuses
+    the question for leaves there: gradients are captured on the edges instead)"""
+    if not needs:
+        return False
+    probe = getattr(torch._C, '_will_engine_execute_node', None)
+    if probe is None or not p.is_leaf:
+        return True
+    try:
+        return bool(probe(torch.autograd.graph.get_gradient_edge(p).node))
+    except RuntimeError:
+        return None
 
 
 def _ln_defer_ok():

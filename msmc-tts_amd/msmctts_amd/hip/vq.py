@@ -91,7 +91,7 @@ def vq_search(x, embed_t, enorm, shortlist=None):
     True = the shortlist kernel whatever the size (it must have an image), False = the exact kernel."""
     image = getattr(embed_t, 'shortlist_image', None) if (SHORTLIST if shortlist is None else shortlist) else None
     if shortlist and image is None:
-        raise RuntimeError('msmc_vq_search_shortlist does not take this shape (or MSMC_VQ_SHORTLIST=0)')
+        raise RuntimeError('msmc_vq_search_shortlist does not take this shape (vq_prepare attached no shortlist image to this codebook)')
     return _VQSearch.apply(x, embed_t, enorm, image, bool(shortlist))
 
 

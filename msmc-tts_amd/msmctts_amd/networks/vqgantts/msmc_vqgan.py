@@ -295,6 +295,24 @@ class MSMCVQGAN(nn.Module):
         self._bank.prepare(self.hip_dtype)
         return True
 
+    def _prepare_banks(self, dev, vocoder):
+        """the kernel-layout weight images of every network of this pass in ONE refresh (hip/convnet.py prepare_together):
+        an optimizer step moved all of them, and each module refreshing its own bank when the pass reaches it is a dozen
+        launches on the critical chain"""
+        if not (self.use_hip and (dev.type == 'cuda' or _interpreter_bound())):
+            return
+        from ...hip import convnet
+        if self._bank is None:
+            self._hip_ready(dev)
+        pairs = [(self._bank, self.hip_dtype)] + [(enc._hip()[0], enc.hip_dtype) for enc in self.encoder.encoders]
+        if self.quantizer.use_hip:
+            pairs.append((self.quantizer._hip()[0], self.quantizer.hip_dtype))
+        if hasattr(self, 'frame_decoder'):
+            pairs.append((self.frame_decoder._hip()[0], self.frame_decoder.hip_dtype))
+        if vocoder:
+            pairs.append((self.decoder._hip()[0], self.decoder.hip_dtype))
+        convnet.prepare_together(pairs)
+
     def _linear(self, module, x, hip):
         """in_linear / mel_predictor as 1-tap implicit GEMMs (bias fused, compute dtype in and out)"""
         if not hip:
@@ -309,6 +327,7 @@ class MSMCVQGAN(nn.Module):
     def forward(self, mel, mel_length, warmup=False, window=None):
         if self.training:
             hipnorm.advance_seed(mel.device)        # fresh dropout masks for the fused kernels of this step
+        self._prepare_banks(mel.device, vocoder=not warmup)
         hip = self._hip_ready(mel.device)
         enc = self.encoder(self._linear(self.in_linear, mel, hip), mel_length)
         with hipvq.ema_side(mel.device):              # (the codebooks' EMA updates: a side branch, joined before this returns)

@@ -311,17 +311,26 @@ class VQGANTrainer(BaseTrainer):
         reducer = getattr(self.model, 'grad_reducer', None)
         if reducer is not None:
             reducer.hooks_enabled = False        # (serial exchange: no collectives inside capture; overlap: _capture arms them)
-        lengths = batch.get('mel_length_host')
-        if lengths is None:
-            lengths = batch['mel_length'].tolist()
         # the captured window gather reads wav[start * frameshift : (start + frame_lengths) * frameshift] unchecked: a waveform
         # shorter than its mel says (wrong hop in the data) must fail here, on the host, not as a GPU memory fault
         if phase == 2:
+            lengths = batch.get('mel_length_host')
+            if lengths is None:                  # (a device read-back: loaders hand the host copy along, datasets/DeviceLoader)
+                lengths = batch['mel_length'].tolist()
             have, need = batch['wav'].numel() // len(lengths), (int(max(lengths)) - 1) * self.frameshift      # (windows end at frame n - 1)
             if have < need:
                 raise ValueError('batch["wav"] holds %d samples per utterance, mel_length x frameshift (%d) asks for %d'
                                  % (have, self.frameshift, need))
         if g is None:
+            if phase == 2 and self._graphs_warm is not None:
+                # training has left the warm-up phase for good (iterations only grow): its graphs, static batch, gradient
+                # tensors, memory pool and optimizer tables go BEFORE the GAN phase allocates its own -- the peak at step
+                # warmup_steps + 1 is one phase's working set, not two (an out-of-memory there would come 50k steps into a run)
+                self._graphs_warm = None
+                if hasattr(self.optimizer, 'release'):
+                    self.optimizer.release(None, 'phase0')
+                import gc as _gc
+                _gc.collect()
             g = self._capture(batch, phase)
             if phase == 2:
                 self._graphs = g
@@ -472,9 +481,10 @@ class VQGANTrainer(BaseTrainer):
         g['codebooks'] = list(hipvq.PENDING)    # (sync_codebook_stats: the stages whose statistics segment A refills)
         del hipvq.PENDING[:]
         torch.cuda.synchronize()
-        prepare = getattr(self.optimizer, 'prepare', lambda names=None: None)
+        tag = 'phase%d' % phase
+        prepare = getattr(self.optimizer, 'prepare', lambda names=None, tag=None: None)
         if phase == 2:
-            prepare(['discriminator'])          # (tensor tables over the static gradients segment A just allocated)
+            prepare(['discriminator'], tag)     # (tensor tables over the static gradients segment A just allocated)
         with torch.cuda.graph(gb, pool=ga.pool(), stream=side, capture_error_mode=mode):
             if overlap:
                 reducer.hooks_enabled = True
@@ -482,7 +492,7 @@ class VQGANTrainer(BaseTrainer):
             exchange_in_graph()
         keys = [k for k, v in st.losses.items() if torch.is_tensor(v)]
         torch.cuda.synchronize()
-        prepare(['autoencoder'])
+        prepare(['autoencoder'], tag)
         with torch.cuda.graph(gc, pool=ga.pool(), stream=side, capture_error_mode=mode):
             self._segment_c(st)
             loss_vec = torch.stack([st.losses[k].detach().float().reshape(()) for k in keys])
@@ -612,14 +622,21 @@ class PredictorTrainer(BaseTrainer):
     def _train_step_graphed(self, batch):
         g = self._graphs
         shapes = tuple((k, tuple(batch[k].shape)) for k in self._KEYS)
-        if g is not None and g['shapes'] != shapes:
-            losses = self._forward_backward(batch)
-            self._sync_grads()
-            self._update(losses)
-            return {'loss': {k: (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()}}
         reducer = getattr(self.model, 'grad_reducer', None)
         if reducer is not None:
+            # Under data parallelism every rank decides replay-or-eager from ITS OWN batch shape, so both branches below
+            # exchange gradients the same way: the hooks stay off and ONE flat all-reduce of the child's gradients runs after
+            # the backward pass (``allreduce_child``: the same collective, element for element, whether a rank's gradients
+            # are the graphs' static tensors or this step's eager ones).  Before round 6 the eager branch relied on hooks the
+            # first replay had switched off: it exchanged nothing, and a rank in it met no collective while a replaying
+            # rank waited in one.
             reducer.hooks_enabled = False
+        if g is not None and g['shapes'] != shapes:
+            losses = self._forward_backward(batch)
+            if reducer is not None:
+                reducer.allreduce_child(self.model.predictor)
+            self._update(losses)
+            return {'loss': {k: (v.detach() if torch.is_tensor(v) else v) for k, v in losses.items()}}
         if g is None:
             g = self._graphs = self._capture(batch, shapes)
         for k in self._KEYS:
@@ -628,7 +645,7 @@ class PredictorTrainer(BaseTrainer):
         hipconvnet.refresh_stale_banks()
         g['ab'].replay()
         if reducer is not None:
-            reducer.allreduce_child(self.model.predictor, grads=g['grads'])
+            reducer.allreduce_child(self.model.predictor, grads=g.get('grads'))
         g['c'].replay()
         hipconvnet.graphs_replayed()
         vec = g['loss_vec'].clone()
@@ -683,8 +700,8 @@ class PredictorTrainer(BaseTrainer):
         with torch.cuda.graph(gab, stream=side, capture_error_mode=mode):
             losses = self._forward_backward(static, static=True)
         torch.cuda.synchronize()
-        prepare = getattr(self.optimizer, 'prepare', lambda names=None: None)
-        prepare(['predictor'])                                   # (tensor tables over the static gradients the capture allocated)
+        prepare = getattr(self.optimizer, 'prepare', lambda names=None, tag=None: None)
+        prepare(['predictor'], 'predictor')                                   # (tensor tables over the static gradients the capture allocated)
         with torch.cuda.graph(gc, pool=gab.pool(), stream=side, capture_error_mode=mode):
             self._update(losses)
             keys = [k for k, v in losses.items() if torch.is_tensor(v)]

@@ -78,11 +78,18 @@ class Optimizer(object):
         for k in self._names(names):
             self.optimizers[k].step()
 
-    def prepare(self, names=None):
-        """optimizers that keep device-side tables of their tensors build them now (called outside hipGraph capture)"""
+    def prepare(self, names=None, tag='graph'):
+        """optimizers that keep device-side tables of their tensors build them now (called outside hipGraph capture) and keep
+        them until ``release(names, tag)``"""
         for k in self._names(names):
             if hasattr(self.optimizers[k], 'prepare'):
-                self.optimizers[k].prepare()
+                self.optimizers[k].prepare(tag)
+
+    def release(self, names=None, tag='graph'):
+        """the captured steps that asked for tables under ``tag`` were dropped"""
+        for k in self._names(names):
+            if hasattr(self.optimizers[k], 'release'):
+                self.optimizers[k].release(tag)
 
     def clip_and_step(self, name, max_norm):
         """clip the global gradient norm of child ``name`` to ``max_norm`` and step it; returns the pre-clip norm

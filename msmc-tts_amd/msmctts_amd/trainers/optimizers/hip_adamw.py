@@ -58,17 +58,30 @@ class HipAdamW(Optimizer):
         group['flat'] = flat
         return ps
 
-    def _table(self, group, ps):
+    def _table(self, group, ps, pin=None):
+        """device table (+ partial-sum buffer) over the parameters that have a gradient now.  Tables are keyed by the
+        gradient-storage signature.  ``pin`` (a tag, from ``prepare``): the table belongs to a captured step -- graphs of
+        different phases (warm-up / GAN) each replay with the table of THEIR static gradient tensors, and a table a graph
+        points at must outlive it -- and stays until ``release(tag)``.  Eager steps (``Optimizer.zero_grad`` sets gradients
+        to None, so autograd allocates new ones every step and the signature keeps changing) share ONE replaceable slot:
+        a 200k-step eager run holds one table, not one per step."""
         if not ps:
             return None, None, 0, 0
         live = [p for p in ps if p.grad is not None]
         sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in live)
-        # one table per gradient-storage signature, all kept: captured steps of different phases (warm-up / GAN) each replay
-        # with the table of THEIR static gradient tensors, and a table a graph points at must not be freed
-        tables = group.setdefault('tables', {})
-        cached = tables.get(sig)
-        if cached is not None:
-            return cached
+        tables = group.setdefault('tables', {})              # signature -> [entry, tags]
+        hit = tables.get(sig)
+        if hit is not None:
+            if pin is not None:
+                hit[1].add(pin)
+            return hit[0]
+        slot = group.get('eager_table')
+        if slot is not None and slot[0] == sig:
+            if pin is None:
+                return slot[1]
+            tables[sig] = [slot[1], {pin}]                   # (an eager step's table a capture is about to point at)
+            group['eager_table'] = None
+            return slot[1]
         chunk = lib.get().msmc_opt_chunk()
         items = (lib.OptTensor * max(1, len(live)))()
         blocks = 0
@@ -85,13 +98,27 @@ class HipAdamW(Optimizer):
                                'call optimizer.prepare() between the backward pass and the captured step')
         table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
         partial = torch.empty(max(1, blocks), dtype=torch.float32, device=dev)
-        tables[sig] = (table, partial, len(live), blocks)
-        return tables[sig]
+        entry = (table, partial, len(live), blocks)
+        if pin is not None:
+            tables[sig] = [entry, {pin}]
+        else:
+            group['eager_table'] = (sig, entry)              # replaces the previous eager table (stream-ordered release)
+        return entry
 
-    def prepare(self):
-        """build the flat state and the tensor table for the gradients that exist now (before capturing a step)"""
+    def prepare(self, tag='graph'):
+        """build the flat state and the tensor table for the gradients that exist now (before capturing a step); the
+        table is pinned under ``tag`` until ``release(tag)``"""
         for group in self.param_groups:
-            self._table(group, self._ensure_state(group))
+            self._table(group, self._ensure_state(group), pin=tag)
+
+    def release(self, tag='graph'):
+        """the captured steps that pinned their tables under ``tag`` are gone: drop the tables nothing else pins"""
+        for group in self.param_groups:
+            tables = group.get('tables', {})
+            for sig in [s for s, (_, tags) in tables.items() if tag in tags]:
+                tables[sig][1].discard(tag)
+                if not tables[sig][1]:
+                    del tables[sig]
 
     @torch.no_grad()
     def step(self, closure=None, max_norm=0.0):
@@ -121,6 +148,7 @@ class HipAdamW(Optimizer):
         for group in self.param_groups:
             group.pop('flat', None)
             group.pop('tables', None)
+            group.pop('eager_table', None)
             if not torch.is_tensor(group['lr']):
                 dev = group['params'][0].device
                 group['lr'] = torch.tensor(float(group['lr']), dtype=torch.float32, device=dev)
@@ -134,6 +162,7 @@ class HipAdamW(Optimizer):
         for g in sd['param_groups']:
             g.pop('flat', None)
             g.pop('tables', None)
+            g.pop('eager_table', None)
             if torch.is_tensor(g['lr']):
                 g['lr'] = float(g['lr'])
         for st in sd['state'].values():           # torch.optim.AdamW layout: a 0-dim fp32 ``step`` per parameter

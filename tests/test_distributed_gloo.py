@@ -266,6 +266,99 @@ def test_vqgan_trainer_sync_codebook_stats_keeps_codebooks_identical():
     assert n >= 6
 
 
+def _predictor_worker(rank, world, port, out):
+    """PredictorTrainer in graph mode under data parallelism with batch shapes that differ between ranks and steps: a rank
+    whose batch has the captured shape replays, the other steps eagerly -- both must meet in the SAME collective and keep
+    their parameters identical.  torch.cuda.graph does not exist on the CPU: ``_capture`` is replaced by a stand-in whose
+    'graphs' run the two halves of the step eagerly (what a replay does, minus the recording); everything else -- the
+    replay-or-eager decision, the exchange, the optimizer -- is the product's."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'msmc-tts_amd'), os.path.join(ROOT, 'tests')]
+    import _parity
+    from msmctts_amd.distributed.distributed import init_distributed
+    from msmctts_amd.hip import lib
+    from msmctts_amd.tasks import build_task
+    from msmctts_amd.trainers import build_trainer
+    from msmctts_amd.trainers.optimizers import build_optimizer
+    from msmctts_amd.utils.config import Config
+    torch.set_num_threads(2)
+    lib.use_library_for_tests(os.path.join(ROOT, 'tests', 'emu', 'libmsmc_emu.so'))
+    init_distributed(rank, world, 'g', 'gloo', 'tcp://127.0.0.1:%d' % port)
+    z = _parity.load_npz('small_predictor.npz')
+    cfg = Config({'id': 'small_predictor_dp', 'task': {'_name': 'MSMCTTS', '_mode': 'train_predictor', 'predictor': _parity.small_predictor_cfg()},
+                  'trainer': dict(_parity.PREDICTOR_TRAINER, _name='PredictorTrainer'),
+                  'optimizer': {'_default': dict(_name='Adam', learning_rate=2e-4, betas=[0.9, 0.98], eps=1e-9, weight_decay=0)},
+                  'dataset': dict(samplerate=24000, feature=['mel', 'wav'], frameshift=[300, 1])})
+    task = build_task(cfg, mode='train')
+    task.load_state_dict({k[len('state.'):]: _parity.t(v) for k, v in z.items() if k.startswith('state.')})
+    task = task.train()
+    _, atask = _parity.build_small('cpu')
+    tr = build_trainer(cfg, task, num_gpus=world, rank=rank)
+    tr.autoencoder = atask.autoencoder
+    tr.optimizer = build_optimizer(task, cfg.optimizer)
+    tr.use_graphs = True
+    full = {k[len('batch.'):]: _parity.t(v) for k, v in z.items() if k.startswith('batch.')}
+    B = full['mel'].shape[0]
+    assert B >= 2
+    short = {k: v[:B - 1].clone() for k, v in full.items()}           # one utterance less: every tensor changes shape
+
+    class _Replay(object):
+        def __init__(self, fn):
+            self.fn = fn
+
+        def replay(self):
+            self.fn()
+
+    def fake_capture(batch, shapes):
+        static = {k: batch[k].clone() for k in tr._KEYS}
+        box = {}
+        vec = torch.zeros(16)
+
+        def ab():
+            box['losses'] = tr._forward_backward(static, static=True)
+
+        def c():
+            tr._update(box['losses'])
+            keys = [k for k, v in box['losses'].items() if torch.is_tensor(v)]
+            g['loss_keys'] = keys
+            vec[:len(keys)] = torch.stack([box['losses'][k].detach().float().reshape(()) for k in keys])
+        g = dict(ab=_Replay(ab), c=_Replay(c), batch=static, shapes=shapes, loss_vec=vec, loss_keys=[])
+        return g
+    tr._capture = fake_capture
+    # step 0: both ranks capture on the full batch; step 1: rank 0 meets another shape (eager) while rank 1 replays;
+    # step 2: the other way round; step 3: both eager
+    plan = [(full, full), (short, full), (full, short), (short, short)]
+    calls = []
+    real = tr.model.grad_reducer.allreduce_child
+    tr.model.grad_reducer.allreduce_child = lambda child, grads=None: (calls.append(grads is None), real(child, grads=grads))[1]
+    for it, pair in enumerate(plan):
+        log = tr.train_step({k: v.clone() for k, v in pair[rank].items()}, it)
+        assert all(bool(torch.isfinite(v)) for v in log['loss'].values() if torch.is_tensor(v))
+    out[rank] = dict(state={k: v.clone() for k, v in tr.model.state_dict().items()}, calls=calls,
+                     init={k[len('state.'):]: _parity.t(v) for k, v in z.items() if k.startswith('state.')})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_predictor_graph_mode_two_ranks_with_different_batch_shapes_stay_in_sync():
+    """round-5 advisor finding: the eager branch of PredictorTrainer._train_step_graphed exchanged nothing under data
+    parallelism (the first replay had switched the reducer's hooks off) and a rank in it met no collective while a replaying
+    rank waited in one -- a hang from the second step on with segment_length = -1.  Both branches now issue the one flat
+    all-reduce of the child (a wrong pairing would time out here or leave the ranks' parameters different)."""
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'tests', 'emu')])
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_predictor_worker, args=(2, port, out), nprocs=2, join=True)
+    s0, s1 = out[0]['state'], out[1]['state']
+    moved = 0
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+        if s0[k].dtype.is_floating_point and k in out[0]['init']:
+            moved += int(not torch.equal(s0[k], out[0]['init'][k]))
+    assert moved > 50                                     # the four steps really trained
+    assert len(out[0]['calls']) == len(out[1]['calls']) == 4       # exactly one exchange per step on either rank
+
+
 # ---- bench.py as the driver launches it: ``python bench.py --gpus N`` with WORLD_SIZE unset must start its own ranks ----
 def _bench(argv, env=None, timeout=300):
     e = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}

@@ -1240,6 +1240,43 @@ def test_layernorm_parameter_gradients_delivered_once_per_pass():
             assert float((a - b).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max()))
 
 
+def test_layernorm_parameter_gradients_under_restricted_passes():
+    """hip/norm.py with the deferred parameter-gradient launch on: ``backward(inputs=[...])`` delivers exactly the requested
+    parameter gradients (none when only the activation is asked for), and ``torch.autograd.grad`` on the LayerNorm parameters
+    gets their gradients (autograd's own route: that pass accumulates nothing into ``.grad``)."""
+    from msmctts_amd.hip import norm
+    torch.manual_seed(5)
+    N, C = 37, 64
+    x, g = torch.randn(N, C, requires_grad=True), torch.randn(N, C)
+    gm, bt = torch.full((C,), 0.75, requires_grad=True), torch.full((C,), 0.25, requires_grad=True)
+    ref = torch.nn.functional.layer_norm(x, (C,), gm, bt)
+    want_gm, want_bt, want_x = torch.autograd.grad((ref * g).sum(), [gm, bt, x])
+    assert norm.LN_PARAM_DEFER
+    # both parameters requested (and nothing else): delivered by the end-of-pass launch
+    (norm.add_layer_norm(x, None, gm, bt) * g).sum().backward(inputs=[gm, bt])
+    _parity.close(gm.grad, want_gm, 2e-4, 1e-3, 'dgamma')
+    _parity.close(bt.grad, want_bt, 2e-4, 1e-3, 'dbeta')
+    assert x.grad is None
+    gm.grad = bt.grad = None
+    # one of the two: autograd's own route for it, nothing for the other
+    (norm.add_layer_norm(x, None, gm, bt) * g).sum().backward(inputs=[gm])
+    _parity.close(gm.grad, want_gm, 2e-4, 1e-3, 'dgamma alone')
+    assert bt.grad is None and x.grad is None
+    gm.grad = None
+    # only the activation: no parameter gradient is computed or delivered
+    (norm.add_layer_norm(x, None, gm, bt) * g).sum().backward(inputs=[x])
+    _parity.close(x.grad, want_x, 2e-4, 1e-3, 'dx')
+    assert gm.grad is None and bt.grad is None
+    x.grad = None
+    # torch.autograd.grad: the gradients come back on the edges, .grad stays untouched
+    a, b = torch.autograd.grad((norm.add_layer_norm(x, None, gm, bt) * g).sum(), [gm, bt])
+    _parity.close(a, want_gm, 2e-4, 1e-3, 'dgamma (autograd.grad)')
+    _parity.close(b, want_bt, 2e-4, 1e-3, 'dbeta (autograd.grad)')
+    (c,) = torch.autograd.grad((norm.add_layer_norm(x, None, gm, bt) * g).sum(), [bt])
+    _parity.close(c, want_bt, 2e-4, 1e-3, 'dbeta alone (autograd.grad)')
+    assert gm.grad is None and bt.grad is None and x.grad is None
+
+
 def test_train_steps_match_reference_with_the_fused_fft_prologue():
     """the same reference fixture with MSMC_FFT_PROLOGUE on (FFT stacks called with lengths instead of positions)"""
     from msmctts_amd.networks.acoustic_models import transformer
