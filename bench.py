@@ -520,9 +520,8 @@ def make_timer():
             n, e = wn_elems.get(_val(items), (0, 2))
             return 0.0, float(n * per_elem_of(e))
         return work
-    # prepare: v read once, both kernel layouts written (+ the transposing pass's second read); backward: dW read and
-    # re-zeroed, v read, gradient written
-    timer.wrap_abi(L0, 'msmc_wn_prepare_multi_tiled', wn_bytes(lambda e: 8 + 2 * e))
+    # prepare: v read once, both kernel layouts written; backward: dW read and re-zeroed, v read, gradient written
+    timer.wrap_abi(L0, 'msmc_wn_prepare_multi_tiles', wn_bytes(lambda e: 4 + 2 * e))
     timer.wrap_abi(L0, 'msmc_wn_backward_multi_rows', wn_bytes(lambda e: 16))
     timer.wrap_abi(L0, 'msmc_opt_clip_adamw', lambda table, nt, nblocks, max_norm, *rest:
                    (0.0, float(nblocks) * chunk * (28 + (4 if max_norm > 0 else 0))))
@@ -533,6 +532,9 @@ def make_timer():
         for o in gc.get_objects():
             if isinstance(o, ConvBank) and getattr(o, 'items_dev', None) is not None:
                 wn_elems[o.items_dev.data_ptr()] = (o.w1.numel(), o.w1.element_size())
+        from msmctts_amd.hip import convnet as _cn
+        for hit in _cn._TOGETHER.values():           # (several banks refreshed by one call: hip/convnet.py prepare_together)
+            wn_elems[hit[0].data_ptr()] = (hit[6], hit[7])
 
     return timer, register_banks
 

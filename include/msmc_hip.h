@@ -299,6 +299,19 @@ int msmc_wn_prepare_multi(const msmc_wn_item* items, int nitems, int total_block
  * without dst2 own none); T <= MSMC_CONV_MAX_TAPS. */
 int msmc_wn_prepare_multi_tiled(const msmc_wn_item* items, int nitems, int total_blocks, int total_tile_blocks,
                                 msmc_stream stream);
+/* Round 6: both layouts from ONE read of the parameters.  A norms-only row pass over the weight-normalised rows and a tiled
+ * pass in which a workgroup reads a tile of rows x columns x all taps in the parameter's own order and writes it out twice --
+ * layout 1 with b fastest, layout 2 with a fastest: both must have unit stride there (s1[2] == 1, s2[1] == 1), dst2 may be NULL.
+ * Item i owns tile-blocks [tblock0, tblock0 + msmc_wn_tile_blocks(A, Bc, T)) of total_tile_blocks; ``max_taps`` = the largest T
+ * among the items (sizes the tile buffer), <= MSMC_CONV_MAX_TAPS.  Device index maps replace the per-workgroup search of the
+ * item table: row_item[r] = item of row r (r as block0 counts rows, total_blocks entries), norm_rows[k] = the k-th row of a
+ * weight-normalised item (n_norm_rows entries, 0: no such item -- no row pass), tile_item[t] = item of tile-block t (may be NULL:
+ * searched).  Replaces msmc_wn_prepare_multi_tiled's row pass (strided re-read of v, a workgroup per row) and its 64 x 16
+ * transposing pass: the autoencoder's 36.7 M weights 91 + 138 us -> profiles/README.md. */
+int msmc_wn_tile_blocks(int A, int Bc, int T);
+int msmc_wn_prepare_multi_tiles(const msmc_wn_item* items, int nitems, int total_blocks, int total_tile_blocks, int max_taps,
+                                const int* row_item, const int* norm_rows, int n_norm_rows, const int* tile_item,
+                                msmc_stream stream);
 int msmc_wn_backward_multi(const msmc_wn_item* items, int nitems, int total_blocks, msmc_stream stream);
 /* accumulate != 0: gv / gg / gb += instead of = (a second backward before the gradients were reset: torch .grad semantics) */
 int msmc_wn_backward_multi_acc(const msmc_wn_item* items, int nitems, int total_blocks, int accumulate, msmc_stream stream);

@@ -2599,20 +2599,30 @@ MSMC_DEV void wg2_body(const msmc_conv_desc& d, const unsigned short* __restrict
 // workgroups, so it runs in two levels there: groups of consecutive splits are summed into `groups` intermediate
 // regions (stored), then the groups are added to dW / db.  A member is one such pass: nsplit source regions of
 // `stride` floats -> either an intermediate region (dst_ws) or the final dw | db pair.
-struct WgReduceArgs {
+template <int M>
+struct WgReduceArgsT {
     int n;
-    int first[MSMC_GROUP_MAX + 1];          // first block of member k
-    int eblocks[MSMC_GROUP_MAX];            // blocks per group of member k (1024 floats each)
-    const float* src[MSMC_GROUP_MAX];
-    long stride[MSMC_GROUP_MAX];
-    long n_dw[MSMC_GROUP_MAX];
-    int nsplit[MSMC_GROUP_MAX], per_group[MSMC_GROUP_MAX], n_db[MSMC_GROUP_MAX];
-    float* dst_ws[MSMC_GROUP_MAX];          // not NULL: intermediate level, group gi stores its sums at dst_ws + gi * stride
-    float* dw[MSMC_GROUP_MAX];              // final level (one group): dw[e] += sum, db[e - n_dw] += sum
-    float* db[MSMC_GROUP_MAX];
+    int first[M + 1];                       // first block of member k
+    int eblocks[M];                         // blocks per group of member k (1024 floats each)
+    const float* src[M];
+    long stride[M];
+    long n_dw[M];
+    int nsplit[M], per_group[M], n_db[M];
+    float* dst_ws[M];                       // not NULL: intermediate level, group gi stores its sums at dst_ws + gi * stride
+    float* dw[M];                           // final level (one group): dw[e] += sum, db[e - n_dw] += sum
+    float* db[M];
 };
-__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WgReduceArgs a) {
-    const int k = cv_group_member(a.first, a.n);
+typedef WgReduceArgsT<MSMC_GROUP_MAX> WgReduceArgs;
+// the merged second stage of a whole backward pass (msmc_conv_wgrad_reduce_pending): as many members per launch as a kernel
+// argument block (4 KB) carries -- the discriminator's ~40 records went out as seven launches of six members, back to back on
+// the critical chain in front of its optimizer step (profiles/r06_step_timeline_start_of_round.txt: 143 us)
+#define WG_PENDING_MAX 40
+typedef WgReduceArgsT<WG_PENDING_MAX> WgReduceArgsBig;
+static_assert(sizeof(WgReduceArgsBig) <= 4000, "kernel argument block");
+template <int M>
+MSMC_DEV void wgrad_reduce_body(const WgReduceArgsT<M>& a) {
+    int k = 0;
+    while (k + 1 < a.n && (int)blockIdx.x >= a.first[k + 1]) ++k;
     const int id = blockIdx.x - a.first[k];
     const int gi = id / a.eblocks[k], eb = id - gi * a.eblocks[k];
     const long stride = a.stride[k], n_dw = a.n_dw[k], total = n_dw + a.n_db[k];
@@ -2625,8 +2635,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WgReduceArgs a) 
     float* mid = a.dst_ws[k] ? a.dst_ws[k] + (size_t)gi * stride : nullptr;
     // (regions are padded to a multiple of four floats: an intermediate level may run past `total` inside them)
     if ((n_dw & 3) == 0 && (mid ? e0 + 4 <= stride : e0 + 4 <= n_dw)) {
+        // (the splits are added in split order -- bit-reproducible -- but LOADED eight at a time: with one load in flight per
+        //  work-item a member of 64 splits was 64 dependent memory round trips, and the pass ran at ~1 TB/s)
         f32x4 sum = *(const f32x4*)(ws + e0);
-        for (int s_ = 1; s_ < S; ++s_) {
+        int s_ = 1;
+        for (; s_ + 8 <= S; s_ += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(ws + (size_t)(s_ + j) * stride + e0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum = sum + v[j];
+        }
+        for (; s_ < S; ++s_) {
             const f32x4 v = *(const f32x4*)(ws + (size_t)s_ * stride + e0);
             sum = sum + v;
         }
@@ -2643,6 +2663,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WgReduceArgs a) 
         else if (a.db[k]) a.db[k][e - n_dw] = a.db[k][e - n_dw] + sum;
     }
 }
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(WgReduceArgs a) { wgrad_reduce_body(a); }
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_pending_kernel(WgReduceArgsBig a) { wgrad_reduce_body(a); }
 
 // plan of the second stage for one weight gradient: groups == 1 -> one level
 struct Wg3Reduce {
@@ -2669,7 +2691,8 @@ static Wg3Reduce wg3_reduce_plan(long total, int nsplit) {
 // issues the recorded reductions of a whole backward pass together (msmc_conv_wgrad_reduce_pending).
 static thread_local msmc_wg_pending* wg_defer_sink = nullptr;
 static thread_local int wg_defer_cap = 0, wg_defer_n = 0;
-static void wg3_reduce_add(WgReduceArgs& a, int* blocks, const float* ws, long stride, long n_dw, int n_db, int nsplit,
+template <int M>
+static void wg3_reduce_add(WgReduceArgsT<M>& a, int* blocks, const float* ws, long stride, long n_dw, int n_db, int nsplit,
                            float* mid, float* dw, float* db, int level) {
     if (!ws) return;
     if (wg_defer_sink) {
@@ -2853,10 +2876,10 @@ extern "C" int msmc_conv_wgrad_reduce_pending(const msmc_wg_pending* items, int 
     for (int level = 0; level < 2 && !rc; ++level) {
         int i = 0;
         while (i < n && !rc) {
-            WgReduceArgs a;
+            WgReduceArgsBig a;
             a.n = 0;
             int blocks = 0;
-            for (; i < n && a.n < MSMC_GROUP_MAX; ++i) {
+            for (; i < n && a.n < WG_PENDING_MAX; ++i) {
                 const msmc_wg_pending& p = items[i];
                 if (level == 1) {
                     // a layer applied twice in one backward pass (D(real) and D(fake) as separate calls, rb(rb(x))) has two
@@ -2871,7 +2894,9 @@ extern "C" int msmc_conv_wgrad_reduce_pending(const msmc_wg_pending* items, int 
             }
             if (!a.n) continue;
             a.first[a.n] = blocks;
-            rc = wg3_reduce_launch(a, blocks, stream);
+            MSMC_LAUNCH(conv_wgrad_reduce_pending_kernel, dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
+            ++msmc_conv_launches;
+            rc = msmc_check_launch();
         }
     }
     wg_defer_sink = keep;
@@ -3553,6 +3578,168 @@ __global__ __launch_bounds__(256) void wn_transpose_kernel(const msmc_wn_item* _
     }
 }
 
+// Norms of the weight-normalised rows alone (msmc_wn_prepare_multi_tiles): block k takes row norm_rows[k] (an index into the
+// grid of ALL rows, as block0 counts them) of item row_item[that row] -- two dependent loads where the binary search over the
+// items' block0 was eight, a search that cost each of the 16 000 row workgroups of the autoencoder ~4 us before its first load.
+__global__ __launch_bounds__(256) void wn_norm_kernel(const msmc_wn_item* __restrict__ items, const int* __restrict__ row_item,
+                                                      const int* __restrict__ norm_rows) {
+    __shared__ float red[4];
+    const int grow = norm_rows[blockIdx.x];
+    const msmc_wn_item it = items[row_item[grow]];
+    const int a = grow - it.block0;
+    const int n = it.Bc * it.T;
+    const float* v = it.v + (size_t)a * n;
+    float ss = 0.f;
+    if ((n & 3) == 0) {
+        const f32x4* v4 = (const f32x4*)v;
+        for (int e = threadIdx.x; e < (n >> 2); e += 256) {
+            const f32x4 q = v4[e];
+            ss = fmaf(q[0], q[0], ss);
+            ss = fmaf(q[1], q[1], ss);
+            ss = fmaf(q[2], q[2], ss);
+            ss = fmaf(q[3], q[3], ss);
+        }
+    } else {
+        for (int e = threadIdx.x; e < n; e += 256) ss = fmaf(v[e], v[e], ss);
+    }
+    ss = block_sum_fast(ss, red);
+    if (threadIdx.x == 0) it.inv_norm[a] = 1.f / sqrtf(ss);
+}
+
+// Both kernel layouts from ONE read of the parameter (round 6).  The row pass + transposing pass above moved the autoencoder's
+// 36.7 M weights in 91 + 138 us per step -- three reads of v, a workgroup per row, 16 of a wave's 64 lanes loading in the
+// transposing pass of every one-tap layer -- for 8 bytes per weight of real traffic, alone on the chip at the head of the step
+// (profiles/r06_step_timeline_*.txt).  Here a workgroup owns a tile of TA rows (a) x TB columns (b) x all T taps, TA / TB chosen
+// from T so that a row's share of the tile is ~128 contiguous floats or more: the tile is read in the parameter's own order
+// (coalesced, whole wave) into LDS and written twice -- layout 2 with a fastest (TA consecutive elements per store), layout 1
+// with b fastest (TB consecutive per store; both banks' layouts have s1[2] == 1 and s2[1] == 1, checked by the launcher's
+// caller).  The scale g / ||v|| of weight-normalised rows comes from a norms-only row pass in front (wn_norm_kernel).
+MSMC_DEV_INLINE int wn_tile_a(int T) { return T <= 4 ? 64 : 32; }
+MSMC_DEV_INLINE int wn_tile_b(int T) { return T == 1 ? 128 : T == 2 ? 64 : 32; }
+__global__ __launch_bounds__(256) void wn_layout_kernel(const msmc_wn_item* __restrict__ items, int nitems,
+                                                        const int* __restrict__ tile_item) {
+    MSMC_DYN_LDS(smem);
+    float* tile = (float*)smem;
+    __shared__ float scl[64];
+    const msmc_wn_item it = items[tile_item ? tile_item[blockIdx.x] : wn_find_tile(items, nitems, blockIdx.x)];
+    const int T = it.T, TA = wn_tile_a(T), TB = wn_tile_b(T);
+    const int tb = blockIdx.x - it.tblock0;
+    const int nbt = (it.Bc + TB - 1) / TB;
+    const int ti = tb / nbt;
+    const int a0 = ti * TA, b0 = (tb - ti * nbt) * TB;
+    const int nb = it.Bc - b0 < TB ? it.Bc - b0 : TB, na = it.A - a0 < TA ? it.A - a0 : TA;
+    const int ncol = nb * T, pitch = TB * T + 1;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if ((int)threadIdx.x < TA)
+        scl[threadIdx.x] = (it.g && (int)threadIdx.x < na) ? it.g[a0 + threadIdx.x] * it.inv_norm[a0 + threadIdx.x] : 1.f;
+    {
+        // a wave reads rows w, w + 4, .. of the tile, 64 consecutive floats per load; SIXTEEN loads are issued before the first
+        // of them is written to LDS (one in flight per work-item made the tile a chain of memory round trips)
+        const float* __restrict__ vb = it.v + ((size_t)a0 * it.Bc + b0) * T;
+        const size_t rowlen = (size_t)it.Bc * T;
+        const int n_k = (ncol + 63) >> 6;
+        const int nr = na > w ? (na - w + 3) >> 2 : 0;
+        const int P = nr * n_k;
+        for (int q0 = 0; q0 < P; q0 += 16) {
+            float buf[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int q = q0 + i;
+                buf[i] = 0.f;
+                if (q < P) {
+                    const int j = q / n_k, c = lane + 64 * (q - j * n_k);
+                    if (c < ncol) buf[i] = vb[(size_t)(w + 4 * j) * rowlen + c];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int q = q0 + i;
+                if (q < P) {
+                    const int j = q / n_k, c = lane + 64 * (q - j * n_k);
+                    if (c < ncol) tile[(w + 4 * j) * pitch + c] = buf[i];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // Stores: FOUR consecutive elements per lane (8 bytes of bf16, 16 of fp32) wherever the fastest axis of a layout is a
+    // multiple of four -- a wave instruction of 2-byte stores is 64 separate write requests to the memory pipeline whatever
+    // their addresses (the first version of this kernel, one element per lane, moved 1.3 TB/s: no faster than the two
+    // passes it replaces); single elements otherwise (the one- and two-channel first layers of the discriminators).
+    if (it.dst2) {
+        if ((it.A & 3) == 0) {
+            // layout 2, a fastest: a lane takes rows 4l .. 4l+3 of one column (b, t); TA / 4 lanes per column
+            const int lpc = TA >> 2, cpw = 64 / lpc, csub = lane / lpc, al = (lane - csub * lpc) * 4;
+            const int step = 4 * cpw, qs = step / T, rs = step - qs * T;
+            int c = w * cpw + csub;
+            int b = c / T, t = c - b * T;
+            const bool live = al < na;                 // (na is a multiple of four here)
+            const float s0 = live ? scl[al] : 0.f, s1_ = live ? scl[al + 1] : 0.f, s2_ = live ? scl[al + 2] : 0.f,
+                        s3 = live ? scl[al + 3] : 0.f;
+            const float* col = tile + al * pitch;
+            for (; c < ncol; c += step) {
+                if (live) {
+                    const long o = t * it.s2[0] + (a0 + al) + (long)(b0 + b) * it.s2[2];
+                    const float x0 = col[c] * s0, x1 = col[pitch + c] * s1_, x2 = col[2 * pitch + c] * s2_, x3 = col[3 * pitch + c] * s3;
+                    if (it.dtype == 0) {
+                        const f32x4 q = {x0, x1, x2, x3};
+                        *(f32x4*)((float*)it.dst2 + o) = q;
+                    } else {
+                        const u32x2 q = {pack_bf16x2(x0, x1), pack_bf16x2(x2, x3)};
+                        *(u32x2*)((unsigned short*)it.dst2 + o) = q;
+                    }
+                }
+                b += qs;
+                t += rs;
+                if (t >= T) { t -= T; ++b; }
+            }
+        } else {
+            const int cpw = 64 / TA, csub = lane / TA, al = lane - csub * TA;
+            const int step = 4 * cpw, qs = step / T, rs = step - qs * T;
+            int c = w * cpw + csub;
+            int b = c / T, t = c - b * T;
+            const float sc = al < na ? scl[al] : 0.f;
+            for (; c < ncol; c += step) {
+                if (al < na)
+                    wn_store(it.dst2, it.dtype, t * it.s2[0] + (a0 + al) * it.s2[1] + (b0 + b) * it.s2[2], tile[al * pitch + c] * sc);
+                b += qs;
+                t += rs;
+                if (t >= T) { t -= T; ++b; }
+            }
+        }
+    }
+    if ((it.Bc & 3) == 0) {
+        // layout 1, b fastest: a lane takes columns 4l .. 4l+3 of one run (a, t); TB / 4 lanes per run
+        const int lpr = TB >> 2, rpw = 64 / lpr, sub = lane / lpr, bl = (lane - sub * lpr) * 4;
+        const int nrun = na * T;
+        for (int run = w * rpw + sub; run < nrun; run += 4 * rpw) {
+            if (bl >= nb) continue;                    // (nb is a multiple of four here)
+            const int a = run / T, t = run - a * T;
+            const float sc = scl[a];
+            const long o = t * it.s1[0] + (a0 + a) * it.s1[1] + (b0 + bl);
+            const float* row = tile + a * pitch + t + bl * T;
+            const float x0 = row[0] * sc, x1 = row[T] * sc, x2 = row[2 * T] * sc, x3 = row[3 * T] * sc;
+            if (it.dtype == 0) {
+                const f32x4 q = {x0, x1, x2, x3};
+                *(f32x4*)((float*)it.dst1 + o) = q;
+            } else {
+                const u32x2 q = {pack_bf16x2(x0, x1), pack_bf16x2(x2, x3)};
+                *(u32x2*)((unsigned short*)it.dst1 + o) = q;
+            }
+        }
+    } else {
+        const int lpr = TB < 64 ? TB : 64, rpw = 64 / lpr, sub = lane / lpr, bl = lane - sub * lpr;
+        const int nrun = na * T;
+        for (int run = w * rpw + sub; run < nrun; run += 4 * rpw) {
+            const int a = run / T, t = run - a * T;
+            const float sc = scl[a];
+            const long o = t * it.s1[0] + (a0 + a) * it.s1[1] + (long)b0 * it.s1[2];
+            const float* row = tile + a * pitch + t;
+            for (int bb = bl; bb < nb; bb += lpr) wn_store(it.dst1, it.dtype, o + bb * it.s1[2], row[bb * T] * sc);
+        }
+    }
+}
+
 // Row pass of the backward: dW arrives in layout 1 (tap-major), v / gv live in the parameter's own order.  Rows of up
 // to WN_ROW_MAX parameters go through LDS: dW is read TAP-OUTER (64 consecutive floats per wave load, privatised copies
 // folded and zeroed on the way), then everything else runs in the parameter's order (coalesced v reads, coalesced gv
@@ -3979,6 +4166,35 @@ int msmc_wn_prepare_multi_tiled(const msmc_wn_item* items, int nitems, int total
     int rc = msmc_check_launch();
     if (rc || total_tile_blocks == 0) return rc;
     MSMC_LAUNCH(wn_transpose_kernel, dim3(total_tile_blocks), dim3(256), 0, (msmc_stream_t)stream, items, nitems);
+    return msmc_check_launch();
+}
+
+// tile-blocks of one item under wn_layout_kernel's tile rule (the host lays tblock0 out with it)
+int msmc_wn_tile_blocks(int A, int Bc, int T) {
+    if (A <= 0 || Bc <= 0 || T <= 0) return 0;
+    const int ta = T <= 4 ? 64 : 32, tb = T == 1 ? 128 : T == 2 ? 64 : 32;
+    return ((A + ta - 1) / ta) * ((Bc + tb - 1) / tb);
+}
+int msmc_wn_prepare_multi_tiles(const msmc_wn_item* items, int nitems, int total_blocks, int total_tile_blocks, int max_taps,
+                                const int* row_item, const int* norm_rows, int n_norm_rows, const int* tile_item,
+                                msmc_stream stream) {
+    if (!items || nitems <= 0 || total_blocks <= 0 || total_tile_blocks <= 0 || max_taps <= 0 || max_taps > MSMC_CONV_MAX_TAPS ||
+        n_norm_rows < 0 || (n_norm_rows > 0 && (!row_item || !norm_rows)))
+        return MSMC_E_SHAPE;
+    if (n_norm_rows > 0) {
+        MSMC_LAUNCH(wn_norm_kernel, dim3(n_norm_rows), dim3(256), 0, (msmc_stream_t)stream, items, row_item, norm_rows);
+        int rc = msmc_check_launch();
+        if (rc) return rc;
+    }
+    size_t lds = 0;
+    for (int T = 1; T <= max_taps; ++T) {
+        const int ta = T <= 4 ? 64 : 32, tb = T == 1 ? 128 : T == 2 ? 64 : 32;
+        const size_t l = (size_t)ta * (tb * T + 1) * sizeof(float);
+        if (l > lds) lds = l;
+    }
+    int rc = msmc_allow_lds((const void*)wn_layout_kernel, (int)lds);
+    if (rc) return rc;
+    MSMC_LAUNCH(wn_layout_kernel, dim3(total_tile_blocks), dim3(256), lds, (msmc_stream_t)stream, items, nitems, tile_item);
     return msmc_check_launch();
 }
 

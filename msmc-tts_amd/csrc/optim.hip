@@ -38,9 +38,22 @@ __global__ __launch_bounds__(256) void opt_gradsq_kernel(const msmc_opt_tensor* 
     const msmc_opt_tensor t = table[opt_find(table, nt, blockIdx.x)];
     const long e0 = (long)(blockIdx.x - t.first_chunk) * OPT_CHUNK;
     float s = 0.f;
-    for (int k = threadIdx.x; k < OPT_CHUNK; k += 256) {
-        const long e = e0 + k;
-        if (e < t.n) s = fmaf(t.g[e], t.g[e], s);
+    if (e0 + OPT_CHUNK <= t.n && ((size_t)(t.g + e0) & 15) == 0) {
+        // whole chunk, aligned: four 16-byte loads per work-item, all in flight at once.  The per-work-item order of the
+        // additions differs from the scalar form below (elements 4k .. 4k+3 of a work-item are consecutive here); which form
+        // a chunk takes depends on the tensor's size and alignment only, so a given model sums the same way every step
+        f32x4 g4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g4[i] = *(const f32x4*)(t.g + e0 + threadIdx.x * 4 + 1024 * i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s = fmaf(g4[i][q], g4[i][q], s);
+    } else {
+        for (int k = threadIdx.x; k < OPT_CHUNK; k += 256) {
+            const long e = e0 + k;
+            if (e < t.n) s = fmaf(t.g[e], t.g[e], s);
+        }
     }
     s = opt_block_sum(s, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;

@@ -4,7 +4,7 @@
 UnivNet discriminator):
   * the kernel-layout weights (forward slices ``[T, Cout, Cin]`` and data-gradient slices
     ``[T, Cin, Cout]`` in the compute dtype), refreshed from ``weight_v / weight_g`` by ONE
-    ``msmc_wn_prepare_multi_tiled`` call (two launches) per forward pass of the network;
+    ``msmc_wn_prepare_multi_tiles`` call (two launches) per forward pass of the network;
   * fp32 weight-gradient accumulators in kernel layout, filled by ``msmc_conv_wgrad`` from each
     convolution's backward, and turned into ``weight_v.grad / weight_g.grad / bias.grad`` by ONE
     ``msmc_wn_backward_multi`` launch at the end of the backward pass (autograd engine callback).
@@ -208,7 +208,7 @@ def refresh_stale_banks():
 # parameters ONE optimizer step moves together, so at the head of the next forward pass all of them are stale -- and each
 # refreshed its images when its module was reached: six calls of two launches, 12 nodes and 0.26 ms on the critical chain of
 # the step (profiles/r06_step_timeline_start_of_round.txt).  ``prepare_together`` refreshes every stale bank of a list in
-# ONE msmc_wn_prepare_multi_tiled call over the concatenation of their item tables (block offsets re-based); the banks' own
+# ONE msmc_wn_prepare_multi_tiles call over the concatenation of their item tables (block offsets re-based); the banks' own
 # ``prepare`` calls further down then find themselves clean.  MSMC_PREPARE_TOGETHER=0: each bank on its own (A/B).
 PREPARE_TOGETHER = os.environ.get('MSMC_PREPARE_TOGETHER', '1') != '0'
 _TOGETHER = {}
@@ -248,12 +248,35 @@ def prepare_together(pairs):
         if dev.type == 'cuda' and torch.cuda.is_current_stream_capturing():
             return                      # (a table built during capture would be a host-to-device copy node: banks one by one)
         table = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
-        hit = _TOGETHER[key] = (table, n, blk, tblk, [weakref.ref(b) for b in banks])
-    table, n, blk, tblk, _ = hit
-    lib.check(lib.get().msmc_wn_prepare_multi_tiled(lib.ptr(table), n, blk, tblk, lib.stream(banks[0].w1)),
-              'msmc_wn_prepare_multi_tiled(together)')
+        hit = _TOGETHER[key] = (table, n, blk, tblk, max(b.max_taps for b in banks), _wn_maps(items, dev),
+                                sum(b.w1.numel() for b in banks), banks[0].w1.element_size())
+    table, n, blk, tblk, max_taps, maps = hit[:6]
+    _wn_prepare(table, maps, n, blk, tblk, max_taps, lib.stream(banks[0].w1), 'msmc_wn_prepare_multi_tiles(together)')
     for bank, versions, capturing in stale:
         bank._refreshed(versions, capturing)
+
+
+def _wn_maps(items, device):
+    """device index maps of msmc_wn_prepare_multi_tiles over a host item table: (int32 tensor, offset of norm_rows, number of
+    them, offset of tile_item) -- row_item first.  Block k of the norms pass / the layout pass reads its item from these
+    instead of searching the item table (eight dependent loads per workgroup)."""
+    L = lib.get()
+    row_item, norm_rows, tile_item = [], [], []
+    for i, it in enumerate(items):
+        row_item += [i] * it.A
+        if it.g:
+            norm_rows += range(it.block0, it.block0 + it.A)
+        tile_item += [i] * int(L.msmc_wn_tile_blocks(it.A, it.Bc, it.T))
+    flat = torch.tensor(row_item + norm_rows + tile_item + [0], dtype=torch.int32).to(device)
+    return flat, len(row_item), len(norm_rows), len(row_item) + len(norm_rows)
+
+
+def _wn_prepare(table, maps, n, blk, tblk, max_taps, stream, what):
+    flat, o_norm, n_norm, o_tile = maps
+    base = flat.data_ptr()
+    lib.check(lib.get().msmc_wn_prepare_multi_tiles(lib.ptr(table), n, blk, tblk, max_taps, ctypes.c_void_p(base),
+                                                    ctypes.c_void_p(base + 4 * o_norm), n_norm,
+                                                    ctypes.c_void_p(base + 4 * o_tile), stream), what)
 
 
 class ConvBank(object):
@@ -394,8 +417,8 @@ class ConvBank(object):
             it.A, it.Bc, it.T = A, v.shape[1], l.taps
             it.dtype = 0 if dtype == torch.float32 else 1
             it.block0 = blk
-            it.tblock0 = tblk                      # tiles of 64 (dim 0) x 16 (dim 1) of the transposing pass
-            tblk += ((A + 63) // 64) * ((v.shape[1] + 15) // 16)
+            it.tblock0 = tblk                      # tiles (rows x columns x all taps) of the layout pass, csrc/conv.hip wn_layout_kernel
+            tblk += int(lib.get().msmc_wn_tile_blocks(A, v.shape[1], l.taps))
             it.nbias = l.cout
             it.db, it.gb = self.db.data_ptr() + odb * 4, self.gb.data_ptr() + ob * 4
             w1 = self.w1[ow:ow + n]
@@ -418,11 +441,13 @@ class ConvBank(object):
             ow, oa, ob, blk = ow + pad8(n), oa + A, ob + l.cout, blk + A
             odw, odb = odw + pad8(n * R), odb + pad8(l.cout * R)
         self.total_blocks, self.total_tile_blocks = blk, tblk
+        self.max_taps = max(l.taps for l in self.layers)
         self.max_row = max(l.weight.shape[1] * l.taps for l in self.layers)      # longest normalised row (parameters)
         raw = bytes(items)
         self._items_host = items
         self._copy_checks = 6              # backward passes after which idle privatised copies are looked for
         self.items_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.maps = _wn_maps(items, dev)
         self.dtype = dtype
         self._build_version = getattr(self, '_build_version', 0) + 1       # (prepare_together: combined tables are rebuilt)
 
@@ -476,9 +501,8 @@ class ConvBank(object):
         stale, versions, capturing = self._stale(dtype, force)
         if not stale:
             return
-        lib.check(lib.get().msmc_wn_prepare_multi_tiled(lib.ptr(self.items_dev), len(self.layers), self.total_blocks,
-                                                        self.total_tile_blocks, lib.stream(self.w1)),
-                  'msmc_wn_prepare_multi_tiled')
+        _wn_prepare(self.items_dev, self.maps, len(self.layers), self.total_blocks, self.total_tile_blocks, self.max_taps,
+                    lib.stream(self.w1), 'msmc_wn_prepare_multi_tiles')
         self._refreshed(versions, capturing)
 
     # -- end-of-backward: kernel-layout dW -> parameter gradients --------------------------------------

@@ -122,6 +122,8 @@ _SIGNATURES.update({
     'msmc_attn_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, ctypes.c_longlong, _vp]),
     'msmc_wn_prepare_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_wn_prepare_multi_tiled': (_i, [_vp, _i, _i, _i, _vp]),
+    'msmc_wn_tile_blocks': (_i, [_i, _i, _i]),
+    'msmc_wn_prepare_multi_tiles': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     'msmc_wn_backward_multi': (_i, [_vp, _i, _i, _vp]),
     'msmc_wn_backward_multi_acc': (_i, [_vp, _i, _i, _i, _vp]),
     'msmc_wn_backward_multi_rows': (_i, [_vp, _i, _i, _i, _i, _vp]),

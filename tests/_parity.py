@@ -617,6 +617,75 @@ def check_resblock_standalone(dev):
             close(got[n], p.grad, 2e-4, 2e-3, what=n)
 
 
+def check_weight_image_tiles(dev):
+    """msmc_wn_prepare_multi_tiles (norms-only row pass + one tiled pass writing both kernel layouts) against the definition
+    w = v * g / ||v|| (plain layers: w = v) over shapes that end inside a tile on either axis, every tap count the tile rule
+    distinguishes (1, 2, 3-4, 5+) up to the limit, convolution and transposed-convolution stride sets, fp32 and bf16 images,
+    several items in one call -- and against the previous two-pass form msmc_wn_prepare_multi_tiled on the same items."""
+    import ctypes
+    from msmctts_amd.hip import lib
+    L = lib.get()
+    torch.manual_seed(23)
+    shapes = [(70, 33, 1, True, 'conv'), (64, 128, 1, False, 'conv'), (5, 7, 2, True, 'convT'), (96, 40, 3, False, 'conv'),
+              (33, 65, 4, True, 'conv'), (40, 31, 5, True, 'convT'), (17, 50, 7, False, 'conv'), (32, 32, 9, True, 'conv'),
+              (130, 20, 11, True, 'conv'), (9, 70, 12, True, 'convT'), (3, 3, 16, False, 'conv'), (1, 1, 1, True, 'conv')]
+    for dtype, tol in ((torch.float32, 3e-7), (torch.bfloat16, 4e-3)):
+        esz = 4 if dtype == torch.float32 else 2
+        vs = [torch.randn(A, Bc, T, device=dev) for A, Bc, T, _, _ in shapes]
+        gs = [torch.rand(A, device=dev) + 0.5 for A, _, _, _, _ in shapes]
+        pad8 = lambda n: (n + 7) // 8 * 8
+        tot = sum(pad8(v.numel()) for v in vs)
+
+        def run(entry):
+            w1 = torch.full((tot,), float('nan'), dtype=dtype, device=dev)
+            w2 = torch.full((tot,), float('nan'), dtype=dtype, device=dev)
+            inv = torch.zeros(sum(v.shape[0] for v in vs), device=dev)
+            items = (lib.WnItem * len(shapes))()
+            ow = oa = blk = tblk = 0
+            for it, v, g, (A, Bc, T, normed, kind) in zip(items, vs, gs, shapes):
+                it.v, it.g = v.data_ptr(), (g.data_ptr() if normed else None)
+                it.dst1, it.dst2 = w1.data_ptr() + ow * esz, w2.data_ptr() + ow * esz
+                it.inv_norm = inv.data_ptr() + oa * 4
+                it.A, it.Bc, it.T, it.dtype = A, Bc, T, (0 if dtype == torch.float32 else 1)
+                it.block0, it.tblock0 = blk, tblk
+                # conv: v (Cout, Cin, T) -> [T][Cout][Cin] and [T][Cin][Cout]; convT: v (Cin, Cout, T) -> [T][Cin][Cout] and [T][Cout][Cin]
+                it.s1[0], it.s1[1], it.s1[2] = A * Bc, Bc, 1
+                it.s2[0], it.s2[1], it.s2[2] = A * Bc, 1, A
+                blk += A
+                tblk += (int(L.msmc_wn_tile_blocks(A, Bc, T)) if entry == 'tiles' else ((A + 63) // 64) * ((Bc + 15) // 16))
+                ow, oa = ow + pad8(v.numel()), oa + A
+            dev_items = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(dev)
+            st = lib.stream(w1)
+            if entry == 'tiles':
+                from msmctts_amd.hip import convnet
+                convnet._wn_prepare(dev_items, convnet._wn_maps(items, torch.device(dev)), len(shapes), blk, tblk,
+                                    max(s[2] for s in shapes), st, 'msmc_wn_prepare_multi_tiles')
+            else:
+                lib.check(L.msmc_wn_prepare_multi_tiled(lib.ptr(dev_items), len(shapes), blk, tblk, st), 'msmc_wn_prepare_multi_tiled')
+            return w1, w2, inv
+        w1, w2, inv = run('tiles')
+        o1, o2, oinv = run('tiled')
+        ow = oa = 0
+        for v, g, (A, Bc, T, normed, kind) in zip(vs, gs, shapes):
+            n = v.numel()
+            norm = v.reshape(A, -1).double().norm(dim=1)
+            w = (v.double() * (g.double() / norm).view(A, 1, 1)) if normed else v.double()
+            want1 = w.permute(2, 0, 1).reshape(-1)                   # [T][A][Bc]
+            want2 = w.permute(2, 1, 0).reshape(-1)                   # [T][Bc][A]
+            what = '%s %dx%dx%d %s' % (str(dtype).split('.')[-1], A, Bc, T, 'wn' if normed else 'plain')
+            close(w1[ow:ow + n].double(), want1, tol, tol, 'layout 1 ' + what)
+            close(w2[ow:ow + n].double(), want2, tol, tol, 'layout 2 ' + what)
+            close(o1[ow:ow + n].double(), want1, tol, tol, 'previous form, layout 1 ' + what)
+            close(o2[ow:ow + n].double(), want2, tol, tol, 'previous form, layout 2 ' + what)
+            if normed:
+                close(inv[oa:oa + A].double(), 1.0 / norm, 3e-7, 3e-7, 'inv_norm ' + what)
+            assert not torch.isnan(w1[ow:ow + n].float()).any() and not torch.isnan(w2[ow:ow + n].float()).any(), what
+            pad = pad8(n) - n
+            if pad:                                                   # nothing written past an item's image
+                assert torch.isnan(w1[ow + n:ow + n + pad].float()).all() and torch.isnan(w2[ow + n:ow + n + pad].float()).all(), what
+            ow, oa = ow + pad8(n), oa + A
+
+
 def check_codebook_split_update(dev):
     """msmc_vq_ema_stats + msmc_vq_ema_apply (the two halves around the cross-rank sum of sync_codebook_stats) are, on
     one rank, bit for bit the fused msmc_vq_ema_update"""

@@ -39,6 +39,11 @@ def test_predictor_step_matches_reference():
     _parity.check_predictor_step(DEV)
 
 
+def test_weight_images_in_one_tiled_pass_match_the_definition():
+    """msmc_wn_prepare_multi_tiles (round 6: both kernel layouts from one read of the parameters) on the GPU"""
+    _parity.check_weight_image_tiles(torch.device(DEV))
+
+
 @pytest.mark.parametrize('shortlist', [None, True, False], ids=['product', 'shortlist-kernel', 'exact-kernel'])
 @pytest.mark.parametrize('H,K,D,N', [(1, 64, 256, 777), (4, 64, 256, 6400), (4, 256, 256, 1600), (8, 512, 256, 530),
                                      (4, 16, 32, 51), (2, 48, 24, 1), (4, 64, 256, 16), (4, 64, 256, 17)])

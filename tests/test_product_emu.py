@@ -580,6 +580,10 @@ def test_resblock_standalone_matches_stock_operators():
     _parity.check_resblock_standalone('cpu')
 
 
+def test_weight_images_in_one_tiled_pass_match_the_definition():
+    _parity.check_weight_image_tiles(torch.device('cpu'))
+
+
 def test_train_steps_match_reference_with_ungrouped_launches():
     """MSMC_GROUPED=0 path (one launch per convolution; tap gradients through _HipConv, incl. the reflect-padded MRD
     layers' fold + add) against the same reference fixture"""
@@ -1299,13 +1303,13 @@ def test_bench_attributes_work_to_every_kernel_family_of_a_step():
     from msmctts_amd.trainers.optimizers import build_optimizer
     L = lib.get()
     saved = {name: getattr(L, name) for name in list(bench.abi_work_models()) +
-             ['msmc_wn_prepare_multi_tiled', 'msmc_wn_backward_multi_rows', 'msmc_opt_clip_adamw']}
+             ['msmc_wn_prepare_multi_tiles', 'msmc_wn_backward_multi_rows', 'msmc_opt_clip_adamw']}
     timer = bench.KernelTimer()
     try:
         for name, work in bench.abi_work_models().items():
             timer.wrap_abi(L, name, work)
         seen = []
-        for name in ('msmc_wn_prepare_multi_tiled', 'msmc_wn_backward_multi_rows', 'msmc_opt_clip_adamw'):
+        for name in ('msmc_wn_prepare_multi_tiles', 'msmc_wn_backward_multi_rows', 'msmc_opt_clip_adamw'):
             timer.wrap_abi(L, name, (lambda nm: lambda *a: (seen.append(nm), (0.0, 64.0))[1])(name))
         cfg, task = _parity.build_small('cpu')
         tr = build_trainer(cfg, task, num_gpus=0, rank=0)
@@ -1323,7 +1327,7 @@ def test_bench_attributes_work_to_every_kernel_family_of_a_step():
     finally:
         for name, fn in saved.items():
             setattr(L, name, fn)
-    assert set(seen) == {'msmc_wn_prepare_multi_tiled', 'msmc_wn_backward_multi_rows', 'msmc_opt_clip_adamw'}
+    assert set(seen) == {'msmc_wn_prepare_multi_tiles', 'msmc_wn_backward_multi_rows', 'msmc_opt_clip_adamw'}
     called = set(timer.shapes)
     for family in ('msmc_add_ln_fwd', 'msmc_add_ln_bwd', 'msmc_add_ln_param_multi', 'msmc_l1_multi_fwd_ws', 'msmc_mse_const_multi_bwd', 'msmc_stft_frames_fwd',
                    'msmc_spec_mag_bwd', 'msmc_vq_backward', 'msmc_vq_prepare', 'msmc_tanh_fwd', 'msmc_gate_bwd'):
@@ -1373,7 +1377,7 @@ def test_clean_weight_banks_skip_their_refresh_and_notice_every_kind_of_update()
             L.msmc_prof_read(i, buf, 128, ctypes.byref(ms))
             names.append(buf.value.decode())
         L.msmc_prof_enable(0)
-        return out, sum(1 for n in names if n.startswith('wn_prepare'))
+        return out, sum(1 for n in names if n.startswith('wn_layout'))          # (one layout pass per refresh)
 
     y0, n0 = prepares(lambda: blk(x))
     assert n0 == 1                                           # first use: the images are built
