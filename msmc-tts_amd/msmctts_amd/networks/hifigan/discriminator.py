@@ -171,22 +171,41 @@ class Discriminator(nn.Module):
         self._bank = None
 
     def _hip(self):
+        """-> ((resolution bank, period bank), (resolution layers, period layers)).  TWO banks since round 6: the period
+        family holds 10.3 M of the 12.9 M parameters and its backward chain (on the caller's stream) ends first, so its bank
+        delivers early -- pending weight gradients, their second stages and the weight-norm backward leave on a side stream
+        while the resolution family still back-propagates (0.23 ms of the discriminator step's tail ran alone on the chip
+        before its optimizer could start), and under data parallelism its buckets travel under that backward (the review's
+        item 7; ONE bank kept all 51 MB exposed)."""
         if self._bank is None:
             mrd = [d.hip_layers() for d in self.mrd.discriminators]
             mpd = [d.hip_layers() for d in self.mpd.discriminators]
-            self._bank = ConvBank([l for ls in mrd + mpd for l in ls])
+            self._bank_r = ConvBank([l for ls in mrd for l in ls])
+            self._bank_p = ConvBank([l for ls in mpd for l in ls])
+            self._bank = (self._bank_r, self._bank_p)
             self._layers = (mrd, mpd)
             dev = next(self.parameters()).device
             self._streams = make_streams(dev, len(mrd) + len(mpd))
             # grouped execution: the resolution stacks' chain on ONE side stream, the period stacks' on the caller's (D_FORK)
             self._fork = convnet.own_streams(dev, 1, 'd-fork') if (convnet.GROUPED and D_FORK and dev.type == 'cuda') else []
-            self._bank.streams = self._streams or self._fork
+            if self._streams:             # (MSMC_GROUPED=0: a stream per sub-discriminator, either bank's nodes on several)
+                self._bank_r.streams = self._streams[:len(mrd)]
+                self._bank_p.streams = self._streams[len(mrd):]
+            else:
+                self._bank_r.streams = self._fork
         return self._bank, self._layers
+
+    def _prepare(self):
+        (bank_r, bank_p), _ = self._hip()
+        convnet.prepare_together([(bank_r, self.hip_dtype), (bank_p, self.hip_dtype)])
+        bank_r.prepare(self.hip_dtype)
+        bank_p.prepare(self.hip_dtype)
+        return bank_r, bank_p
 
     def prepare_weights(self):
         """refresh the kernel-layout weight images on the calling stream if the parameters changed (forward does it too; a
         caller that is about to run two passes on two streams does it once, before the fork)"""
-        self._hip()[0].prepare(self.hip_dtype)
+        self._prepare()
 
     def spectral_fronts(self, y):
         """the resolution discriminators' images of waveforms ``y`` (B, L) / (B, 1, L) WITHOUT gradient history, as an
@@ -199,16 +218,16 @@ class Discriminator(nn.Module):
         images instead of framing and transforming ``y`` again (grouped execution only)"""
         if y.dim() == 2:
             y = y.unsqueeze(1)
-        bank, (mrd, mpd) = self._hip()
-        bank.prepare(self.hip_dtype)
+        _, (mrd, mpd) = self._hip()
+        bank_r, bank_p = self._prepare()
         if convnet.GROUPED:
-            return self._forward_grouped(bank, mrd, mpd, y, fronts)
+            return self._forward_grouped(bank_r, bank_p, mrd, mpd, y, fronts)
         # the ten sub-discriminators are independent chains of small launches: one HIP stream each
-        outs = fork_join(self._streams, self.mrd.thunks(bank, mrd, y, self.hip_dtype) +
-                         self.mpd.thunks(bank, mpd, y, self.hip_dtype), inputs=(y,))
+        outs = fork_join(self._streams, self.mrd.thunks(bank_r, mrd, y, self.hip_dtype) +
+                         self.mpd.thunks(bank_p, mpd, y, self.hip_dtype), inputs=(y,))
         return [o[0] for o in outs], [o[1] for o in outs]
 
-    def _forward_grouped(self, bank, mrd, mpd, y, fronts=None):
+    def _forward_grouped(self, bank, bank_p, mrd, mpd, y, fronts=None):
         """The sub-discriminators advance layer by layer: layer i of all six resolution (all five period) stacks is ONE
         grouped launch (hip_conv_group) -- each of them alone is a grid of tens to hundreds of workgroups."""
         dtype = self.hip_dtype
@@ -253,7 +272,7 @@ class Discriminator(nn.Module):
         fork = self._fork if torch.is_grad_enabled() else []
         (r_scores, r_fmaps), (p_scores, p_fmaps) = fork_join(
             fork, [resolution_stacks], inputs=tuple(wavs),
-            main_thunk=lambda: self._period_stacks(bank, mpd, y, copies, dtype))
+            main_thunk=lambda: self._period_stacks(bank_p, mpd, y, copies, dtype))
         return r_scores + p_scores, r_fmaps + p_fmaps
 
     def _period_stacks(self, bank, mpd, y, copies, dtype):

@@ -257,7 +257,9 @@ def graphed_vs_eager(arm_reducer=False, exchange='serial', iterations=(6, 7), wa
             log = tr.train_step(batch, it)
             logs.append({k: float(v) for k, v in log['loss'].items()})
         if graphed and warmup_steps is not None:
-            assert tr._graphs_warm is not None and (tr._graphs is not None) == (max(iterations) > warmup_steps)
+            # the GAN phase captured: the warm-up phase's graphs (pool, static batch, optimizer tables) were released first
+            gan = max(iterations) > warmup_steps
+            assert (tr._graphs is not None) == gan and (tr._graphs_warm is None) == gan
         log, log2 = logs[0], logs[-1]
         results.append((log, log2, {k: v.detach().clone() for k, v in task.state_dict().items()}))
     (e1, e2, es), (g1, g2, gs) = results
