@@ -791,11 +791,18 @@ class Watchdog(object):
     def __init__(self, limit, rank=0):
         import threading
         self.limit, self.rank, self.last, self.what = float(limit), rank, time.perf_counter(), 'start'
+        self.on_stall = None
         if self.limit > 0:
             threading.Thread(target=self._run, daemon=True).start()
 
     def beat(self, what):
         self.last, self.what = time.perf_counter(), what
+
+    def guard(self, on_stall, limit):
+        """SECONDARY measurements (the exchange modes timed after the headline on N > 1 ranks): a stall from here on calls
+        ``on_stall(what)`` -- rank 0 prints the line with what it has -- and ends the rank with exit code 0: a collective that
+        wedges in an untried mode must not cost the run its headline"""
+        self.on_stall, self.limit, self.last = on_stall, min(self.limit, float(limit)) if self.limit > 0 else float(limit), time.perf_counter()
 
     def _run(self):
         while True:
@@ -804,6 +811,12 @@ class Watchdog(object):
             if idle > self.limit:
                 sys.stderr.write('bench.py: rank %d made no progress for %.0f s (last: %s) -- giving up\n' % (self.rank, idle, self.what))
                 sys.stderr.flush()
+                if self.on_stall is not None:
+                    try:
+                        self.on_stall(self.what)
+                    finally:
+                        sys.stdout.flush()
+                        os._exit(0)
                 os._exit(5)
 
 
@@ -919,11 +932,16 @@ def main():
                     help='self-spawned N > 1 job: seconds before the launcher kills it (exit 124)')
     ap.add_argument('--stall-timeout', type=int, default=int(os.environ.get('MSMC_BENCH_STALL_TIMEOUT', '300')),
                     help='seconds without progress before a rank gives up (exit 5); also the process-group timeout')
-    ap.add_argument('--exchange', default=os.environ.get('MSMC_GRAPH_EXCHANGE', 'serial'), choices=['serial', 'overlap', 'both'],
-                    help='graph mode, N > 1: serial = one flat all-reduce per child between the replayed segments (default); '
+    ap.add_argument('--exchange', default=os.environ.get('MSMC_GRAPH_EXCHANGE', 'auto'),
+                    choices=['auto', 'serial', 'overlap', 'both', 'all'],
+                    help='graph mode, N > 1: serial = one flat all-reduce per child between the replayed segments (the headline); '
                          'overlap = bucketed all-reduces captured into the segments on the RCCL stream (DESIGN.md section 6: '
                          'only ever run on one GPU); both = serial is the headline, the overlap mode is timed after it in the same '
-                         'run and reported under exchange_modes')
+                         'run and reported under exchange_modes; all = serial, then serial with bf16 on the wire, then overlap.  '
+                         'auto (default) = all when N > 1: the secondary modes run under a guard (--secondary-timeout) that prints '
+                         'the line with the headline and exits 0 if one of them wedges')
+    ap.add_argument('--secondary-timeout', type=int, default=int(os.environ.get('MSMC_BENCH_SECONDARY_TIMEOUT', '90')),
+                    help='N > 1: seconds without progress in a SECONDARY exchange mode before the line is printed without it')
     ap.add_argument('--kernel-timing-steps', type=int, default=3, help='extra steps timed kernel by kernel (rank 0)')
     ap.add_argument('--kernels-out', default=os.path.join(ROOT, 'gpurun_out', 'bench_kernels.json'),
                     help='JSON side file for the per-kernel-symbol table (the printed line only names it)')
@@ -956,7 +974,7 @@ def main():
     wd = Watchdog(args.stall_timeout, rank)
     if args.backend == 'gloo' and not (args.dry or args.share_gpu):
         raise SystemExit('bench.py: --backend gloo is for --dry (the product path has no CPU execution path) or --share-gpu (test mode)')
-    if args.share_gpu and (args.backend != 'gloo' or args.exchange != 'serial'):
+    if args.share_gpu and (args.backend != 'gloo' or args.exchange not in ('serial', 'auto', 'all')):
         raise SystemExit('bench.py: --share-gpu needs --backend gloo and the serial exchange (RCCL refuses two ranks on one device; '
                          'gloo collectives cannot be captured)')
     if args.dry and args.backend == 'gloo':
@@ -983,8 +1001,12 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         sys.exit(rc)
-    both_modes = args.exchange == 'both'
-    if both_modes:
+    if args.exchange == 'auto':
+        args.exchange = 'all' if (world > 1 and args.backend == 'nccl' and not args.share_gpu) else 'serial'
+    secondary = {'both': ['overlap'], 'all': ['serial_bf16_wire', 'overlap']}.get(args.exchange, [])
+    if args.share_gpu:
+        secondary = [m for m in secondary if m != 'overlap']          # (gloo collectives cannot be captured)
+    if secondary:
         args.exchange = 'serial'
 
     from msmctts_amd.hip import lib, vq as hipvq
@@ -1022,6 +1044,25 @@ def main():
         torch.cuda.synchronize()
         wd.beat('warm-up step %d' % i)
         say('warm-up step %d done' % i)
+    def headline(elapsed_max, per_rank, frames, modes):
+        """the contract fields of the line from the headline measurement (all a stalled secondary mode leaves us with)"""
+        return {
+            'metric': 'mel-frames/sec MSMC-VQ-GAN train step (GAN phase)', 'value': frames / (elapsed_max / args.steps),
+            'unit': 'mel-frames/s', 'n_gpus': world, 'world_size_seen': dist.get_world_size() if world > 1 else 1,
+            'backend': ('nccl (RCCL)' if args.backend == 'nccl' else 'gloo, ranks sharing a GPU (test mode: not a measurement)') if world > 1 else None,
+            'per_rank_ms_per_step': per_rank, 'exchange_modes': modes,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed_max / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': '%s: %d-stage %d-head x %d-codeword VQ + HifiGAN + MPD/MRD, GAN phase'
+                                   % (preset['name'], len(args.model_kw.get('downsample_scales', (1, 4))), args.heads, args.codewords),
+                       'baseline_config': args.config, 'in_dim': args.in_dim,
+                       'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'frames': args.frames,
+                       'mel_frames_per_step': frames, 'parallelism': 'dp%d' % world,
+                       'vq_search': 'fp32 (bit-exact indices)',
+                       'execution': 'hipGraph replay (3 segments/step)' if args.graph else 'eager, multi-stream',
+                       'gradient_exchange': None if world == 1 else (args.exchange if args.graph else 'bucketed from hooks')},
+        }
+
     def timed_steps(first):
         '''exactly K steps between barrier + synchronize on both sides; per-step durations from events recorded on the step's
         stream between the steps (no host synchronisation inside the timed region: the headline stays the wall clock over all
@@ -1055,19 +1096,45 @@ def main():
 
     elapsed, per_step, log = timed_steps(args.warmup)
     exchange_modes = None
-    if both_modes and world > 1 and args.graph:
-        # the same K steps with the bucketed all-reduces captured INTO the segments, after a fresh capture
+    core = {}
+    if secondary and world > 1 and args.graph:
+        # Everything the line needs from the HEADLINE (serial exchange, fp32 on the wire) first -- its collectives included --,
+        # then the secondary modes under the guard: each is the same K steps, the riskiest (RCCL captured into the graphs: only
+        # ever run on one GPU) last.  A mode that raises or wedges is reported as such; the headline stands.
         e_serial, ranks_serial = over_ranks(elapsed)
-        trainer._graphs, trainer.graph_exchange = None, 'overlap'
-        for i in range(max(2, args.warmup)):
-            step(i)
-            torch.cuda.synchronize()
-            wd.beat('overlap warm-up step %d' % i)
-        e_over, _, _ = timed_steps(args.warmup)
-        e_over, ranks_over = over_ranks(e_over)
-        exchange_modes = {'serial': dict(ms_per_step=e_serial / args.steps * 1e3, per_rank_ms_per_step=ranks_serial),
-                          'overlap': dict(ms_per_step=e_over / args.steps * 1e3, per_rank_ms_per_step=ranks_over)}
-        trainer._graphs, trainer.graph_exchange = None, 'serial'
+        fr = torch.tensor([float(sum(lengths_host))], device=device, dtype=torch.float64)
+        dist.all_reduce(fr)
+        core = dict(elapsed=e_serial, per_rank=ranks_serial, frames=float(fr.item()))
+        exchange_modes = {'serial': dict(ms_per_step=e_serial / args.steps * 1e3, per_rank_ms_per_step=ranks_serial)}
+
+        def emergency(what):
+            if rank == 0:
+                exchange_modes['stalled'] = what
+                print(emit_line(headline(core['elapsed'], core['per_rank'], core['frames'], exchange_modes), None))
+        wd.guard(emergency, args.secondary_timeout)
+        reducer = trainer.model.grad_reducer
+        for mode in secondary:
+            wd.beat('exchange mode %s' % mode)
+            try:
+                if mode == 'serial_bf16_wire':
+                    reducer.exchange_dtype = torch.bfloat16          # (the flat buffers are rebuilt for the new wire type)
+                else:
+                    trainer._graphs, trainer.graph_exchange = None, 'overlap'
+                for i in range(max(2, min(args.warmup, 4))):
+                    step(i)
+                    torch.cuda.synchronize()
+                    wd.beat('%s warm-up step %d' % (mode, i))
+                e_m, _, _ = timed_steps(args.warmup)
+                e_m, ranks_m = over_ranks(e_m)
+                exchange_modes[mode] = dict(ms_per_step=e_m / args.steps * 1e3, per_rank_ms_per_step=ranks_m)
+                say('exchange mode %s: %.2f ms/step' % (mode, e_m / args.steps * 1e3))
+            except Exception as e:                                    # (the process group may be unusable now: stop here)
+                exchange_modes[mode] = dict(error='%s: %s' % (type(e).__name__, str(e)[:200]))
+                say('exchange mode %s failed: %s' % (mode, exchange_modes[mode]['error']))
+                break
+            finally:
+                reducer.exchange_dtype = torch.float32
+        trainer.graph_exchange = 'serial'
     ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     # second pass over the same steps with HIP events around every hand-written launch (the events cost a
     # few percent of host time, so the headline value above is taken without them)
@@ -1133,38 +1200,32 @@ def main():
         finally:
             trainer.use_graphs, trainer.amp_dtype = keep
         wd.beat('fp32 steps')
-    if world > 1:
-        dist.barrier()
-    elapsed, per_rank_ms = over_ranks(elapsed)
-    if world > 1:
-        fr = torch.tensor([float(sum(lengths_host))], device=device, dtype=torch.float64)
-        dist.all_reduce(fr)
-        frames_per_step = float(fr.item())
+    if core:                                   # (N > 1 with secondary modes: reduced over ranks before they ran)
+        elapsed, per_rank_ms, frames_per_step = core['elapsed'], core['per_rank'], core['frames']
     else:
-        frames_per_step = float(sum(lengths_host))
+        if world > 1:
+            dist.barrier()
+        elapsed, per_rank_ms = over_ranks(elapsed)
+        if world > 1:
+            fr = torch.tensor([float(sum(lengths_host))], device=device, dtype=torch.float64)
+            dist.all_reduce(fr)
+            frames_per_step = float(fr.item())
+        else:
+            frames_per_step = float(sum(lengths_host))
     wd.beat('reductions over ranks')
     ms_per_step = elapsed / args.steps * 1e3
     value = frames_per_step / (elapsed / args.steps)
     say('timed %d steps: %.2f ms/step' % (args.steps, ms_per_step))
 
     if rank != 0:
+        if core:
+            sys.stdout.flush()
+            os._exit(0)                          # (no further collective after a secondary mode: the group may be unusable)
         return
     kernels, roof, step_roof = summarize_kernels(timer, args.dtype, args.kernel_timing_steps, ms_per_step)
-    out = {
-        'metric': 'mel-frames/sec MSMC-VQ-GAN train step (GAN phase)', 'value': value, 'unit': 'mel-frames/s',
-        'n_gpus': world, 'world_size_seen': dist.get_world_size() if world > 1 else 1, 'backend': ('nccl (RCCL)' if args.backend == 'nccl' else 'gloo, ranks sharing a GPU (test mode: not a measurement)') if world > 1 else None,
-        'per_rank_ms_per_step': per_rank_ms, 'exchange_modes': exchange_modes,
-        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+    out = headline(elapsed, per_rank_ms, frames_per_step, exchange_modes)
+    out.update({
         'ms_per_step_median': ms_median, 'ms_per_step_min': per_step[0], 'ms_per_step_max': per_step[-1],
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': '%s: %d-stage %d-head x %d-codeword VQ + HifiGAN + MPD/MRD, GAN phase'
-                               % (preset['name'], len(args.model_kw.get('downsample_scales', (1, 4))), args.heads, args.codewords),
-                   'baseline_config': args.config, 'in_dim': args.in_dim,
-                   'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'frames': args.frames,
-                   'mel_frames_per_step': frames_per_step, 'parallelism': 'dp%d' % world,
-                   'vq_search': 'fp32 (bit-exact indices)',
-                   'execution': 'hipGraph replay (3 segments/step)' if args.graph else 'eager, multi-stream',
-                   'gradient_exchange': None if world == 1 else (args.exchange if args.graph else 'bucketed from hooks')},
         'step_tflops': (FLOP_PER_STEP_ELIDED * (args.batch / 16.0) * world / (elapsed / args.steps) / 1e12) if args.config in (2, 3) else None,
         'step_flop_model': 'SURVEY 8d: 3.006 TFLOP/step at B=16,T=400 minus the elided D weight-grads of the G step '
                            '= 2.65 TFLOP',
@@ -1181,7 +1242,7 @@ def main():
         'runtime': {'DEBUG_CLR_GRAPH_PACKET_CAPTURE': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'),
                     'note': 'hipGraph memset nodes are mis-ordered on the AQL packet-capture path of ROCm 7.2 '
                             '(tools/repro_graph_memset.py); the package disables that path before the first HIP call'},
-    }
+    })
     bad = [k for k, v in out['losses'].items() if v != v or v in (float('inf'), float('-inf'))]
     if bad:
         sys.stderr.write('bench.py: non-finite losses after the timed steps: %s -- the step does not train; '
@@ -1219,7 +1280,10 @@ def main():
                                    warmup_phase=dict(value=sample_frames / wsec, unit='mel-frames/s', s_per_step=wsec))
         out['speedup_vs_cpu'] = value / out['cpu_baseline']['value']
     print(emit_line(out, args.kernels_out))
+    sys.stdout.flush()
     if world > 1:
+        if core:
+            os._exit(0)                          # (the line is out; tearing down a group that ran untried modes may wedge)
         dist.destroy_process_group()
 
 

@@ -457,3 +457,25 @@ def test_bench_two_ranks_sharing_the_gpu_run_the_whole_data_parallel_path():
     assert len(line['per_rank_ms_per_step']) == 2 and all(t > 0 for t in line['per_rank_ms_per_step'])
     assert line['config']['global_batch'] == 8 and line['config']['gradient_exchange'] == 'serial' and line['config']['parallelism'] == 'dp2'
     assert line['value'] > 0 and all(v == v for v in line['losses'].values())
+
+
+def test_bench_two_ranks_time_the_secondary_exchange_modes_under_the_guard():
+    """``--exchange all`` (what ``auto`` resolves to at N > 1 over RCCL) on the shared GPU over gloo: the headline's reductions
+    over ranks happen BEFORE the secondary modes, the bf16-wire mode is timed after it under ``Watchdog.guard`` and reported in
+    ``exchange_modes`` (the captured-collective mode is dropped here: gloo cannot be captured), the ranks leave without a
+    further collective, one line, exit code 0."""
+    import json, subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--share-gpu', '--backend', 'gloo', '--batch', '4',
+                          '--steps', '3', '--warmup', '2', '--no-microbench', '--cpu-steps', '0', '--fp32-steps', '0', '--exchange', 'all',
+                          '--kernel-timing-steps', '0', '--warmup-phase-steps', '0', '--stall-timeout', '240', '--job-timeout', '500'],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    modes = line['exchange_modes']
+    assert set(modes) == {'serial', 'serial_bf16_wire'} and all(m['ms_per_step'] > 0 for m in modes.values()), modes
+    assert abs(line['ms_per_step'] - modes['serial']['ms_per_step']) < 1e-6 and line['config']['gradient_exchange'] == 'serial'
+    assert line['n_gpus'] == 2 and line['value'] > 0 and all(v == v for v in line['losses'].values())

@@ -316,3 +316,21 @@ def test_interpreter_runtime_declares_the_same_primitives_as_the_gfx950_runtime(
             text = open(os.path.join(csrc, f)).read()
             used |= {n for n in gfn if re.search(r'\b%s\s*(<[^;(]*>)?\s*\(' % n, text)}
     assert len(used) >= 25, sorted(used)
+
+
+def test_bench_watchdog_guard_turns_a_stalled_secondary_measurement_into_a_line_and_exit_0(tmp_path):
+    """bench.py at N > 1 times the untried exchange modes AFTER the headline, under ``Watchdog.guard``: a stall there must
+    print what rank 0 has and end the process with exit code 0 (a stall before it: exit 5, nothing printed)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, time; sys.path.insert(0, %r); import bench\n"
+        "wd = bench.Watchdog(1.0, 0)\n"
+        "if sys.argv[1] == 'guarded':\n"
+        "    wd.guard(lambda what: print('LINE after ' + what), 1.0)\n"
+        "wd.beat('the untried mode')\n"
+        "time.sleep(30)\n" % ROOT)
+    r = subprocess.run([sys.executable, '-c', code, 'guarded'], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and 'LINE after the untried mode' in r.stdout, (r.returncode, r.stdout, r.stderr[-300:])
+    r = subprocess.run([sys.executable, '-c', code, 'plain'], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 5 and 'LINE' not in r.stdout, (r.returncode, r.stdout, r.stderr[-300:])
