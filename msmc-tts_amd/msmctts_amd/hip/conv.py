@@ -65,9 +65,12 @@ _PLANS = {}
 # (msmc_conv_desc.variant / .split_shift) once and keeps the fastest -- tile heuristics cannot see L2 / LDS effects
 # that differ by 2x between layers of equal arithmetic.  Off inside hipGraph capture and on the interpreter.
 AUTOTUNE = os.environ.get('MSMC_AUTOTUNE', '1') != '0'
-_GATHER_CANDIDATES = tuple((v, 0) for v in (1, 2, 3, 4, 5, 8, 9, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 34, 35,
-                                             40, 41, 42, 43, 44, 45, 46, 47, 50, 56, 59, 60, 61, 63))
-_WGRAD_CANDIDATES = ((4, 0), (4, -1), (9, 0), (9, -1), (7, 0), (8, 0), (3, 0), (3, -1), (3, -2), (3, 1), (2, 0), (2, -1), (2, 1), (1, 0))
+# (round 6: 22, 23, 30 and 43 left the candidates and the library -- never chosen by the tuner over configurations 1-5)
+_GATHER_CANDIDATES = tuple((v, 0) for v in (1, 2, 3, 4, 5, 8, 9, 16, 17, 18, 19, 20, 21, 24, 25, 26, 27, 28, 29, 31, 32, 34, 35,
+                                             40, 41, 42, 44, 45, 46, 47, 50, 56, 59, 60, 61, 63))
+# (round 6: (3, 0), (3, -2), (3, 1) and the first generation (1, 0) left the candidates: never chosen over configurations 1-5;
+#  the third generation stays reachable through its one chosen split and as wgrad5's fallback)
+_WGRAD_CANDIDATES = ((4, 0), (4, -1), (9, 0), (9, -1), (7, 0), (8, 0), (3, -1), (2, 0), (2, -1), (2, 1))
 TUNED = {}                                    # (kind, shape signature) -> (variant, split_shift, {candidate: ms})
 TUNE_CACHE = os.environ.get('MSMC_TUNE_CACHE', os.path.join(os.path.dirname(os.path.abspath(__file__)),
                                                             'tuned_gfx950.json'))
@@ -491,7 +494,7 @@ def _snapshot(desc, stream):
 _GROUP_CODES = {'single': 0, 'group': 1, 'group4': 2, 'uniform': 3}
 # grouped forward / data-gradient calls whose members chose different kernel families become several launches; the tuner
 # also times the call with ONE variant imposed on every member (where all of them accept it): a single grid
-_UNIFORM_CANDIDATES = (2, 3, 4, 5, 8, 9, 16, 17, 20, 21, 24, 25, 26, 27, 28, 29, 30, 31, 40, 41, 42, 44, 45, 46, 47, 50, 56, 59, 60, 61, 63)
+_UNIFORM_CANDIDATES = (2, 3, 4, 5, 8, 9, 16, 17, 20, 21, 24, 25, 26, 27, 28, 29, 31, 40, 41, 42, 44, 45, 46, 47, 50, 56, 59, 60, 61, 63)
 
 
 def _group_choice(kind, snaps, grouped_fn, single_fn, group4_fn=None, uniform_fn=None):
