@@ -740,7 +740,7 @@ def bench_predictor(args, device, wd):
     print(emit_line(out, args.kernels_out))
 
 
-def self_spawn(argv, n, job_timeout):
+def self_spawn(argv, n, job_timeout, capture=False):
     """``python bench.py --gpus N`` with WORLD_SIZE unset: start the N ranks ourselves (reference launcher train_dist.py:14-36
     starts one process per GPU the same way).  Returns the job's exit code; a job that outlives ``job_timeout`` seconds is
     killed (its own process group) and reported as 124."""
@@ -753,12 +753,18 @@ def self_spawn(argv, n, job_timeout):
     sock.close()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
-    env = dict(os.environ)
+    # (a rank that starts a job of its own -- the overlapped exchange mode as a CHILD job -- must not hand its own rendezvous on)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK',
+                                                              'ROLE_RANK', 'ROLE_NAME', 'ROLE_WORLD_SIZE', 'GROUP_WORLD_SIZE',
+                                                              'MASTER_ADDR', 'MASTER_PORT') and not k.startswith('TORCHELASTIC_')}
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this driver (RCCL across processes)
     env.setdefault('OMP_NUM_THREADS', str(max(1, host_cores() // n)))
     say('starting %d ranks: %s' % (n, ' '.join(cmd[1:])))
-    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True, stdout=subprocess.PIPE if capture else None, text=capture or None)
     try:
+        if capture:
+            text, _ = proc.communicate(timeout=job_timeout)
+            return proc.returncode, text
         return proc.wait(timeout=job_timeout)
     except subprocess.TimeoutExpired:
         sys.stderr.write('bench.py: the %d-rank job did not finish within %d s: killing it\n' % (n, job_timeout))
@@ -780,7 +786,7 @@ def self_spawn(argv, n, job_timeout):
             except ProcessLookupError:
                 pass
         proc.wait()
-        return 124
+        return (124, '') if capture else 124
 
 
 class Watchdog(object):
@@ -940,6 +946,10 @@ def main():
                          'run and reported under exchange_modes; all = serial, then serial with bf16 on the wire, then overlap.  '
                          'auto (default) = all when N > 1: the secondary modes run under a guard (--secondary-timeout) that prints '
                          'the line with the headline and exits 0 if one of them wedges')
+    ap.add_argument('--overlap-in-process', action='store_true',
+                    help='time the overlapped exchange inside this job (default for an explicit --exchange both / overlap); '
+                         'auto / all run it as a CHILD job of rank 0 after the other ranks have left, so that nothing it does '
+                         '-- RCCL captured into hipGraphs has only ever met one rank -- can cost this job its line or exit code')
     ap.add_argument('--secondary-timeout', type=int, default=int(os.environ.get('MSMC_BENCH_SECONDARY_TIMEOUT', '90')),
                     help='N > 1: seconds without progress in a SECONDARY exchange mode before the line is printed without it')
     ap.add_argument('--kernel-timing-steps', type=int, default=3, help='extra steps timed kernel by kernel (rank 0)')
@@ -1004,6 +1014,11 @@ def main():
     if args.exchange == 'auto':
         args.exchange = 'all' if (world > 1 and args.backend == 'nccl' and not args.share_gpu) else 'serial'
     secondary = {'both': ['overlap'], 'all': ['serial_bf16_wire', 'overlap']}.get(args.exchange, [])
+    # (MSMC_BENCH_CHILD_ARGS: TEST HOOK -- extra arguments for the child job, so that its orchestration can run on a one-GPU box)
+    child_extra = os.environ.get('MSMC_BENCH_CHILD_ARGS', '').split()
+    child_overlap = args.exchange == 'all' and not args.overlap_in_process and (not args.share_gpu or bool(child_extra))
+    if child_overlap:
+        secondary = [m for m in secondary if m != 'overlap']
     if args.share_gpu:
         secondary = [m for m in secondary if m != 'overlap']          # (gloo collectives cannot be captured)
     if secondary:
@@ -1097,7 +1112,7 @@ def main():
     elapsed, per_step, log = timed_steps(args.warmup)
     exchange_modes = None
     core = {}
-    if secondary and world > 1 and args.graph:
+    if (secondary or child_overlap) and world > 1 and args.graph:
         # Everything the line needs from the HEADLINE (serial exchange, fp32 on the wire) first -- its collectives included --,
         # then the secondary modes under the guard: each is the same K steps, the riskiest (RCCL captured into the graphs: only
         # ever run on one GPU) last.  A mode that raises or wedges is reported as such; the headline stands.
@@ -1135,6 +1150,31 @@ def main():
             finally:
                 reducer.exchange_dtype = torch.float32
         trainer.graph_exchange = 'serial'
+        if child_overlap:
+            # The overlapped exchange -- RCCL all-reduces captured INTO the hipGraphs -- has only ever met one rank.  It runs as a
+            # job of its own, started by rank 0 once every other rank of THIS job has left (their GPUs are free again): whatever
+            # it does (raise, wedge, take the runtime down with it) costs this job neither its line nor its exit code.
+            if rank != 0:
+                sys.stdout.flush()
+                os._exit(0)
+            wd.guard(emergency, args.stall_timeout + 120)
+            wd.beat('child job: overlapped exchange')
+            child = ['--gpus', str(world), '--exchange', 'overlap', '--config', str(args.config), '--batch', str(args.batch),
+                     '--frames', str(args.frames), '--steps', str(args.steps), '--warmup', str(args.warmup), '--dtype', args.dtype,
+                     '--no-microbench', '--cpu-steps', '0', '--fp32-steps', '0', '--kernel-timing-steps', '0',
+                     '--warmup-phase-steps', '0', '--stall-timeout', str(min(args.stall_timeout, 120))] + child_extra
+            try:
+                rc, text = self_spawn(child, world, min(args.stall_timeout + 60, 420), capture=True)
+                lines = [l for l in (text or '').splitlines() if l.startswith('{')]
+                if rc == 0 and lines:
+                    got = json.loads(lines[-1])
+                    exchange_modes['overlap'] = dict(ms_per_step=got['ms_per_step'], per_rank_ms_per_step=got['per_rank_ms_per_step'],
+                                                     note='a job of its own (same ranks, same batch), started after this one')
+                else:
+                    exchange_modes['overlap'] = dict(error='the child job ended with exit code %s and %d result lines' % (rc, len(lines)))
+            except Exception as e:
+                exchange_modes['overlap'] = dict(error='%s: %s' % (type(e).__name__, str(e)[:200]))
+            say('exchange mode overlap (child job): %s' % exchange_modes['overlap'])
     ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     # second pass over the same steps with HIP events around every hand-written launch (the events cost a
     # few percent of host time, so the headline value above is taken without them)
