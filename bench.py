@@ -247,6 +247,9 @@ def abi_work_models():
         'msmc_gate_bwd': lambda x, g, gx, N, C, p, seed, salt, dt, st: (0.0, float(N * C * 5 * E(dt))),
         'msmc_tanh_fwd': lambda x, y, n, dt, st: (0.0, float(n * 2 * E(dt))),
         'msmc_tanh_bwd': lambda y, g, gx, n, dt, st: (0.0, float(n * 3 * E(dt))),
+        'msmc_tanh_f32_fwd': lambda x, y, n, dt, st: (0.0, float(n * (4 + E(dt)))),
+        'msmc_tanh_f32_bwd': lambda y, g, gx, n, dt, st: (0.0, float(n * (8 + E(dt)))),
+        'msmc_window_gather': lambda s_, w, f, t, B, nf, hop, L, st: (0.0, float(B * nf * hop * 8 + B * nf * 8)),
         'msmc_lrelu_bwd': lambda g, y, gx, n, slope, dt, st: (0.0, float(n * 3 * E(dt))),
         'msmc_lrelu_bwd_multi': lambda g, y, gx, nelem, n, slope, dt, st:
             (0.0, float(sum(int(nelem[k]) for k in range(int(n))) * 3 * E(dt))),

@@ -403,6 +403,11 @@ int msmc_wave_fan_fwd(const float* y, void* const* copies, const int* padded_len
                       msmc_stream stream);
 int msmc_wave_fan_bwd(const float* const* g32, int n32, const void* const* gcopies, const int* padded_len, int n, float* gy,
                       int B, int L, int dtype, msmc_stream stream);
+/* Vocoder windows of a captured step (reference msmctts_trainer.py:211-219, window starts on the device): frames[b][i] = starts[b] + i
+ * (int64, i < nframes) and target[b][j] = wav[b][starts[b] * hop + j] (j < nframes * hop; wav [B][L] fp32).  The caller guarantees
+ * starts[b] * hop + nframes * hop <= L (VQGANTrainer checks the batch on the host). */
+int msmc_window_gather(const long* starts, const float* wav, long* frames, float* target, int B, int nframes, int hop, long L,
+                       msmc_stream stream);
 
 /* y = log(max(x, lo)) and its backward gx = g * (x > lo ? 1/x : 0) over n elements (stft_loss.py:110-114). */
 int msmc_log_clamp_fwd(const float* x, float* y, long n, float lo, msmc_stream stream);
@@ -521,6 +526,10 @@ int msmc_gate_bwd(const void* x, const void* g, void* gx, long N, int C, float p
 /* y = tanh(x); gx = g * (1 - y*y) over n elements. */
 int msmc_tanh_fwd(const void* x, void* y, long n, int dtype, msmc_stream stream);
 int msmc_tanh_bwd(const void* y, const void* g, void* gx, long n, int dtype, msmc_stream stream);
+/* y (fp32) = tanh(x) for x in the compute dtype (``dtype``: 0 fp32, 1 bf16) -- the vocoder's output activation, reference
+ * hifigan/generator.py:52-54 -- and its backward gx (compute dtype) = g (fp32) * (1 - y^2) */
+int msmc_tanh_f32_fwd(const void* x, float* y, long n, int dtype, msmc_stream stream);
+int msmc_tanh_f32_bwd(const float* y, const float* g, void* gx, long n, int dtype, msmc_stream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * O1  gradient-norm clipping + AdamW for all tensors of one child in three launches (csrc/optim.hip).

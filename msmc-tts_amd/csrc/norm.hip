@@ -345,6 +345,20 @@ __global__ __launch_bounds__(256) void tanh_bwd_kernel(const T* __restrict__ y, 
     }
 }
 
+// the vocoder's output activation (reference hifigan/generator.py:52-54: tanh of the fp32 waveform): the compute-dtype output of the
+// last convolution in, fp32 out -- cast + tanh were two launches forward and two backward (the gradient leaves in the compute dtype)
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_f32_fwd_kernel(const T* __restrict__ x, float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = tanhf(nm_ld(x, i));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void tanh_f32_bwd_kernel(const float* __restrict__ y, const float* __restrict__ g, T* __restrict__ gx, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float t = y[i];
+        nm_st(gx, i, g[i] * (1.f - t * t));
+    }
+}
+
 // ---- FFT-stack prologue ---------------------------------------------------------------------------------------
 // The head of FFTBlocks.forward (reference acoustic_models/transformer.py:375-395) with the positions of
 // vqgantts/msmc_vqgan.py:56-58 (1 .. len per utterance, 0 on padding) folded in -- one launch instead of the chain
@@ -514,6 +528,24 @@ int msmc_tanh_fwd(const void* x, void* y, long n, int dtype, msmc_stream stream)
     const dim3 grid((unsigned)nm_grid(n));
     if (dtype == 0) MSMC_LAUNCH(tanh_fwd_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, (const float*)x, (float*)y, n);
     else if (dtype == 1) MSMC_LAUNCH(tanh_fwd_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)x, (unsigned short*)y, n);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+int msmc_tanh_f32_fwd(const void* x, float* y, long n, int dtype, msmc_stream stream) {
+    if (!x || !y || n < 0) return MSMC_E_SHAPE;
+    if (n == 0) return 0;
+    const dim3 grid((unsigned)nm_grid(n));
+    if (dtype == 0) MSMC_LAUNCH(tanh_f32_fwd_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, (const float*)x, y, n);
+    else if (dtype == 1) MSMC_LAUNCH(tanh_f32_fwd_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)x, y, n);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+int msmc_tanh_f32_bwd(const float* y, const float* g, void* gx, long n, int dtype, msmc_stream stream) {
+    if (!y || !g || !gx || n < 0) return MSMC_E_SHAPE;
+    if (n == 0) return 0;
+    const dim3 grid((unsigned)nm_grid(n));
+    if (dtype == 0) MSMC_LAUNCH(tanh_f32_bwd_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, y, g, (float*)gx, n);
+    else if (dtype == 1) MSMC_LAUNCH(tanh_f32_bwd_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, y, g, (unsigned short*)gx, n);
     else return MSMC_E_SHAPE;
     return msmc_check_launch();
 }

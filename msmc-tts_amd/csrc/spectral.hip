@@ -217,6 +217,21 @@ __global__ __launch_bounds__(256) void wave_fan_bwd_kernel(WaveFanArgs a, float*
     }
 }
 
+// The vocoder windows of a captured step (reference msmctts_trainer.py:211-219 random_select, as device arithmetic): frame indices
+// start_b + i and the waveform window wav[b][start_b * hop + j] of every utterance in ONE launch -- the operator chain (two
+// aranges, a multiply, two broadcast adds, a gather) was six launches at the head of the step's critical chain.
+__global__ __launch_bounds__(256) void window_gather_kernel(const long* __restrict__ starts, const float* __restrict__ wav,
+                                                           long* __restrict__ frames, float* __restrict__ target, int nframes,
+                                                           int hop, long L, long total) {
+    const long per = (long)nframes * hop;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long b = e / per, j = e - b * per;
+        const long s0 = starts[b];
+        target[e] = wav[b * L + s0 * hop + j];
+        if (j < nframes) frames[b * nframes + j] = s0 + j;
+    }
+}
+
 extern "C" {
 
 int msmc_stft_frames_fwd(const float* x, float* frames, int B, int L, int T, int n_fft, int NP, int hop, int pad,
@@ -327,6 +342,14 @@ int msmc_wave_fan_bwd(const float* const* g32, int n32, const void* const* gcopi
     const long total = (long)B * L;
     if (dtype == 0) MSMC_LAUNCH(wave_fan_bwd_kernel<float>, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, a, gy, L, total);
     else MSMC_LAUNCH(wave_fan_bwd_kernel<unsigned short>, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, a, gy, L, total);
+    return msmc_check_launch();
+}
+int msmc_window_gather(const long* starts, const float* wav, long* frames, float* target, int B, int nframes, int hop, long L,
+                       msmc_stream stream) {
+    if (!starts || !wav || !frames || !target || B <= 0 || nframes <= 0 || hop <= 0 || L < (long)nframes * hop) return MSMC_E_SHAPE;
+    const long total = (long)B * nframes * hop;
+    MSMC_LAUNCH(window_gather_kernel, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, starts, wav, frames, target, nframes, hop, L,
+                total);
     return msmc_check_launch();
 }
 }  // extern "C"

@@ -79,6 +79,7 @@ class TensorTable(ctypes.Structure):
 
 
 _SIGNATURES.update({
+    'msmc_window_gather': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_long, _vp]),
     'msmc_stft_frames_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'msmc_stft_frames_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'msmc_spec_mag_fwd': (_i, [_vp, _vp, ctypes.c_long, _i, _i, _i, _f, _i, _vp]),
@@ -148,6 +149,8 @@ _SIGNATURES.update({
     'msmc_gate_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _i, _f, _vp, ctypes.c_longlong, _i, _vp]),
     'msmc_tanh_fwd': (_i, [_vp, _vp, ctypes.c_long, _i, _vp]),
     'msmc_tanh_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _i, _vp]),
+    'msmc_tanh_f32_fwd': (_i, [_vp, _vp, ctypes.c_long, _i, _vp]),
+    'msmc_tanh_f32_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _i, _vp]),
     'msmc_opt_chunk': (_i, []),
     'msmc_opt_clip_adamw': (_i, [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _vp]),
     'msmc_lrelu_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _f, _i, _vp]),

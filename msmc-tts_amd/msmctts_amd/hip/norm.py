@@ -273,3 +273,28 @@ class _Tanh(torch.autograd.Function):
 
 def tanh(x):
     return _Tanh.apply(x)
+
+
+class _TanhF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        assert x.dtype in _DT and x.is_contiguous()
+        y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        lib.check(lib.get().msmc_tanh_f32_fwd(lib.ptr(x), lib.ptr(y), x.numel(), _DT[x.dtype], lib.stream(x)), 'msmc_tanh_f32_fwd')
+        ctx.save_for_backward(y)
+        ctx.dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        gx = torch.empty(y.shape, dtype=ctx.dtype, device=y.device)
+        g = g.contiguous().float()
+        lib.check(lib.get().msmc_tanh_f32_bwd(lib.ptr(y), lib.ptr(g), lib.ptr(gx), y.numel(), _DT[ctx.dtype], lib.stream(y)),
+                  'msmc_tanh_f32_bwd')
+        return gx
+
+
+def tanh_f32(x):
+    """tanh(x) in fp32 for x in the compute dtype (the cast rides in the kernel, the gradient comes back in x's dtype)"""
+    return _TanhF32.apply(x)

@@ -382,3 +382,15 @@ def wave_fan(y, n_alias, padded, dtype):
     """-> (aliases of y for fp32 readers, reflection-padded copies of y in ``dtype``): see _WaveFan"""
     outs = _WaveFan.apply(y, int(n_alias), tuple(int(v) for v in padded), dtype)
     return list(outs[:n_alias]), list(outs[n_alias:])
+
+
+def window_gather(starts, wav, nframes, hop):
+    """vocoder windows from per-utterance start frames (int64 [B], on the device) -> (frame indices [B, nframes] int64, waveform
+    windows [B, nframes * hop] fp32) in one launch (msmc_window_gather); ``wav`` [B, L] fp32 contiguous"""
+    B, L = wav.shape
+    assert starts.dtype == torch.int64 and starts.numel() == B and wav.dtype == torch.float32 and wav.is_contiguous()
+    frames = torch.empty((B, nframes), dtype=torch.int64, device=wav.device)
+    target = torch.empty((B, nframes * hop), dtype=torch.float32, device=wav.device)
+    lib.check(lib.get().msmc_window_gather(lib.ptr(starts), lib.ptr(wav), lib.ptr(frames), lib.ptr(target), B, int(nframes), int(hop),
+                                           int(L), lib.stream(wav)), 'msmc_window_gather')
+    return frames, target

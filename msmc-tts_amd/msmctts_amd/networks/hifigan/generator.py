@@ -95,4 +95,5 @@ class Generator(nn.Module):
                               out_div=float(nk) if j == nk - 1 else 1.0)
             x = xs
         x = hip_conv(bank, L['post'], x, in_slope=0.01)       # F.leaky_relu default slope (generator.py:52)
-        return torch.tanh(x.float()).reshape(x.shape[0], 1, x.shape[2])
+        from ...hip import norm as hipnorm
+        return hipnorm.tanh_f32(x).reshape(x.shape[0], 1, x.shape[2])       # (cast + tanh in one launch, fp32 out)

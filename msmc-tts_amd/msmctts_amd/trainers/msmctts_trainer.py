@@ -403,13 +403,17 @@ class VQGANTrainer(BaseTrainer):
                             v.zero_()
 
     def _build_windows(self, g, st):
-        """Frame / sample index tensors from the per-utterance window starts (device arithmetic only)."""
-        starts = g['starts']
+        """Frame / sample index tensors from the per-utterance window starts (device arithmetic only: one launch)."""
+        from ..hip import spectral as hipspectral
+        starts, wav = g['starts'], g['wav']
         fl = self.frame_lengths
+        if wav.dtype == torch.float32 and wav.is_contiguous() and (wav.is_cuda or hipspectral.lib._host_pointers_ok):
+            st.frame_window, st.target = hipspectral.window_gather(starts, wav, fl, self.frameshift)
+            return
         st.frame_window = starts.unsqueeze(1) + torch.arange(fl, device=starts.device).unsqueeze(0)
         sidx = (starts * self.frameshift).unsqueeze(1) + torch.arange(fl * self.frameshift,
                                                                       device=starts.device).unsqueeze(0)
-        st.target = torch.gather(g['wav'], 1, sidx)
+        st.target = torch.gather(wav, 1, sidx)
 
     def _capture(self, batch, phase=2):
         """Warm up eagerly on a side stream, then record segments A, B, C into three graphs sharing one pool.  ``phase`` 2: the

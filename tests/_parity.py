@@ -686,6 +686,33 @@ def check_weight_image_tiles(dev):
             ow, oa = ow + pad8(n), oa + A
 
 
+def check_window_gather_and_output_tanh(dev):
+    """msmc_window_gather against the operator chain it replaces (VQGANTrainer._build_windows: arange + add, multiply + arange +
+    add, gather) and msmc_tanh_f32_fwd / _bwd against ``tanh(x.float())`` and its gradient, fp32 and bf16 inputs"""
+    from msmctts_amd.hip import norm as hipnorm
+    from msmctts_amd.hip import spectral
+    g = torch.Generator().manual_seed(9)
+    B, L, fl, hop = 5, 4000, 7, 300
+    wav = torch.randn(B, L, generator=g).to(dev)
+    starts = torch.tensor([0, 3, 6, 1, 2], dtype=torch.int64, device=dev)          # (6 + 7) * 300 = 3900 <= L
+    frames, target = spectral.window_gather(starts, wav, fl, hop)
+    want_f = starts.unsqueeze(1) + torch.arange(fl, device=dev).unsqueeze(0)
+    sidx = (starts * hop).unsqueeze(1) + torch.arange(fl * hop, device=dev).unsqueeze(0)
+    assert torch.equal(frames, want_f) and torch.equal(target, torch.gather(wav, 1, sidx))
+    for dtype, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1e-2)):
+        x = torch.randn(3, 1, 501, 1, generator=g).to(dev).to(dtype).requires_grad_(True)
+        go = torch.randn(3, 1, 501, 1, generator=g).to(dev)
+        y = hipnorm.tanh_f32(x)
+        assert y.dtype == torch.float32
+        (y * go).sum().backward()
+        xr = x.detach().clone().requires_grad_(True)
+        yr = torch.tanh(xr.float())
+        (yr * go).sum().backward()
+        close(y, yr, 1e-6, what='tanh_f32 %s' % dtype)
+        assert x.grad.dtype == dtype
+        close(x.grad.float(), xr.grad.float(), tol, tol, what='tanh_f32 gradient %s' % dtype)
+
+
 def check_codebook_split_update(dev):
     """msmc_vq_ema_stats + msmc_vq_ema_apply (the two halves around the cross-rank sum of sync_codebook_stats) are, on
     one rank, bit for bit the fused msmc_vq_ema_update"""

@@ -580,6 +580,10 @@ def test_resblock_standalone_matches_stock_operators():
     _parity.check_resblock_standalone('cpu')
 
 
+def test_window_gather_and_output_tanh_match_the_operator_chains():
+    _parity.check_window_gather_and_output_tanh(torch.device('cpu'))
+
+
 def test_weight_images_in_one_tiled_pass_match_the_definition():
     _parity.check_weight_image_tiles(torch.device('cpu'))
 
