@@ -211,6 +211,21 @@ def abi_work_models():
     E = lambda code: 4 if int(_val(code)) == 0 else 2
     HEAD = 64
 
+    def spectral_multi_work(ops, n, st):
+        """msmc_spectral_multi: the sum of its members' work, each priced like the single-stage entry point"""
+        total = 0.0
+        for i in range(int(_val(n))):
+            o = ops[i]
+            if o.kind in (0, 1):
+                total += 4.0 * o.B * (o.L + o.T * o.NP)
+            elif o.kind == 2:
+                total += 4.0 * o.R * 3 * o.F
+            elif o.kind == 3:
+                total += 4.0 * o.R * 6 * o.F
+            else:
+                total += float(o.B * o.T * o.F * ((4 if o.kind == 4 else 8) + 2 * E(o.dtype)))
+        return 0.0, total
+
     def table_bytes(tab_ref, passes):
         tab = tab_ref._obj
         e = E(tab.dtype)
@@ -265,6 +280,7 @@ def abi_work_models():
         'msmc_masked_mean_bwd': lambda a, b, ln, l64, B, T, C, adt, bdt, mode, out, gout, ga, gb, st:
             (0.0, float(B * T * C * ((E(adt) + E(bdt)) * (1 if mode else 0) + (E(adt) if ga else 0) + (E(bdt) if gb else 0)))),
         'msmc_conv_wgrad_reduce_pending': pending,
+        'msmc_spectral_multi': spectral_multi_work,
         'msmc_stft_frames_fwd': lambda x, fr, B, L, T, n_fft, NP, hop, pad, st: (0.0, 4.0 * B * (L + T * NP)),
         'msmc_stft_frames_bwd': lambda gf, gx, B, L, T, n_fft, NP, hop, pad, st: (0.0, 4.0 * B * (L + T * NP)),
         'msmc_spec_mag_fwd': lambda spec, mag, R, F, CP, FP, lo, mode, st: (0.0, 4.0 * R * (2 * F + F)),

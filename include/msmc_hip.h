@@ -403,6 +403,24 @@ int msmc_wave_fan_fwd(const float* y, void* const* copies, const int* padded_len
                       msmc_stream stream);
 int msmc_wave_fan_bwd(const float* const* g32, int n32, const void* const* gcopies, const int* padded_len, int n, float* gy,
                       int B, int L, int dtype, msmc_stream stream);
+/* Several element-wise stages of the spectral front-ends in ONE launch (the resolution discriminators' five chains advance in lock
+ * step: five framings, five magnitudes, five images -- forward and backward).  kind: 0 msmc_stft_frames_fwd (a = x, out = frames),
+ * 1 _bwd (a = gframes, out = gx), 2 msmc_spec_mag_fwd (a = spec, out = mag), 3 _bwd (a = spec, b = mag, c = gmag, out = gspec),
+ * 4 msmc_mrd_image_fwd_dt (a = mel, out = img), 5 _bwd_dt (a = mel, b = gimg, out = gmel); the remaining fields are the arguments of
+ * those entry points. */
+#define MSMC_SPECTRAL_MULTI_MAX 8
+typedef struct msmc_spectral_op {
+    int kind, dtype;
+    const void* a;
+    const void* b;
+    const void* c;
+    void* out;
+    int B, L, T, n_fft, NP, hop, pad;
+    int F, CP, FP, clamp_mode;
+    float lo;
+    long R;
+} msmc_spectral_op;
+int msmc_spectral_multi(const msmc_spectral_op* ops, int n, msmc_stream stream);
 /* Vocoder windows of a captured step (reference msmctts_trainer.py:211-219, window starts on the device): frames[b][i] = starts[b] + i
  * (int64, i < nframes) and target[b][j] = wav[b][starts[b] * hop + j] (j < nframes * hop; wav [B][L] fp32).  The caller guarantees
  * starts[b] * hop + nframes * hop <= L (VQGANTrainer checks the batch on the host). */

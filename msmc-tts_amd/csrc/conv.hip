@@ -1816,6 +1816,12 @@ static int cv_group_launch(const msmc_conv_desc* descs, int n, msmc_stream strea
         for (int i = 0; i < n; ++i) done4[i] = done4[i] || done6[i];
     }
     {
+        bool dones[MSMC_GROUP_LIMIT];                           // split-bf16 constant-matrix GEMMs (variants 36 / 37): one grid per tile width
+        const int rc = g1s_group_launch(descs, n, stream, dones);
+        if (rc) return rc;
+        for (int i = 0; i < n; ++i) done4[i] = done4[i] || dones[i];
+    }
+    {
         bool doneks[MSMC_GROUP_LIMIT];                          // wave-split members (variant 9): one grid per configuration
         const int rc = cv_ks_group_launch<T>(descs, n, stream, doneks);
         if (rc) return rc;

@@ -15,9 +15,9 @@ MSMC_DEV int sp_reflect(int i, int n) {
     return i;
 }
 
-__global__ __launch_bounds__(256) void stft_frames_fwd_kernel(const float* __restrict__ x, float* __restrict__ fr, int L,
-                                                             int T, int n_fft, int NP, int hop, int pad, long total) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+MSMC_DEV void stft_frames_fwd_body(const float* __restrict__ x, float* __restrict__ fr, int L,
+                                                             int T, int n_fft, int NP, int hop, int pad, long total, int bid, int nb) {
+    for (long e = (long)bid * 256 + threadIdx.x; e < total; e += (long)nb * 256) {
         const int j = (int)(e % NP);
         const long r = e / NP;
         const int t = (int)(r % T);
@@ -27,14 +27,18 @@ __global__ __launch_bounds__(256) void stft_frames_fwd_kernel(const float* __res
         fr[e] = v;
     }
 }
+__global__ __launch_bounds__(256) void stft_frames_fwd_kernel(const float* __restrict__ x, float* __restrict__ fr, int L,
+                                                             int T, int n_fft, int NP, int hop, int pad, long total) {
+    stft_frames_fwd_body(x, fr, L, T, n_fft, NP, hop, pad, total, (int)blockIdx.x, (int)gridDim.x);
+}
 
 // gx[b][l]: frames read padded position p = t*hop + j; sample l is read at p = l + pad and, through the
 // reflection, at p = pad - l (l >= 1, left border) and p = 2(L-1) - l + pad (l <= L-2, right border).
-__global__ __launch_bounds__(256) void stft_frames_bwd_kernel(const float* __restrict__ gfr, float* __restrict__ gx,
+MSMC_DEV void stft_frames_bwd_body(const float* __restrict__ gfr, float* __restrict__ gx,
                                                              int L, int T, int n_fft, int NP, int hop, int pad,
-                                                             long total) {
+                                                             long total, int bid, int nb) {
     const int Lp = (T - 1) * hop + n_fft;           // padded positions actually covered by frames
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    for (long e = (long)bid * 256 + threadIdx.x; e < total; e += (long)nb * 256) {
         const int l = (int)(e % L);
         const long b = e / L;
         int ps[3], np = 0;
@@ -57,10 +61,15 @@ __global__ __launch_bounds__(256) void stft_frames_bwd_kernel(const float* __res
         gx[e] = s;
     }
 }
+__global__ __launch_bounds__(256) void stft_frames_bwd_kernel(const float* __restrict__ gfr, float* __restrict__ gx,
+                                                             int L, int T, int n_fft, int NP, int hop, int pad,
+                                                             long total) {
+    stft_frames_bwd_body(gfr, gx, L, T, n_fft, NP, hop, pad, total, (int)blockIdx.x, (int)gridDim.x);
+}
 
-__global__ __launch_bounds__(256) void spec_mag_fwd_kernel(const float* __restrict__ spec, float* __restrict__ mag, int F,
-                                                          int CP, int FP, float lo, int clamp_mode, long total) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+MSMC_DEV void spec_mag_fwd_body(const float* __restrict__ spec, float* __restrict__ mag, int F,
+                                                          int CP, int FP, float lo, int clamp_mode, long total, int bid, int nb) {
+    for (long e = (long)bid * 256 + threadIdx.x; e < total; e += (long)nb * 256) {
         const int f = (int)(e % FP);
         const long r = e / FP;
         float v = 0.f;
@@ -73,11 +82,15 @@ __global__ __launch_bounds__(256) void spec_mag_fwd_kernel(const float* __restri
         mag[e] = v;
     }
 }
+__global__ __launch_bounds__(256) void spec_mag_fwd_kernel(const float* __restrict__ spec, float* __restrict__ mag, int F,
+                                                          int CP, int FP, float lo, int clamp_mode, long total) {
+    spec_mag_fwd_body(spec, mag, F, CP, FP, lo, clamp_mode, total, (int)blockIdx.x, (int)gridDim.x);
+}
 
-__global__ __launch_bounds__(256) void spec_mag_bwd_kernel(const float* __restrict__ spec, const float* __restrict__ mag,
+MSMC_DEV void spec_mag_bwd_body(const float* __restrict__ spec, const float* __restrict__ mag,
                                                           const float* __restrict__ gmag, float* __restrict__ gspec,
-                                                          int F, int CP, int FP, float lo, int clamp_mode, long total) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+                                                          int F, int CP, int FP, float lo, int clamp_mode, long total, int bid, int nb) {
+    for (long e = (long)bid * 256 + threadIdx.x; e < total; e += (long)nb * 256) {
         const int c = (int)(e % CP);
         const long r = e / CP;
         float g = 0.f;
@@ -89,6 +102,11 @@ __global__ __launch_bounds__(256) void spec_mag_bwd_kernel(const float* __restri
         }
         gspec[e] = g;
     }
+}
+__global__ __launch_bounds__(256) void spec_mag_bwd_kernel(const float* __restrict__ spec, const float* __restrict__ mag,
+                                                          const float* __restrict__ gmag, float* __restrict__ gspec,
+                                                          int F, int CP, int FP, float lo, int clamp_mode, long total) {
+    spec_mag_bwd_body(spec, mag, gmag, gspec, F, CP, FP, lo, clamp_mode, total, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // img[b][f][t][0..1] <- mel[(b*T + t)][f]   (transposed write; reads are the strided side, tiny tensors)
@@ -104,9 +122,9 @@ MSMC_DEV void sp_load2(const unsigned short* p, float& a, float& b) {
     b = __uint_as_float(v & 0xffff0000u);
 }
 template <typename O>
-__global__ __launch_bounds__(256) void mrd_image_fwd_kernel(const float* __restrict__ mel, O* __restrict__ img, int T,
-                                                           int F, int FP, long total) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+MSMC_DEV void mrd_image_fwd_body(const float* __restrict__ mel, O* __restrict__ img, int T,
+                                                           int F, int FP, long total, int bid, int nb) {
+    for (long e = (long)bid * 256 + threadIdx.x; e < total; e += (long)nb * 256) {
         const int t = (int)(e % T);
         long r = e / T;
         const int f = (int)(r % F);
@@ -117,11 +135,16 @@ __global__ __launch_bounds__(256) void mrd_image_fwd_kernel(const float* __restr
         sp_store2(img + e * 2, m, lg);
     }
 }
+template <typename O>
+__global__ __launch_bounds__(256) void mrd_image_fwd_kernel(const float* __restrict__ mel, O* __restrict__ img, int T,
+                                                           int F, int FP, long total) {
+    mrd_image_fwd_body<O>(mel, img, T, F, FP, total, (int)blockIdx.x, (int)gridDim.x);
+}
 
 template <typename O>
-__global__ __launch_bounds__(256) void mrd_image_bwd_kernel(const float* __restrict__ mel, const O* __restrict__ gimg,
-                                                           float* __restrict__ gmel, int T, int F, int FP, long total) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+MSMC_DEV void mrd_image_bwd_body(const float* __restrict__ mel, const O* __restrict__ gimg,
+                                                           float* __restrict__ gmel, int T, int F, int FP, long total, int bid, int nb) {
+    for (long e = (long)bid * 256 + threadIdx.x; e < total; e += (long)nb * 256) {
         const int f = (int)(e % FP);
         const long r = e / FP;              // b*T + t
         const int t = (int)(r % T);
@@ -138,6 +161,11 @@ __global__ __launch_bounds__(256) void mrd_image_bwd_kernel(const float* __restr
         gmel[e] = g;
     }
 }
+template <typename O>
+__global__ __launch_bounds__(256) void mrd_image_bwd_kernel(const float* __restrict__ mel, const O* __restrict__ gimg,
+                                                           float* __restrict__ gmel, int T, int F, int FP, long total) {
+    mrd_image_bwd_body<O>(mel, gimg, gmel, T, F, FP, total, (int)blockIdx.x, (int)gridDim.x);
+}
 
 __global__ __launch_bounds__(256) void log_clamp_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
                                                            float lo) {
@@ -151,6 +179,37 @@ __global__ __launch_bounds__(256) void log_clamp_bwd_kernel(const float* __restr
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
         const float v = x[e];
         gx[e] = v > lo ? g[e] / v : 0.f;
+    }
+}
+
+// Several of the element-wise stages above in ONE launch (msmc_spectral_multi): the five resolution discriminators' front-ends
+// are five identical chains frames -> DFT -> magnitude -> filter bank -> image over different hop lengths, each stage a launch of
+// 5-10 us for a microsecond of work, and a chain of 25 such launches sat on the step's critical chain forward and again
+// backward (profiles/r06_step_timeline_start_of_round.txt).  A block looks its operation up in the argument and runs the stage's
+// own body over its share of the operation's elements.
+struct SpMultiArgs {
+    int n;
+    int first[MSMC_SPECTRAL_MULTI_MAX + 1];
+    msmc_spectral_op op[MSMC_SPECTRAL_MULTI_MAX];
+};
+__global__ __launch_bounds__(256) void spectral_multi_kernel(SpMultiArgs a) {
+    int k = 0;
+    while (k + 1 < a.n && (int)blockIdx.x >= a.first[k + 1]) ++k;
+    const msmc_spectral_op& o = a.op[k];
+    const int bid = (int)blockIdx.x - a.first[k], nb = a.first[k + 1] - a.first[k];
+    switch (o.kind) {
+        case 0: stft_frames_fwd_body((const float*)o.a, (float*)o.out, o.L, o.T, o.n_fft, o.NP, o.hop, o.pad, (long)o.B * o.T * o.NP, bid, nb); break;
+        case 1: stft_frames_bwd_body((const float*)o.a, (float*)o.out, o.L, o.T, o.n_fft, o.NP, o.hop, o.pad, (long)o.B * o.L, bid, nb); break;
+        case 2: spec_mag_fwd_body((const float*)o.a, (float*)o.out, o.F, o.CP, o.FP, o.lo, o.clamp_mode, o.R * o.FP, bid, nb); break;
+        case 3: spec_mag_bwd_body((const float*)o.a, (const float*)o.b, (const float*)o.c, (float*)o.out, o.F, o.CP, o.FP, o.lo, o.clamp_mode, o.R * o.CP, bid, nb); break;
+        case 4:
+            if (o.dtype == 0) mrd_image_fwd_body<float>((const float*)o.a, (float*)o.out, o.T, o.F, o.FP, (long)o.B * o.F * o.T, bid, nb);
+            else mrd_image_fwd_body<unsigned short>((const float*)o.a, (unsigned short*)o.out, o.T, o.F, o.FP, (long)o.B * o.F * o.T, bid, nb);
+            break;
+        default:
+            if (o.dtype == 0) mrd_image_bwd_body<float>((const float*)o.a, (const float*)o.b, (float*)o.out, o.T, o.F, o.FP, (long)o.B * o.T * o.FP, bid, nb);
+            else mrd_image_bwd_body<unsigned short>((const float*)o.a, (const unsigned short*)o.b, (float*)o.out, o.T, o.F, o.FP, (long)o.B * o.T * o.FP, bid, nb);
+            break;
     }
 }
 
@@ -350,6 +409,38 @@ int msmc_window_gather(const long* starts, const float* wav, long* frames, float
     const long total = (long)B * nframes * hop;
     MSMC_LAUNCH(window_gather_kernel, sp_grid(total), dim3(256), 0, (msmc_stream_t)stream, starts, wav, frames, target, nframes, hop, L,
                 total);
+    return msmc_check_launch();
+}
+int msmc_spectral_multi(const msmc_spectral_op* ops, int n, msmc_stream stream) {
+    if (!ops || n <= 0 || n > MSMC_SPECTRAL_MULTI_MAX) return MSMC_E_SHAPE;
+    SpMultiArgs a;
+    a.n = n;
+    int blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        const msmc_spectral_op& o = ops[k];
+        long total;
+        if (!o.a || !o.out) return MSMC_E_SHAPE;
+        switch (o.kind) {
+            case 0: case 1:
+                if (o.B <= 0 || o.L <= o.pad || o.T <= 0 || o.NP < o.n_fft || o.hop <= 0 || o.pad < 0) return MSMC_E_SHAPE;
+                total = o.kind == 0 ? (long)o.B * o.T * o.NP : (long)o.B * o.L;
+                break;
+            case 2: case 3:
+                if (o.R <= 0 || o.F <= 0 || o.CP < 2 * o.F || o.FP < o.F || (o.kind == 3 && (!o.b || !o.c))) return MSMC_E_SHAPE;
+                total = o.kind == 2 ? o.R * o.FP : o.R * o.CP;
+                break;
+            case 4: case 5:
+                if (o.B <= 0 || o.T <= 0 || o.F <= 0 || o.FP < o.F || o.dtype < 0 || o.dtype > 1 || (o.kind == 5 && !o.b)) return MSMC_E_SHAPE;
+                total = o.kind == 4 ? (long)o.B * o.F * o.T : (long)o.B * o.T * o.FP;
+                break;
+            default: return MSMC_E_SHAPE;
+        }
+        a.first[k] = blocks;
+        a.op[k] = o;
+        blocks += (int)sp_grid(total).x;
+    }
+    a.first[n] = blocks;
+    MSMC_LAUNCH(spectral_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (msmc_stream_t)stream, a);
     return msmc_check_launch();
 }
 }  // extern "C"

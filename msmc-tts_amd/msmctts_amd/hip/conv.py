@@ -483,6 +483,38 @@ def const_gemm_split(x, wimg, cout):
     return out
 
 
+def const_gemm_split_group(xs, wimgs, couts):
+    """``const_gemm_split`` of several independent (x, matrix image) pairs as ONE grouped call: members of one tile width share a
+    grid (csrc/gemm1.inc conv_gemm1s_group_kernel) -- the five resolution front-ends' DFT (or filter-bank) GEMMs in one launch"""
+    assert 0 < len(xs) <= 16
+    snaps, outs = [], []
+    stream = lib.stream(xs[0])
+    for x, wimg, cout in zip(xs, wimgs, couts):
+        B, _, T, Cin = x.shape
+        assert x.dtype == torch.float32 and wimg.dtype == torch.bfloat16 and wimg.shape[0] == cout and wimg.is_contiguous()
+        assert wimg.shape[1] * 32 >= Cin and wimg.shape[2] == 64, (tuple(wimg.shape), Cin)
+        key = ('g1s', B, T, Cin, cout)
+        desc = _PLANS.get(key)
+        if desc is None:
+            _bounded(_PLANS)
+            desc = _PLANS[key] = _build_desc(torch.float32, B, 1, T, Cin, 1, T, cout, (1, T, 0, 1, 0, 1, 1, 1, 0, 0), ((0, 0, 0),), 0,
+                                             1.0, 1.0, 1.0, 1.0)
+            desc.variant = 37 if ((B * T + 127) // 128) * ((cout + 127) // 128) < 192 else 36
+        _dev_ok(x)
+        _dev_ok(wimg)
+        out = torch.empty((B, 1, T, cout), dtype=torch.float32, device=x.device)
+        desc.x, desc.w, desc.out = x.data_ptr(), wimg.data_ptr(), out.data_ptr()
+        desc.bias = desc.res = desc.res2 = desc.mask_src = None
+        if not getattr(desc, '_tuned', False):
+            fn = lib.get().msmc_conv_gather
+            _tune('gather-split', desc, lambda: fn(ctypes.byref(desc), stream), _SPLIT_CANDIDATES)
+        snaps.append(lib.ConvDesc.from_buffer_copy(desc))
+        outs.append(out)
+    arr = (lib.ConvDesc * len(snaps))(*snaps)
+    lib.check(lib.get().msmc_conv_gather_group(arr, len(snaps), stream), 'msmc_conv_gather_group(split constant GEMMs)')
+    return outs
+
+
 def _snapshot(desc, stream):
     """by-value copy of a (tuned) descriptor: grouped calls may meet the same cached descriptor twice"""
     if not getattr(desc, '_tuned', False):

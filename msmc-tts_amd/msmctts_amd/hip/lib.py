@@ -64,6 +64,16 @@ class WnItem(ctypes.Structure):
                 ('dw_copy_stride', ctypes.c_long), ('db_copy_stride', ctypes.c_long)]
 
 
+class SpectralOp(ctypes.Structure):
+    """msmc_spectral_op of include/msmc_hip.h."""
+    _fields_ = [('kind', _i), ('dtype', _i), ('a', _vp), ('b', _vp), ('c', _vp), ('out', _vp),
+                ('B', _i), ('L', _i), ('T', _i), ('n_fft', _i), ('NP', _i), ('hop', _i), ('pad', _i),
+                ('F', _i), ('CP', _i), ('FP', _i), ('clamp_mode', _i), ('lo', _f), ('R', ctypes.c_long)]
+
+
+SPECTRAL_MULTI_MAX = 8
+
+
 class OptTensor(ctypes.Structure):
     """msmc_opt_tensor of include/msmc_hip.h."""
     _fields_ = [('p', _vp), ('g', _vp), ('m', _vp), ('v', _vp), ('n', ctypes.c_long), ('first_chunk', _i), ('pad_', _i)]
@@ -79,6 +89,7 @@ class TensorTable(ctypes.Structure):
 
 
 _SIGNATURES.update({
+    'msmc_spectral_multi': (_i, [ctypes.POINTER(SpectralOp), _i, _vp]),
     'msmc_window_gather': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, ctypes.c_long, _vp]),
     'msmc_stft_frames_fwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'msmc_stft_frames_bwd': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

@@ -266,6 +266,142 @@ class MrdFront(object):
         return gx
 
 
+# ---- the front-ends of SEVERAL hop lengths in lock step (round 6) -------------------------------------------------------------
+# The five resolution discriminators' chains frames -> DFT -> magnitude -> filter bank -> image are independent and identical in
+# shape; one after the other they were 25 launches of 5-10 us forward and 25 backward on the step's critical chain.  Here every
+# stage of all chains is ONE launch (msmc_spectral_multi for the element-wise stages, a grouped call for the constant-matrix
+# GEMMs): 5 + 5.  MSMC_FRONTS_LOCKSTEP=0: chain by chain (A/B).
+FRONTS_LOCKSTEP = _os.environ.get('MSMC_FRONTS_LOCKSTEP', '1') != '0'
+
+
+def _multi(ops):
+    L = lib.get()
+    for i in range(0, len(ops), lib.SPECTRAL_MULTI_MAX):
+        part = ops[i:i + lib.SPECTRAL_MULTI_MAX]
+        arr = (lib.SpectralOp * len(part))(*part)
+        lib.check(L.msmc_spectral_multi(arr, len(part), part[0]._stream), 'msmc_spectral_multi')
+
+
+def _op(kind, stream, a, out, b=None, c=None, dtype=0, **kw):
+    o = lib.SpectralOp()
+    o.kind, o.dtype = kind, dtype
+    o.a, o.b, o.c, o.out = a.data_ptr(), (b.data_ptr() if b is not None else None), (c.data_ptr() if c is not None else None), out.data_ptr()
+    for k, v in kw.items():
+        setattr(o, k, v)
+    o._stream = stream
+    o._keep = (a, b, c, out)
+    return o
+
+
+def _gemms(xs, ws, split, dgrad=False):
+    """one constant-matrix GEMM per chain: a grouped call in the split-bf16 form, chain by chain in exact fp32"""
+    if split:
+        return K.const_gemm_split_group(xs, [split_image(w) for w in ws], [w.shape[1] for w in ws])
+    return [_const_gemm(x, w, _geom1(x.shape[2]), False, dgrad=dgrad) for x, w in zip(xs, ws)]
+
+
+def mrd_fronts(x, specs, dtype, split=None):
+    """``MrdFront(x, n_fft, hop, dft, fb, dtype)`` for every (n_fft, hop, dft, fb) of ``specs``, all chains advancing together"""
+    fronts = [MrdFront.__new__(MrdFront) for _ in specs]
+    B, L = x.shape
+    xc = x.detach().contiguous().float()
+    st = lib.stream(xc)
+    split = (dtype == torch.bfloat16 and SPLIT_BF16) if split is None else bool(split)
+    frs, ops = [], []
+    for f, (n_fft, hop, dft, fb) in zip(fronts, specs):
+        f.B, f.L, f.n_fft, f.hop, f.dft, f.fb, f.dtype, f.split = B, L, n_fft, hop, dft, fb, dtype, split
+        f.F, f.T = n_fft // 2 + 1, L // hop + 1
+        lo, n_eff = dft[2], dft[3]
+        f.frame_args = (f.T, n_eff, _pad4(n_eff), hop, n_fft // 2 - lo)
+        fr = torch.empty((B, 1, f.T, _pad4(n_eff)), dtype=torch.float32, device=x.device)
+        frs.append(fr)
+        ops.append(_op(0, st, xc, fr, B=B, L=L, T=f.T, n_fft=n_eff, NP=_pad4(n_eff), hop=hop, pad=n_fft // 2 - lo))
+    _multi(ops)
+    specs_t = _gemms(frs, [f.dft[0] for f in fronts], split)
+    ops = []
+    for f, sp in zip(fronts, specs_t):
+        f.spec = sp
+        f.mag = torch.empty((B, 1, f.T, _pad4(f.F)), dtype=torch.float32, device=x.device)
+        ops.append(_op(2, st, sp, f.mag, R=B * f.T, F=f.F, CP=sp.shape[-1], FP=_pad4(f.F), lo=1e-7, clamp_mode=1))
+    _multi(ops)
+    with_fb = [f for f in fronts if f.fb is not None]
+    for f, mel in zip(with_fb, _gemms([f.mag for f in with_fb], [f.fb[0] for f in with_fb], split) if with_fb else []):
+        f.mel = mel
+    ops = []
+    for f in fronts:
+        if f.fb is None:
+            f.mel = f.mag
+        f.img = torch.empty((B, f.F, f.T, 2), dtype=dtype, device=x.device)
+        ops.append(_op(4, st, f.mel, f.img, dtype=_IMG_DT[dtype], B=B, T=f.T, F=f.F, FP=_pad4(f.F)))
+    _multi(ops)
+    return fronts
+
+
+def backward_rows_lockstep(fronts, gs, r0, r1):
+    """``MrdFront.backward_rows(g, r0, r1)`` of several fronts, every stage of all chains in one launch; ``gs[i]`` None: no gradient"""
+    live = [(f, g) for f, g in zip(fronts, gs) if g is not None]
+    out = [None] * len(fronts)
+    if not live:
+        return out
+    b = r1 - r0
+    ops, gms, st = [], [], None
+    for f, g in live:
+        g = g.contiguous()
+        if g.dtype != f.dtype:
+            g = g.to(f.dtype)
+        st = lib.stream(g)
+        mel = f.mel[r0:r1]
+        gm = torch.empty_like(mel)
+        gms.append(gm)
+        ops.append(_op(5, st, mel, gm, b=g, dtype=_IMG_DT[f.dtype], B=b, T=f.T, F=f.F, FP=f.mag.shape[-1]))
+    _multi(ops)
+    with_fb = [i for i, (f, _) in enumerate(live) if f.fb is not None]
+    if with_fb:
+        for i, gm in zip(with_fb, _gemms([gms[i] for i in with_fb], [live[i][0].fb[1] for i in with_fb], live[0][0].split, dgrad=True)):
+            gms[i] = gm
+    ops, gss = [], []
+    for (f, _), gm in zip(live, gms):
+        spec, mag = f.spec[r0:r1], f.mag[r0:r1]
+        gsp = torch.empty_like(spec)
+        gss.append(gsp)
+        ops.append(_op(3, st, spec, gsp, b=mag, c=gm, R=b * f.T, F=f.F, CP=spec.shape[-1], FP=mag.shape[-1], lo=1e-7, clamp_mode=1))
+    _multi(ops)
+    gfrs = _gemms(gss, [f.dft[1] for f, _ in live], live[0][0].split, dgrad=True)
+    ops, gxs = [], []
+    for (f, _), gfr in zip(live, gfrs):
+        T_, n_eff, NP, hop, pad = f.frame_args
+        gx = torch.empty((b, f.L), dtype=torch.float32, device=gfr.device)
+        gxs.append(gx)
+        ops.append(_op(1, st, gfr, gx, B=b, L=f.L, T=T_, n_fft=n_eff, NP=NP, hop=hop, pad=pad))
+    _multi(ops)
+    it = iter(gxs)
+    for i, g in enumerate(gs):
+        if g is not None:
+            out[i] = next(it)
+    return out
+
+
+class _MrdImageRowsMulti(torch.autograd.Function):
+    """``_MrdImageRows`` of several fronts as ONE node: its backward runs all chains in lock step.  ``xs``: one alias of the
+    waveform rows per front (hip/spectral.py wave_fan: their gradients are summed by the fan's backward launch)"""
+
+    @staticmethod
+    def forward(ctx, fronts, r0, r1, *xs):
+        ctx.fronts, ctx.rows = fronts, (r0, r1)
+        return tuple(f.image(r0, r1) for f in fronts)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return (None, None, None) + tuple(backward_rows_lockstep(ctx.fronts, gs, *ctx.rows))
+
+
+def mrd_image_rows_multi(xs, fronts, r0, r1):
+    """image rows r0 .. r1-1 of every front as functions of the waveform aliases ``xs`` (one backward node for all)"""
+    if not (FRONTS_LOCKSTEP and any(x.requires_grad for x in xs)):
+        return [mrd_image_rows(x, f, r0, r1) for x, f in zip(xs, fronts)]
+    return list(_MrdImageRowsMulti.apply(list(fronts), r0, r1, *[x.contiguous() for x in xs]))
+
+
 class _MrdImage2(torch.autograd.Function):
     """the whole chain as ONE autograd node: forward = MrdFront(x), backward = MrdFront.backward_rows over all rows"""
 

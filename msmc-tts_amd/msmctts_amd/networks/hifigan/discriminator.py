@@ -159,7 +159,7 @@ class SpectralFronts(object):
         if wavs is None:
             wav = self.wav.squeeze(1) if self.wav.dim() == 3 else self.wav
             wavs = [wav] * len(self.fronts)
-        return [spectral.mrd_image_rows(w.float(), f, self.r0, self.r1) for w, f in zip(wavs, self.fronts)]
+        return spectral.mrd_image_rows_multi([w.float() for w in wavs], self.fronts, self.r0, self.r1)
 
 
 class Discriminator(nn.Module):
@@ -210,7 +210,12 @@ class Discriminator(nn.Module):
     def spectral_fronts(self, y):
         """the resolution discriminators' images of waveforms ``y`` (B, L) / (B, 1, L) WITHOUT gradient history, as an
         object later passes can take rows from (``forward(.., fronts=...)``)"""
+        from ...hip import spectral
         wav = y.squeeze(1) if y.dim() == 3 else y
+        if spectral.FRONTS_LOCKSTEP:          # every stage of the five chains in one launch (hip/spectral.py mrd_fronts)
+            with torch.autocast(device_type=wav.device.type, enabled=False):
+                specs = [(stft.fft_size, stft.hop_size) + tuple(stft.consts(wav.device)) for stft in self.mrd.stfts]
+                return SpectralFronts(spectral.mrd_fronts(wav.detach().float(), specs, self.hip_dtype), 0, wav.shape[0])
         return SpectralFronts([stft.front(wav.detach(), self.hip_dtype) for stft in self.mrd.stfts], 0, wav.shape[0])
 
     def forward(self, y, fronts=None):

@@ -713,6 +713,35 @@ def check_window_gather_and_output_tanh(dev):
         close(x.grad.float(), xr.grad.float(), tol, tol, what='tanh_f32 gradient %s' % dtype)
 
 
+def check_fronts_lockstep(dev):
+    """hip/spectral.py mrd_fronts / backward_rows_lockstep (every stage of several front-end chains in one launch: msmc_spectral_multi,
+    grouped split-bf16 constant GEMMs) against the chains run one after the other (MrdFront / backward_rows): the same kernels'
+    bodies on the same data -- bit-identical images, intermediates and waveform gradients, in the fp32 and the bf16 configuration,
+    with and without a filter bank, on a row range"""
+    from msmctts_amd.hip import spectral
+    from msmctts_amd.utils.audio import TorchSTFT
+    g = torch.Generator().manual_seed(21)
+    B, L = 6, 2400
+    x = torch.randn(B, L, generator=g).to(dev)
+    stfts = [TorchSTFT(fft_size=h * 4, hop_size=h, win_size=h * 4, normalized=True, domain='double', mel_scale=(h != 30),
+                       sample_rate=24000) for h in (15, 30, 50, 120)]
+    for dtype in (torch.float32, torch.bfloat16):
+        specs = [(s_.fft_size, s_.hop_size) + tuple(s_.consts(x.device)) for s_ in stfts]
+        together = spectral.mrd_fronts(x, specs, dtype)
+        alone = [spectral.MrdFront(x, n_fft, hop, dft, fb, dtype) for n_fft, hop, dft, fb in specs]
+        for a, b in zip(together, alone):
+            for name in ('spec', 'mag', 'mel', 'img'):
+                assert torch.equal(getattr(a, name), getattr(b, name)), (dtype, a.hop, name)
+        gs = [torch.randn(3, f.F, f.T, 2, generator=g).to(dev).to(dtype) for f in alone]
+        gs[1] = None                                                    # (a front whose image nobody differentiated)
+        got = spectral.backward_rows_lockstep(together, gs, 2, 5)
+        for a, b, gi in zip(got, alone, gs):
+            if gi is None:
+                assert a is None
+            else:
+                assert torch.equal(a, b.backward_rows(gi, 2, 5)), (dtype, b.hop)
+
+
 def check_codebook_split_update(dev):
     """msmc_vq_ema_stats + msmc_vq_ema_apply (the two halves around the cross-rank sum of sync_codebook_stats) are, on
     one rank, bit for bit the fused msmc_vq_ema_update"""

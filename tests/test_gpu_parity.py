@@ -43,6 +43,10 @@ def test_window_gather_and_output_tanh_match_the_operator_chains():
     _parity.check_window_gather_and_output_tanh(torch.device(DEV))
 
 
+def test_front_end_chains_in_lock_step_equal_the_chains_one_by_one():
+    _parity.check_fronts_lockstep(torch.device(DEV))
+
+
 def test_weight_images_in_one_tiled_pass_match_the_definition():
     """msmc_wn_prepare_multi_tiles (round 6: both kernel layouts from one read of the parameters) on the GPU"""
     _parity.check_weight_image_tiles(torch.device(DEV))
