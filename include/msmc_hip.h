@@ -406,8 +406,8 @@ int msmc_wave_fan_bwd(const float* const* g32, int n32, const void* const* gcopi
 /* Several element-wise stages of the spectral front-ends in ONE launch (the resolution discriminators' five chains advance in lock
  * step: five framings, five magnitudes, five images -- forward and backward).  kind: 0 msmc_stft_frames_fwd (a = x, out = frames),
  * 1 _bwd (a = gframes, out = gx), 2 msmc_spec_mag_fwd (a = spec, out = mag), 3 _bwd (a = spec, b = mag, c = gmag, out = gspec),
- * 4 msmc_mrd_image_fwd_dt (a = mel, out = img), 5 _bwd_dt (a = mel, b = gimg, out = gmel); the remaining fields are the arguments of
- * those entry points. */
+ * 4 msmc_mrd_image_fwd_dt (a = mel, out = img), 5 _bwd_dt (a = mel, b = gimg, out = gmel), 6 msmc_log_clamp_fwd (a = x, out = y, R = n),
+ * 7 _bwd (a = x, b = g, out = gx, R = n); the remaining fields are the arguments of those entry points. */
 #define MSMC_SPECTRAL_MULTI_MAX 8
 typedef struct msmc_spectral_op {
     int kind, dtype;

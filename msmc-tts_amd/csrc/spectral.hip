@@ -167,19 +167,27 @@ __global__ __launch_bounds__(256) void mrd_image_bwd_kernel(const float* __restr
     mrd_image_bwd_body<O>(mel, gimg, gmel, T, F, FP, total, (int)blockIdx.x, (int)gridDim.x);
 }
 
-__global__ __launch_bounds__(256) void log_clamp_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
-                                                           float lo) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+MSMC_DEV void log_clamp_fwd_body(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                           float lo, int bid, int nb) {
+    for (long e = (long)bid * 256 + threadIdx.x; e < n; e += (long)nb * 256) {
         const float v = x[e];
         y[e] = logf(v < lo ? lo : v);
     }
 }
-__global__ __launch_bounds__(256) void log_clamp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                           float* __restrict__ gx, long n, float lo) {
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+__global__ __launch_bounds__(256) void log_clamp_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                                                           float lo) {
+    log_clamp_fwd_body(x, y, n, lo, (int)blockIdx.x, (int)gridDim.x);
+}
+MSMC_DEV void log_clamp_bwd_body(const float* __restrict__ x, const float* __restrict__ g,
+                                                           float* __restrict__ gx, long n, float lo, int bid, int nb) {
+    for (long e = (long)bid * 256 + threadIdx.x; e < n; e += (long)nb * 256) {
         const float v = x[e];
         gx[e] = v > lo ? g[e] / v : 0.f;
     }
+}
+__global__ __launch_bounds__(256) void log_clamp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                           float* __restrict__ gx, long n, float lo) {
+    log_clamp_bwd_body(x, g, gx, n, lo, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Several of the element-wise stages above in ONE launch (msmc_spectral_multi): the five resolution discriminators' front-ends
@@ -206,6 +214,8 @@ __global__ __launch_bounds__(256) void spectral_multi_kernel(SpMultiArgs a) {
             if (o.dtype == 0) mrd_image_fwd_body<float>((const float*)o.a, (float*)o.out, o.T, o.F, o.FP, (long)o.B * o.F * o.T, bid, nb);
             else mrd_image_fwd_body<unsigned short>((const float*)o.a, (unsigned short*)o.out, o.T, o.F, o.FP, (long)o.B * o.F * o.T, bid, nb);
             break;
+        case 6: log_clamp_fwd_body((const float*)o.a, (float*)o.out, o.R, o.lo, bid, nb); break;
+        case 7: log_clamp_bwd_body((const float*)o.a, (const float*)o.b, (float*)o.out, o.R, o.lo, bid, nb); break;
         default:
             if (o.dtype == 0) mrd_image_bwd_body<float>((const float*)o.a, (const float*)o.b, (float*)o.out, o.T, o.F, o.FP, (long)o.B * o.T * o.FP, bid, nb);
             else mrd_image_bwd_body<unsigned short>((const float*)o.a, (const unsigned short*)o.b, (float*)o.out, o.T, o.F, o.FP, (long)o.B * o.T * o.FP, bid, nb);
@@ -432,6 +442,10 @@ int msmc_spectral_multi(const msmc_spectral_op* ops, int n, msmc_stream stream) 
             case 4: case 5:
                 if (o.B <= 0 || o.T <= 0 || o.F <= 0 || o.FP < o.F || o.dtype < 0 || o.dtype > 1 || (o.kind == 5 && !o.b)) return MSMC_E_SHAPE;
                 total = o.kind == 4 ? (long)o.B * o.F * o.T : (long)o.B * o.T * o.FP;
+                break;
+            case 6: case 7:
+                if (o.R <= 0 || (o.kind == 7 && !o.b)) return MSMC_E_SHAPE;
+                total = o.R;
                 break;
             default: return MSMC_E_SHAPE;
         }

@@ -478,6 +478,61 @@ def log_mel(y, n_fft, hop, dft, mel, num_mels, split=False):
     return _LogClamp.apply(m, 1e-5)[..., :num_mels]
 
 
+class _LogMelPair(torch.autograd.Function):
+    """``log_mel`` of a prediction (with gradient) and of its target (without) -- MelLoss.forward's two chains, identical in shape
+    -- with every stage of both chains in one launch (msmc_spectral_multi / a grouped call for the two constant-matrix GEMMs): five
+    launches instead of ten; the backward pass is the prediction's chain alone (five launches on the saved tensors)."""
+
+    @staticmethod
+    def forward(ctx, y, t, n_fft, hop, dft, mel, num_mels, split):
+        B, L = y.shape
+        F = n_fft // 2 + 1
+        pad = int((n_fft - hop) / 2)
+        T = (L + 2 * pad - n_fft) // hop + 1
+        lo, n_eff = dft[2], dft[3]
+        NP, FP = _pad4(n_eff), _pad4(F)
+        ys = [y.contiguous().float(), t.detach().contiguous().float()]
+        st = lib.stream(ys[0])
+        frs = [torch.empty((B, 1, T, NP), dtype=torch.float32, device=y.device) for _ in ys]
+        _multi([_op(0, st, x, fr, B=B, L=L, T=T, n_fft=n_eff, NP=NP, hop=hop, pad=pad - lo) for x, fr in zip(ys, frs)])
+        specs = _gemms(frs, [dft[0], dft[0]], split)
+        mags = [torch.empty((B, 1, T, FP), dtype=torch.float32, device=y.device) for _ in ys]
+        _multi([_op(2, st, sp, mg, R=B * T, F=F, CP=sp.shape[-1], FP=FP, lo=1e-9, clamp_mode=0) for sp, mg in zip(specs, mags)])
+        ms = _gemms(mags, [mel[0], mel[0]], split)
+        outs = [torch.empty_like(m) for m in ms]
+        _multi([_op(6, st, m, o, R=m.numel(), lo=1e-5) for m, o in zip(ms, outs)])
+        ctx.save_for_backward(specs[0], mags[0], ms[0])
+        ctx.args = (B, L, T, n_eff, NP, hop, pad - lo, F, FP, dft, mel, split, num_mels)
+        return outs[0][..., :num_mels], outs[1][..., :num_mels]
+
+    @staticmethod
+    def backward(ctx, g, g_unused):
+        spec, mag, m = ctx.saved_tensors
+        B, L, T, n_eff, NP, hop, pad, F, FP, dft, mel, split, num_mels = ctx.args
+        Lb = lib.get()
+        geom = _geom1(T)
+        gfull = torch.zeros_like(m) if m.shape[-1] != num_mels else None
+        if gfull is not None:
+            gfull[..., :num_mels] = g
+            g = gfull
+        g = g.contiguous()
+        gm = torch.empty_like(m)
+        lib.check(Lb.msmc_log_clamp_bwd(lib.ptr(m), lib.ptr(g), lib.ptr(gm), m.numel(), 1e-5, lib.stream(g)), 'msmc_log_clamp_bwd')
+        gmag = _const_gemm(gm, mel[1], geom, split, dgrad=True)
+        gs = torch.empty_like(spec)
+        lib.check(Lb.msmc_spec_mag_bwd(lib.ptr(spec), lib.ptr(mag), lib.ptr(gmag), lib.ptr(gs), B * T, F, spec.shape[-1], FP, 1e-9, 0,
+                                       lib.stream(g)), 'msmc_spec_mag_bwd')
+        gfr = _const_gemm(gs, dft[1], geom, split, dgrad=True)
+        gy = torch.empty((B, L), dtype=torch.float32, device=g.device)
+        lib.check(Lb.msmc_stft_frames_bwd(lib.ptr(gfr), lib.ptr(gy), B, L, T, n_eff, NP, hop, pad, lib.stream(g)), 'msmc_stft_frames_bwd')
+        return gy, None, None, None, None, None, None, None
+
+
+def log_mel_pair(y, t, n_fft, hop, dft, mel, num_mels, split=False):
+    """(log_mel(y), log_mel(t)) with t taken as a constant: both chains in lock step (see _LogMelPair)"""
+    return _LogMelPair.apply(y, t, n_fft, hop, dft, mel, num_mels, bool(split))
+
+
 class _WaveFan(torch.autograd.Function):
     """y (B, L) fp32 -> ``n_alias`` aliases of y (for consumers that read it in fp32: the resolution sub-discriminators'
     front-ends) followed by one copy per entry of ``padded`` in ``dtype``, reflection-padded on the right to that length (the

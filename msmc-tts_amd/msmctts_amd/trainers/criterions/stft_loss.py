@@ -71,8 +71,18 @@ class MelLoss(nn.Module):
 
     def forward(self, predicts, targets):
         from ...hip import losses as hiploss
+        from ...hip import spectral
         with torch.autocast(device_type=predicts.device.type, enabled=False):
-            a, b = self.mel_spectrogram(predicts), self.mel_spectrogram(targets)
+            if (spectral.FRONTS_LOCKSTEP and hiploss.usable(predicts, targets) and predicts.shape == targets.shape
+                    and not targets.requires_grad):
+                # both chains in lock step (hip/spectral.py log_mel_pair): five launches instead of ten
+                dft, mel = self._consts(predicts.device)
+                split = getattr(self, 'hip_dtype', torch.float32) == torch.bfloat16 and spectral.SPLIT_BF16
+                a, b = spectral.log_mel_pair(predicts.float(), targets.float(), self.fft_size, self.hop_size, dft, mel,
+                                             self.num_mels, split=split)
+                a, b = a.squeeze(1).transpose(1, 2), b.squeeze(1).transpose(1, 2)
+            else:
+                a, b = self.mel_spectrogram(predicts), self.mel_spectrogram(targets)
             if hiploss.usable(a, b) and a.dtype == b.dtype == torch.float32:
                 # mean |a - b| as the multi-tensor L1 kernel's one-member call (two launches, one backward) instead of the
                 # operator chain's subtract / abs / mean and their four backward launches

@@ -1337,7 +1337,7 @@ def test_bench_attributes_work_to_every_kernel_family_of_a_step():
             setattr(L, name, fn)
     assert set(seen) == {'msmc_wn_prepare_multi_tiles', 'msmc_wn_backward_multi_rows', 'msmc_opt_clip_adamw'}
     called = set(timer.shapes)
-    for family in ('msmc_add_ln_fwd', 'msmc_add_ln_bwd', 'msmc_add_ln_param_multi', 'msmc_l1_multi_fwd_ws', 'msmc_mse_const_multi_bwd', 'msmc_stft_frames_fwd',
+    for family in ('msmc_add_ln_fwd', 'msmc_add_ln_bwd', 'msmc_add_ln_param_multi', 'msmc_l1_multi_fwd_ws', 'msmc_mse_const_multi_bwd', 'msmc_spectral_multi',
                    'msmc_spec_mag_bwd', 'msmc_vq_backward', 'msmc_vq_prepare', 'msmc_tanh_fwd', 'msmc_gate_bwd'):
         assert family in called, (family, sorted(called))
     assert summary, 'the interpreter build logs its launches too'
