@@ -504,6 +504,14 @@ int msmc_triple_loss(const float* p, const int64_t* trg, const float* embed_t, c
 int msmc_add_ln_fwd(const void* x, const void* res, const float* gamma, const float* beta, const unsigned char* keep_row,
                     void* y, void* v, float* mean, float* rstd, long N, int C, float eps, float p_drop,
                     const long long* seed, long long salt, int dtype, msmc_stream stream);
+/* The attention sub-layer's tail in one launch (bf16): y = layer_norm(dropout(a W^T + bias) + res) * keep_row with the same mask
+ * hash, saved tensors (v, mean, rstd) and rounding points as msmc_conv_gather (1 tap) followed by msmc_add_ln_fwd -- reference
+ * acoustic_models/transformer.py:259-266.  a [N][K], W [C][K] bf16 (the projection's forward slice), bias fp32 [C] (required),
+ * res / y / v [N][C] bf16; K % 32 == 0, C % 4 == 0, C <= 640.  The backward pass is the two-launch chain's (msmc_add_ln_bwd, then the
+ * projection's data / weight gradient). */
+int msmc_fc_add_ln_fwd(const void* a, const void* W, const float* bias, const void* res, const float* gamma, const float* beta,
+                       const unsigned char* keep_row, void* y, void* v, float* mean, float* rstd, long N, int C, int K, float eps,
+                       float p_drop, const long long* seed, long long salt, msmc_stream stream);
 size_t msmc_add_ln_bwd_workspace(long N, int C);
 /* gx = d/dx, gres = d/dres (may be NULL), dgamma / dbeta fp32 [C] (accumulate != 0: +=), fixed reduction order.
  * dgamma == dbeta == NULL: only the per-workgroup partials are produced -- they stay in `workspace`

@@ -141,6 +141,135 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
     }
 }
 
+// ---- the attention sub-layer's tail in ONE launch (round 6): h = a W^T + bias (the output projection ``fc``, reference
+// acoustic_models/transformer.py:259-262) and layer_norm(dropout(h) + residual) * non_pad_mask (:262-266) -- before: a 1-tap GEMM
+// launch writing h and the fused add + LayerNorm launch reading it back, each ~6 us for a fraction of a microsecond of work, 12
+// times per forward pass.  A workgroup owns SIXTEEN whole rows: v_mfma_f32_16x16x32_bf16 with the operand roles swapped (A = weight
+// rows, B = activation rows), so a lane ends up with runs of four consecutive channels of ONE row -- bias, dropout, residual,
+// both LayerNorm reductions (lane-local, two cross-lane steps, one LDS exchange between the four waves) and the 8-byte stores all
+// happen in registers.  Both operands come straight from global memory as 16-byte fragments (K = heads x d_v = 128: the whole
+// contraction is four MFMA steps; the 64 KB weight matrix stays in L2).  h is rounded to bf16 before the dropout exactly as the
+// GEMM's epilogue rounds it, so v (the saved pre-normalisation sum) is bit-identical to the two-launch chain's and the
+// statistics differ only by the order of their sums.  Wave w owns the 16-channel tiles w, w + 4, ..: NT of them.
+// Every global read of a lane is issued before the first use (the weight fragments of KU contraction steps at a time, the
+// activation fragments, residual, bias, gamma, beta, the row mask): addresses past the edges are clamped instead of branched
+// around, so the kernel pays ~two memory latencies, not one per load.
+template <int NT, int KU>
+__global__ __launch_bounds__(256) void fc_add_ln_fwd_kernel(const unsigned short* __restrict__ a, const unsigned short* __restrict__ W,
+                                                            const float* __restrict__ bias, const unsigned short* __restrict__ res,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const unsigned char* __restrict__ keep_row, unsigned short* __restrict__ y,
+                                                            unsigned short* __restrict__ v_out, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, long N, int C, int K, float eps,
+                                                            float p_drop, const long long* seed, long long salt) {
+    __shared__ float red[2][4][16];
+    const int tid = threadIdx.x, w = wave_uniform(tid >> 6), lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const long row = (long)blockIdx.x * 16 + j;
+    const long rl = row < N ? row : N - 1;
+    const int MT = (C + 15) >> 4, nku = K / (32 * KU);
+    const unsigned short* arow = a + rl * K + 8 * g;
+    const unsigned short* wrow[NT];
+    int c0[NT], cc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        int t = w + 4 * i;
+        if (t >= MT) t = MT - 1;                          // (tiles past the last: a valid tile, results unused)
+        int ch = 16 * t + j;
+        if (ch >= C) ch = C - 1;
+        wrow[i] = W + (size_t)ch * K + 8 * g;
+        c0[i] = 16 * (w + 4 * i) + 4 * g;                 // this lane's four channels of tile i
+        cc[i] = c0[i] < C ? c0[i] : C - 4;
+    }
+    // first batch of fragments, then everything the epilogue reads
+    u32x4 bf[KU], af[NT][KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) bf[u] = *(const u32x4*)(arow + 32 * u);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int u = 0; u < KU; ++u) af[i][u] = *(const u32x4*)(wrow[i] + 32 * u);
+    float r[NT][4], bs[NT][4], gm[NT][4], bt[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        nm_ldv<4>(res, rl * C + cc[i], r[i]);
+        nm_ldv<4>(bias, cc[i], bs[i]);
+        nm_ldv<4>(gamma, cc[i], gm[i]);
+        nm_ldv<4>(beta, cc[i], bt[i]);
+    }
+    const bool live = !keep_row || keep_row[rl] != 0;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < nku; ++kb) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                acc[i] = mfma_bf16_16x16x32(__builtin_bit_cast(bf16x8, af[i][u]), __builtin_bit_cast(bf16x8, bf[u]), acc[i]);
+        if (kb + 1 < nku) {
+            const int k0 = 32 * KU * (kb + 1);
+#pragma unroll
+            for (int u = 0; u < KU; ++u) bf[u] = *(const u32x4*)(arow + k0 + 32 * u);
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int u = 0; u < KU; ++u) af[i][u] = *(const u32x4*)(wrow[i] + k0 + 32 * u);
+        }
+    }
+    const unsigned long long key = nm_key(seed, salt);
+    const unsigned int thresh = p_drop > 0.f ? (unsigned int)(p_drop * 4294967296.0) : 0u;
+    const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    float v[NT][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const bool in = c0[i] < C;
+        const long e0 = rl * C + cc[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float h = acc[i][q] + bs[i][q];
+            h = bf16_bits_to_f32(f32_to_bf16_bits(h));                           // (the GEMM's epilogue stores h in bf16)
+            if (thresh) h = nm_keep(key, (unsigned long long)(e0 + q), thresh) ? h * scale : 0.f;
+            h = h + r[i][q];
+            v[i][q] = in ? h : 0.f;
+            sum = sum + v[i][q];
+        }
+    }
+    sum = sum + wave_xor(sum, 16);
+    sum = sum + wave_xor(sum, 32);
+    if (g == 0) red[0][w][j] = sum;
+    __syncthreads();
+    const float mean = (((red[0][0][j] + red[0][1][j]) + red[0][2][j]) + red[0][3][j]) / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const bool in = c0[i] < C;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float dv = in ? v[i][q] - mean : 0.f;
+            sq = fmaf(dv, dv, sq);
+        }
+    }
+    sq = sq + wave_xor(sq, 16);
+    sq = sq + wave_xor(sq, 32);
+    if (g == 0) red[1][w][j] = sq;
+    __syncthreads();
+    const float rstd = 1.f / sqrtf((((red[1][0][j] + red[1][1][j]) + red[1][2][j]) + red[1][3][j]) / C + eps);
+    if (row >= N) return;
+    if (w == 0 && g == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        if (c0[i] < C) {
+            const long e0 = row * C + c0[i];
+            float o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = live ? (v[i][q] - mean) * rstd * gm[i][q] + bt[i][q] : 0.f;
+            nm_stv<4>(v_out, e0, v[i]);
+            nm_stv<4>(y, e0, o);
+        }
+    }
+}
+
 // backward: gy = g * live; dxhat = gy * gamma; dv = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat));
 // gres = dv; gx = dv * dropmask * scale.  Parameter-gradient partials per workgroup: part[block][0][c] = sum gy*xhat,
 // part[block][1][c] = sum gy (reduced in a fixed order by add_ln_param_kernel).
@@ -418,6 +547,34 @@ int msmc_add_ln_fwd(const void* x, const void* res, const float* gamma, const fl
     else if (dtype == 1) { if (vec) NM_FWD(unsigned short, 4); else NM_FWD(unsigned short, 1); }
     else return MSMC_E_SHAPE;
 #undef NM_FWD
+    return msmc_check_launch();
+}
+
+// the fused output projection + add + LayerNorm of the attention sub-layer (bf16): a [N][K], W [C][K] (the projection's forward
+// kernel-layout slice), bias [C] fp32, res / y / v [N][C]; K % 32 == 0, C % 4 == 0, C <= 640; bias / gamma / beta 16-byte aligned.
+int msmc_fc_add_ln_fwd(const void* a, const void* W, const float* bias, const void* res, const float* gamma, const float* beta,
+                       const unsigned char* keep_row, void* y, void* v, float* mean, float* rstd, long N, int C, int K, float eps,
+                       float p_drop, const long long* seed, long long salt, msmc_stream stream) {
+    if (!a || !W || !bias || !res || !gamma || !beta || !y || !v || !mean || !rstd || N < 0 || C <= 0 || (C & 3) || C > 640 || K <= 0 ||
+        (K & 31) || p_drop < 0.f || p_drop >= 1.f)
+        return MSMC_E_SHAPE;
+    if ((((size_t)a) | ((size_t)W) | ((size_t)bias) | ((size_t)gamma) | ((size_t)beta)) & 15) return MSMC_E_SHAPE;
+    if ((((size_t)res) | ((size_t)y) | ((size_t)v)) & 7) return MSMC_E_SHAPE;
+    if (N == 0) return 0;
+    const dim3 grid((unsigned)((N + 15) / 16));
+#define NM_FC(NT_, KU_)                                                                                                     \
+    MSMC_LAUNCH((fc_add_ln_fwd_kernel<NT_, KU_>), grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)a,      \
+                (const unsigned short*)W, bias, (const unsigned short*)res, gamma, beta, keep_row, (unsigned short*)y,      \
+                (unsigned short*)v, mean, rstd, N, C, K, eps, p_drop, seed, salt)
+    if (C <= 256) {
+        if ((K & 127) == 0) NM_FC(4, 4);
+        else if ((K & 63) == 0) NM_FC(4, 2);
+        else NM_FC(4, 1);
+    } else {
+        if ((K & 63) == 0) NM_FC(10, 2);
+        else NM_FC(10, 1);
+    }
+#undef NM_FC
     return msmc_check_launch();
 }
 

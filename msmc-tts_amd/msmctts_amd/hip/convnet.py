@@ -633,7 +633,7 @@ def _tap_grad(g_tap, like):
 class _HipConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, res2, weight_token, bank, layer, in_slope, out_slope, out_div, tap=False, in_act=1.0,
-                out_masked=False):
+                out_masked=False, defer_out=False):
         # ``in_act`` != 1: x was activated by its producer's epilogue (that producer ran with out_slope = in_act and
         # ``out_masked``); forward and weight gradient read it as it is, the data gradient applies the activation's
         # derivative (sign of the activated value = sign of the pre-activation).  ``out_masked``: this convolution's ONLY
@@ -642,7 +642,14 @@ class _HipConv(torch.autograd.Function):
         # map and goes through the derivative as well: (fold + tap) * lrelu'.
         m = layer.module
         assert in_act == 1.0 or (in_slope == 1.0 and (layer.reflect or not tap))
-        if layer.kind == 'conv':
+        if defer_out:
+            # the forward product is computed by the CONSUMER's launch (hip_conv_add_ln: the fused projection + add + LayerNorm
+            # kernel reads x and the weight slice itself): this node only holds the layer's place in the autograd graph --
+            # its backward pass (data gradient, weight gradient, the bank's bookkeeping) is the ordinary one
+            assert layer.kind == 'conv' and layer.taps == 1 and res is None and res2 is None and not tap
+            assert in_slope == 1.0 and out_slope == 1.0 and out_div == 1.0 and in_act == 1.0
+            out = x.new_empty(x.shape[:-1] + (layer.cout,))
+        elif layer.kind == 'conv':
             geom = layer.geom(x.shape[1], x.shape[2])
             out = K.conv_forward(x, layer.wf, geom, bias=m.bias, in_slope=in_slope, res=res, res2=res2,
                                  out_div=out_div, out_slope=out_slope)
@@ -678,7 +685,7 @@ class _HipConv(torch.autograd.Function):
             if ctx.counted:
                 ctx.counted = False
                 bank.node_closed()
-            return (g_tap,) + (None,) * 11
+            return (g_tap,) + (None,) * 12
         g = g.contiguous()
         g_tap = _tap_grad(g_tap, g)
         if ctx.out_slope != 1.0 and not ctx.out_masked:        # y = lrelu(z): dz = dy * (y > 0 ? 1 : slope)
@@ -737,7 +744,7 @@ class _HipConv(torch.autograd.Function):
             bank.node_closed()
         # weight_token (the layer's weight_v) only ties the output to the parameters in the autograd graph;
         # parameter gradients are produced in kernel layout and delivered by ConvBank._finish_backward.
-        return (gx, (g if ctx.has_res else None), (g if ctx.has_res2 else None)) + (None,) * 9
+        return (gx, (g if ctx.has_res else None), (g if ctx.has_res2 else None)) + (None,) * 10
 
 
 class _HipConvGroup(torch.autograd.Function):
@@ -893,3 +900,28 @@ def hip_conv(bank, layer, x, res=None, res2=None, in_slope=1.0, out_slope=1.0, o
     produced, instead of in every load of the consumer (a must have no other consumer)."""
     return _HipConv.apply(x, res, res2, layer.weight, bank, layer, float(in_slope), float(out_slope),
                           float(out_div), bool(tap), float(in_act), bool(out_masked))
+
+
+# 1 (default): a 1-tap projection whose only consumer is a fused add + LayerNorm runs INSIDE that launch (csrc/norm.hip
+# fc_add_ln_fwd_kernel: the attention sub-layer's output projection, 12 launches and 12 round trips of h per forward pass
+# less); MSMC_FC_LN_FUSE=0 keeps the two launches (A/B, and what fp32 and shapes the kernel does not take always run)
+FC_LN_FUSE = os.environ.get('MSMC_FC_LN_FUSE', '1') != '0'
+
+
+def fc_ln_fusable(layer, x):
+    return (FC_LN_FUSE and x.dtype == torch.bfloat16 and layer.kind == 'conv' and layer.taps == 1 and x.shape[1] == 1 and
+            layer.cin % 32 == 0 and layer.cout % 4 == 0 and layer.cout <= 640 and layer.module.bias is not None)
+
+
+def hip_conv_add_ln(bank, layer, x, res, gamma, beta, keep_row=None, p_drop=0.0, salt=0, eps=1e-5):
+    """layer_norm(dropout(conv_1tap(x) + bias) + res) * keep_row for x [B, 1, T, Cin], res [B, T, Cout]: one launch where the
+    fused kernel takes the case, hip_conv followed by hip/norm.py add_layer_norm otherwise (same masks, same saved tensors,
+    same backward nodes either way)"""
+    from . import norm
+    aligned = all(t is not None and t.data_ptr() % 16 == 0 for t in (layer.module.bias, gamma, beta))
+    if not (fc_ln_fusable(layer, x) and aligned):
+        return norm.add_layer_norm(hip_conv(bank, layer, x).squeeze(1), res, gamma, beta, keep_row=keep_row, p_drop=p_drop,
+                                   salt=salt, eps=eps)
+    h = _HipConv.apply(x, None, None, layer.weight, bank, layer, 1.0, 1.0, 1.0, False, 1.0, False, True).squeeze(1)
+    return norm.add_layer_norm(h, res, gamma, beta, keep_row=keep_row, p_drop=p_drop, salt=salt, eps=eps,
+                               fc=(x, layer.wf, layer.module.bias))

@@ -151,6 +151,8 @@ _SIGNATURES.update({
     'msmc_colsum_ws': (_i, [_vp, _vp, ctypes.c_long, _i, _i, _i, _vp, _sz, _vp]),
     'msmc_add_ln_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _i, _f, _f, _vp, ctypes.c_longlong,
                         _i, _vp]),
+    'msmc_fc_add_ln_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_long, _i, _i, _f, _f, _vp,
+                           ctypes.c_longlong, _vp]),
     'msmc_add_ln_bwd_workspace': (_sz, [ctypes.c_long, _i]),
     'msmc_add_ln_param_multi': (_i, [_vp, _i, _vp]),
     'msmc_add_ln_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, ctypes.c_long, _i, _f, _vp,

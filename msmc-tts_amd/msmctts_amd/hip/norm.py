@@ -47,17 +47,30 @@ def _rows(x):
 
 class _AddLayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, gamma, beta, keep_row, p_drop, salt, eps):
+    def forward(ctx, x, res, gamma, beta, keep_row, p_drop, salt, eps, fc=None):
         assert x.dtype in _DT and x.is_contiguous() and (res is None or (res.dtype == x.dtype and res.is_contiguous()))
         N, C = _rows(x)
         y, v = torch.empty_like(x), torch.empty_like(x)
         mean = torch.empty(N, dtype=torch.float32, device=x.device)
         rstd = torch.empty(N, dtype=torch.float32, device=x.device)
         seed = seed_word(x.device) if p_drop > 0 else None
-        lib.check(lib.get().msmc_add_ln_fwd(lib.ptr(x), lib.ptr(res), lib.ptr(gamma, torch.float32), lib.ptr(beta, torch.float32),
-                                            lib.ptr(keep_row, torch.uint8), lib.ptr(y), lib.ptr(v), lib.ptr(mean), lib.ptr(rstd),
-                                            N, C, float(eps), float(p_drop), lib.ptr(seed), salt, _DT[x.dtype], lib.stream(x)),
-                  'msmc_add_ln_fwd')
+        if fc is not None:
+            # x is the placeholder output of a deferred 1-tap projection (hip/convnet.py hip_conv_add_ln): this launch computes
+            # the product a W^T + bias itself and never reads x
+            a, w, bias = fc
+            K = a.shape[-1]
+            assert x.dtype == torch.bfloat16 and res is not None and a.is_contiguous() and a.dtype == x.dtype
+            assert a.numel() == N * K and w.dtype == x.dtype and w.is_contiguous() and w.numel() == C * K
+            lib.check(lib.get().msmc_fc_add_ln_fwd(lib.ptr(a), lib.ptr(w), lib.ptr(bias, torch.float32), lib.ptr(res),
+                                                   lib.ptr(gamma, torch.float32), lib.ptr(beta, torch.float32),
+                                                   lib.ptr(keep_row, torch.uint8), lib.ptr(y), lib.ptr(v), lib.ptr(mean),
+                                                   lib.ptr(rstd), N, C, K, float(eps), float(p_drop), lib.ptr(seed), salt,
+                                                   lib.stream(x)), 'msmc_fc_add_ln_fwd')
+        else:
+            lib.check(lib.get().msmc_add_ln_fwd(lib.ptr(x), lib.ptr(res), lib.ptr(gamma, torch.float32), lib.ptr(beta, torch.float32),
+                                                lib.ptr(keep_row, torch.uint8), lib.ptr(y), lib.ptr(v), lib.ptr(mean), lib.ptr(rstd),
+                                                N, C, float(eps), float(p_drop), lib.ptr(seed), salt, _DT[x.dtype], lib.stream(x)),
+                      'msmc_add_ln_fwd')
         ctx.save_for_backward(v, mean, rstd, gamma, keep_row)
         ctx.p_drop, ctx.salt, ctx.has_res = float(p_drop), salt, res is not None
         # leaf parameters: their gradients can leave in the pass's ONE parameter-gradient launch (_ln_flush) instead of a launch
@@ -97,7 +110,7 @@ class _AddLayerNorm(torch.autograd.Function):
                                     lib.stream(v)), 'msmc_add_ln_bwd')
         if defer:
             _ln_queue(ws, (N + 15) // 16, C, ctx.params[0], ctx.params[1])
-        return gx, gres, (dgamma if want_g else None), (dbeta if want_b else None), None, None, None, None
+        return gx, gres, (dgamma if want_g else None), (dbeta if want_b else None), None, None, None, None, None
 
 
 # ---- parameter gradients of all LayerNorms of a backward pass in one launch --------------------------------------------
@@ -182,10 +195,11 @@ def _ln_flush():
                         convnet.GRAD_READY_HOOK(p)
 
 
-def add_layer_norm(x, res, gamma, beta, keep_row=None, p_drop=0.0, salt=0, eps=1e-5):
+def add_layer_norm(x, res, gamma, beta, keep_row=None, p_drop=0.0, salt=0, eps=1e-5, fc=None):
     """LayerNorm(dropout(x) + res) * gamma + beta over the last axis, rows with ``keep_row == 0`` zeroed.
-    x / res: same dtype (fp32 or bf16), contiguous; gamma / beta fp32; keep_row uint8 [rows] or None."""
-    return _AddLayerNorm.apply(x, res, gamma, beta, keep_row, p_drop, salt, eps)
+    x / res: same dtype (fp32 or bf16), contiguous; gamma / beta fp32; keep_row uint8 [rows] or None.
+    ``fc = (a, w, bias)``: x is the not-yet-computed a w^T + bias of a deferred projection (hip/convnet.py hip_conv_add_ln)."""
+    return _AddLayerNorm.apply(x, res, gamma, beta, keep_row, p_drop, salt, eps, fc)
 
 
 class _Gate(torch.autograd.Function):

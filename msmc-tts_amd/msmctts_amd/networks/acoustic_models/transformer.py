@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 from ...hip import attn as hipattn
 from ...hip import norm as hipnorm
-from ...hip.convnet import ConvBank, ConvLayer, hip_conv
+from ...hip.convnet import ConvBank, ConvLayer, hip_conv, hip_conv_add_ln
 
 
 def get_sinusoid_encoding_table(n_position, d_hid, padding_idx=None):
@@ -114,10 +114,10 @@ class MultiHeadAttention(nn.Module):
         else:       # padded key bias (hip/attn.py): the attention core on the kernels, q / k / v read in place
             out = hipattn.attention(qkv.transpose(1, 2).reshape(bs, T, H * (2 * dk + dv)), key_keep[0], H,
                                     1.0 / att.temperature, p, self._salt_attn).unsqueeze(1)
-        h = hip_conv(bank, l_fc, out).squeeze(1)
         pd = self.dropout.p if self.training else 0.0
-        return hipnorm.add_layer_norm(h, x, self.layer_norm.weight, self.layer_norm.bias, keep_row=keep_row, p_drop=pd,
-                                      salt=self._salt, eps=self.layer_norm.eps)
+        # (the output projection runs inside the add + LayerNorm launch where the fused kernel takes the shape)
+        return hip_conv_add_ln(bank, l_fc, out, x, self.layer_norm.weight, self.layer_norm.bias, keep_row=keep_row, p_drop=pd,
+                               salt=self._salt, eps=self.layer_norm.eps)
 
 
 class PositionwiseFeedForward(nn.Module):

@@ -315,6 +315,79 @@ def check_norm_kernels(dev, dtype, tol):
     assert not torch.equal(y2 != 0, y != 0)
 
 
+def check_fc_add_ln(dev):
+    """The attention sub-layer's tail in one launch (csrc/norm.hip fc_add_ln_fwd_kernel behind hip/convnet.py hip_conv_add_ln) against
+    (a) the stock fp32 chain layer_norm(linear(a) + res) * keep with every gradient, (b) the two-launch chain on the same bf16
+    inputs: identical dropout masks, outputs within bf16 rounding of each other (the sums run in another order); ragged row
+    counts, both tile counts (C <= 256 and C = 384), a shape the kernel refuses (falls back), and the launch count"""
+    import torch.nn as nn
+    from msmctts_amd.hip import convnet, lib, norm
+    torch.manual_seed(3)
+    dt = torch.bfloat16
+    L = lib.get()
+    for (B, T, K, C, p) in ((3, 37, 128, 256, 0.0), (2, 21, 64, 384, 0.0), (1, 16, 32, 36, 0.0), (3, 50, 128, 256, 0.2)):
+        fc = nn.Linear(K, C).to(dev)
+        ln = nn.LayerNorm(C).to(dev)
+        with torch.no_grad():
+            ln.weight.add_(torch.randn(C, device=dev) * 0.2)
+            ln.bias.add_(torch.randn(C, device=dev) * 0.2)
+        layer = convnet.ConvLayer(fc, 'conv', (1, 1), plain=True)
+        bank = convnet.ConvBank([layer])
+        a0 = torch.randn(B, 1, T, K, device=dev).to(dt)
+        r0 = torch.randn(B, T, C, device=dev).to(dt)
+        keep = (torch.rand(B * T, device=dev) > 0.25).to(torch.uint8)
+        go = torch.randn(B, T, C, device=dev).to(dt).float()
+        salt = norm.new_salt()
+
+        def run(fused):
+            saved, convnet.FC_LN_FUSE = convnet.FC_LN_FUSE, fused
+            try:
+                for q in list(fc.parameters()) + list(ln.parameters()):
+                    q.grad = None
+                bank.prepare(dt)
+                a, r = a0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+                before = L.msmc_conv_launch_count()
+                y = convnet.hip_conv_add_ln(bank, layer, a, r, ln.weight, ln.bias, keep_row=keep, p_drop=p, salt=salt, eps=ln.eps)
+                launched = L.msmc_conv_launch_count() - before
+                (y.float() * go).sum().backward()
+                return y.detach().float(), a.grad.float(), r.grad.float(), [q.grad.clone() for q in (fc.weight, fc.bias, ln.weight, ln.bias)], launched
+            finally:
+                convnet.FC_LN_FUSE = saved
+        yf, af, rf, pf, n_f = run(True)
+        yu, au, ru, pu, n_u = run(False)
+        assert convnet.fc_ln_fusable(layer, a0) and n_f == 0 and n_u >= 1, (n_f, n_u)      # (the projection left the conv launches; a first call of a shape also times its candidates)
+        assert torch.equal(yf == 0, yu == 0)
+        scale = lambda t: max(1.0, float(t.abs().max()))
+        close(yf, yu, 0.04 * scale(yu), what='fused vs two launches')
+        for g, w in zip([af, rf] + pf, [au, ru] + pu):
+            close(g, w, 0.03 * scale(w), what='fused vs two launches: gradients')
+        if p == 0.0:
+            ar, rr = a0.float().requires_grad_(True), r0.float().requires_grad_(True)
+            ref_fc, ref_ln = nn.Linear(K, C).to(dev), nn.LayerNorm(C).to(dev)
+            with torch.no_grad():
+                ref_fc.weight.copy_(fc.weight.to(dt).float()); ref_fc.bias.copy_(fc.bias)
+                ref_ln.weight.copy_(ln.weight); ref_ln.bias.copy_(ln.bias)
+            yr = ref_ln(ref_fc(ar).squeeze(1) + rr) * keep.float().view(B, T, 1)
+            (yr * go).sum().backward()
+            close(yf, yr, 0.03 * scale(yr), what='fused vs stock fp32 chain')
+            close(af, ar.grad, 0.03 * scale(ar.grad), what='d a')
+            close(rf, rr.grad, 0.03 * scale(rr.grad), what='d res')
+            for g, w in zip(pf, (ref_fc.weight.grad, ref_fc.bias.grad, ref_ln.weight.grad, ref_ln.bias.grad)):
+                close(g, w, 0.03 * scale(w), what='parameter gradients')
+        else:
+            kept = float((yf[keep.view(B, T).bool()] != 0).float().mean())
+            assert kept > 0.99                                   # (dropout acts before the residual: every live row is dense)
+    # shapes the kernel does not take run the two launches: fp32, K % 32 != 0
+    fc = nn.Linear(48, 64).to(dev)
+    layer = convnet.ConvLayer(fc, 'conv', (1, 1), plain=True)
+    assert not convnet.fc_ln_fusable(layer, torch.zeros(1, 1, 4, 48, device=dev, dtype=dt))
+    fc = nn.Linear(64, 64).to(dev)
+    layer = convnet.ConvLayer(fc, 'conv', (1, 1), plain=True)
+    assert not convnet.fc_ln_fusable(layer, torch.zeros(1, 1, 4, 64, device=dev))
+    bad = L.msmc_fc_add_ln_fwd(None, None, None, None, None, None, None, None, None, None, None, 4, 64, 64, 1e-5, 0.0, None, 0, None)
+    assert bad != 0
+
+
 def check_hip_adamw(dev):
     """csrc/optim.hip (grad-norm clip + AdamW of all tensors in three launches) against clip_grad_norm_ + torch.optim.AdamW
     over several steps, odd sizes and unaligned views; state_dict round trip both ways"""

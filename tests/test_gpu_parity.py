@@ -43,6 +43,10 @@ def test_window_gather_and_output_tanh_match_the_operator_chains():
     _parity.check_window_gather_and_output_tanh(torch.device(DEV))
 
 
+def test_output_projection_inside_the_add_layernorm_launch():
+    _parity.check_fc_add_ln(DEV)
+
+
 def test_front_end_chains_in_lock_step_equal_the_chains_one_by_one():
     _parity.check_fronts_lockstep(torch.device(DEV))
 
