@@ -521,6 +521,12 @@ def make_timer():
         return 6.0 * m * x.shape[-1] * cout, 4.0 * (x.numel() + m * cout) + 2.0 * wimg.numel()
 
     timer.wrap(hipconv, 'const_gemm_split', last_kernel, split_gemm_work)
+
+    def split_gemm_group_work(xs, wimgs, couts):          # the members of one grouped call (round 6: the resolution front-ends)
+        works = [split_gemm_work(x, w, c) for x, w, c in zip(xs, wimgs, couts)]
+        return sum(f for f, _ in works), sum(b for _, b in works)
+
+    timer.wrap(hipconv, 'const_gemm_split_group', last_kernel, split_gemm_group_work)
     for fn, work in (('conv_forward', conv_work), ('conv_dgrad', dgrad_work), ('conv_wgrad', wgrad_work),
                      ('conv_transpose1d_forward', convt_work), ('conv_transpose1d_dgrad', convt_dgrad_work),
                      ('conv_transpose1d_wgrad', convt_wgrad_work)):
