@@ -3776,18 +3776,48 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
         // loads of the same array the compiler must keep every load behind the previous store (it cannot prove o' != o), so the
         // loop ran one memory round trip per element: SQ_WAIT_ANY 89 % of the wave cycles, 18 % of the HBM roofline (round 4).
         const float* __restrict__ dwr = dw;
-        for (int t = 0; t < T; ++t) {
-            const long o1 = t * it.s1[0] + a * it.s1[1];
-            for (int b = threadIdx.x; b < Bc; b += NT) {
-                const long o = o1 + b * it.s1[2];
-                float sum = dwr[o];
-                for (int r = 1; r < R; ++r) sum = sum + dwr[o + r * it.dw_copy_stride];      // privatised copies: fold
-                row[b * T + t] = sum;
+        // (the loads of four steps go out together: one memory round trip per four elements of a work-item instead of one per
+        //  element -- the loop bounds are run-time values, so the compiler does not do this on its own)
+        if (R == 1) {
+            const int nb = (Bc + NT - 1) / NT, steps = T * nb;           // step s: tap s / nb, channel threadIdx.x + NT * (s % nb)
+            for (int s0 = 0; s0 < steps; s0 += 4) {
+                float q[4];
+                int dst[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int s = s0 + u, t = s / nb, b = threadIdx.x + NT * (s - t * nb);
+                    const bool ok = s < steps && b < Bc;
+                    dst[u] = ok ? b * T + t : -1;
+                    q[u] = ok ? dwr[t * it.s1[0] + a * it.s1[1] + b * it.s1[2]] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (dst[u] >= 0) row[dst[u]] = q[u];
+            }
+        } else {
+            for (int t = 0; t < T; ++t) {
+                const long o1 = t * it.s1[0] + a * it.s1[1];
+                for (int b = threadIdx.x; b < Bc; b += NT) {
+                    const long o = o1 + b * it.s1[2];
+                    float sum = dwr[o];
+                    for (int r = 1; r < R; ++r) sum = sum + dwr[o + r * it.dw_copy_stride];      // privatised copies: fold
+                    row[b * T + t] = sum;
+                }
             }
         }
         __syncthreads();
-        if (it.g)
-            for (int e = threadIdx.x; e < n; e += NT) dot = fmaf(row[e], v[e], dot);
+        if (it.g) {
+            const float* __restrict__ vd = v;
+            int e = threadIdx.x;
+            for (; e + 3 * NT < n; e += 4 * NT) {
+                const float v0 = vd[e], v1 = vd[e + NT], v2 = vd[e + 2 * NT], v3 = vd[e + 3 * NT];
+                dot = fmaf(row[e], v0, dot);
+                dot = fmaf(row[e + NT], v1, dot);
+                dot = fmaf(row[e + 2 * NT], v2, dot);
+                dot = fmaf(row[e + 3 * NT], v3, dot);
+            }
+            for (; e < n; e += NT) dot = fmaf(row[e], vd[e], dot);
+        }
     } else {
         int b = 0, t = threadIdx.x;
         while (t >= T) { t -= T; ++b; }
@@ -3821,7 +3851,15 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
         if (accumulate) {
             for (int e = threadIdx.x; e < n; e += NT) gvr[e] = gvr[e] + k1 * (row[e] - vr[e] * k2);
         } else {
-            for (int e = threadIdx.x; e < n; e += NT) gvr[e] = k1 * (row[e] - vr[e] * k2);
+            int e = threadIdx.x;
+            for (; e + 3 * NT < n; e += 4 * NT) {             // (v was just read by the dot pass: these are cache hits, issued together)
+                const float v0 = vr[e], v1 = vr[e + NT], v2 = vr[e + 2 * NT], v3 = vr[e + 3 * NT];
+                gvr[e] = k1 * (row[e] - v0 * k2);
+                gvr[e + NT] = k1 * (row[e + NT] - v1 * k2);
+                gvr[e + 2 * NT] = k1 * (row[e + 2 * NT] - v2 * k2);
+                gvr[e + 3 * NT] = k1 * (row[e + 3 * NT] - v3 * k2);
+            }
+            for (; e < n; e += NT) gvr[e] = k1 * (row[e] - vr[e] * k2);
         }
         for (int t = 0; t < T; ++t) {                      // each accumulator element has exactly this one reader: leave zeros
             const long o1 = t * it.s1[0] + a * it.s1[1];

@@ -120,6 +120,32 @@ def test_synthetic_batch_contract():
     assert not torch.equal(b['mel'], b2['mel'])
 
 
+def test_every_decision_of_the_shipped_table_names_a_kernel_the_library_still_has():
+    """hip/tuned_gfx950.json against the candidate lists of hip/conv.py: a retired kernel configuration (round 6 refused and
+    de-instantiated gather3 22 / 23 / 30, gather5 43 and four weight-gradient candidates) must not survive in a decision --
+    the launch it selects would fail at run time on the one shape that kept it"""
+    from msmctts_amd.hip import conv
+    gather = {v for v, _ in conv._GATHER_CANDIDATES}
+    wgrad = set(conv._WGRAD_CANDIDATES)
+    uniform = {v for v, _ in conv._UNIFORM_CANDIDATES} if isinstance(conv._UNIFORM_CANDIDATES[0], tuple) else set(conv._UNIFORM_CANDIDATES)
+    split = {v for v, _ in conv._SPLIT_CANDIDATES}
+    assert len(conv.TUNED) > 1000
+    for key, dec in conv.TUNED.items():
+        kind = key[0]
+        if kind == 'gather':
+            assert dec[0] in gather, (key, dec[:2])
+        elif kind == 'wgrad':
+            assert (dec[0], dec[1]) in wgrad, (key, dec[:2])
+        elif kind == 'gather-split':
+            assert dec[0] in split, (key, dec[:2])
+        elif kind == 'gather-group':
+            assert dec[0] in (0, 1, 3) and (dec[0] != 3 or dec[1] in uniform), (key, dec[:2])
+        elif kind == 'wgrad-group':
+            assert dec[0] in (0, 1, 2), (key, dec[:2])
+        else:
+            raise AssertionError('unknown kind of decision: %r' % (kind,))
+
+
 def test_tuner_borrows_the_nearest_tuned_shape_of_the_same_class():
     """variable-length batches: a new padded length does not trigger timing launches when a shape of the same
     channel / tap / stride class is already tuned; the nearest pixel count wins; another class does not match"""
