@@ -637,9 +637,9 @@ def _phases(size, k, stride, dil, pad):
     return out
 
 
-def _dgrad_descs(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
+def _dgrad_descs(g, wb, geom, mask_src=None, mask_slope=1.0, res=None, out_div=1.0):
     """per-phase descriptors (pointers filled in; None = phase no tap reaches, already written) and the output"""
-    key = ('d', g.dtype, g.shape[0], wb.shape[1], wb.shape[2], mask_slope)
+    key = ('d', g.dtype, g.shape[0], wb.shape[1], wb.shape[2], mask_slope, out_div)
     plan = geom.plans.get(key)
     if plan is None:
         _check(g, wb, mask_src, res)
@@ -650,7 +650,7 @@ def _dgrad_descs(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
         descs = []
         for lattice, taps, ry, rx in phases:
             descs.append((None, ry, rx) if not taps else
-                         (_build_desc(g.dtype, B, Hout, Wout, Cout, Hx, Wx, Cin, lattice, taps, 0, 1.0, mask_slope, 1.0,
+                         (_build_desc(g.dtype, B, Hout, Wout, Cout, Hx, Wx, Cin, lattice, taps, 0, 1.0, mask_slope, out_div,
                                       1.0), ry, rx))
         plan = geom.plans[key] = (descs, (B, Hx, Wx, Cin))
     descs, oshape = plan
@@ -661,7 +661,7 @@ def _dgrad_descs(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
     live = []
     for desc, ry, rx in descs:
         if desc is None:                      # phase that no kernel tap reaches: gradient is the epilogue of zero
-            gx[:, ry::geom.sy, rx::geom.sx] = 0 if res is None else res[:, ry::geom.sy, rx::geom.sx]
+            gx[:, ry::geom.sy, rx::geom.sx] = 0 if res is None else res[:, ry::geom.sy, rx::geom.sx] / out_div
             continue
         desc.x, desc.w, desc.out, desc.mask_src, desc.res = gp, wp, op, mp, rp
         desc.bias = desc.res2 = None
@@ -669,14 +669,14 @@ def _dgrad_descs(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
     return live, gx
 
 
-def conv_dgrad(g, wb, geom, mask_src=None, mask_slope=1.0, res=None):
+def conv_dgrad(g, wb, geom, mask_src=None, mask_slope=1.0, res=None, out_div=1.0):
     """Data gradient of ``conv_forward``: g [B,Hout,Wout,Cout] -> gx [B,Hin(+2p),Win(+2p),Cin].
 
     wb [kh*kw, Cin, Cout] (channel roles swapped).  For reflect-padded convolutions the gradient is
     returned on the PADDED grid (Hin+2py, Win+2px); the caller folds the border back.
-    Epilogue: gx = gx * lrelu'(mask_src) + res.
+    Epilogue: gx = (gx * lrelu'(mask_src) + res) / out_div.
     """
-    descs, gx = _dgrad_descs(g, wb, geom, mask_src, mask_slope, res)
+    descs, gx = _dgrad_descs(g, wb, geom, mask_src, mask_slope, res, out_div)
     stream = lib.stream(g)
     for desc in descs:
         _gather(desc, stream, 'msmc_conv_gather(dgrad)')
@@ -722,9 +722,9 @@ def conv_transpose1d_forward(x, w, k, stride, padding, bias=None, in_slope=1.0):
     return out
 
 
-def conv_transpose1d_dgrad(g, wb, k, stride, padding, Lin, mask_src=None, mask_slope=1.0, res=None):
+def conv_transpose1d_dgrad(g, wb, k, stride, padding, Lin, mask_src=None, mask_slope=1.0, res=None, out_div=1.0):
     """g [B,1,Lout,Cout] -> gx [B,1,Lin,Cin];  wb [k, Cin, Cout]:  gx[q] = sum_k g[q*stride + k - padding] wb[k]
-    (epilogue: * lrelu'(mask_src) + res)."""
+    (epilogue: (* lrelu'(mask_src) + res) / out_div)."""
     _check(g, wb, mask_src, res)
     B, _, Lout, Cout = g.shape
     Cin = wb.shape[1]
@@ -732,7 +732,7 @@ def conv_transpose1d_dgrad(g, wb, k, stride, padding, Lin, mask_src=None, mask_s
     taps = [(0, kk, kk) for kk in range(k)]
     lattice = (1, Lin, 0, 1, 0, 1, 1, stride, 0, -padding)
     d = _fill(None, g, wb, gx, B, 1, Lout, Cout, 1, Lin, Cin, lattice, taps, 0, mask_src=mask_src, res=res,
-              mask_slope=mask_slope)
+              mask_slope=mask_slope, out_div=out_div)
     _gather(d, lib.stream(g), 'msmc_conv_gather(convT dgrad)')
     return gx
 

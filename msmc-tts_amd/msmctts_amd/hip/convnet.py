@@ -633,7 +633,11 @@ def _tap_grad(g_tap, like):
 class _HipConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, res2, weight_token, bank, layer, in_slope, out_slope, out_div, tap=False, in_act=1.0,
-                out_masked=False, defer_out=False):
+                out_masked=False, defer_out=False, in_grad_div=1.0, grad_predivided=False):
+        # ``out_div`` in the backward pass is a division of the whole incoming gradient -- a stock tensor pass per use.  Where
+        # the output has ONE consumer and that consumer is a convolution, the consumer's data-gradient launch delivers the
+        # gradient already divided (its ``in_grad_div`` = this node's ``out_div``: the division runs in that launch's epilogue)
+        # and this node is told so (``grad_predivided``).
         # ``in_act`` != 1: x was activated by its producer's epilogue (that producer ran with out_slope = in_act and
         # ``out_masked``); forward and weight gradient read it as it is, the data gradient applies the activation's
         # derivative (sign of the activated value = sign of the pre-activation).  ``out_masked``: this convolution's ONLY
@@ -661,6 +665,8 @@ class _HipConv(torch.autograd.Function):
         ctx.in_slope, ctx.out_slope, ctx.out_div = in_slope, out_slope, out_div
         ctx.mask_slope = in_act if in_act != 1.0 else in_slope
         ctx.out_masked = bool(out_masked)
+        ctx.in_grad_div, ctx.grad_predivided = float(in_grad_div), bool(grad_predivided)
+        assert ctx.in_grad_div == 1.0 or not (tap or layer.reflect)
         ctx.has_res, ctx.has_res2 = res is not None, res2 is not None
         ctx.need_w = layer.weight.requires_grad
         ctx.counted = bool(ctx.need_w and ctx.needs_input_grad[3])      # (a graph is being recorded and the weight is in it)
@@ -685,12 +691,12 @@ class _HipConv(torch.autograd.Function):
             if ctx.counted:
                 ctx.counted = False
                 bank.node_closed()
-            return (g_tap,) + (None,) * 12
+            return (g_tap,) + (None,) * 14
         g = g.contiguous()
         g_tap = _tap_grad(g_tap, g)
         if ctx.out_slope != 1.0 and not ctx.out_masked:        # y = lrelu(z): dz = dy * (y > 0 ? 1 : slope)
             g = K.lrelu_bwd(g, out, ctx.out_slope)
-        if ctx.out_div != 1.0:
+        if ctx.out_div != 1.0 and not ctx.grad_predivided:
             g = g / ctx.out_div
         gx = None
         if ctx.needs_input_grad[0]:
@@ -708,10 +714,12 @@ class _HipConv(torch.autograd.Function):
                     if g_tap is not None:
                         gx = gx + g_tap
                 else:
-                    gx = K.conv_dgrad(g, layer.wb, geom, mask_src=mask, mask_slope=ctx.mask_slope, res=g_tap)
+                    gx = K.conv_dgrad(g, layer.wb, geom, mask_src=mask, mask_slope=ctx.mask_slope, res=g_tap,
+                                      out_div=ctx.in_grad_div)
             else:
                 gx = K.conv_transpose1d_dgrad(g, layer.wb, layer.kernel[1], layer.stride[1], layer.padding[1],
-                                              x.shape[2], mask_src=mask, mask_slope=ctx.mask_slope, res=g_tap)
+                                              x.shape[2], mask_src=mask, mask_slope=ctx.mask_slope, res=g_tap,
+                                              out_div=ctx.in_grad_div)
             if g_tap is not None:
                 bank._hold.append(g_tap)               # (read by a launch that may replay on another stream)
                 bank._queue_finish()
@@ -744,7 +752,7 @@ class _HipConv(torch.autograd.Function):
             bank.node_closed()
         # weight_token (the layer's weight_v) only ties the output to the parameters in the autograd graph;
         # parameter gradients are produced in kernel layout and delivered by ConvBank._finish_backward.
-        return (gx, (g if ctx.has_res else None), (g if ctx.has_res2 else None)) + (None,) * 10
+        return (gx, (g if ctx.has_res else None), (g if ctx.has_res2 else None)) + (None,) * 12
 
 
 class _HipConvGroup(torch.autograd.Function):
@@ -892,15 +900,21 @@ GROUPED = os.environ.get('MSMC_GROUPED', '1') != '0'
 
 
 def hip_conv(bank, layer, x, res=None, res2=None, in_slope=1.0, out_slope=1.0, out_div=1.0, tap=False, in_act=1.0,
-             out_masked=False):
+             out_masked=False, in_grad_div=1.0, grad_predivided=False):
     """``tap=True``: returns (out, x_tap) -- x_tap aliases x and is what x's other consumer should read, so that its
     gradient is added inside this convolution's data-gradient launch (see _HipConv.forward).
     Activation in the PRODUCER's epilogue: ``a = hip_conv(.., out_slope=s, out_masked=True)`` followed by
     ``hip_conv(.., a, in_act=s)`` computes conv(lrelu_s(conv(..))) with the activation applied once, where the value is
-    produced, instead of in every load of the consumer (a must have no other consumer)."""
+    produced, instead of in every load of the consumer (a must have no other consumer).
+    ``y = hip_conv(.., out_div=n, grad_predivided=True)`` followed by ``hip_conv(.., y, in_grad_div=n)`` (y's only
+    consumer): the backward division by n runs in the consumer's data-gradient epilogue (see _HipConv.forward)."""
     return _HipConv.apply(x, res, res2, layer.weight, bank, layer, float(in_slope), float(out_slope),
-                          float(out_div), bool(tap), float(in_act), bool(out_masked))
+                          float(out_div), bool(tap), float(in_act), bool(out_masked), False, float(in_grad_div),
+                          bool(grad_predivided))
 
+
+# 1 (default): see _HipConv.forward ``in_grad_div`` (the generator's mean over its parallel ResBlocks)
+GRAD_DIV_FUSE = os.environ.get('MSMC_GRAD_DIV_FUSE', '1') != '0'
 
 # 1 (default): a 1-tap projection whose only consumer is a fused add + LayerNorm runs INSIDE that launch (csrc/norm.hip
 # fc_add_ln_fwd_kernel: the attention sub-layer's output projection, 12 launches and 12 round trips of h per forward pass

@@ -61,8 +61,12 @@ class Generator(nn.Module):
         nk = self.num_kernels
         x = mel.transpose(1, 2).unsqueeze(1).contiguous().to(self.hip_dtype)          # channels-last [B, 1, T, C]
         x = hip_conv(bank, L['pre'], x)
+        # the mean over the nk parallel ResBlocks divides by nk in the last block's epilogue; backward, that division runs in
+        # the data-gradient epilogue of the stage output's only consumer (the next up-sampling layer, ``conv_post``) instead
+        # of as a tensor pass of its own (MSMC_GRAD_DIV_FUSE=0: the stock division, A/B)
+        fuse_div = convnet.GRAD_DIV_FUSE
         for i in range(self.num_upsamples):
-            x = hip_conv(bank, L['ups'][i], x, in_slope=LRELU_SLOPE)
+            x = hip_conv(bank, L['ups'][i], x, in_slope=LRELU_SLOPE, in_grad_div=float(nk) if (fuse_div and i > 0) else 1.0)
             def block_body(j, x=x):
                 """all but the last convolution of parallel ResBlock j (independent of the other blocks)"""
                 c1s, c2s = L['rb'][i * nk + j]
@@ -92,8 +96,9 @@ class Generator(nn.Module):
             xs = None
             for j, (y, t) in enumerate(parts):    # block outputs, running sum over blocks and the final mean
                 xs = hip_conv(bank, L['rb'][i * nk + j][1][-1], t, res=y, res2=xs, in_act=LRELU_SLOPE,
-                              out_div=float(nk) if j == nk - 1 else 1.0)
+                              out_div=float(nk) if j == nk - 1 else 1.0, grad_predivided=fuse_div and j == nk - 1)
             x = xs
-        x = hip_conv(bank, L['post'], x, in_slope=0.01)       # F.leaky_relu default slope (generator.py:52)
+        x = hip_conv(bank, L['post'], x, in_slope=0.01,       # F.leaky_relu default slope (generator.py:52)
+                     in_grad_div=float(nk) if (fuse_div and self.num_upsamples > 0) else 1.0)
         from ...hip import norm as hipnorm
         return hipnorm.tanh_f32(x).reshape(x.shape[0], 1, x.shape[2])       # (cast + tanh in one launch, fp32 out)
