@@ -288,6 +288,7 @@ class ConvBank(object):
         # decoder / quantiser / encoders are still back-propagating (EARLY_FINISH; the end-of-pass callback stays as the
         # net for passes the count cannot see through: outputs nobody used, exceptions)
         self._open_nodes = 0
+        self._close_task, self._close_mixed = None, False      # graph task of the nodes closed so far / more than one seen
         self.dirty = True               # kernel-layout weights older than the parameters (see SKIP_CLEAN_PREPARE)
         self.eager_stale = False        # ... as far as an EAGER pass can tell: graph replays moved the parameters (graphs_replayed)
         self._clean_versions = None
@@ -484,6 +485,7 @@ class ConvBank(object):
             del self._hold[:]
             self._dw_stream.clear()
             self._open_nodes, self._side_used, self._finish_stream = 0, [], None
+            self._close_task, self._close_mixed = None, False
         versions = self._versions()
         capturing = self.w1.is_cuda and torch.cuda.is_current_stream_capturing()
         stale = self.eager_stale and not capturing
@@ -542,9 +544,21 @@ class ConvBank(object):
         self._open_nodes += 1
 
     def node_closed(self):
-        """a backward node with a weight gradient has issued it; the last one of the pass completes the bank"""
+        """a backward node with a weight gradient has issued it; the last one of the pass completes the bank.
+        The count is one number per bank, not one per backward pass: when nodes recorded by SEVERAL forward passes of the bank
+        are closed by different backward passes (two graphs over one bank, back-propagated one after the other), a count that
+        reaches zero says nothing about the pass that is running -- such a bank is recognised by the autograd graph-task id
+        of its closing nodes and delivers in the end-of-pass callback, as every bank did before round 4."""
+        task = torch._C._current_graph_task_id() if hasattr(torch._C, '_current_graph_task_id') else -1
         if self._open_nodes > 0:
+            if self._close_task is None:
+                self._close_task = task
+            elif self._close_task != task:
+                self._close_mixed = True
             self._open_nodes -= 1
+            if self._open_nodes == 0 and self._close_mixed:
+                self._close_task, self._close_mixed = None, False
+                return
             # (a bank whose backward nodes run on several streams finishes in the end-of-pass callback, on the caller's stream:
             # nothing orders the caller behind whichever branch happened to close last)
             if self._open_nodes == 0 and EARLY_FINISH and self._touched and not self.streams:
@@ -563,6 +577,7 @@ class ConvBank(object):
                     self._finish_backward(early=True)
 
     def _finish_backward(self, early=False):
+        self._close_task, self._close_mixed = None, False      # (early: the count is back at zero; otherwise the pass is over)
         if not early:
             self._queued = False
             self._open_nodes = 0        # (whatever the count missed -- unused outputs -- ends with the pass)

@@ -388,6 +388,47 @@ def check_fc_add_ln(dev):
     assert bad != 0
 
 
+def check_two_graphs_over_one_bank(dev):
+    """Two forward passes of ONE bank recorded before either is back-propagated, then two separate backward passes (the early
+    delivery of hip/convnet.py counts open nodes per bank: the second pass closes the count the first one left open): the
+    accumulated parameter gradients equal the stock operators', and the bank recognises the case (no early delivery fires while
+    nodes of another graph are open) -- the round-4 advisor item on ``_open_nodes``"""
+    import torch.nn as nn
+    from msmctts_amd.hip import convnet
+    from msmctts_amd.networks.layers import WNConv1d
+    torch.manual_seed(5)
+    conv_a, conv_b = WNConv1d(16, 16, 3, padding=1).to(dev), WNConv1d(16, 16, 5, padding=2).to(dev)
+    la, lb = conv_a.hip_layer(), conv_b.hip_layer()
+    bank = convnet.ConvBank([la, lb])
+    x1 = torch.randn(2, 1, 50, 16, device=dev)
+    x2 = torch.randn(2, 1, 50, 16, device=dev)
+    fired = []
+    orig = convnet.ConvBank._finish_backward
+
+    def spy(self, early=False):
+        fired.append(early)
+        return orig(self, early=early)
+    convnet.ConvBank._finish_backward = spy
+    try:
+        bank.prepare(torch.float32)
+        y1 = convnet.hip_conv(bank, lb, convnet.hip_conv(bank, la, x1))
+        y2 = convnet.hip_conv(bank, lb, convnet.hip_conv(bank, la, x2))
+        y1.sum().backward()
+        assert fired == [False], fired              # nodes of the second graph are still open: end-of-pass delivery only
+        (2.0 * y2).sum().backward()
+        assert True not in fired[:-1]
+    finally:
+        convnet.ConvBank._finish_backward = orig
+    params = [('a.' + n, p) for n, p in conv_a.named_parameters()] + [('b.' + n, p) for n, p in conv_b.named_parameters()]
+    mine = {n: p.grad.clone() for n, p in params}
+    for m in (conv_a, conv_b):
+        m.zero_grad()
+    ref = lambda x: conv_b(conv_a(x.squeeze(1).transpose(1, 2)))
+    (ref(x1).sum() + 2.0 * ref(x2).sum()).backward()
+    for n, p in params:
+        close(mine[n], p.grad, 2e-4 * max(1.0, float(p.grad.abs().max())), what='two graphs over one bank: ' + n)
+
+
 def check_hip_adamw(dev):
     """csrc/optim.hip (grad-norm clip + AdamW of all tensors in three launches) against clip_grad_norm_ + torch.optim.AdamW
     over several steps, odd sizes and unaligned views; state_dict round trip both ways"""

@@ -43,6 +43,10 @@ def test_window_gather_and_output_tanh_match_the_operator_chains():
     _parity.check_window_gather_and_output_tanh(torch.device(DEV))
 
 
+def test_two_autograd_graphs_over_one_bank_back_propagated_one_after_the_other():
+    _parity.check_two_graphs_over_one_bank(DEV)
+
+
 def test_output_projection_inside_the_add_layernorm_launch():
     _parity.check_fc_add_ln(DEV)
 
