@@ -249,6 +249,7 @@ class _FftPrologue(torch.autograd.Function):
                                               lib.stream(seq)), 'msmc_fft_prologue')
         ctx.in_dtype = seq.dtype
         ctx.mark_non_differentiable(keep_row)
+        ctx.set_materialize_grads(False)      # (the engine otherwise zero-fills a gradient for the mask and the bias: two launches)
         if bias is None:
             return out, keep_row
         ctx.mark_non_differentiable(bias)
@@ -256,6 +257,8 @@ class _FftPrologue(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, *_):
+        if g is None:
+            return None, None, None, None, None
         return (g if g.dtype == ctx.in_dtype else g.to(ctx.in_dtype)), None, None, None, None
 
 

@@ -42,6 +42,20 @@ def vq_prepare(embed, frames=None):
     return embed_t, enorm
 
 
+# the fp32 copy of the frames the last search ran on: in a bf16 step the search casts its input, and the EMA update that
+# follows it (same frames, MultiHeadQuantize.forward) would cast them a second time
+_F32_OF = {'last': None}
+
+
+def _f32_frames(x):
+    last = _F32_OF['last']
+    if (last is not None and x.dtype != torch.float32 and last[0] == x.data_ptr() and last[1] == x.dtype
+            and last[3].numel() == x.numel() and x.is_contiguous()):
+        _F32_OF['last'] = None                # (one reader per search: nothing stale can be picked up by a later call)
+        return last[3].view(x.shape)
+    return x.detach().contiguous().float()
+
+
 class _VQSearch(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, embed_t, enorm, image=None, force_shortlist=False):
@@ -49,6 +63,7 @@ class _VQSearch(torch.autograd.Function):
         D = H * d
         assert x.shape[-1] == D, (x.shape, embed_t.shape)
         xc = x.contiguous().float()
+        _F32_OF['last'] = (x.data_ptr(), x.dtype, tuple(x.shape), xc)      # (the EMA update of the same frames reads this copy)
         N = xc.numel() // D
         quant = torch.empty_like(xc)
         diff = torch.empty(xc.shape[:-1] + (d,), dtype=torch.float32, device=x.device)
@@ -67,6 +82,7 @@ class _VQSearch(torch.autograd.Function):
         ctx.heads = H
         ctx.in_dtype = x.dtype
         ctx.mark_non_differentiable(ind)
+        ctx.set_materialize_grads(False)      # (no zero-filled int64 "gradient" for the indices; quant / diff: handled below)
         return quant, diff, ind
 
     @staticmethod
@@ -74,6 +90,8 @@ class _VQSearch(torch.autograd.Function):
         xc, quant = ctx.saved_tensors
         D = xc.shape[-1]
         N = xc.numel() // D
+        if g_quant is None and g_diff is None:
+            return None, None, None, None, None
         if g_quant is None:
             g_quant = torch.zeros_like(xc)
         g_quant = g_quant.contiguous().float()
@@ -143,7 +161,7 @@ def _vq_ema_update(x, ind, length, embed, cluster_size, embed_avg, decay, eps, w
     need = int(L.msmc_vq_ema_workspace(B * T, D, H, K))
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=x.device)
-    xc = x.detach().contiguous().float()
+    xc = _f32_frames(x.detach())
     indc = ind.contiguous()                 # (named: a temporary would be released before the launch reads it)
     length = length.to(device=x.device, dtype=torch.int64).contiguous()
     lib.check(L.msmc_vq_ema_update(lib.ptr(xc), lib.ptr(indc, torch.int64), lib.ptr(length),
