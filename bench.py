@@ -248,6 +248,10 @@ def abi_work_models():
     return {
         'msmc_add_ln_fwd': lambda x, res, g, b, keep, y, v, mean, rstd, N, C, eps, p, seed, salt, dt, st:
             (0.0, float(N * C * E(dt) * (3 + (1 if res else 0)) + 8 * N)),
+        'msmc_sum_n': lambda a, b, c, d, out, n, dt, st: (0.0, float(n * E(dt) * (3 + (1 if c else 0) + (1 if d else 0)))),
+        'msmc_dropout_add_fwd': lambda x, res, y, n, p, seed, salt, dt, st: (0.0, float(n * E(dt) * (2 + (1 if res else 0)))),
+        'msmc_dropout_bwd': lambda g, gx, n, p, seed, salt, dt, st: (0.0, float(n * E(dt) * 2)),
+        'msmc_row_mask': lambda lens, is64, keep, B, T, dt, st: (0.0, float(B * T * E(dt))),
         'msmc_fc_add_ln_fwd': lambda a, w, bias, res, g, b, keep, y, v, mean, rstd, N, C, K, eps, p, seed, salt, st:
             (2.0 * N * C * K, float(2 * (N * K + C * K + 3 * N * C) + 8 * N)),
         'msmc_add_ln_bwd': lambda g, v, mean, rstd, gamma, keep, gx, gres, dga, dbe, ws, wsb, N, C, p, seed, salt, acc, dt, st:

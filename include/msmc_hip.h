@@ -549,6 +549,17 @@ int msmc_gate_fwd(const void* x, void* y, long N, int C, float p_drop, const lon
                   msmc_stream stream);
 int msmc_gate_bwd(const void* x, const void* g, void* gx, long N, int C, float p_drop, const long long* seed, long long salt,
                   int dtype, msmc_stream stream);
+/* Element-wise glue of the quantiser and of the generator's backward pass (round 6; dtype 0 fp32 / 1 bf16, n % 4 == 0, operands
+ * 16-byte (fp32) / 8-byte (bf16) aligned).
+ *   msmc_sum_n: out = ((a + b) + c) + d, c and d optional -- the input gradients of the parallel ResBlocks (hifigan/generator.py:47-52);
+ *   msmc_dropout_add_fwd: y = dropout(x) + res (res optional) with the counter-hash masks of msmc_add_ln_fwd (element index = position),
+ *   msmc_dropout_bwd: gx = g * mask * scale -- F.dropout + the residual adds of vqgantts/msmc_vqgan.py:141-176;
+ *   msmc_row_mask: keep[b][t] = (t < lengths[b]) as 1 / 0 in ``dtype`` -- ~get_mask_from_lengths (utils/utils.py:9-16) cast to the compute dtype. */
+int msmc_sum_n(const void* a, const void* b, const void* c, const void* d, void* out, long n, int dtype, msmc_stream stream);
+int msmc_dropout_add_fwd(const void* x, const void* res, void* y, long n, float p_drop, const long long* seed, long long salt, int dtype,
+                         msmc_stream stream);
+int msmc_dropout_bwd(const void* g, void* gx, long n, float p_drop, const long long* seed, long long salt, int dtype, msmc_stream stream);
+int msmc_row_mask(const void* lengths, int lengths_are_int64, void* keep, int B, int T, int dtype, msmc_stream stream);
 /* y = tanh(x); gx = g * (1 - y*y) over n elements. */
 int msmc_tanh_fwd(const void* x, void* y, long n, int dtype, msmc_stream stream);
 int msmc_tanh_bwd(const void* y, const void* g, void* gx, long n, int dtype, msmc_stream stream);

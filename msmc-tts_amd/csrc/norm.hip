@@ -488,6 +488,59 @@ __global__ __launch_bounds__(256) void tanh_f32_bwd_kernel(const float* __restri
     }
 }
 
+
+// ---- small glue of the quantiser and the generator's backward pass (round 6: stock element-wise launches of the step) ----------------
+// sum_n: out = ((a + b) + c) + d in fp32, rounded once (c, d optional) -- the input gradients of the parallel ResBlocks of a generator
+// stage (reference hifigan/generator.py:47-52: one tensor feeds num_kernels blocks; the autograd engine adds their gradients pairwise).
+// dropout_add: y = dropout(x) + res with the counter-hash masks of this file (res optional); backward gx = g * mask * scale -- the
+// quantiser's F.dropout + residual add (reference vqgantts/msmc_vqgan.py:141-176).  row_mask: keep[b][t] = t < len[b] in the compute
+// dtype (reference utils/utils.py:9-16 get_mask_from_lengths, inverted and cast: four stock launches).
+template <typename T>
+__global__ __launch_bounds__(256) void sum_n_kernel(const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ c,
+                                                    const T* __restrict__ d, T* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float va[4], vb[4], vc[4], vd[4], o[4];
+        nm_ldv<4>(a, 4 * i, va);
+        nm_ldv<4>(b, 4 * i, vb);
+        if (c) nm_ldv<4>(c, 4 * i, vc);
+        if (d) nm_ldv<4>(d, 4 * i, vd);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o[q] = va[q] + vb[q];
+            if (c) o[q] = o[q] + vc[q];
+            if (d) o[q] = o[q] + vd[q];
+        }
+        nm_stv<4>(out, 4 * i, o);
+    }
+}
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void dropout_add_kernel(const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y, long n4,
+                                                          float p_drop, const long long* seed, long long salt) {
+    const unsigned long long key = nm_key(seed, salt);
+    const unsigned int thresh = p_drop > 0.f ? (unsigned int)(p_drop * 4294967296.0) : 0u;
+    const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float v[4], r[4];
+        nm_ldv<4>(x, 4 * i, v);
+        if (!BWD && res) nm_ldv<4>(res, 4 * i, r);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (thresh) v[q] = nm_keep(key, (unsigned long long)(4 * i + q), thresh) ? v[q] * scale : 0.f;
+            if (!BWD && res) v[q] = v[q] + r[q];
+        }
+        nm_stv<4>(y, 4 * i, v);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void row_mask_kernel(const void* __restrict__ lengths, int is64, T* __restrict__ keep, int B, int Tn) {
+    const long n = (long)B * Tn;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / Tn), t = (int)(i - (long)b * Tn);
+        const long len = is64 ? (long)((const long long*)lengths)[b] : (long)((const int*)lengths)[b];
+        nm_st(keep, i, t < len ? 1.f : 0.f);
+    }
+}
+
 // ---- FFT-stack prologue ---------------------------------------------------------------------------------------
 // The head of FFTBlocks.forward (reference acoustic_models/transformer.py:375-395) with the positions of
 // vqgantts/msmc_vqgan.py:56-58 (1 .. len per utterance, 0 on padding) folded in -- one launch instead of the chain
@@ -703,6 +756,45 @@ int msmc_tanh_f32_bwd(const float* y, const float* g, void* gx, long n, int dtyp
     const dim3 grid((unsigned)nm_grid(n));
     if (dtype == 0) MSMC_LAUNCH(tanh_f32_bwd_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, y, g, (float*)gx, n);
     else if (dtype == 1) MSMC_LAUNCH(tanh_f32_bwd_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, y, g, (unsigned short*)gx, n);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+int msmc_sum_n(const void* a, const void* b, const void* c, const void* d, void* out, long n, int dtype, msmc_stream stream) {
+    if (!a || !b || !out || n < 0 || (n & 3) || (d && !c)) return MSMC_E_SHAPE;
+    if ((((size_t)a) | ((size_t)b) | ((size_t)c) | ((size_t)d) | ((size_t)out)) & (dtype == 0 ? 15 : 7)) return MSMC_E_SHAPE;
+    if (n == 0) return 0;
+    const dim3 grid((unsigned)nm_grid(n / 4));
+    if (dtype == 0) MSMC_LAUNCH(sum_n_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, (const float*)a, (const float*)b, (const float*)c, (const float*)d, (float*)out, n / 4);
+    else if (dtype == 1) MSMC_LAUNCH(sum_n_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)a, (const unsigned short*)b, (const unsigned short*)c, (const unsigned short*)d, (unsigned short*)out, n / 4);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+int msmc_dropout_add_fwd(const void* x, const void* res, void* y, long n, float p_drop, const long long* seed, long long salt, int dtype,
+                         msmc_stream stream) {
+    if (!x || !y || n < 0 || (n & 3) || p_drop < 0.f || p_drop >= 1.f) return MSMC_E_SHAPE;
+    if ((((size_t)x) | ((size_t)res) | ((size_t)y)) & (dtype == 0 ? 15 : 7)) return MSMC_E_SHAPE;
+    if (n == 0) return 0;
+    const dim3 grid((unsigned)nm_grid(n / 4));
+    if (dtype == 0) MSMC_LAUNCH((dropout_add_kernel<float, false>), grid, dim3(256), 0, (msmc_stream_t)stream, (const float*)x, (const float*)res, (float*)y, n / 4, p_drop, seed, salt);
+    else if (dtype == 1) MSMC_LAUNCH((dropout_add_kernel<unsigned short, false>), grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)x, (const unsigned short*)res, (unsigned short*)y, n / 4, p_drop, seed, salt);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+int msmc_dropout_bwd(const void* g, void* gx, long n, float p_drop, const long long* seed, long long salt, int dtype, msmc_stream stream) {
+    if (!g || !gx || n < 0 || (n & 3) || p_drop < 0.f || p_drop >= 1.f) return MSMC_E_SHAPE;
+    if ((((size_t)g) | ((size_t)gx)) & (dtype == 0 ? 15 : 7)) return MSMC_E_SHAPE;
+    if (n == 0) return 0;
+    const dim3 grid((unsigned)nm_grid(n / 4));
+    if (dtype == 0) MSMC_LAUNCH((dropout_add_kernel<float, true>), grid, dim3(256), 0, (msmc_stream_t)stream, (const float*)g, (const float*)nullptr, (float*)gx, n / 4, p_drop, seed, salt);
+    else if (dtype == 1) MSMC_LAUNCH((dropout_add_kernel<unsigned short, true>), grid, dim3(256), 0, (msmc_stream_t)stream, (const unsigned short*)g, (const unsigned short*)nullptr, (unsigned short*)gx, n / 4, p_drop, seed, salt);
+    else return MSMC_E_SHAPE;
+    return msmc_check_launch();
+}
+int msmc_row_mask(const void* lengths, int lengths_are_int64, void* keep, int B, int T, int dtype, msmc_stream stream) {
+    if (!lengths || !keep || B <= 0 || T <= 0) return MSMC_E_SHAPE;
+    const dim3 grid((unsigned)nm_grid((long)B * T));
+    if (dtype == 0) MSMC_LAUNCH(row_mask_kernel<float>, grid, dim3(256), 0, (msmc_stream_t)stream, lengths, lengths_are_int64, (float*)keep, B, T);
+    else if (dtype == 1) MSMC_LAUNCH(row_mask_kernel<unsigned short>, grid, dim3(256), 0, (msmc_stream_t)stream, lengths, lengths_are_int64, (unsigned short*)keep, B, T);
     else return MSMC_E_SHAPE;
     return msmc_check_launch();
 }

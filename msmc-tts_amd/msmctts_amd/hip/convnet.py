@@ -880,6 +880,21 @@ class _HipConvGroup(torch.autograd.Function):
         elif w_items:
             with bank.wgrad_side(*([it['x'] for it in w_items] + [it['g'] for it in w_items]), dws=[it['dw'] for it in w_items]):
                 K.conv_wgrad_group(w_items)
+        # members that read the SAME tensor (the parallel ResBlocks of a generator stage all start from the stage's input): their
+        # input gradients leave as one sum -- one launch -- instead of as separate gradients the autograd engine adds pairwise
+        if SUM_SHARED_INPUTS:
+            shared = {}
+            for k in range(n):
+                if grads[ctx.xpos[k]] is not None:
+                    shared.setdefault((xs[k].data_ptr(), tuple(xs[k].shape)), []).append(ctx.xpos[k])
+            for slots in shared.values():
+                if 2 <= len(slots) <= 4:
+                    from . import norm
+                    parts = [grads[p] for p in slots]
+                    grads[slots[0]] = norm.sum_n(parts)
+                    for p in slots[1:]:
+                        grads[p] = None
+                    bank._hold.extend(parts)           # (read by a launch that may replay on another stream)
         bank._queue_finish()
         if ctx.counted:
             ctx.counted = False
@@ -927,6 +942,9 @@ def hip_conv(bank, layer, x, res=None, res2=None, in_slope=1.0, out_slope=1.0, o
                           float(out_div), bool(tap), float(in_act), bool(out_masked), False, float(in_grad_div),
                           bool(grad_predivided))
 
+
+# 1 (default): see _HipConvGroup.backward (input gradients of members that share their input tensor)
+SUM_SHARED_INPUTS = os.environ.get('MSMC_SUM_SHARED_INPUTS', '1') != '0'
 
 # 1 (default): see _HipConv.forward ``in_grad_div`` (the generator's mean over its parallel ResBlocks)
 GRAD_DIV_FUSE = os.environ.get('MSMC_GRAD_DIV_FUSE', '1') != '0'

@@ -160,6 +160,10 @@ _SIGNATURES.update({
     'msmc_fft_prologue': (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'msmc_gate_fwd': (_i, [_vp, _vp, ctypes.c_long, _i, _f, _vp, ctypes.c_longlong, _i, _vp]),
     'msmc_gate_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _i, _f, _vp, ctypes.c_longlong, _i, _vp]),
+    'msmc_sum_n': (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_long, _i, _vp]),
+    'msmc_dropout_add_fwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _f, _vp, ctypes.c_longlong, _i, _vp]),
+    'msmc_dropout_bwd': (_i, [_vp, _vp, ctypes.c_long, _f, _vp, ctypes.c_longlong, _i, _vp]),
+    'msmc_row_mask': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     'msmc_tanh_fwd': (_i, [_vp, _vp, ctypes.c_long, _i, _vp]),
     'msmc_tanh_bwd': (_i, [_vp, _vp, _vp, ctypes.c_long, _i, _vp]),
     'msmc_tanh_f32_fwd': (_i, [_vp, _vp, ctypes.c_long, _i, _vp]),

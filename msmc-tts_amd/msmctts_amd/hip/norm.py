@@ -202,6 +202,69 @@ def add_layer_norm(x, res, gamma, beta, keep_row=None, p_drop=0.0, salt=0, eps=1
     return _AddLayerNorm.apply(x, res, gamma, beta, keep_row, p_drop, salt, eps, fc)
 
 
+def sum_n(tensors):
+    """((t0 + t1) + t2) + t3 of two to four same-shaped contiguous tensors in ONE launch (fp32 sums, one rounding)"""
+    ts = [t.contiguous() for t in tensors]
+    assert 2 <= len(ts) <= 4 and all(t.shape == ts[0].shape and t.dtype == ts[0].dtype for t in ts)
+    a = ts[0]
+    if a.dtype not in _DT or a.numel() % 4 or any(t.data_ptr() % 16 for t in ts):
+        out = ts[0] + ts[1]
+        for t in ts[2:]:
+            out = out + t
+        return out
+    out = torch.empty_like(a)
+    ts = ts + [None] * (4 - len(ts))
+    lib.check(lib.get().msmc_sum_n(lib.ptr(ts[0]), lib.ptr(ts[1]), lib.ptr(ts[2]), lib.ptr(ts[3]), lib.ptr(out), a.numel(),
+                                   _DT[a.dtype], lib.stream(a)), 'msmc_sum_n')
+    return out
+
+
+class _DropoutAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, p_drop, salt):
+        assert x.dtype in _DT and x.is_contiguous() and (res is None or (res.dtype == x.dtype and res.is_contiguous() and res.shape == x.shape))
+        y = torch.empty_like(x)
+        seed = seed_word(x.device) if p_drop > 0 else None
+        lib.check(lib.get().msmc_dropout_add_fwd(lib.ptr(x), lib.ptr(res), lib.ptr(y), x.numel(), float(p_drop), lib.ptr(seed), salt,
+                                                 _DT[x.dtype], lib.stream(x)), 'msmc_dropout_add_fwd')
+        ctx.p_drop, ctx.salt, ctx.has_res = float(p_drop), salt, res is not None
+        ctx.set_materialize_grads(False)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
+        g = g.contiguous()
+        gx = g
+        if ctx.p_drop > 0 and ctx.needs_input_grad[0]:
+            gx = torch.empty_like(g)
+            lib.check(lib.get().msmc_dropout_bwd(lib.ptr(g), lib.ptr(gx), g.numel(), ctx.p_drop, lib.ptr(seed_word(g.device)), ctx.salt,
+                                                 _DT[g.dtype], lib.stream(g)), 'msmc_dropout_bwd')
+        return (gx if ctx.needs_input_grad[0] else None), (g if ctx.has_res else None), None, None
+
+
+def dropout_add_usable(x, res=None):
+    return (x.dtype in _DT and x.numel() % 4 == 0 and (x.is_cuda or lib._host_pointers_ok) and
+            (res is None or (res.dtype == x.dtype and res.shape == x.shape)))
+
+
+def dropout_add(x, res, p_drop, salt):
+    """dropout(x) + res (res may be None) with the counter-hash masks of this module: one launch forward, one backward"""
+    return _DropoutAdd.apply(x.contiguous(), None if res is None else res.contiguous(), float(p_drop), salt)
+
+
+def row_mask(lengths, T, dtype):
+    """keep [B, T] in ``dtype``: 1 where t < lengths[b], 0 on padding (one launch; no gradient)"""
+    assert dtype in _DT and lengths.dtype in (torch.int32, torch.int64)
+    lengths = lengths.contiguous()
+    B = lengths.numel()
+    keep = torch.empty((B, T), dtype=dtype, device=lengths.device)
+    lib.check(lib.get().msmc_row_mask(lib.ptr(lengths, lengths.dtype), int(lengths.dtype == torch.int64), lib.ptr(keep), B, int(T),
+                                      _DT[dtype], lib.stream(lengths)), 'msmc_row_mask')
+    return keep
+
+
 class _Gate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p_drop, salt):

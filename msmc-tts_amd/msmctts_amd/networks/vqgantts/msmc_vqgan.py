@@ -99,7 +99,8 @@ class PriorPredictor(nn.Module):
         its convolutions on the implicit-GEMM kernels and tanh * sigmoid (+ dropout) as one kernel per layer"""
         bank, (pairs, l_proj) = hip
         C = self.enc.hidden_channels
-        keep = (~get_mask_from_lengths(x_lengths.to(x.device), x.shape[1])).unsqueeze(-1).to(x.dtype)       # [B, T, 1]
+        # [B, T, 1]: 1 on frames, 0 on padding -- ~get_mask_from_lengths cast to the compute dtype, one launch
+        keep = hipnorm.row_mask(x_lengths.to(x.device), x.shape[1], x.dtype).unsqueeze(-1)
         x4 = x.unsqueeze(1)
         out = None
         pd = self.enc.drop.p if self.training else 0.0
@@ -163,6 +164,18 @@ class MultiStageQuantizer(nn.Module):
             self._bank = ConvBank(flat)
         return self._bank, self._stages
 
+    def _dropout_add(self, x, res, stage, site):
+        """F.dropout(x, self.dropout) + res (res None: the dropout alone) -- reference msmc_vqgan.py:141-176; on the kernels'
+        dtypes one launch with the counter-hash masks of hip/norm.py (two stock launches and a stored mask otherwise)"""
+        p = self.dropout if self.training else 0.0
+        if self.use_hip and p > 0 and hipnorm.dropout_add_usable(x, res):
+            if not hasattr(self, '_salts'):
+                self._salts = {}
+            salt = self._salts.setdefault((stage, site), hipnorm.new_salt())
+            return hipnorm.dropout_add(x, res, p, salt)
+        x = F.dropout(x, p=self.dropout, training=self.training)
+        return x if res is None else res + x
+
     @staticmethod
     def _stack_hip(bank, pair, x):
         """conv1x1 -> Tanh -> conv1x1 on channels-last x [B, T, C] (pre- / post-processor, msmc_vqgan.py:115-136)"""
@@ -190,7 +203,7 @@ class MultiStageQuantizer(nn.Module):
                     hid, pred_q = self.predictor[i](residual, length)
                 else:
                     hid, pred_q = self.predictor[i].forward_hip(residual.to(dt).contiguous(), length, (bank, stages[i][2]))
-                residual = residual + F.dropout(hid, p=self.dropout, training=self.training)
+                residual = self._dropout_add(hid, residual, i, 0)
             if emb is None:
                 q_in = pred_q
             elif from_encoder:
@@ -203,8 +216,7 @@ class MultiStageQuantizer(nn.Module):
             post_in = quant if residual is None else torch.cat((residual, quant), dim=-1)
             post = (self.postprocessor[i](post_in) if hip is None else
                     self._stack_hip(bank, stages[i][1], post_in.to(dt).contiguous()))
-            post = F.dropout(post, p=self.dropout, training=self.training)
-            residual = post if residual is None else residual + post
+            residual = self._dropout_add(post, residual, i, 1)
             quants.append(quant)
             diffs.append(dff)
             inds.append(ind)

@@ -28,6 +28,21 @@ from .base_trainer import BaseTrainer
 from .criterions.stft_loss import MelLoss, MultiResolutionSTFTLoss
 
 
+_ONES = {}
+
+
+def _one_like(loss):
+    """the seed gradient of ``loss.backward()``: autograd otherwise allocates and fills a ones tensor per call (a launch per
+    backward pass, replayed with every step); one constant per (device, dtype), created on first use -- the eager warm-up
+    steps, before any capture"""
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        assert not (loss.is_cuda and torch.cuda.is_current_stream_capturing()), 'the seed gradient must exist before the capture'
+        one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    return one
+
+
 class QuantizerLoss(nn.Module):
     def __init__(self, lambda_vq=1, lambda_pr=1):
         super().__init__()
@@ -215,7 +230,7 @@ class VQGANTrainer(BaseTrainer):
         d_loss = hiploss.weighted_sum([d_real, d_fake])
         losses['d_loss_real'], losses['d_loss_fake'], losses['d_loss'] = d_real, d_fake, d_loss
         self.optimizer.zero_grad(['discriminator'])
-        d_loss.backward()
+        d_loss.backward(gradient=_one_like(d_loss))
         if side:
             main.wait_stream(side[0])
         losses['stft_loss'] = stl
@@ -254,7 +269,7 @@ class VQGANTrainer(BaseTrainer):
             st.g_loss = hiploss.weighted_sum([st.g_loss, adv])
             losses['fm_loss'], losses['adv_loss'], losses['g_loss'] = fm, adv, st.g_loss
         self.optimizer.zero_grad(['autoencoder'])
-        st.g_loss.backward()
+        st.g_loss.backward(gradient=_one_like(st.g_loss))
         if st.g_loss.is_cuda and st.phase == 2 and hipconvnet.STREAMS_ENABLED:
             # (the side branches' backward nodes hand their results to nodes of this stream, which orders them already; the
             # explicit join costs nothing and does not depend on that)
@@ -594,7 +609,7 @@ class PredictorTrainer(BaseTrainer):
         losses['total_loss'] = losses['total_loss'] + dur.pop('total_loss')
         losses.update(dur)
         self.optimizer.zero_grad(['predictor'])
-        losses['total_loss'].backward()
+        losses['total_loss'].backward(gradient=_one_like(losses['total_loss']))
         return losses
 
     def _update(self, losses):

@@ -429,6 +429,74 @@ def check_two_graphs_over_one_bank(dev):
         close(mine[n], p.grad, 2e-4 * max(1.0, float(p.grad.abs().max())), what='two graphs over one bank: ' + n)
 
 
+def check_glue_kernels(dev):
+    """csrc/norm.hip sum_n / dropout_add / row_mask against the stock operators they replace, and the grouped convolution's
+    one-launch sum of the input gradients of members that share their input (hip/convnet.py SUM_SHARED_INPUTS)"""
+    import torch.nn as nn
+    from msmctts_amd.hip import convnet, norm
+    from msmctts_amd.networks.layers import WNConv1d
+    from msmctts_amd.utils.utils import get_mask_from_lengths
+    torch.manual_seed(9)
+    for dt, tol in ((torch.float32, 1e-6), (torch.bfloat16, 1.6e-2)):
+        ts = [torch.randn(3, 1, 50, 16, device=dev).to(dt) for _ in range(4)]
+        for n in (2, 3, 4):
+            want = sum(t.float() for t in ts[:n])
+            close(norm.sum_n(ts[:n]).float(), want, tol * max(1.0, float(want.abs().max())), what='sum_n %d' % n)
+        odd = [torch.randn(7, device=dev).to(dt) for _ in range(3)]                  # (a size the kernel does not take: stock adds)
+        close(norm.sum_n(odd).float(), sum(t.float() for t in odd), 4 * tol)
+        # dropout + residual add
+        x = torch.randn(4, 30, 64, device=dev).to(dt).requires_grad_(True)
+        r = torch.randn(4, 30, 64, device=dev).to(dt).requires_grad_(True)
+        y = norm.dropout_add(x, r, 0.0, norm.new_salt())
+        close(y.float(), x.detach().float() + r.detach().float(), tol * 4)
+        salt = norm.new_salt()
+        y2 = norm.dropout_add(x.detach(), None, 0.25, salt)                            # the dropout alone: its zeros are the mask
+        kept = (y2 != 0) | (x.detach() == 0)
+        rate = float(kept.float().mean())
+        assert abs(rate - 0.75) < 0.03, rate
+        close(y2.float()[kept], x.detach().float()[kept] / 0.75, tol * 4 * max(1.0, float(x.detach().abs().max())))
+        y = norm.dropout_add(x, r, 0.25, salt)                                         # same seed word, same salt: same mask
+        close(y.float(), y2.float() + r.detach().float(), tol * 4 * max(1.0, float(y.detach().abs().max())))
+        go = torch.randn_like(y)
+        (y.float() * go.float()).sum().backward()
+        live = (y2 != 0) & (go != 0)
+        assert torch.equal((x.grad != 0) & (x.detach() != 0), live)                    # backward regenerated the forward's mask
+        close(r.grad.float(), go.float(), 0.0)
+        scale = (x.grad.float()[live] / go.float()[live])
+        assert float((scale - 1.0 / 0.75).abs().max()) < 2e-2
+        # row mask
+        lens = torch.tensor([5, 0, 17, 9], device=dev, dtype=torch.int32)
+        for L in (lens, lens.long()):
+            keep = norm.row_mask(L, 17, dt)
+            want = (~get_mask_from_lengths(L, 17)).to(dt)
+            assert torch.equal(keep, want)
+    # members of a grouped call that share their input: one summed gradient
+    convs = [WNConv1d(16, 16, k, padding=k // 2).to(dev) for k in (3, 5, 7)]
+    layers = [c.hip_layer() for c in convs]
+    bank = convnet.ConvBank(layers)
+    x0 = torch.randn(2, 1, 40, 16, device=dev)
+    got = {}
+    for flag in (True, False):
+        saved, convnet.SUM_SHARED_INPUTS = convnet.SUM_SHARED_INPUTS, flag
+        try:
+            for c in convs:
+                c.zero_grad()
+            bank.prepare(torch.float32)
+            x = x0.clone().requires_grad_(True)
+            outs = convnet.hip_conv_group(bank, [dict(layer=l, x=x, in_slope=0.1) for l in layers])
+            sum((o * (i + 1)).sum() for i, o in enumerate(outs)).backward()
+            got[flag] = (x.grad.clone(), [p.grad.clone() for c in convs for p in c.parameters()])
+        finally:
+            convnet.SUM_SHARED_INPUTS = saved
+    close(got[True][0], got[False][0], 2e-5 * max(1.0, float(got[False][0].abs().max())), what='shared-input gradient sum')
+    for a, b in zip(got[True][1], got[False][1]):
+        close(a, b, 1e-6 * max(1.0, float(b.abs().max())))
+    xr = x0.clone().requires_grad_(True)
+    act = torch.nn.functional.leaky_relu(xr.squeeze(1).transpose(1, 2), 0.1)
+    sum((c(act) * (i + 1)).sum() for i, c in enumerate(convs)).backward()
+    close(got[True][0], xr.grad, 2e-4 * max(1.0, float(xr.grad.abs().max())), what='shared-input gradient against stock operators')
+
+
 def check_hip_adamw(dev):
     """csrc/optim.hip (grad-norm clip + AdamW of all tensors in three launches) against clip_grad_norm_ + torch.optim.AdamW
     over several steps, odd sizes and unaligned views; state_dict round trip both ways"""

@@ -588,6 +588,10 @@ def test_two_autograd_graphs_over_one_bank_back_propagated_one_after_the_other()
     _parity.check_two_graphs_over_one_bank('cpu')
 
 
+def test_sum_dropout_add_row_mask_kernels_and_shared_input_gradients():
+    _parity.check_glue_kernels('cpu')
+
+
 def test_output_projection_inside_the_add_layernorm_launch():
     _parity.check_fc_add_ln('cpu')
 
