@@ -886,7 +886,10 @@ class _HipConvGroup(torch.autograd.Function):
             shared = {}
             for k in range(n):
                 if grads[ctx.xpos[k]] is not None:
-                    shared.setdefault((xs[k].data_ptr(), tuple(xs[k].shape)), []).append(ctx.xpos[k])
+                    # the same autograd tensor, not merely the same memory: a tap alias of x shares x's storage but its gradient
+                    # takes another route (through its producer's data-gradient epilogue, possibly an activation's derivative)
+                    key = (xs[k].data_ptr(), tuple(xs[k].shape), id(xs[k].grad_fn), xs[k].output_nr, xs[k].is_leaf)
+                    shared.setdefault(key, []).append(ctx.xpos[k])
             for slots in shared.values():
                 if 2 <= len(slots) <= 4:
                     from . import norm
