@@ -2643,18 +2643,19 @@ MSMC_DEV void wgrad_reduce_body(const WgReduceArgsT<M>& a) {
     if ((n_dw & 3) == 0 && (mid ? e0 + 4 <= stride : e0 + 4 <= n_dw)) {
         // (the splits are added in split order -- bit-reproducible -- but LOADED eight at a time: with one load in flight per
         //  work-item a member of 64 splits was 64 dependent memory round trips, and the pass ran at ~1 TB/s)
+        // (round 6: a last batch of fewer than eight goes out together as well -- splits past the end re-read the last one and
+        //  are not added; most members have 2-8 splits and ran entirely in the one-at-a-time remainder loop)
         f32x4 sum = *(const f32x4*)(ws + e0);
-        int s_ = 1;
-        for (; s_ + 8 <= S; s_ += 8) {
+        for (int s_ = 1; s_ < S; s_ += 8) {
             f32x4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4*)(ws + (size_t)(s_ + j) * stride + e0);
+            for (int j = 0; j < 8; ++j) {
+                const int sj = s_ + j < S ? s_ + j : S - 1;
+                v[j] = *(const f32x4*)(ws + (size_t)sj * stride + e0);
+            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum = sum + v[j];
-        }
-        for (; s_ < S; ++s_) {
-            const f32x4 v = *(const f32x4*)(ws + (size_t)s_ * stride + e0);
-            sum = sum + v;
+            for (int j = 0; j < 8; ++j)
+                if (s_ + j < S) sum = sum + v[j];
         }
         if (mid) { *(f32x4*)(mid + e0) = sum; return; }
         f32x4* q = (f32x4*)(a.dw[k] + e0);
@@ -3794,6 +3795,23 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
                 for (int u = 0; u < 4; ++u)
                     if (dst[u] >= 0) row[dst[u]] = q[u];
             }
+        } else if (R <= 8) {
+            // privatised copies (the thin layers: eight accumulators per element): all copies of an element requested together,
+            // folded in copy order
+            for (int t = 0; t < T; ++t) {
+                const long o1 = t * it.s1[0] + a * it.s1[1];
+                for (int b = threadIdx.x; b < Bc; b += NT) {
+                    const long o = o1 + b * it.s1[2];
+                    float q[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) q[r] = r < R ? dwr[o + r * it.dw_copy_stride] : 0.f;
+                    float sum = q[0];
+#pragma unroll
+                    for (int r = 1; r < 8; ++r)
+                        if (r < R) sum = sum + q[r];
+                    row[b * T + t] = sum;
+                }
+            }
         } else {
             for (int t = 0; t < T; ++t) {
                 const long o1 = t * it.s1[0] + a * it.s1[1];
@@ -3884,11 +3902,24 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(const msmc_wn_item* __
     }
     if (it.db && threadIdx.x == 0)
         for (int c = a; c < it.nbias; c += it.A) {
-            float sum = it.db[c];
-            it.db[c] = 0.f;
-            for (int r = 1; r < R; ++r) {
-                sum = sum + it.db[c + r * it.db_copy_stride];
-                it.db[c + r * it.db_copy_stride] = 0.f;
+            float sum;
+            if (R <= 8) {                           // (all copies requested together, folded in copy order: one round trip, not R)
+                const float* __restrict__ dbr = it.db;
+                float q[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) q[r] = r < R ? dbr[c + r * it.db_copy_stride] : 0.f;
+                sum = q[0];
+#pragma unroll
+                for (int r = 1; r < 8; ++r)
+                    if (r < R) sum = sum + q[r];
+                for (int r = 0; r < R; ++r) it.db[c + r * it.db_copy_stride] = 0.f;
+            } else {
+                sum = it.db[c];
+                it.db[c] = 0.f;
+                for (int r = 1; r < R; ++r) {
+                    sum = sum + it.db[c + r * it.db_copy_stride];
+                    it.db[c + r * it.db_copy_stride] = 0.f;
+                }
             }
             it.gb[c] = accumulate ? it.gb[c] + sum : sum;
         }

@@ -12,6 +12,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'lib', 'libmsmc_hip.so'))
+# A/B HOOK (tools): another build of the same library, e.g. the previous commit's, for a same-box comparison
+DEFAULT_PATH = os.environ.get('MSMC_HIP_LIB', DEFAULT_PATH)
 
 _lib = None
 _host_pointers_ok = False
