@@ -1083,6 +1083,62 @@ MSMC_DEV float dir_epilogue(const msmc_conv_desc& d, float v, size_t o, int co) 
 }
 MSMC_DEV float dir_act(float f, float slope) { return (slope == 1.f || f > 0.f) ? f : f * slope; }
 
+// A run of N consecutive output channels (N * sizeof(T) a multiple of 8 bytes, the run aligned to its size): the optional operands
+// arrive as ONE vector load each and the result leaves as one vector store per 16 bytes -- written per element (dir_epilogue in a
+// loop, Elt::st per channel) every work-item issued N two-byte loads per operand and N two-byte stores, each a memory request
+// of its own (round 6: the thin first / last layers of the discriminators ran at 7-12 % of the HBM roofline).  Same arithmetic, in
+// the same order, as dir_epilogue.
+template <typename T, int N>
+MSMC_DEV void dir_epilogue_run(const msmc_conv_desc& d, float (&v)[N], const size_t o, const int co0) {
+    constexpr int BYTES = N * (int)sizeof(T);
+    static_assert(BYTES % 8 == 0, "vector run");
+    alignas(16) T mk[N], r1[N], r2[N], ov[N];
+    auto ldrun = [&](const T* src, T (&dst)[N]) {
+        if constexpr (BYTES % 16 == 0) {
+#pragma unroll
+            for (int q = 0; q < BYTES / 16; ++q) ((u32x4*)dst)[q] = ((const u32x4*)(src + o))[q];
+        } else {
+            *(u32x2*)dst = *(const u32x2*)(src + o);
+        }
+    };
+    if (d.bias) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[q] = v[q] + d.bias[co0 + q];
+    }
+    if (d.mask_src) {
+        ldrun((const T*)d.mask_src, mk);
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[q] = v[q] * (Elt<T>::ld(&mk[q]) > 0.f ? 1.f : d.mask_slope);
+    }
+    if (d.res) {
+        ldrun((const T*)d.res, r1);
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[q] = v[q] + Elt<T>::ld(&r1[q]);
+    }
+    if (d.res2) {
+        ldrun((const T*)d.res2, r2);
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[q] = Elt<T>::ld(&r2[q]) + v[q];
+    }
+    if (d.out_div != 1.f) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[q] = v[q] / d.out_div;
+    }
+    if (d.out_slope != 1.f) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * d.out_slope;
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) Elt<T>::st(&ov[q], v[q]);
+    T* out = (T*)d.out + o;
+    if constexpr (BYTES % 16 == 0) {
+#pragma unroll
+        for (int q = 0; q < BYTES / 16; ++q) ((u32x4*)out)[q] = ((const u32x4*)ov)[q];
+    } else {
+        *(u32x2*)out = *(const u32x2*)ov;
+    }
+}
+
 template <typename T, int CI, int CO>
 MSMC_DEV void dir_small_body(const msmc_conv_desc& d, const long npoints, const int block, const int nblocks) {
     MSMC_DYN_LDS(smem);
@@ -1121,6 +1177,12 @@ MSMC_DEV void dir_small_body(const msmc_conv_desc& d, const long npoints, const 
                 const float xf = dir_act(Elt<T>::ld(&xv[ci]), d.in_slope);
 #pragma unroll
                 for (int co = 0; co < CO; ++co) acc[co] = fmaf(wt[ci * CO + co], xf, acc[co]);
+            }
+        }
+        if constexpr ((CO * sizeof(T)) % 8 == 0) {
+            if (d.Cout == CO) {                     // (the whole channel run of the point: vector operands, vector store)
+                dir_epilogue_run<T, CO>(d, acc, pt.out, 0);
+                continue;
             }
         }
 #pragma unroll
@@ -1210,20 +1272,28 @@ MSMC_DEV void dir_outer_body(const msmc_conv_desc& d, const long nitems, const i
         float acc[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) acc[q] = 0.f;
-        for (int t = 0; t < d.ntaps; ++t) {
-            const long off = dir_in(d, pt, t);
-            if (off < 0) continue;
-            const float xf = dir_act(Elt<T>::ld(x + off), d.in_slope);
-            alignas(16) T wv[VEC];
-            *(u32x4*)wv = *(const u32x4*)(wl + (size_t)t * d.Cout + v * VEC);
+        // the input values of four taps at a time: requested together (taps outside the image re-read element 0 and are skipped
+        // in the sum, as before) -- one memory round trip per four taps instead of one per tap
+        for (int t0 = 0; t0 < d.ntaps; t0 += 4) {
+            float xf[4];
+            bool on[4];
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) acc[q] = fmaf(Elt<T>::ld(&wv[q]), xf, acc[q]);
+            for (int u = 0; u < 4; ++u) {
+                const long off = t0 + u < d.ntaps ? dir_in(d, pt, t0 + u) : -1;
+                on[u] = off >= 0;
+                xf[u] = Elt<T>::ld(x + (on[u] ? off : 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!on[u]) continue;
+                const float xa = dir_act(xf[u], d.in_slope);
+                alignas(16) T wv[VEC];
+                *(u32x4*)wv = *(const u32x4*)(wl + (size_t)(t0 + u) * d.Cout + v * VEC);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) acc[q] = fmaf(Elt<T>::ld(&wv[q]), xa, acc[q]);
+            }
         }
-        const size_t o = pt.out + (size_t)v * VEC;
-        alignas(16) T ov[VEC];
-#pragma unroll
-        for (int q = 0; q < VEC; ++q) Elt<T>::st(&ov[q], dir_epilogue<T>(d, acc[q], o + q, v * VEC + q));
-        *(u32x4*)(out + o) = *(const u32x4*)ov;
+        dir_epilogue_run<T, VEC>(d, acc, pt.out + (size_t)v * VEC, v * VEC);
     }
 }
 
