@@ -497,6 +497,66 @@ def check_glue_kernels(dev):
     close(got[True][0], xr.grad, 2e-4 * max(1.0, float(xr.grad.abs().max())), what='shared-input gradient against stock operators')
 
 
+def check_direct_kernels_with_every_epilogue_operand(dev):
+    """conv_direct_small / outer / dot (descriptor variant 8) with bias, mask (data gradient), both residuals, the division and the
+    output leaky-ReLU at once -- the vector run epilogue of round 6 (dir_epilogue_run) -- against the tiled second-generation kernel
+    (variant 2) on the same operands, fp32 and bf16, channel counts that take the vector path (Cout = 4, 8, 16) and one that does not"""
+    from msmctts_amd.hip import conv
+    torch.manual_seed(21)
+    B, H, W = 2, 9, 37
+    saved = conv._tune
+    state = {'variant': 8}
+    ran = 0
+
+    def forced(kind, desc, launch, candidates):
+        desc.variant, desc.split_shift, desc._tuned = state['variant'], 0, True
+    conv._tune = forced
+    try:
+        for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1.5e-2)):
+            for ci, co in ((2, 4), (4, 8), (1, 16), (8, 4), (2, 3), (64, 1), (1, 64)):
+                x = torch.randn(B, H, W, ci, device=dev).to(dt)
+                w = (torch.randn(9, co, ci, device=dev) / (9 * ci) ** 0.5).to(dt)
+                bias = torch.randn(co, device=dev)
+                res, res2 = torch.randn(B, H, W, co, device=dev).to(dt), torch.randn(B, H, W, co, device=dev).to(dt)
+                geom = conv.Geometry(H, W, (3, 3), (1, 1), (1, 1), (1, 1), False)
+                outs = []
+                for v in (8, 2):
+                    state['variant'] = v
+                    conv._PLANS.clear()
+                    geom.plans.clear()
+                    try:
+                        outs.append(conv.conv_forward(x, w, geom, bias=bias, in_slope=0.2, res=res, res2=res2, out_div=3.0, out_slope=0.1))
+                    except RuntimeError:
+                        outs.append(None)                       # (a shape the direct kernels do not take)
+                if outs[0] is None:
+                    continue
+                ran += 1
+                scale = max(1.0, float(outs[1].float().abs().max()))
+                close(outs[0].float(), outs[1].float(), tol * scale, what='direct forward %d -> %d %s' % (ci, co, dt))
+                # data gradient with the activation mask and a tap gradient as residual
+                g = torch.randn(B, H, W, co, device=dev).to(dt)
+                wb = w.transpose(1, 2).contiguous()
+                mask, tapg = torch.randn(B, H, W, ci, device=dev).to(dt), torch.randn(B, H, W, ci, device=dev).to(dt)
+                outs = []
+                for v in (8, 2):
+                    state['variant'] = v
+                    conv._PLANS.clear()
+                    geom.plans.clear()
+                    try:
+                        outs.append(conv.conv_dgrad(g, wb, geom, mask_src=mask, mask_slope=0.2, res=tapg, out_div=3.0))
+                    except RuntimeError:
+                        outs.append(None)
+                if outs[0] is None:
+                    continue
+                ran += 1
+                scale = max(1.0, float(outs[1].float().abs().max()))
+                close(outs[0].float(), outs[1].float(), tol * scale, what='direct data gradient %d <- %d %s' % (ci, co, dt))
+    finally:
+        conv._tune = saved
+        conv._PLANS.clear()
+    assert ran >= 16, ran                                   # (the direct kernels took the cases: small, dot and outer, both dtypes)
+
+
 def check_hip_adamw(dev):
     """csrc/optim.hip (grad-norm clip + AdamW of all tensors in three launches) against clip_grad_norm_ + torch.optim.AdamW
     over several steps, odd sizes and unaligned views; state_dict round trip both ways"""

@@ -592,6 +592,10 @@ def test_sum_dropout_add_row_mask_kernels_and_shared_input_gradients():
     _parity.check_glue_kernels('cpu')
 
 
+def test_direct_kernels_with_every_epilogue_operand_at_once():
+    _parity.check_direct_kernels_with_every_epilogue_operand('cpu')
+
+
 def test_output_projection_inside_the_add_layernorm_launch():
     _parity.check_fc_add_ln('cpu')
 
